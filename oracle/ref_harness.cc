@@ -1,0 +1,449 @@
+// oracle/ref_harness.cc -- TEST INFRASTRUCTURE, not product code.
+//
+// A thin extern "C" face over the *unmodified* reference library, compiled from
+// the sources where they lie under /root/reference (see oracle/Makefile; output
+// goes to oracle/_ref/libscl_ref.so which is git-ignored).  Nothing from the
+// reference is copied into this file: it only #includes the reference's public
+// headers and calls its functions, so that
+//   * tests/golden/make_golden.py can emit golden vectors, and
+//   * tests / bench.py's cpu_baseline leg can run the real reference CPU path.
+//
+// Element encoding on this face: little-endian 64-bit limbs, 1 limb for
+// Mersenne61 (field tag 0) and 2 limbs for Mersenne127 (field tag 1); this is
+// the byte image FF::write produces (reference include/scl/math/ff.h:300-302).
+// Share matrices are AoS [secret][party], the layout the reference returns
+// (one Vector of n shares per secret, include/scl/ss/shamir.h:52-68).
+
+#include <scl/math/fp.h>
+#include <scl/math/lagrange.h>
+#include <scl/math/matrix.h>
+#include <scl/math/poly.h>
+#include <scl/math/vector.h>
+#include <scl/ss/additive.h>
+#include <scl/ss/shamir.h>
+#include <scl/util/prg.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+using F61 = scl::math::Fp<61>;
+using F127 = scl::math::Fp<127>;
+using scl::math::Matrix;
+using scl::math::Vector;
+using scl::util::PRG;
+
+template <typename F>
+constexpr std::size_t limbs() {
+  return F::byteSize() / 8;
+}
+
+template <typename F>
+F load(const std::uint64_t* p) {
+  return F::read(reinterpret_cast<const unsigned char*>(p));
+}
+
+template <typename F>
+void store(std::uint64_t* p, const F& v) {
+  v.write(reinterpret_cast<unsigned char*>(p));
+}
+
+template <typename F>
+Vector<F> loadVec(const std::uint64_t* p, std::size_t n) {
+  std::vector<F> v;
+  v.reserve(n);
+  for (std::size_t i = 0; i < n; ++i) v.emplace_back(load<F>(p + i * limbs<F>()));
+  return Vector<F>(std::move(v));
+}
+
+template <typename F>
+void storeVec(std::uint64_t* p, const Vector<F>& v) {
+  for (std::size_t i = 0; i < v.size(); ++i) store<F>(p + i * limbs<F>(), v[i]);
+}
+
+PRG makePrg(const unsigned char* seed, std::size_t seed_len) {
+  return PRG::create(seed, seed_len);
+}
+
+enum Op { ADD = 0, SUB = 1, MUL = 2, NEG = 3, INV = 4, DIV = 5 };
+
+template <typename F>
+int ewOp(int op, std::uint64_t* dst, const std::uint64_t* a,
+         const std::uint64_t* b, std::size_t n) {
+  constexpr auto L = limbs<F>();
+  for (std::size_t i = 0; i < n; ++i) {
+    F x = load<F>(a + i * L);
+    F y = b ? load<F>(b + i * L) : F{};
+    switch (op) {
+      case ADD: x += y; break;
+      case SUB: x -= y; break;
+      case MUL: x *= y; break;
+      case NEG: x.negate(); break;
+      case INV: x.invert(); break;
+      case DIV: x /= y; break;
+      default: return -1;
+    }
+    store<F>(dst + i * L, x);
+  }
+  return 0;
+}
+
+template <typename F>
+void shamirShare(const unsigned char* seed, std::size_t seed_len,
+                 const std::uint64_t* secrets, std::size_t N, std::size_t t,
+                 std::size_t n, std::uint64_t* shares) {
+  constexpr auto L = limbs<F>();
+  auto prg = makePrg(seed, seed_len);
+  for (std::size_t s = 0; s < N; ++s) {
+    const auto sh = scl::ss::shamirSecretShare(load<F>(secrets + s * L), t, n, prg);
+    storeVec<F>(shares + s * n * L, sh);
+  }
+}
+
+template <typename F>
+void shamirRecover(const std::uint64_t* shares, std::size_t n, std::size_t N,
+                   std::uint64_t* out) {
+  constexpr auto L = limbs<F>();
+  for (std::size_t s = 0; s < N; ++s) {
+    const auto sh = loadVec<F>(shares + s * n * L, n);
+    store<F>(out + s * L, scl::ss::shamirRecoverP(sh));
+  }
+}
+
+template <typename F>
+void shamirRecoverAt(const std::uint64_t* shares, const std::uint64_t* alphas,
+                     const std::uint64_t* x, std::size_t m, std::size_t N,
+                     std::uint64_t* out) {
+  constexpr auto L = limbs<F>();
+  const auto al = loadVec<F>(alphas, m);
+  const auto xx = load<F>(x);
+  for (std::size_t s = 0; s < N; ++s) {
+    const auto sh = loadVec<F>(shares + s * m * L, m);
+    store<F>(out + s * L, scl::ss::shamirRecoverP(sh, al, xx));
+  }
+}
+
+template <typename F>
+void shamirRecoverD(const std::uint64_t* shares, std::size_t n, std::size_t t,
+                    std::size_t N, std::uint64_t* out, unsigned char* status) {
+  constexpr auto L = limbs<F>();
+  for (std::size_t s = 0; s < N; ++s) {
+    const auto sh = loadVec<F>(shares + s * n * L, n);
+    try {
+      store<F>(out + s * L, scl::ss::shamirRecoverD(sh, t));
+      status[s] = 0;
+    } catch (const std::logic_error&) {
+      store<F>(out + s * L, F{});
+      status[s] = 1;
+    }
+  }
+}
+
+template <typename F>
+void additiveShare(const unsigned char* seed, std::size_t seed_len,
+                   const std::uint64_t* secrets, std::size_t N, std::size_t n,
+                   std::uint64_t* shares) {
+  constexpr auto L = limbs<F>();
+  auto prg = makePrg(seed, seed_len);
+  for (std::size_t s = 0; s < N; ++s) {
+    const auto sh = scl::ss::additiveShare(load<F>(secrets + s * L), n, prg);
+    storeVec<F>(shares + s * n * L, sh);
+  }
+}
+
+template <typename F>
+void additiveRecover(const std::uint64_t* shares, std::size_t n, std::size_t N,
+                     std::uint64_t* out) {
+  constexpr auto L = limbs<F>();
+  for (std::size_t s = 0; s < N; ++s) {
+    store<F>(out + s * L, loadVec<F>(shares + s * n * L, n).sum());
+  }
+}
+
+template <typename F>
+Matrix<F> loadMat(const std::uint64_t* p, std::size_t r, std::size_t c) {
+  Matrix<F> m(r, c);
+  for (std::size_t i = 0; i < r; ++i)
+    for (std::size_t j = 0; j < c; ++j) m(i, j) = load<F>(p + (i * c + j) * limbs<F>());
+  return m;
+}
+
+template <typename F>
+void storeMat(std::uint64_t* p, const Matrix<F>& m) {
+  for (std::size_t i = 0; i < m.rows(); ++i)
+    for (std::size_t j = 0; j < m.cols(); ++j)
+      store<F>(p + (i * m.cols() + j) * limbs<F>(), m(i, j));
+}
+
+}  // namespace
+
+#define DISPATCH(field, ...)       \
+  do {                             \
+    if ((field) == 0) {            \
+      using F = F61;               \
+      __VA_ARGS__;                 \
+    } else if ((field) == 1) {     \
+      using F = F127;              \
+      __VA_ARGS__;                 \
+    } else {                       \
+      return -2;                   \
+    }                              \
+  } while (0)
+
+extern "C" {
+
+int sclref_limbs(int field) { return field == 0 ? 1 : field == 1 ? 2 : -1; }
+
+const char* sclref_field_name(int field) {
+  return field == 0 ? F61::name() : field == 1 ? F127::name() : "";
+}
+
+// returns 0 ok, 1 if the reference threw (message copied to err, NUL terminated)
+int sclref_ew(int field, int op, std::uint64_t* dst, const std::uint64_t* a,
+              const std::uint64_t* b, std::size_t n, char* err, std::size_t errlen) {
+  try {
+    int r = 0;
+    DISPATCH(field, r = ewOp<F>(op, dst, a, b, n));
+    return r;
+  } catch (const std::exception& e) {
+    if (err && errlen) {
+      std::strncpy(err, e.what(), errlen - 1);
+      err[errlen - 1] = 0;
+    }
+    return 1;
+  }
+}
+
+int sclref_from_int(int field, int v, std::uint64_t* dst) {
+  DISPATCH(field, store<F>(dst, F(v)));
+  return 0;
+}
+
+int sclref_from_bytes(int field, const unsigned char* src, std::size_t n,
+                      std::uint64_t* dst) {
+  DISPATCH(field, {
+    for (std::size_t i = 0; i < n; ++i)
+      store<F>(dst + i * limbs<F>(), F::read(src + i * F::byteSize()));
+  });
+  return 0;
+}
+
+int sclref_from_hex(int field, const char* hex, std::uint64_t* dst, char* err,
+                    std::size_t errlen) {
+  try {
+    DISPATCH(field, store<F>(dst, F::fromString(hex)));
+    return 0;
+  } catch (const std::exception& e) {
+    if (err && errlen) {
+      std::strncpy(err, e.what(), errlen - 1);
+      err[errlen - 1] = 0;
+    }
+    return 1;
+  }
+}
+
+int sclref_to_hex(int field, const std::uint64_t* a, char* out, std::size_t outlen) {
+  std::string s;
+  DISPATCH(field, s = load<F>(a).toString());
+  if (s.size() + 1 > outlen) return -1;
+  std::memcpy(out, s.c_str(), s.size() + 1);
+  return 0;
+}
+
+// exp(base, e)  (reference include/scl/math/ff.h:329-346)
+int sclref_exp(int field, const std::uint64_t* base, std::size_t e, std::uint64_t* dst) {
+  DISPATCH(field, store<F>(dst, scl::math::exp(load<F>(base), e)));
+  return 0;
+}
+
+// Concatenated output of successive PRG::next(sizes[i]) calls on one PRG.
+int sclref_prg(const unsigned char* seed, std::size_t seed_len,
+               const std::size_t* sizes, std::size_t ncalls, unsigned char* out) {
+  auto prg = makePrg(seed, seed_len);
+  for (std::size_t i = 0; i < ncalls; ++i) {
+    prg.next(out, sizes[i]);
+    out += sizes[i];
+  }
+  return 0;
+}
+
+int sclref_vector_random(int field, const unsigned char* seed, std::size_t seed_len,
+                         std::size_t n, std::uint64_t* out) {
+  auto prg = makePrg(seed, seed_len);
+  DISPATCH(field, storeVec<F>(out, Vector<F>::random(n, prg)));
+  return 0;
+}
+
+int sclref_shamir_share(int field, const unsigned char* seed, std::size_t seed_len,
+                        const std::uint64_t* secrets, std::size_t N, std::size_t t,
+                        std::size_t n, std::uint64_t* shares) {
+  DISPATCH(field, shamirShare<F>(seed, seed_len, secrets, N, t, n, shares));
+  return 0;
+}
+
+int sclref_shamir_recover(int field, const std::uint64_t* shares, std::size_t n,
+                          std::size_t N, std::uint64_t* out) {
+  DISPATCH(field, shamirRecover<F>(shares, n, N, out));
+  return 0;
+}
+
+int sclref_shamir_recover_at(int field, const std::uint64_t* shares,
+                             const std::uint64_t* alphas, const std::uint64_t* x,
+                             std::size_t m, std::size_t N, std::uint64_t* out,
+                             char* err, std::size_t errlen) {
+  try {
+    DISPATCH(field, shamirRecoverAt<F>(shares, alphas, x, m, N, out));
+    return 0;
+  } catch (const std::exception& e) {
+    if (err && errlen) {
+      std::strncpy(err, e.what(), errlen - 1);
+      err[errlen - 1] = 0;
+    }
+    return 1;
+  }
+}
+
+int sclref_shamir_recover_d(int field, const std::uint64_t* shares, std::size_t n,
+                            std::size_t t, std::size_t N, std::uint64_t* out,
+                            unsigned char* status) {
+  DISPATCH(field, shamirRecoverD<F>(shares, n, t, N, out, status));
+  return 0;
+}
+
+int sclref_lagrange_basis(int field, const std::uint64_t* nodes, std::size_t m,
+                          const std::uint64_t* x, std::uint64_t* out, char* err,
+                          std::size_t errlen) {
+  try {
+    DISPATCH(field, storeVec<F>(out, scl::math::computeLagrangeBasis(
+                                         loadVec<F>(nodes, m), load<F>(x))));
+    return 0;
+  } catch (const std::exception& e) {
+    if (err && errlen) {
+      std::strncpy(err, e.what(), errlen - 1);
+      err[errlen - 1] = 0;
+    }
+    return 1;
+  }
+}
+
+int sclref_additive_share(int field, const unsigned char* seed, std::size_t seed_len,
+                          const std::uint64_t* secrets, std::size_t N, std::size_t n,
+                          std::uint64_t* shares) {
+  DISPATCH(field, additiveShare<F>(seed, seed_len, secrets, N, n, shares));
+  return 0;
+}
+
+int sclref_additive_recover(int field, const std::uint64_t* shares, std::size_t n,
+                            std::size_t N, std::uint64_t* out) {
+  DISPATCH(field, additiveRecover<F>(shares, n, N, out));
+  return 0;
+}
+
+int sclref_dot(int field, const std::uint64_t* a, const std::uint64_t* b,
+               std::size_t n, std::uint64_t* out) {
+  DISPATCH(field, store<F>(out, loadVec<F>(a, n).dot(loadVec<F>(b, n))));
+  return 0;
+}
+
+int sclref_sum(int field, const std::uint64_t* a, std::size_t n, std::uint64_t* out) {
+  DISPATCH(field, store<F>(out, loadVec<F>(a, n).sum()));
+  return 0;
+}
+
+int sclref_scalar_mul(int field, const std::uint64_t* a, const std::uint64_t* scalar,
+                      std::size_t n, std::uint64_t* out) {
+  DISPATCH(field, storeVec<F>(out, loadVec<F>(a, n).scalarMultiply(load<F>(scalar))));
+  return 0;
+}
+
+int sclref_poly_eval(int field, const std::uint64_t* coeffs, std::size_t ncoeff,
+                     const std::uint64_t* xs, std::size_t nx, std::uint64_t* out) {
+  DISPATCH(field, {
+    const auto p = scl::math::Polynomial<F>::create(loadVec<F>(coeffs, ncoeff));
+    for (std::size_t i = 0; i < nx; ++i)
+      store<F>(out + i * limbs<F>(), p.evaluate(load<F>(xs + i * limbs<F>())));
+  });
+  return 0;
+}
+
+// V(i,j) = xs[i]^j ; xs == NULL -> the reference's default nodes 1..n
+int sclref_vandermonde(int field, std::size_t n, std::size_t m, const std::uint64_t* xs,
+                       std::uint64_t* out) {
+  DISPATCH(field, {
+    const auto v = xs ? Matrix<F>::vandermonde(n, m, loadVec<F>(xs, n))
+                      : Matrix<F>::vandermonde(n, m);
+    storeMat<F>(out, v);
+  });
+  return 0;
+}
+
+int sclref_hyper_invertible(int field, std::size_t n, std::size_t m, std::uint64_t* out) {
+  DISPATCH(field, storeMat<F>(out, Matrix<F>::hyperInvertible(n, m)));
+  return 0;
+}
+
+// C[n x m] = A[n x k] * B[k x m], row-major
+int sclref_matmul(int field, const std::uint64_t* A, const std::uint64_t* B,
+                  std::size_t n, std::size_t k, std::size_t m, std::uint64_t* C) {
+  DISPATCH(field, storeMat<F>(C, loadMat<F>(A, n, k).multiply(loadMat<F>(B, k, m))));
+  return 0;
+}
+
+int sclref_mat_invert(int field, const std::uint64_t* A, std::size_t n, std::uint64_t* out) {
+  DISPATCH(field, {
+    auto m = loadMat<F>(A, n, n);
+    storeMat<F>(out, m.invert());
+  });
+  return 0;
+}
+
+// The reference CPU path, timed: per secret shamirSecretShare(...) followed by
+// shamirRecoverP(shares), exactly as a user of the library would call them
+// (one heap Vector per secret, basis recomputed per call).  Secrets are
+// FF(int(s mod 2^31)).  Returns seconds spent in share / recover and the number
+// of secrets whose recovered value differed from the input (must be 0).
+int sclref_time_shamir(int field, std::size_t N, std::size_t t, std::size_t n,
+                       const unsigned char* seed, std::size_t seed_len,
+                       double* share_s, double* recover_s, std::uint64_t* mismatches,
+                       std::uint64_t* checksum) {
+  using clk = std::chrono::steady_clock;
+  DISPATCH(field, {
+    auto prg = makePrg(seed, seed_len);
+    double ts = 0, tr = 0;
+    std::uint64_t bad = 0, acc = 0;
+    constexpr std::size_t CH = 4096;
+    std::vector<Vector<F>> held;
+    held.reserve(CH);
+    for (std::size_t s0 = 0; s0 < N; s0 += CH) {
+      const std::size_t cnt = std::min(CH, N - s0);
+      held.clear();
+      auto a = clk::now();
+      for (std::size_t i = 0; i < cnt; ++i)
+        held.emplace_back(scl::ss::shamirSecretShare(
+            F((int)((s0 + i) & 0x7fffffff)), t, n, prg));
+      auto b = clk::now();
+      for (std::size_t i = 0; i < cnt; ++i) {
+        const F r = scl::ss::shamirRecoverP(held[i]);
+        std::uint64_t w[2] = {0, 0};
+        store<F>(w, r);
+        acc += w[0];
+        bad += !(r == F((int)((s0 + i) & 0x7fffffff)));
+      }
+      auto c = clk::now();
+      ts += std::chrono::duration<double>(b - a).count();
+      tr += std::chrono::duration<double>(c - b).count();
+    }
+    *share_s = ts;
+    *recover_s = tr;
+    *mismatches = bad;
+    *checksum = acc;
+  });
+  return 0;
+}
+
+}  // extern "C"

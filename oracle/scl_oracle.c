@@ -1,0 +1,754 @@
+/* oracle/scl_oracle.c -- TEST INFRASTRUCTURE, not product code.  See scl_oracle.h.
+ *
+ * Plain-C CPU restatement of the reference hot path.  Citations are relative
+ * to /root/reference.  Nothing here is reachable from the product library
+ * (secure-computation-library_amd/); it is loaded by tests/, smoke() and
+ * bench.py's cpu_baseline leg only.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "scl_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------ AES-128 */
+/* FIPS-197 AES-128 encryption.  The reference uses the AES-NI instructions
+ * (src/scl/util/prg.cc:34-80); the portable path below computes the same
+ * function from the specification, the NI path uses the same instructions. */
+
+static unsigned char g_sbox[256];
+static int g_sbox_ready = 0;
+static int g_force_ni = -1;
+
+static unsigned char gf256_mul(unsigned char a, unsigned char b) {
+  unsigned char r = 0;
+  while (b) {
+    if (b & 1) r ^= a;
+    a = (unsigned char)((a << 1) ^ ((a & 0x80) ? 0x1b : 0));
+    b >>= 1;
+  }
+  return r;
+}
+
+static void sbox_init(void) {
+  if (g_sbox_ready) return;
+  for (int x = 0; x < 256; ++x) {
+    /* multiplicative inverse in GF(2^8) (0 -> 0) by exhaustive search, then the affine map */
+    unsigned char inv = 0;
+    if (x) {
+      for (int y = 1; y < 256; ++y)
+        if (gf256_mul((unsigned char)x, (unsigned char)y) == 1) { inv = (unsigned char)y; break; }
+    }
+    unsigned char s = inv, r = inv;
+    for (int i = 0; i < 4; ++i) {
+      s = (unsigned char)((s << 1) | (s >> 7));
+      r ^= s;
+    }
+    g_sbox[x] = (unsigned char)(r ^ 0x63);
+  }
+  g_sbox_ready = 1;
+}
+
+/* round keys as 11 x 16 bytes, column-major state order = byte order in memory */
+static void aes128_expand(const unsigned char key[16], unsigned char rk[176]) {
+  sbox_init();
+  memcpy(rk, key, 16);
+  unsigned char rcon = 1;
+  for (int i = 16; i < 176; i += 4) {
+    unsigned char t[4] = {rk[i - 4], rk[i - 3], rk[i - 2], rk[i - 1]};
+    if (i % 16 == 0) {
+      unsigned char t0 = t[0];
+      t[0] = (unsigned char)(g_sbox[t[1]] ^ rcon);
+      t[1] = g_sbox[t[2]];
+      t[2] = g_sbox[t[3]];
+      t[3] = g_sbox[t0];
+      rcon = (unsigned char)((rcon << 1) ^ ((rcon & 0x80) ? 0x1b : 0));
+    }
+    for (int j = 0; j < 4; ++j) rk[i + j] = (unsigned char)(rk[i - 16 + j] ^ t[j]);
+  }
+}
+
+static void aes128_encrypt_c(const unsigned char rk[176], const unsigned char in[16],
+                             unsigned char out[16]) {
+  unsigned char s[16], t[16];
+  for (int i = 0; i < 16; ++i) s[i] = (unsigned char)(in[i] ^ rk[i]);
+  for (int round = 1; round <= 10; ++round) {
+    /* SubBytes + ShiftRows: byte (row r, col c) lives at index 4c+r */
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r) t[4 * c + r] = g_sbox[s[4 * ((c + r) & 3) + r]];
+    if (round < 10) {
+      for (int c = 0; c < 4; ++c) {
+        unsigned char a0 = t[4 * c], a1 = t[4 * c + 1], a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+        s[4 * c + 0] = (unsigned char)(gf256_mul(a0, 2) ^ gf256_mul(a1, 3) ^ a2 ^ a3);
+        s[4 * c + 1] = (unsigned char)(a0 ^ gf256_mul(a1, 2) ^ gf256_mul(a2, 3) ^ a3);
+        s[4 * c + 2] = (unsigned char)(a0 ^ a1 ^ gf256_mul(a2, 2) ^ gf256_mul(a3, 3));
+        s[4 * c + 3] = (unsigned char)(gf256_mul(a0, 3) ^ a1 ^ a2 ^ gf256_mul(a3, 2));
+      }
+    } else {
+      memcpy(s, t, 16);
+    }
+    for (int i = 0; i < 16; ++i) s[i] ^= rk[16 * round + i];
+  }
+  memcpy(out, s, 16);
+}
+
+#if defined(__x86_64__)
+__attribute__((target("aes,sse2"))) static void aes128_encrypt_ni(const unsigned char rk[176],
+                                                                  const unsigned char in[16],
+                                                                  unsigned char out[16]) {
+  const __m128i* k = (const __m128i*)rk;
+  __m128i m = _mm_loadu_si128((const __m128i*)in);
+  m = _mm_xor_si128(m, _mm_loadu_si128(k));
+  for (int r = 1; r < 10; ++r) m = _mm_aesenc_si128(m, _mm_loadu_si128(k + r));
+  m = _mm_aesenclast_si128(m, _mm_loadu_si128(k + 10));
+  _mm_storeu_si128((__m128i*)out, m);
+}
+static int have_ni(void) {
+  if (g_force_ni == 0) return 0;
+  return __builtin_cpu_supports("aes");
+}
+#else
+static int have_ni(void) { return 0; }
+#endif
+
+void sclo_aes_force(int use_aesni) { g_force_ni = use_aesni; }
+
+/* ---------------------------------------------------------------------- PRG */
+/* util::PRG (include/scl/util/prg.h:64-173, src/scl/util/prg.cc:88-146):
+ *   key   = seed zero-padded / truncated to 16 bytes        (prg.cc:88-101)
+ *   block = AES_key( LE64(counter) || LE64(PRG_NONCE) ), counter from 0
+ *           (prg.h:34-43, prg.cc:82-84: _mm_set_epi64x(NONCE, counter))
+ *   next(buf,n) emits ceil(n/16) whole blocks, keeps the first n bytes and
+ *   discards the rest; nothing is buffered across calls     (prg.cc:124-146) */
+#define SCLO_PRG_NONCE 0x0123456789ABCDEFULL
+
+typedef struct {
+  unsigned char rk[176];
+  uint64_t counter;
+  int ni;
+} sclo_prg_t;
+
+static void prg_init(sclo_prg_t* g, const unsigned char* seed, size_t seed_len) {
+  unsigned char key[16] = {0};
+  if (seed) memcpy(key, seed, seed_len > 16 ? 16 : seed_len);
+  aes128_expand(key, g->rk);
+  g->counter = 0;
+  g->ni = have_ni();
+}
+
+static void prg_block(const sclo_prg_t* g, uint64_t counter, unsigned char out[16]) {
+  unsigned char in[16];
+  const uint64_t nonce = SCLO_PRG_NONCE;
+  memcpy(in, &counter, 8); /* little-endian host, as the reference assumes */
+  memcpy(in + 8, &nonce, 8);
+#if defined(__x86_64__)
+  if (g->ni) { aes128_encrypt_ni(g->rk, in, out); return; }
+#endif
+  aes128_encrypt_c(g->rk, in, out);
+}
+
+static void prg_next(sclo_prg_t* g, unsigned char* buf, size_t n) {
+  if (n == 0) return;
+  size_t nblocks = (n + 15) / 16;
+  unsigned char blk[16];
+  for (size_t i = 0; i < nblocks; ++i) {
+    prg_block(g, g->counter++, blk);
+    size_t off = 16 * i;
+    memcpy(buf + off, blk, n - off < 16 ? n - off : 16);
+  }
+}
+
+int sclo_prg(const unsigned char* seed, size_t seed_len, const size_t* sizes, size_t ncalls,
+             unsigned char* out) {
+  sclo_prg_t g;
+  prg_init(&g, seed, seed_len);
+  for (size_t i = 0; i < ncalls; ++i) {
+    prg_next(&g, out, sizes[i]);
+    out += sizes[i];
+  }
+  return SCLO_OK;
+}
+
+int sclo_prg_blocks(const unsigned char* seed, size_t seed_len, uint64_t counter0, size_t nblocks,
+                    unsigned char* out) {
+  sclo_prg_t g;
+  prg_init(&g, seed, seed_len);
+  for (size_t i = 0; i < nblocks; ++i) prg_block(&g, counter0 + i, out + 16 * i);
+  return SCLO_OK;
+}
+
+/* ------------------------------------------------------------- hex helpers */
+/* util::fromHexString<T> (include/scl/util/str.h:49-76): big-endian hex, no 0x,
+ * odd length / bad character are errors, bits shifted past the word are lost. */
+static int hex_parse(const char* s, u128* out, int bits) {
+  size_t n = strlen(s);
+  if (n % 2) return SCLO_BAD_HEX_LEN;
+  u128 t = 0;
+  for (size_t i = 0; i < n; ++i) {
+    char c = s[i];
+    unsigned v;
+    if (c >= '0' && c <= '9') v = (unsigned)(c - '0');
+    else if (c >= 'a' && c <= 'f') v = (unsigned)(c - 'a' + 10);
+    else if (c >= 'A' && c <= 'F') v = (unsigned)(c - 'A' + 10);
+    else return SCLO_BAD_HEX_CHAR;
+    t = (t << 4) + v;
+    if (bits == 64) t &= (u128)0xFFFFFFFFFFFFFFFFULL;
+  }
+  *out = t;
+  return SCLO_OK;
+}
+
+static int hex_u64(uint64_t v, char* out, size_t outlen, int pad16) {
+  char tmp[17];
+  int len = 0;
+  if (pad16) {
+    for (int i = 15; i >= 0; --i) tmp[len++] = "0123456789abcdef"[(v >> (4 * i)) & 15];
+  } else {
+    int started = 0;
+    for (int i = 15; i >= 0; --i) {
+      unsigned d = (unsigned)((v >> (4 * i)) & 15);
+      if (d || started || i == 0) { tmp[len++] = "0123456789abcdef"[d]; started = 1; }
+    }
+  }
+  if ((size_t)len + 1 > outlen) return -1;
+  memcpy(out, tmp, (size_t)len);
+  out[len] = 0;
+  return len;
+}
+
+/* =============================================================== Mersenne61 */
+/* include/scl/math/fields/mersenne61.h:29-49, src/scl/math/fields/mersenne61.cc:33-100,
+ * helpers src/scl/math/fields/small_ff.h:28-92 */
+#define P61 0x1FFFFFFFFFFFFFFFULL
+
+static inline uint64_t m61_add(uint64_t a, uint64_t b) { /* small_ff.h:29-34 */
+  uint64_t t = a + b;
+  return t >= P61 ? t - P61 : t;
+}
+static inline uint64_t m61_sub(uint64_t a, uint64_t b) { /* small_ff.h:40-46 */
+  return b > a ? a + P61 - b : a - b;
+}
+static inline uint64_t m61_neg(uint64_t a) { return a ? P61 - a : 0; } /* small_ff.h:52-56 */
+static inline uint64_t m61_mul(uint64_t x, uint64_t y) { /* mersenne61.cc:58-69 */
+  u128 z = (u128)x * y;
+  uint64_t a = (uint64_t)(z >> 61);
+  uint64_t b = (uint64_t)z & P61;
+  return m61_add(a, b);
+}
+static inline int m61_inv(uint64_t* out, uint64_t v) { /* small_ff.h:61-92, S = int64 */
+  if (v == 0) return SCLO_ZERO_INVERSE;
+  int64_t k = 0, nk = 1, r = (int64_t)P61, nr = (int64_t)v;
+  while (nr != 0) {
+    int64_t q = r / nr, tmp;
+    tmp = nk; nk = k - q * tmp; k = tmp;
+    tmp = nr; nr = r - q * tmp; r = tmp;
+  }
+  if (k < 0) k += (int64_t)P61;
+  *out = (uint64_t)k;
+  return SCLO_OK;
+}
+static inline uint64_t m61_from_int(int v) { /* mersenne61.cc:37-40 */
+  return v < 0 ? (uint64_t)((int64_t)v + (int64_t)P61) : (uint64_t)v;
+}
+static inline uint64_t m61_from_bytes(const unsigned char* src) { /* mersenne61.cc:86-90 */
+  uint64_t w;
+  memcpy(&w, src, 8);
+  return w % P61;
+}
+static inline uint64_t m61_ld(const uint64_t* p) { return p[0]; }
+static inline void m61_st(uint64_t* p, uint64_t v) { p[0] = v; }
+static inline int m61_is_zero(uint64_t v) { return v == 0; }
+
+#define FE uint64_t
+#define FN(name) m61_##name
+#define LIMBS 1
+#include "scl_oracle_generic.inc"
+#undef FE
+#undef FN
+#undef LIMBS
+
+/* ============================================================== Mersenne127 */
+/* include/scl/math/fields/mersenne127.h:29-49, src/scl/math/fields/mersenne127.cc:33-128 */
+#define P127 ((((u128)0x7FFFFFFFFFFFFFFFULL) << 64) | (u128)0xFFFFFFFFFFFFFFFFULL)
+
+static inline u128 m127_add(u128 a, u128 b) {
+  u128 t = a + b;
+  return t >= P127 ? t - P127 : t;
+}
+static inline u128 m127_sub(u128 a, u128 b) { return b > a ? a + P127 - b : a - b; }
+static inline u128 m127_neg(u128 a) { return a ? P127 - a : 0; }
+
+/* 128x128 -> 256 by four 64x64 products (mersenne127.cc:66-83) */
+static inline void mul_wide(u128 x, u128 y, u128* hi, u128* lo) {
+  uint64_t a = (uint64_t)(x >> 64), b = (uint64_t)x, c = (uint64_t)(y >> 64), d = (uint64_t)y;
+  u128 ac = (u128)a * c, ad = (u128)a * d, bc = (u128)b * c, bd = (u128)b * d;
+  u128 carry = (u128)(uint64_t)ad + (u128)(uint64_t)bc + (bd >> 64);
+  *hi = ac + (ad >> 64) + (bc >> 64) + (carry >> 64);
+  *lo = (ad << 64) + (bc << 64) + bd;
+}
+static inline u128 m127_mul(u128 x, u128 y) { /* mersenne127.cc:87-97 */
+  u128 hi, lo;
+  mul_wide(x, y, &hi, &lo);
+  u128 a = (hi << 1) | (lo >> 127);
+  u128 b = lo & P127;
+  return m127_add(a, b);
+}
+static inline int m127_inv(u128* out, u128 v) { /* small_ff.h:61-92, S = __int128 */
+  if (v == 0) return SCLO_ZERO_INVERSE;
+  i128 k = 0, nk = 1, r = (i128)P127, nr = (i128)v;
+  while (nr != 0) {
+    i128 q = r / nr, tmp;
+    tmp = nk; nk = k - q * tmp; k = tmp;
+    tmp = nr; nr = r - q * tmp; r = tmp;
+  }
+  if (k < 0) k += (i128)P127;
+  *out = (u128)k;
+  return SCLO_OK;
+}
+static inline u128 m127_from_int(int v) { /* mersenne127.cc:37-40 */
+  return v < 0 ? (u128)((i128)v + (i128)P127) : (u128)v;
+}
+static inline u128 m127_from_bytes(const unsigned char* src) { /* mersenne127.cc:114-118 */
+  u128 w;
+  memcpy(&w, src, 16);
+  return w % P127;
+}
+static inline u128 m127_ld(const uint64_t* p) { return ((u128)p[1] << 64) | p[0]; }
+static inline void m127_st(uint64_t* p, u128 v) { p[0] = (uint64_t)v; p[1] = (uint64_t)(v >> 64); }
+static inline int m127_is_zero(u128 v) { return v == 0; }
+
+#define FE u128
+#define FN(name) m127_##name
+#define LIMBS 2
+#include "scl_oracle_generic.inc"
+#undef FE
+#undef FN
+#undef LIMBS
+
+/* ================================================================= MONT128 */
+/* PARITY UNPINNED plug-in field: a generic odd prime p < 2^128 with elements
+ * held in Montgomery form x*R mod p, R = 2^128 -- the N=2-limb analogue of the
+ * reference's only Montgomery code, include/scl/math/fields/ff_ops_gmp.h:44-260
+ * (instantiated there for the 256-bit secp256k1 fields only). */
+static u128 g_mp = 0, g_mmc = 0, g_mr2 = 0, g_mone = 0;
+
+static inline u128 mont_reduce_once(u128 t, int carry) { /* ff_ops_gmp.h:96-99 */
+  return (carry || t >= g_mp) ? t - g_mp : t;
+}
+static inline u128 mont128_add(u128 a, u128 b) { /* montyModAdd, ff_ops_gmp.h:128-134 */
+  u128 t = a + b;
+  return mont_reduce_once(t, t < a);
+}
+static inline u128 mont128_sub(u128 a, u128 b) { /* montyModSub, ff_ops_gmp.h:142-148 */
+  return a >= b ? a - b : a - b + g_mp;
+}
+static inline u128 mont128_neg(u128 a) { return a ? g_mp - a : 0; } /* ff_ops_gmp.h:156-162 */
+/* montyModMul (ff_ops_gmp.h:174-191) computes a*b/R mod p; any correct REDC yields
+ * the same unique residue.  t = (a*b + ((a*b mod R)*mc mod R)*p) / R */
+static inline u128 mont128_mul(u128 a, u128 b) {
+  u128 thi, tlo, mhi, mlo;
+  mul_wide(a, b, &thi, &tlo);
+  u128 m = tlo * g_mmc;
+  mul_wide(m, g_mp, &mhi, &mlo);
+  u128 lo = tlo + mlo; /* == 0 mod 2^128 by construction */
+  u128 c0 = lo < tlo;
+  u128 hi = thi + mhi;
+  int carry = hi < thi;
+  u128 hi2 = hi + c0;
+  carry |= hi2 < hi;
+  return mont_reduce_once(hi2, carry);
+}
+static inline u128 mont128_pow(u128 base, u128 e) { /* montyModExp, ff_ops_gmp.h:225-237 */
+  u128 r = g_mone;
+  int started = 0;
+  for (int i = 127; i >= 0; --i) {
+    if (started) r = mont128_mul(r, r);
+    if ((e >> i) & 1) { r = mont128_mul(r, base); started = 1; }
+  }
+  return r;
+}
+static inline int mont128_inv(u128* out, u128 v) { /* montyModInv: Fermat, ff_ops_gmp.h:250-260 */
+  if (v == 0) return SCLO_ZERO_INVERSE;
+  *out = mont128_pow(v, g_mp - 2);
+  return SCLO_OK;
+}
+static inline u128 mont128_to_mont(u128 x) { return mont128_mul(x, g_mr2); } /* montyIn */
+static inline u128 mont128_from_mont(u128 x) { return mont128_mul(x, 1); }   /* montyRedc */
+static inline u128 mont128_from_int(int v) { /* montyInFromInt, ff_ops_gmp.h:108-114 */
+  u128 x = (u128)(v < 0 ? -(int64_t)v : (int64_t)v);
+  if (v < 0) x = g_mp - x;
+  return mont128_to_mont(x);
+}
+static inline u128 mont128_from_bytes(const unsigned char* src) { /* montyFromBytes: BIG-endian, ff_ops_gmp.h:279-290 */
+  u128 x = 0;
+  for (int i = 0; i < 16; ++i) x = (x << 8) | src[i];
+  return mont128_to_mont(x);
+}
+static inline u128 mont128_ld(const uint64_t* p) { return ((u128)p[1] << 64) | p[0]; }
+static inline void mont128_st(uint64_t* p, u128 v) { p[0] = (uint64_t)v; p[1] = (uint64_t)(v >> 64); }
+static inline int mont128_is_zero(u128 v) { return v == 0; }
+
+int sclo_mont128_set_prime(const uint64_t p[2]) {
+  u128 pp = ((u128)p[1] << 64) | p[0];
+  if (!(pp & 1) || pp < 3) return SCLO_BAD_ARG;
+  g_mp = pp;
+  /* mc = -p^{-1} mod 2^128 by Newton iteration (5 doublings from 3 correct bits... 7 to be safe) */
+  u128 inv = pp; /* correct to 3 bits for odd p */
+  for (int i = 0; i < 7; ++i) inv *= 2 - pp * inv;
+  g_mmc = (u128)0 - inv;
+  /* R mod p and R^2 mod p by repeated doubling */
+  u128 r = 1 % pp;
+  for (int i = 0; i < 256; ++i) {
+    u128 t = r + r;
+    int c = t < r;
+    r = (c || t >= pp) ? t - pp : t;
+    if (i == 127) g_mone = r;
+  }
+  g_mr2 = r;
+  return SCLO_OK;
+}
+void sclo_mont128_get_prime(uint64_t p[2]) { p[0] = (uint64_t)g_mp; p[1] = (uint64_t)(g_mp >> 64); }
+
+static void mont128_ensure(void) {
+  if (g_mp == 0) {
+    /* default p = 2^128 - 159 (the largest prime below 2^128) */
+    const uint64_t p[2] = {0xFFFFFFFFFFFFFF61ULL, 0xFFFFFFFFFFFFFFFFULL};
+    sclo_mont128_set_prime(p);
+  }
+}
+
+#define FE u128
+#define FN(name) mont128_##name
+#define LIMBS 2
+#include "scl_oracle_generic.inc"
+#undef FE
+#undef FN
+#undef LIMBS
+
+/* ================================================================ GF(2^128) */
+/* PARITY UNPINNED plug-in field (absent from the reference):
+ * GF(2)[x] / (x^128 + x^7 + x^2 + x + 1), bit i of the little-endian 128-bit
+ * word is the coefficient of x^i.  Bitwise shift-xor multiplication. */
+static inline u128 gf128_add(u128 a, u128 b) { return a ^ b; }
+static inline u128 gf128_sub(u128 a, u128 b) { return a ^ b; }
+static inline u128 gf128_neg(u128 a) { return a; }
+static inline u128 gf128_mul(u128 a, u128 b) {
+  u128 r = 0;
+  for (int i = 0; i < 128; ++i) {
+    if ((b >> i) & 1) r ^= a;
+    int top = (int)(a >> 127);
+    a <<= 1;
+    if (top) a ^= 0x87;
+  }
+  return r;
+}
+static inline int gf128_inv(u128* out, u128 v) { /* a^(2^128-2) */
+  if (v == 0) return SCLO_ZERO_INVERSE;
+  u128 r = 1, sq = v;
+  for (int i = 1; i < 128; ++i) { /* exponent bits 1..127 set */
+    sq = gf128_mul(sq, sq);
+    r = gf128_mul(r, sq);
+  }
+  *out = r;
+  return SCLO_OK;
+}
+static inline u128 gf128_from_int(int v) { return (u128)(v < 0 ? -(int64_t)v : (int64_t)v); }
+static inline u128 gf128_from_bytes(const unsigned char* src) {
+  u128 w;
+  memcpy(&w, src, 16);
+  return w;
+}
+static inline u128 gf128_ld(const uint64_t* p) { return ((u128)p[1] << 64) | p[0]; }
+static inline void gf128_st(uint64_t* p, u128 v) { p[0] = (uint64_t)v; p[1] = (uint64_t)(v >> 64); }
+static inline int gf128_is_zero(u128 v) { return v == 0; }
+
+#define FE u128
+#define FN(name) gf128_##name
+#define LIMBS 2
+#include "scl_oracle_generic.inc"
+#undef FE
+#undef FN
+#undef LIMBS
+
+/* ================================================================ dispatch */
+int sclo_limbs(int field) { return field == SCLO_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : -1; }
+
+const char* sclo_field_name(int field) {
+  switch (field) {
+    case SCLO_M61: return "Mersenne61";   /* mersenne61.h:38 */
+    case SCLO_M127: return "Mersenne127"; /* mersenne127.h:38 */
+    case SCLO_MONT128: return "Mont128";
+    case SCLO_GF2_128: return "GF(2^128)";
+    default: return "";
+  }
+}
+
+const char* sclo_status_message(int status) {
+  switch (status) {
+    case SCLO_OK: return "";
+    case SCLO_ZERO_INVERSE: return "0 not invertible modulo prime"; /* small_ff.h:70 */
+    case SCLO_BAD_HEX_LEN: return "odd-length hex string";          /* str.h:52 */
+    case SCLO_BAD_HEX_CHAR: return "encountered invalid hex character"; /* str.h:38 */
+    case SCLO_ERROR_DETECTED: return "error detected during recovery";  /* shamir.h:135 */
+    default: return "bad argument";
+  }
+}
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+/* FIELD_SWITCH(field, BODY): BODY(P) is expanded once per field with P = its prefix */
+#define FIELD_SWITCH(field, BODY)                          \
+  switch (field) {                                         \
+    case SCLO_M61: { BODY(m61_) } break;                   \
+    case SCLO_M127: { BODY(m127_) } break;                 \
+    case SCLO_MONT128: { mont128_ensure(); BODY(mont128_) } break; \
+    case SCLO_GF2_128: { BODY(gf128_) } break;             \
+    default: break;                                        \
+  }                                                        \
+  return SCLO_BAD_ARG;
+
+int sclo_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n) {
+#define BODY(P) return CAT(P, ew)(op, dst, a, b, n);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_from_int(int field, int v, uint64_t* dst) {
+#define BODY(P) CAT(P, st)(dst, CAT(P, from_int)(v)); return SCLO_OK;
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_from_bytes(int field, const unsigned char* src, size_t n, uint64_t* dst) {
+  const size_t L = (size_t)sclo_limbs(field);
+#define BODY(P) for (size_t i = 0; i < n; ++i) CAT(P, st)(dst + i * L, CAT(P, from_bytes)(src + i * L * 8)); return SCLO_OK;
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+/* convertTo(string): parse big-endian hex into the value type, then "% p"
+ * (mersenne61.cc:42-46, mersenne127.cc:42-46) */
+int sclo_from_hex(int field, const char* hex, uint64_t* dst) {
+  u128 v;
+  int st = hex_parse(hex, &v, field == SCLO_M61 ? 64 : 128);
+  if (st) return st;
+  switch (field) {
+    case SCLO_M61: dst[0] = (uint64_t)v % P61; return SCLO_OK;
+    case SCLO_M127: m127_st(dst, v % P127); return SCLO_OK;
+    case SCLO_MONT128: mont128_ensure(); mont128_st(dst, mont128_to_mont(v)); return SCLO_OK;
+    case SCLO_GF2_128: gf128_st(dst, v); return SCLO_OK;
+    default: return SCLO_BAD_ARG;
+  }
+}
+
+/* toString: std::hex of the u64 (mersenne61.cc:97-100); for u128 the reference prints
+ * the top word (if non-zero) then the low word WITHOUT zero padding
+ * (src/scl/util/str.cc:23-39) -- reproduced as is. */
+int sclo_to_hex(int field, const uint64_t* a, char* out, size_t outlen) {
+  if (field == SCLO_M61) return hex_u64(a[0], out, outlen, 0) < 0 ? SCLO_BAD_ARG : SCLO_OK;
+  if (field == SCLO_M127) {
+    if (a[0] == 0 && a[1] == 0) return hex_u64(0, out, outlen, 0) < 0 ? SCLO_BAD_ARG : SCLO_OK;
+    int len = 0;
+    if (a[1]) {
+      len = hex_u64(a[1], out, outlen, 0);
+      if (len < 0) return SCLO_BAD_ARG;
+    }
+    return hex_u64(a[0], out + len, outlen - (size_t)len, 0) < 0 ? SCLO_BAD_ARG : SCLO_OK;
+  }
+  if (field == SCLO_MONT128 || field == SCLO_GF2_128) {
+    u128 v = ((u128)a[1] << 64) | a[0];
+    if (field == SCLO_MONT128) { mont128_ensure(); v = mont128_from_mont(v); }
+    uint64_t hi = (uint64_t)(v >> 64), lo = (uint64_t)v;
+    int len = 0;
+    if (hi) {
+      len = hex_u64(hi, out, outlen, 0);
+      if (len < 0) return SCLO_BAD_ARG;
+    }
+    return hex_u64(lo, out + len, outlen - (size_t)len, hi != 0) < 0 ? SCLO_BAD_ARG : SCLO_OK;
+  }
+  return SCLO_BAD_ARG;
+}
+
+int sclo_exp(int field, const uint64_t* base, size_t e, uint64_t* dst) {
+#define BODY(P) CAT(P, st)(dst, CAT(P, exp)(CAT(P, ld)(base), e)); return SCLO_OK;
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_vector_random(int field, const unsigned char* seed, size_t seed_len, size_t n,
+                       uint64_t* out) {
+  const size_t L = (size_t)sclo_limbs(field);
+  sclo_prg_t g;
+  prg_init(&g, seed, seed_len);
+  unsigned char* buf = (unsigned char*)malloc(n * L * 8 + 16);
+  if (!buf) return SCLO_BAD_ARG;
+  prg_next(&g, buf, n * L * 8);
+  int st = sclo_from_bytes(field, buf, n, out);
+  free(buf);
+  return st;
+}
+
+int sclo_shamir_share(int field, const unsigned char* seed, size_t seed_len,
+                      const uint64_t* secrets, size_t N, size_t t, size_t n, uint64_t* shares) {
+#define BODY(P) return CAT(P, shamir_share)(seed, seed_len, secrets, N, t, n, shares);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_shamir_share_coeffs(int field, const uint64_t* secrets, const uint64_t* coeffs, size_t N,
+                             size_t t, size_t n, uint64_t* shares) {
+#define BODY(P) return CAT(P, shamir_share_coeffs)(secrets, coeffs, N, t, n, shares);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_shamir_recover(int field, const uint64_t* shares, size_t n, size_t N, uint64_t* out) {
+#define BODY(P) return CAT(P, shamir_recover)(shares, n, N, out);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_shamir_recover_lambda(int field, const uint64_t* shares, const uint64_t* lambda,
+                               size_t n, size_t N, uint64_t* out) {
+#define BODY(P) return CAT(P, shamir_recover_lambda)(shares, lambda, n, N, out);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_shamir_recover_at(int field, const uint64_t* shares, const uint64_t* alphas,
+                           const uint64_t* x, size_t m, size_t N, uint64_t* out) {
+#define BODY(P) return CAT(P, shamir_recover_at)(shares, alphas, x, m, N, out);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_shamir_recover_d(int field, const uint64_t* shares, size_t n, size_t t, size_t N,
+                          uint64_t* out, unsigned char* status) {
+#define BODY(P) return CAT(P, shamir_recover_d)(shares, n, t, N, out, status);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_lagrange_basis(int field, const uint64_t* nodes, size_t m, const uint64_t* x,
+                        uint64_t* out) {
+  switch (field) {
+    case SCLO_M61: {
+      uint64_t* o = (uint64_t*)malloc((m + 1) * 8);
+      if (!o) return SCLO_BAD_ARG;
+      int st = m61_lagrange_basis(nodes, m, x[0], o);
+      if (!st) memcpy(out, o, m * 8);
+      free(o);
+      return st;
+    }
+#define BODY128(P)                                                     \
+  {                                                                    \
+    u128* nd = (u128*)calloc(2 * (m + 1), sizeof(u128));                  \
+    if (!nd) return SCLO_BAD_ARG;                                      \
+    u128* o = nd + (m + 1);                                            \
+    CAT(P, ldv)(nd, nodes, m);                                         \
+    int st = CAT(P, lagrange_basis)(nd, m, CAT(P, ld)(x), o);          \
+    if (!st) for (size_t i = 0; i < m; ++i) CAT(P, st)(out + 2 * i, o[i]); \
+    free(nd);                                                          \
+    return st;                                                         \
+  }
+    case SCLO_M127: BODY128(m127_)
+    case SCLO_MONT128: mont128_ensure(); BODY128(mont128_)
+    case SCLO_GF2_128: BODY128(gf128_)
+#undef BODY128
+    default: return SCLO_BAD_ARG;
+  }
+}
+
+int sclo_additive_share(int field, const unsigned char* seed, size_t seed_len,
+                        const uint64_t* secrets, size_t N, size_t n, uint64_t* shares) {
+#define BODY(P) return CAT(P, additive_share)(seed, seed_len, secrets, N, n, shares);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_additive_recover(int field, const uint64_t* shares, size_t n, size_t N, uint64_t* out) {
+#define BODY(P) return CAT(P, additive_recover)(shares, n, N, out);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_dot(int field, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+#define BODY(P) CAT(P, st)(out, CAT(P, vdot)(a, b, n)); return SCLO_OK;
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_sum(int field, const uint64_t* a, size_t n, uint64_t* out) {
+#define BODY(P) CAT(P, st)(out, CAT(P, vsum)(a, n)); return SCLO_OK;
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+/* Vector::scalarMultiply: r_i = scalar * v_i (vector.h:274-285) */
+int sclo_scalar_mul(int field, const uint64_t* a, const uint64_t* scalar, size_t n, uint64_t* out) {
+  const size_t L = (size_t)sclo_limbs(field);
+#define BODY(P) for (size_t i = 0; i < n; ++i) CAT(P, st)(out + i * L, CAT(P, mul)(CAT(P, ld)(scalar), CAT(P, ld)(a + i * L))); return SCLO_OK;
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_poly_eval(int field, const uint64_t* coeffs, size_t ncoeff, const uint64_t* xs,
+                   size_t nx, uint64_t* out) {
+  const size_t L = (size_t)sclo_limbs(field);
+  switch (field) {
+    case SCLO_M61: {
+      for (size_t i = 0; i < nx; ++i) out[i] = m61_horner(coeffs, ncoeff, xs[i]);
+      return SCLO_OK;
+    }
+#define BODY128(P)                                                             \
+  {                                                                            \
+    u128* c = (u128*)malloc((ncoeff + 1) * sizeof(u128));                      \
+    if (!c) return SCLO_BAD_ARG;                                               \
+    CAT(P, ldv)(c, coeffs, ncoeff);                                            \
+    for (size_t i = 0; i < nx; ++i)                                            \
+      CAT(P, st)(out + i * L, CAT(P, horner)(c, ncoeff, CAT(P, ld)(xs + i * L))); \
+    free(c);                                                                   \
+    return SCLO_OK;                                                            \
+  }
+    case SCLO_M127: BODY128(m127_)
+    case SCLO_MONT128: mont128_ensure(); BODY128(mont128_)
+    case SCLO_GF2_128: BODY128(gf128_)
+#undef BODY128
+    default: return SCLO_BAD_ARG;
+  }
+}
+
+int sclo_vandermonde(int field, size_t n, size_t m, const uint64_t* xs, uint64_t* out) {
+#define BODY(P) CAT(P, vandermonde)(n, m, xs, out); return SCLO_OK;
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_matmul(int field, const uint64_t* A, const uint64_t* B, size_t n, size_t k, size_t m,
+                uint64_t* C) {
+#define BODY(P) CAT(P, matmul)(A, B, n, k, m, C); return SCLO_OK;
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
+int sclo_time_shamir(int field, size_t N, size_t t, size_t n, const unsigned char* seed,
+                     size_t seed_len, double* share_s, double* recover_s, uint64_t* mismatches,
+                     uint64_t* checksum) {
+#define BODY(P) return CAT(P, time_shamir)(N, t, n, seed, seed_len, share_s, recover_s, mismatches, checksum);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}

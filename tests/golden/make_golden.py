@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden_v1.json from the REAL reference.
+
+Run in the build container only (needs /root/reference):
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+Every expected value in the fixture is produced by oracle/_ref/libscl_ref.so,
+i.e. by the reference's own code compiled from /root/reference (see
+oracle/Makefile, oracle/ref_harness.cc).  Inputs are stored next to outputs, so
+the fixture does not depend on this script's random generator.  Elements are
+hex strings of the integer value; byte strings are hex.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O  # noqa: E402
+
+
+def hx(arr):
+    return [format(v, "x") for v in O.to_ints(arr)]
+
+
+def main():
+    ref = O.Ref()
+    rng = np.random.default_rng(20261003)
+    doc = {"generator": "tests/golden/make_golden.py", "source": "oracle/_ref/libscl_ref.so (reference 0.1.0)",
+           "fields": {}, "prg": []}
+
+    # ---- PRG streams (src/scl/util/prg.cc) ----
+    for seed in (b"", b"shamir passive", b"0123456789abcdefXYZ-longer-than-16", b"\x00\x01\x02"):
+        for sizes in ([16], [8, 8, 8], [1, 15, 16, 17, 31, 32, 33, 0, 100], [4096]):
+            doc["prg"].append({"seed": seed.hex(), "sizes": sizes, "out": ref.prg(seed, sizes).hex()})
+
+    for f, name in ((O.M61, "Mersenne61"), (O.M127, "Mersenne127")):
+        L, p = O.LIMBS[f], O.P[f]
+        fd = {"limbs": L, "p": format(p, "x")}
+        edge = [0, 1, 2, 3, p - 1, p - 2, p - 3, (p - 1) // 2, (p + 1) // 2, 1 << 32, (1 << 32) - 1,
+                (1 << 60), (1 << 60) + 1, 0xFFFFFFFF00000000 % p, 0x123456789ABCDEF]
+        rnd = [int.from_bytes(rng.bytes(16), "little") % p for _ in range(100)]
+        va = edge + rnd
+        vb = rnd[::-1] + edge[::-1]
+        a, b = O.from_ints(va, L), O.from_ints(vb, L)
+        nz = O.from_ints([v for v in va if v], L)
+        nzb = O.from_ints([v for v in vb if v][: nz.shape[0]], L)
+        fd["ew"] = {
+            "a": hx(a), "b": hx(b),
+            "add": hx(ref.ew(f, O.ADD, a, b)), "sub": hx(ref.ew(f, O.SUB, a, b)),
+            "mul": hx(ref.ew(f, O.MUL, a, b)), "neg": hx(ref.ew(f, O.NEG, a)),
+            "nz": hx(nz), "nzb": hx(nzb[: nz.shape[0]]),
+            "inv": hx(ref.ew(f, O.INV, nz)),
+            "div": hx(ref.ew(f, O.DIV, nz[: nzb.shape[0]], nzb)),
+        }
+        # all-pairs products of the edge values
+        ea = O.from_ints([x for x in edge for _ in edge], L)
+        eb = O.from_ints([y for _ in edge for y in edge], L)
+        fd["ew_edge_pairs"] = {"a": hx(ea), "b": hx(eb), "mul": hx(ref.ew(f, O.MUL, ea, eb)),
+                               "add": hx(ref.ew(f, O.ADD, ea, eb)), "sub": hx(ref.ew(f, O.SUB, ea, eb))}
+        try:
+            ref.ew(f, O.INV, O.from_ints([0], L))
+            fd["inv0_error"] = None
+        except O.OracleError as e:
+            fd["inv0_error"] = e.message
+
+        ints = [0, 1, -1, 5, -5, 123, 2 ** 31 - 1, -(2 ** 31), 65536, -65536]
+        fd["from_int"] = {"in": ints, "out": [hx(ref.from_int(f, v).reshape(1, L))[0] for v in ints]}
+
+        # fromBytes: "% p" of the raw little-endian word, incl. pre-reduction edge words
+        words = [0, 1, p, p + 1, p - 1, (1 << (64 * L)) - 1, 1 << 61, (1 << 64) - 1, 2 * p, 2 * p + 5]
+        words = [w % (1 << (64 * L)) for w in words] + [int.from_bytes(rng.bytes(8 * L), "little") for _ in range(40)]
+        raw = b"".join(w.to_bytes(8 * L, "little") for w in words)
+        fd["from_bytes"] = {"raw": raw.hex(), "out": hx(ref.from_bytes(f, raw))}
+
+        hexes = ["7b", "41621e", "00", "0000000000000001", "ffffffffffffffff", "1fffffffffffffff",
+                 "2000000000000000", "ABCDEF0123456789", "58797a14d0653d22a05c11c60e1aacf4",
+                 "80000000000000000000000000000000", "7fffffffffffffffffffffffffffffff",
+                 "ffffffffffffffffffffffffffffffff", "0123456789abcdef0123456789abcdef01"]
+        fh = {"in": hexes, "out": [], "to_hex": []}
+        for h in hexes:
+            v = ref.from_hex(f, h)
+            fh["out"].append(hx(v.reshape(1, L))[0])
+            fh["to_hex"].append(ref.to_hex(f, v))
+        errs = {}
+        for bad in ("abc", "zz", "0g"):
+            try:
+                ref.from_hex(f, bad)
+                errs[bad] = None
+            except O.OracleError as e:
+                errs[bad] = e.message
+        fh["errors"] = errs
+        fd["hex"] = fh
+        fd["to_hex"] = {"in": hx(a[:40]), "out": [ref.to_hex(f, a[i]) for i in range(40)]}
+
+        fd["exp"] = [{"base": hx(a[i].reshape(1, L))[0], "e": e, "out": hx(ref.exp(f, a[i], e).reshape(1, L))[0]}
+                     for i, e in ((15, 0), (16, 1), (17, 2), (18, 65537), (19, 2 ** 61 - 3), (20, 2 ** 63 + 12345))]
+
+        fd["vector_random"] = [{"seed": s.hex(), "n": n, "out": hx(ref.vector_random(f, s, n))}
+                               for s, n in ((b"shamir passive", 4), (b"", 1), (b"vec", 43), (b"vec", 7))]
+
+        # ---- Shamir ----
+        sh = []
+        for (n, t, N, seed) in ((4, 3, 8, b"shamir passive"), (3, 1, 8, b"s31"), (10, 3, 32, b"scl-bench-c2"),
+                                (10, 0, 4, b"t0"), (40, 13, 12, b"scl-bench-c4"), (128, 42, 6, b"scl-bench-c5"),
+                                (100, 5, 3, b"shamir recons"), (7, 6, 5, b"full-degree")):
+            secrets = O.from_ints([123] + [int.from_bytes(rng.bytes(16), "little") % p for _ in range(N - 2)] + [p - 1], L)
+            shares = ref.shamir_share(f, seed, secrets, t, n)
+            rec = ref.shamir_recover(f, shares)
+            alph = O.from_ints(list(range(1, n + 1)), L)
+            lam = ref.lagrange_basis(f, alph, ref.from_int(f, 0))
+            sh.append({"n": n, "t": t, "seed": seed.hex(), "secrets": hx(secrets), "shares": hx(shares),
+                       "recovered_all_n": hx(rec), "lambda_1_to_n_at_0": hx(lam)})
+        fd["shamir"] = sh
+
+        # Lagrange bases with explicit nodes / evaluation points (test/scl/ss/test_shamir.cc:42-66)
+        lb = []
+        for nodes, x in (([4, 5, 6, 7, 8, 9], 0), ([4, 5, 6, 7, 8, 9], 27), ([42, 43, 44, 45], 0), ([1, 2, 3], 2),
+                         ([1], 0), ([5, 3, 9, 1 << 20], -7)):
+            nd = O.from_ints(nodes, L)
+            lb.append({"nodes": nodes, "x": x, "out": hx(ref.lagrange_basis(f, nd, ref.from_int(f, x)))})
+        fd["lagrange"] = lb
+        try:
+            ref.lagrange_basis(f, O.from_ints([1, 2, 2], L), ref.from_int(f, 0))
+            fd["lagrange_dup_error"] = None
+        except O.OracleError as e:
+            fd["lagrange_dup_error"] = e.message
+
+        # recover at other nodes/x: polynomial evaluated at 42..48 (test_shamir.cc:81-109)
+        coeffs = O.from_ints([123] + rnd[:3], L)
+        xs = O.from_ints(list(range(42, 49)), L)
+        ys = ref.poly_eval(f, coeffs, xs)
+        fd["poly_eval"] = {"coeffs": hx(coeffs), "xs": hx(xs), "ys": hx(ys)}
+        fd["recover_at"] = [{"alphas": hx(xs), "x": hx(xv.reshape(1, L))[0], "shares": hx(ys),
+                             "out": hx(ref.shamir_recover_at(f, ys.reshape(1, 7, L), xs, xv))[0]}
+                            for xv in (ref.from_int(f, 0), xs[0], ref.from_int(f, 1000))]
+
+        # error detection, short overload (test_shamir.cc:68-79)
+        secrets = O.from_ints([123, 5, p - 1, 77, 0, 9], L)
+        shares = ref.shamir_share(f, b"shamir detect", secrets, 4, 9)
+        shares[1, 2] = ref.from_int(f, 4)      # checked? (no: index 2 < d+1 defines the polynomial)
+        shares[2, 5] = ref.from_int(f, 4)      # index 5 = t+1 is checked
+        shares[3, 8] = ref.from_int(f, 4)      # index 8 = 2t is NOT checked (quirk, SURVEY note E)
+        shares[4, 7] = ref.from_int(f, 1)      # index 7 = 2t-1 is checked
+        out, status = ref.shamir_recover_d(f, shares, 4)
+        fd["recover_d"] = {"t": 4, "n": 9, "shares": hx(shares), "out": hx(out), "status": status.tolist()}
+
+        # ---- additive ----
+        ad = []
+        for (n, N, seed) in ((3, 16, b""), (10, 6, b"additive"), (1, 3, b"one"), (2, 5, b"two")):
+            secrets = O.from_ints([12345] + [int.from_bytes(rng.bytes(16), "little") % p for _ in range(N - 1)], L)
+            shares = ref.additive_share(f, seed, secrets, n)
+            ad.append({"n": n, "seed": seed.hex(), "secrets": hx(secrets), "shares": hx(shares),
+                       "sum": hx(ref.additive_recover(f, shares))})
+        fd["additive"] = ad
+
+        # ---- vector / matrix ----
+        fd["dot"] = {"a": hx(a), "b": hx(b), "out": hx(ref.dot(f, a, b).reshape(1, L))[0]}
+        fd["sum"] = {"a": hx(a), "out": hx(ref.sum(f, a).reshape(1, L))[0]}
+        fd["scalar_mul"] = {"a": hx(a), "scalar": hx(b[3].reshape(1, L))[0], "out": hx(ref.scalar_mul(f, a, b[3]))}
+        xs = O.from_ints([7, p - 1, 0, 1, rnd[5]], L)
+        fd["vandermonde"] = [{"n": 3, "m": 3, "xs": None, "out": hx(ref.vandermonde(f, 3, 3))},
+                             {"n": 10, "m": 4, "xs": None, "out": hx(ref.vandermonde(f, 10, 4))},
+                             {"n": 5, "m": 6, "xs": hx(xs), "out": hx(ref.vandermonde(f, 5, 6, xs))},
+                             {"n": 128, "m": 43, "xs": None, "sha": None, "out": hx(ref.vandermonde(f, 128, 43))}]
+        A = O.from_ints(rnd[:20], L).reshape(2, 10, L)
+        B = O.from_ints(rnd[20:50], L).reshape(10, 3, L)
+        A2 = O.from_ints([1, 2, 3, 4], L).reshape(2, 2, L)
+        B2 = O.from_ints([5, 6, 7, 8], L).reshape(2, 2, L)
+        fd["matmul"] = [{"n": 2, "k": 10, "m": 3, "A": hx(A), "B": hx(B), "C": hx(ref.matmul(f, A, B))},
+                        {"n": 2, "k": 2, "m": 2, "A": hx(A2), "B": hx(B2), "C": hx(ref.matmul(f, A2, B2))}]
+        # Vandermonde evaluation == sharing (test/scl/math/test_matrix.cc:342-365)
+        V = ref.vandermonde(f, 10, 4)
+        Cm = O.from_ints(rnd[50:50 + 4 * 5], L).reshape(4, 5, L)
+        fd["vandermonde_eval"] = {"n": 10, "m": 4, "N": 5, "C": hx(Cm), "out": hx(ref.matmul(f, V, Cm))}
+        doc["fields"][name] = fd
+
+    path = os.path.join(HERE, "golden_v1.json")
+    with open(path, "w") as fh_:
+        json.dump(doc, fh_, indent=0, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
