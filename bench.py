@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- Shamir reconstructions/sec on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: shamirSecretShare of N secrets
+(coefficients resident in HBM) followed by shamirRecoverP of all N from all n shares, for the
+configuration BASELINE.json quotes the metric on: Shamir (n=10, t=3) over Mersenne61, 100 M
+secrets per GPU.  Inputs are generated on the device before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: the batch of independent secrets shards across ranks (rank r owns its own N secrets,
+weak scaling, no data-path collective); time = max over ranks.
+
+Prints ONE JSON line on rank 0 (fields described in DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "secure-computation-library_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FIELD_TAGS = {"m61": 0, "m127": 1, "mont128": 2, "gf2_128": 3}
+FIELD_NAMES = {"m61": "Mersenne61", "m127": "Mersenne127", "mont128": "Mont128", "gf2_128": "GF(2^128)"}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
+
+
+def cpu_baseline(field_key, n, t, sample):
+    """The reference CPU path on this box's host cores (single thread, like SCL itself): per secret
+    shamirSecretShare + shamirRecoverP(shares).  oracle/_ref (the real reference, prebuilt) when it
+    is there, else the oracle port."""
+    import oracle_lib as O
+    kind = "reference"
+    try:
+        lib = O.Ref()
+    except Exception:
+        lib, kind = O.Port(), "port"
+    f = FIELD_TAGS[field_key]
+    r = lib.time_shamir(f, sample, t, n)
+    if r["mismatches"]:
+        raise RuntimeError("CPU baseline failed its own round trip")
+    total = r["share_s"] + r["recover_s"]
+    return {
+        "value": sample / total, "unit": "reconstructions/s", "cores": 1, "kind": kind,
+        "sample": f"{sample} secrets, per-secret shamirSecretShare + shamirRecoverP (n={n}, t={t}), "
+                  f"share {r['share_s']:.2f}s + recover {r['recover_s']:.2f}s",
+        "recover_only_per_s": sample / r["recover_s"], "share_only_per_s": sample / r["share_s"],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--field", default="m61", choices=sorted(FIELD_TAGS))
+    ap.add_argument("--n", type=int, default=10)
+    ap.add_argument("--t", type=int, default=3)
+    ap.add_argument("--secrets", type=int, default=100_000_000, help="secrets per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="secrets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--share-mode", default="coeffs", choices=["coeffs", "prg"],
+                    help="coeffs: polynomial coefficients resident in HBM; prg: AES-CTR PRG inside the share kernel")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import scl_amd as scl
+
+    f = FIELD_TAGS[args.field]
+    L = scl.limbs(f)
+    E = 8 * L
+    n, t, N = args.n, args.t, args.secrets
+
+    # ---- synthetic inputs, generated on the device (uniform field elements from the AES-CTR PRG) ----
+    seed = f"scl-bench-{args.field}-{rank}".encode()
+    secrets = scl.vector_random(f, N, seed + b"-secrets")
+    coeffs = None
+    if args.share_mode == "coeffs" and t:
+        coeffs = scl.empty(f, t, N)
+        for k in range(t):
+            blocks_per_row = (N * E + 15) // 16
+            coeffs[k].copy_(scl.vector_random(f, N, seed + b"-coeffs", counter0=k * blocks_per_row))
+    shares = scl.empty(f, n, N)
+    out = scl.empty(f, N)
+    lam = scl.lagrange_basis(f, n)
+
+    def step(timers=None):
+        if timers:
+            timers[0].start()
+        if args.share_mode == "coeffs":
+            scl.shamir_share(f, secrets, coeffs, n, out=shares)
+        else:
+            scl.shamir_share_prg(f, secrets, t, n, seed, out=shares)
+        if timers:
+            timers[0].stop()
+            timers[1].start()
+        scl.shamir_recover(f, shares, lam, out=out)
+        if timers:
+            timers[1].stop()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    timers = [(scl.Timer(), scl.Timer()) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(timers[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-kernel durations from the HIP events recorded inside the timed region -------------------
+    share_ms = sum(tm[0].elapsed_ms() for tm in timers) / max(1, args.steps)
+    rec_ms = sum(tm[1].elapsed_ms() for tm in timers) / max(1, args.steps)
+    verified = bool(scl.equals(f, out, secrets))
+
+    # measured copy bandwidth of the same device (read+write bytes / time), for context
+    probe_bytes = min(4 << 30, shares.numel() * 8 // 2) & ~15
+    src = shares.view(-1)[: probe_bytes // 8]
+    dst = shares.view(-1)[probe_bytes // 8: 2 * (probe_bytes // 8)]
+    scl.stream_copy(dst, src)
+    tm = scl.Timer()
+    tm.start()
+    for _ in range(5):
+        scl.stream_copy(dst, src)
+    tm.stop()
+    copy_gbps = 2 * probe_bytes * 5 / (tm.elapsed_ms() * 1e-3) / 1e9
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    rec_bytes = (n + 1) * E            # n shares in, 1 secret out            
+    share_bytes = (1 + t) * E + n * E if args.share_mode == "coeffs" else E + n * E
+    kernels = {
+        "shamir_recover": {"ms": rec_ms, "bytes_per_secret": rec_bytes, "GBps": rec_bytes * N / (rec_ms * 1e-3) / 1e9},
+        "shamir_share": {"ms": share_ms, "bytes_per_secret": share_bytes,
+                         "GBps": share_bytes * N / (share_ms * 1e-3) / 1e9},
+    }
+    dom = "shamir_share" if share_ms >= rec_ms else "shamir_recover"
+    ach = kernels[dom]["GBps"]
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": ach / copy_gbps}
+    total = N * world * args.steps
+    line = {
+        "metric": "shamir_reconstructions_per_sec", "value": total / elapsed, "unit": "reconstructions/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64" if L == 1 else "u128", "data": "synthetic",
+        "config": {"workload": f"shamir_share+reconstruct n={n} t={t} {FIELD_NAMES[args.field]} "
+                               f"{N} secrets/GPU (BASELINE configs[1])" if (n, t, args.field, N) == (10, 3, "m61", 100_000_000)
+                   else f"shamir_share+reconstruct n={n} t={t} {FIELD_NAMES[args.field]} {N} secrets/GPU",
+                   "field": FIELD_NAMES[args.field], "n": n, "t": t, "secrets_per_gpu": N,
+                   "share_mode": args.share_mode, "layout": "SoA [party][secret]", "parallelism": f"shard{world}"},
+        "roofline": roofline, "kernels": kernels, "verified": verified,
+        "reconstruct_only_per_s": N * world / (rec_ms * 1e-3), "share_only_per_s": N * world / (share_ms * 1e-3),
+    }
+    if world == 1 and args.cpu_sample > 0:
+        line["cpu_baseline"] = cpu_baseline(args.field, n, t, args.cpu_sample)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+/* include/scl_hip.h -- the drop-in boundary: a C ABI over the MI355X (gfx950)
+ * finite-field / secret-sharing engine in libscl_hip.so.
+ *
+ * The reference (anderspkd/secure-computation-library 0.1.0) has no FFI of its
+ * own: its batch-shaped call sites are C++ header templates that own their
+ * storage in std::vector.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference tree);
+ * INTEGRATION.md shows the binding a maintainer would add on the reference
+ * side.
+ *
+ * Conventions
+ *  - field tags: SCL_M61 = scl::math::ff::Mersenne61 (1 uint64 limb),
+ *    SCL_M127 = Mersenne127 (2 limbs, little-endian, 16-byte aligned);
+ *    SCL_MONT128 / SCL_GF2_128 are plug-in fields the reference does not have
+ *    (2 limbs).  An element's limbs are the byte image of FF::write
+ *    (include/scl/math/ff.h:300-302).
+ *  - values are canonical (in [0,p)) on entry and on exit.
+ *  - "dev" pointers are device (HBM) pointers, "host" pointers are host
+ *    memory.  The caller owns every buffer.
+ *  - share matrices are SoA: row i is party i's share vector, element s of
+ *    row i lives at base + (i*stride + s)*limbs uint64 words; stride >= N lets
+ *    a caller pass a window of a larger matrix (sharding, chunking).  An AoS
+ *    [secret][party] image (the reference's Vector per secret) converts with
+ *    scl_hip_aos_to_soa / scl_hip_soa_to_aos.
+ *  - stream is a hipStream_t passed as void* (NULL = the default stream);
+ *    calls are asynchronous w.r.t. the host unless they return a host value or
+ *    must report a data-dependent error (documented per function).
+ *  - every function returns an scl_status; scl_hip_last_error() gives the
+ *    thread's last diagnostic and scl_hip_status_message() the text of the
+ *    exception the reference throws for that condition.
+ *  - thread-safe: no shared mutable state except a per-thread scratch cache.
+ */
+#ifndef SCL_HIP_H
+#define SCL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { SCL_M61 = 0, SCL_M127 = 1, SCL_MONT128 = 2, SCL_GF2_128 = 3 } scl_field;
+
+typedef enum { SCL_OP_ADD = 0, SCL_OP_SUB = 1, SCL_OP_MUL = 2, SCL_OP_NEG = 3, SCL_OP_INV = 4,
+               SCL_OP_DIV = 5 } scl_op;
+
+typedef enum {
+  SCL_OK = 0,
+  SCL_ERR_SIZE_MISMATCH = 1,  /* std::invalid_argument("Vec sizes mismatch")             vector.h:481-485 */
+  SCL_ERR_ZERO_INVERSE = 2,   /* std::logic_error("0 not invertible modulo prime")       small_ff.h:70    */
+  SCL_ERR_BAD_ARG = 3,
+  SCL_ERR_HIP = 4,            /* a HIP runtime call failed; see scl_hip_last_error()                       */
+  SCL_ERR_NO_DEVICE = 5,
+  SCL_ERR_ERROR_DETECTED = 6, /* std::logic_error("error detected during recovery")      shamir.h:135     */
+  SCL_ERR_NOT_ENOUGH_SHARES = 7, /* std::logic_error("not enough shares provided to detect errors") shamir.h:123 */
+  SCL_ERR_MATMUL_DIMS = 8,    /* std::invalid_argument("matmul: this->cols() != that->rows()") matrix.h:480 */
+  SCL_ERR_VANDERMONDE_XS = 9, /* std::invalid_argument("|xs| != number of rows")         matrix.h:449     */
+  SCL_ERR_INVALID_RANGE = 10  /* std::invalid_argument("invalid range")                  vector.h:493     */
+} scl_status;
+
+int scl_hip_abi_version(void);
+const char* scl_hip_last_error(void);
+const char* scl_hip_status_message(int status);
+int scl_hip_limbs(int field);              /* FF::byteSize()/8, ff.h:43-45 */
+const char* scl_hip_field_name(int field); /* FF::name(), ff.h:57-59 */
+
+/* ---- device plumbing (for callers without their own HIP runtime) ---------- */
+int scl_hip_device_count(int* count);
+int scl_hip_set_device(int device);
+int scl_hip_malloc(void** dev, size_t bytes);
+int scl_hip_free(void* dev);
+int scl_hip_memcpy_h2d(void* dev, const void* host, size_t bytes, void* stream);
+int scl_hip_memcpy_d2h(void* host, const void* dev, size_t bytes, void* stream);
+int scl_hip_memset(void* dev, int value, size_t bytes, void* stream);
+int scl_hip_stream_create(void** stream);
+int scl_hip_stream_destroy(void* stream);
+int scl_hip_stream_sync(void* stream);
+/* HIP-event timing on `stream`: start, stop -> elapsed milliseconds */
+int scl_hip_timer_create(void** timer);
+int scl_hip_timer_destroy(void* timer);
+int scl_hip_timer_start(void* timer, void* stream);
+int scl_hip_timer_stop(void* timer, void* stream);
+int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the stop event */
+/* launch geometry knobs for tuning (0 = built-in default) */
+int scl_hip_set_tuning(const char* key, long value);
+
+/* ---- element-wise: scl::math::Vector<FF> members ------------------------- */
+/* Vector::add / subtract / multiplyEntryWise (+InPlace) (vector.h:199-245,521-556),
+ * FF::negate / invert / operator/ per element (ff.h:203-246).  dst may alias a or b.
+ * b is ignored for NEG and INV.  INV and DIV are synchronous: a zero operand yields
+ * SCL_ERR_ZERO_INVERSE after the launch completes (the reference throws at the
+ * first zero; here every other element is still computed, the zero's slot gets 0). */
+int scl_hip_ew(int field, int op, uint64_t* dst_dev, const uint64_t* a_dev, const uint64_t* b_dev,
+               size_t n, void* stream);
+/* Vector::scalarMultiply(InPlace) (vector.h:274-301): dst[i] = scalar * a[i] */
+int scl_hip_scalar_mul(int field, uint64_t* dst_dev, const uint64_t* a_dev,
+                       const uint64_t* scalar_host, size_t n, void* stream);
+/* Vector::sum (vector.h:261-267) and Vector::dot / innerProd (vector.h:45-52,252-255);
+ * synchronous, result to host. */
+int scl_hip_sum(int field, uint64_t* out_host, const uint64_t* a_dev, size_t n, void* stream);
+int scl_hip_dot(int field, uint64_t* out_host, const uint64_t* a_dev, const uint64_t* b_dev,
+                size_t n, void* stream);
+/* Vector::equals (vector.h:558-570): *equal_host = 1 iff all n elements match; synchronous */
+int scl_hip_equals(int field, int* equal_host, const uint64_t* a_dev, const uint64_t* b_dev,
+                   size_t n, void* stream);
+
+/* ---- randomness: scl::util::PRG and FF::read ------------------------------ */
+/* PRG::next as a counter-addressed stream (src/scl/util/prg.cc:124-146): writes
+ * nblocks*16 bytes, block i = AES128_key(LE64(counter0+i) || LE64(PRG_NONCE)), key = seed
+ * zero-padded / truncated to 16 bytes (prg.cc:88-101). */
+int scl_hip_prg_blocks(unsigned char* dst_dev, size_t nblocks, const unsigned char* seed_host,
+                       size_t seed_len, uint64_t counter0, void* stream);
+/* FF::read / ff::fromBytes (mersenne61.cc:86-90, mersenne127.cc:114-118): n elements from
+ * n*byteSize raw bytes, reduced mod p. */
+int scl_hip_from_bytes(int field, uint64_t* dst_dev, const unsigned char* src_dev, size_t n,
+                       void* stream);
+/* Vector::random(n, prg) for a PRG whose counter stands at counter0 (vector.h:507-519):
+ * consumes ceil(n*byteSize/16) blocks. */
+int scl_hip_vector_random(int field, uint64_t* dst_dev, size_t n, const unsigned char* seed_host,
+                          size_t seed_len, uint64_t counter0, void* stream);
+
+/* ---- Shamir: scl::ss::shamirSecretShare / shamirRecoverP ------------------ */
+/* computeLagrangeBasis(nodes, x) (include/scl/math/lagrange.h:54-71) on the host:
+ * lambda[i] = prod_{j!=i} (x - a_j)/(a_i - a_j).  alphas_host == NULL means
+ * Vector::range(1, m+1) (vector.h:490-505); x_host == NULL means 0.  Duplicate nodes give
+ * SCL_ERR_ZERO_INVERSE like the reference's exception. */
+int scl_hip_lagrange_basis(int field, uint64_t* lambda_host, const uint64_t* alphas_host, size_t m,
+                           const uint64_t* x_host);
+/* Batched shamirSecretShare (include/scl/ss/shamir.h:51-68) with explicit coefficients:
+ * shares[i][s] = secrets[s] + sum_{k=1..t} coeffs[k-1][s] * alpha_i^k for i < n.
+ * coeffs is SoA [t][N] with row stride coeff_stride; alphas_host NULL = 1..n. */
+int scl_hip_shamir_share(int field, uint64_t* shares_dev, size_t share_stride,
+                         const uint64_t* secrets_dev, const uint64_t* coeffs_dev,
+                         size_t coeff_stride, size_t N, size_t t, size_t n,
+                         const uint64_t* alphas_host, void* stream);
+/* The same driven by the reference's PRG discipline: bit-identical to calling
+ * shamirSecretShare(secret_s, t, n, prg) for s = first_secret .. first_secret+N-1 on ONE PRG
+ * seeded with `seed` (secret s uses counters [s*B, (s+1)*B), B = ceil((t+1)*byteSize/16);
+ * the draw for c_0 is made and discarded, shamir.h:56-57). */
+int scl_hip_shamir_share_prg(int field, uint64_t* shares_dev, size_t share_stride,
+                             const uint64_t* secrets_dev, size_t N, size_t t, size_t n,
+                             const unsigned char* seed_host, size_t seed_len,
+                             uint64_t first_secret, void* stream);
+/* Batched shamirRecoverP (shamir.h:81-104) with the basis hoisted out of the per-secret
+ * call: out[s] = sum_{i<m} lambda[i] * shares[i][s]. */
+int scl_hip_shamir_recover(int field, uint64_t* out_dev, const uint64_t* shares_dev,
+                           size_t share_stride, const uint64_t* lambda_host, size_t m, size_t N,
+                           void* stream);
+/* Batched shamirRecoverD(shares, alphas, t, d, x) (shamir.h:116-139): the first d+1 shares
+ * define the polynomial, shares d+1..d+t-1 are checked.  status_dev[s] = 1 where the
+ * reference would throw "error detected during recovery" (out[s] = 0 there).
+ * Synchronous; returns SCL_ERR_ERROR_DETECTED if any status is set, with
+ * *num_bad_host = how many.  alphas_host NULL = 1..m, x_host NULL = 0. */
+int scl_hip_shamir_recover_detect(int field, uint64_t* out_dev, unsigned char* status_dev,
+                                  const uint64_t* shares_dev, size_t share_stride, size_t m,
+                                  size_t N, size_t t, size_t d, const uint64_t* alphas_host,
+                                  const uint64_t* x_host, size_t* num_bad_host, void* stream);
+
+/* ---- additive: scl::ss::additiveShare, Vector::sum ------------------------ */
+/* additiveShare (include/scl/ss/additive.h:41-53) with explicit randomness rnd [n-1][N]:
+ * shares[i] = rnd[i] for i < n-1, shares[n-1] = secret - sum. */
+int scl_hip_additive_share(int field, uint64_t* shares_dev, size_t share_stride,
+                           const uint64_t* secrets_dev, const uint64_t* rnd_dev, size_t rnd_stride,
+                           size_t N, size_t n, void* stream);
+/* PRG-driven: secret s, share i < n-1 is FF::random on counter (first_secret+s)*(n-1)+i. */
+int scl_hip_additive_share_prg(int field, uint64_t* shares_dev, size_t share_stride,
+                               const uint64_t* secrets_dev, size_t N, size_t n,
+                               const unsigned char* seed_host, size_t seed_len,
+                               uint64_t first_secret, void* stream);
+/* reconstruct = Vector::sum per secret (vector.h:261-267): out[s] = sum_i shares[i][s] */
+int scl_hip_additive_recover(int field, uint64_t* out_dev, const uint64_t* shares_dev,
+                             size_t share_stride, size_t n, size_t N, void* stream);
+
+/* ---- matrices: scl::math::Matrix ------------------------------------------ */
+/* Matrix::vandermonde(n, m, xs) (matrix.h:444-460), row-major into V_dev; xs NULL = 1..n */
+int scl_hip_vandermonde(int field, uint64_t* V_dev, size_t n, size_t m, const uint64_t* xs_host,
+                        void* stream);
+/* Matrix::multiply (matrix.h:477-495): C[M x N] = A[M x K] * B[K x N], all row-major, with
+ * leading dimensions lda/ldb/ldc in elements. */
+int scl_hip_matmul(int field, uint64_t* C_dev, size_t ldc, const uint64_t* A_dev, size_t lda,
+                   const uint64_t* B_dev, size_t ldb, size_t M, size_t K, size_t N, void* stream);
+
+/* ---- layout ---------------------------------------------------------------- */
+/* AoS [N][n] (one reference Vector per secret) <-> SoA [n][stride] */
+int scl_hip_aos_to_soa(int field, uint64_t* soa_dev, size_t stride, const uint64_t* aos_dev,
+                       size_t N, size_t n, void* stream);
+int scl_hip_soa_to_aos(int field, uint64_t* aos_dev, const uint64_t* soa_dev, size_t stride,
+                       size_t N, size_t n, void* stream);
+
+/* ---- roofline probe -------------------------------------------------------- */
+/* plain device copy kernel (16 B per lane) used to measure achievable HBM bandwidth */
+int scl_hip_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+
+/* MONT128: choose the modulus (odd, < 2^128); default 2^128 - 159.  Process-wide. */
+int scl_hip_mont128_set_prime(const uint64_t p[2]);
+int scl_hip_mont128_get_prime(uint64_t p[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCL_HIP_H */

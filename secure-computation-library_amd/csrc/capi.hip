@@ -1,0 +1,966 @@
+// csrc/capi.hip -- the extern "C" boundary of libscl_hip.so (include/scl_hip.h).
+//
+// Host-side work done here is table building only: AES key schedule, Lagrange
+// basis / alpha / Vandermonde tables (O(n^2) field ops, hoisted out of the
+// per-secret path exactly once per batch) and the final fold of per-block
+// reduction partials.  There is NO CPU fallback for any batch operation: if no
+// HIP device is usable the calls fail with SCL_ERR_NO_DEVICE / SCL_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/scl_hip.h"
+#include "field.hpp"
+#include "kernels.hpp"
+
+using namespace sclhip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(e_ == hipErrorNoDevice ? SCL_ERR_NO_DEVICE : SCL_ERR_HIP,                    \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+  } while (0)
+
+#define SCL_TRY(expr)        \
+  do {                       \
+    int s_ = (expr);         \
+    if (s_ != SCL_OK) return s_; \
+  } while (0)
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- tuning --------------------------------------------------------------------------------------
+std::atomic<long> g_max_blocks{0};
+std::atomic<long> g_nontemporal{1};
+std::atomic<long> g_force_scalar{0};
+std::atomic<long> g_force_table{0};
+
+unsigned grid_for(size_t work_items) {
+  size_t blocks = (work_items + BLOCK - 1) / BLOCK;
+  long cap = g_max_blocks.load();
+  if (cap <= 0) cap = 256 * 16;  // 256 CUs x 16 blocks; grid-stride covers the rest
+  if (blocks > (size_t)cap) blocks = (size_t)cap;
+  if (blocks == 0) blocks = 1;
+  return (unsigned)blocks;
+}
+
+// ---- Mont128 process-wide modulus ---------------------------------------------------------------
+std::mutex g_mont_mu;
+Mont128::Ctx g_mont = {0, 0, 0, 0};
+
+int mont_set(u128 p) {
+  if (!(p & 1) || p < 3) return fail(SCL_ERR_BAD_ARG, "mont128: modulus must be odd and >= 3");
+  Mont128::Ctx c;
+  c.p = p;
+  u128 inv = p;  // 3 correct bits; Newton doubles them
+  for (int i = 0; i < 7; ++i) inv *= 2 - p * inv;
+  c.mc = (u128)0 - inv;
+  u128 r = 1 % p;
+  for (int i = 0; i < 256; ++i) {
+    const u128 t = r + r;
+    r = (t < r || t >= p) ? t - p : t;
+    if (i == 127) c.one = r;
+  }
+  c.r2 = r;
+  std::lock_guard<std::mutex> lk(g_mont_mu);
+  g_mont = c;
+  return SCL_OK;
+}
+
+Mont128::Ctx mont_ctx() {
+  {
+    std::lock_guard<std::mutex> lk(g_mont_mu);
+    if (g_mont.p) return g_mont;
+  }
+  mont_set((((u128)0xFFFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFF61ull);  // 2^128 - 159
+  std::lock_guard<std::mutex> lk(g_mont_mu);
+  return g_mont;
+}
+
+template <class Fn>
+int with_field(int field, Fn&& fn) {
+  switch (field) {
+    case SCL_M61: return fn(M61{}, M61::Ctx{});
+    case SCL_M127: return fn(M127{}, M127::Ctx{});
+    case SCL_MONT128: return fn(Mont128{}, mont_ctx());
+    case SCL_GF2_128: return fn(Gf128{}, Gf128::Ctx{});
+    default: return fail(SCL_ERR_BAD_ARG, "unknown field tag");
+  }
+}
+
+// ---- per-thread device scratch (only used by calls that synchronise before returning) -------------
+struct Scratch {
+  int device = -1;
+  void* dev = nullptr;
+  size_t bytes = 0;
+};
+thread_local Scratch g_scratch;
+
+int scratch(size_t bytes, void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (g_scratch.dev && (g_scratch.device != dev || g_scratch.bytes < bytes)) {
+    (void)hipFree(g_scratch.dev);
+    g_scratch = Scratch{};
+  }
+  if (!g_scratch.dev) {
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    HIP_TRY(hipMalloc(&g_scratch.dev, want));
+    g_scratch.device = dev;
+    g_scratch.bytes = want;
+  }
+  *out = g_scratch.dev;
+  return SCL_OK;
+}
+
+// ---- host tables ---------------------------------------------------------------------------------
+template <class F>
+void default_nodes(const typename F::Ctx& ctx, size_t n, std::vector<typename F::E>& out) {
+  // Vector::range(1, n+1): FF(int i) (vector.h:490-505) -- equal to the x++ walk of shamir.h:62-65 in
+  // every prime field; for GF(2^128) the nodes are the bit patterns of 1..n.
+  out.resize(n);
+  for (size_t i = 0; i < n; ++i) out[i] = F::from_u64(ctx, (u64)(i + 1));
+}
+
+template <class F>
+void load_host(const u64* src, size_t n, std::vector<typename F::E>& out) {
+  out.resize(n);
+  for (size_t i = 0; i < n; ++i) out[i] = F::ld(src + i * F::LIMBS);
+}
+
+// computeLagrangeBasis (lagrange.h:54-71)
+template <class F>
+int lagrange(const typename F::Ctx& ctx, const std::vector<typename F::E>& nodes, typename F::E x,
+             typename F::E* out) {
+  const size_t m = nodes.size();
+  for (size_t i = 0; i < m; ++i) {
+    typename F::E num = F::one(ctx), den = F::one(ctx);
+    for (size_t j = 0; j < m; ++j) {
+      if (i == j) continue;
+      const typename F::E d = F::sub(ctx, nodes[i], nodes[j]);
+      if (F::is_zero(d)) return fail(SCL_ERR_ZERO_INVERSE, scl_hip_status_message(SCL_ERR_ZERO_INVERSE));
+      num = F::mul(ctx, num, F::sub(ctx, x, nodes[j]));
+      den = F::mul(ctx, den, d);
+    }
+    out[i] = F::mul(ctx, num, F::inv(ctx, den));
+  }
+  return SCL_OK;
+}
+
+// ---- AES-128 key schedule + T-table (FIPS-197), host side ----------------------------------------------
+struct AesHost {
+  unsigned char sbox[256];
+  AesHost() {
+    auto mul = [](unsigned a, unsigned b) {
+      unsigned r = 0;
+      while (b) {
+        if (b & 1) r ^= a;
+        a = ((a << 1) ^ ((a & 0x80) ? 0x11b : 0)) & 0xff;
+        b >>= 1;
+      }
+      return r;
+    };
+    // inverse table via generator 3: log/antilog
+    unsigned char exp[256], log[256] = {0};
+    unsigned v = 1;
+    for (int i = 0; i < 255; ++i) {
+      exp[i] = (unsigned char)v;
+      log[v] = (unsigned char)i;
+      v = mul(v, 3);
+    }
+    for (int x = 0; x < 256; ++x) {
+      unsigned inv = x ? exp[(255 - log[x]) % 255] : 0;
+      unsigned s = inv, r = inv;
+      for (int i = 0; i < 4; ++i) {
+        s = ((s << 1) | (s >> 7)) & 0xff;
+        r ^= s;
+      }
+      sbox[x] = (unsigned char)(r ^ 0x63);
+    }
+  }
+};
+
+const AesHost& aes_host() {
+  static const AesHost h;
+  return h;
+}
+
+// key = seed zero-padded / truncated to 16 bytes (prg.cc:88-101)
+void make_aes_key(const unsigned char* seed, size_t seed_len, AesKey& k) {
+  const AesHost& h = aes_host();
+  unsigned char rk[176] = {0};
+  if (seed) std::memcpy(rk, seed, seed_len > 16 ? 16 : seed_len);
+  unsigned rcon = 1;
+  for (int i = 16; i < 176; i += 4) {
+    unsigned char t[4] = {rk[i - 4], rk[i - 3], rk[i - 2], rk[i - 1]};
+    if (i % 16 == 0) {
+      const unsigned char t0 = t[0];
+      t[0] = (unsigned char)(h.sbox[t[1]] ^ rcon);
+      t[1] = h.sbox[t[2]];
+      t[2] = h.sbox[t[3]];
+      t[3] = h.sbox[t0];
+      rcon = ((rcon << 1) ^ ((rcon & 0x80) ? 0x11b : 0)) & 0xff;
+    }
+    for (int j = 0; j < 4; ++j) rk[i + j] = (unsigned char)(rk[i - 16 + j] ^ t[j]);
+  }
+  for (int w = 0; w < 44; ++w)
+    k.rk[w] = (u32)rk[4 * w] | ((u32)rk[4 * w + 1] << 8) | ((u32)rk[4 * w + 2] << 16) | ((u32)rk[4 * w + 3] << 24);
+  for (int x = 0; x < 256; ++x) {
+    const unsigned s = h.sbox[x];
+    const unsigned s2 = ((s << 1) ^ ((s & 0x80) ? 0x11b : 0)) & 0xff;
+    const unsigned s3 = s2 ^ s;
+    k.te0[x] = s2 | (s << 8) | (s << 16) | (s3 << 24);
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Decide the per-lane vector width for M61 rows: 2 needs 16-byte aligned bases and even strides.
+template <class F>
+int vec_width(std::initializer_list<const void*> ptrs, std::initializer_list<size_t> strides) {
+  if (F::LIMBS != 1) return 1;
+  if (g_force_scalar.load()) return 1;
+  for (const void* p : ptrs)
+    if (p && !aligned16(p)) return 1;
+  for (size_t s : strides)
+    if (s & 1) return 1;
+  return 2;
+}
+
+template <class F>
+int check_align(std::initializer_list<const void*> ptrs) {
+  const uintptr_t mask = F::LIMBS == 1 ? 7 : 15;
+  for (const void* p : ptrs)
+    if (p && (reinterpret_cast<uintptr_t>(p) & mask))
+      return fail(SCL_ERR_BAD_ARG, F::LIMBS == 1 ? "pointer not 8-byte aligned" : "pointer not 16-byte aligned");
+  return SCL_OK;
+}
+
+template <class F>
+int alpha_table(const typename F::Ctx& ctx, const u64* alphas_host, size_t n, BigTable<F>& tab) {
+  if (n > (size_t)BigTable<F>::CAP)
+    return fail(SCL_ERR_BAD_ARG, "share: more parties than the table kernels hold (256 for M61, 128 for 128-bit fields)");
+  std::vector<typename F::E> nodes;
+  if (alphas_host) load_host<F>(alphas_host, n, nodes);
+  else default_nodes<F>(ctx, n, nodes);
+  for (size_t i = 0; i < n; ++i) tab.v[i] = nodes[i];
+  return SCL_OK;
+}
+
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+// Runs body(VEC-tag, first_element, npacks) for the vectorisable head and the scalar tail of [0,N).
+template <class F, class Body>
+int split_vec(int vec, size_t N, Body&& body) {
+  if constexpr (F::LIMBS == 1) {
+    if (vec == 2) {
+      const size_t head = N & ~(size_t)1;
+      if (head) SCL_TRY(body(std::integral_constant<int, 2>{}, (size_t)0, head / 2));
+      if (N & 1) SCL_TRY(body(std::integral_constant<int, 1>{}, head, (size_t)1));
+      return SCL_OK;
+    }
+  }
+  if (N) SCL_TRY(body(std::integral_constant<int, 1>{}, (size_t)0, N));
+  return SCL_OK;
+}
+
+template <class F, int M>
+struct RecoverFixed {
+  template <int VEC>
+  static int run(const typename F::Ctx& ctx, u64* out, const u64* shares, size_t stride, const Table<F>& lam, int m,
+                 size_t npacks, hipStream_t st) {
+    if (m == M) {
+      if (g_nontemporal.load())
+        hipLaunchKernelGGL((k_recover_fixed<F, VEC, M, true>), dim3(grid_for(npacks)), dim3(BLOCK), 0, st, ctx, out,
+                           shares, stride, lam, npacks);
+      else
+        hipLaunchKernelGGL((k_recover_fixed<F, VEC, M, false>), dim3(grid_for(npacks)), dim3(BLOCK), 0, st, ctx, out,
+                           shares, stride, lam, npacks);
+      return SCL_OK;
+    }
+    if constexpr (M > 1) return RecoverFixed<F, M - 1>::template run<VEC>(ctx, out, shares, stride, lam, m, npacks, st);
+    return fail(SCL_ERR_BAD_ARG, "recover: m out of range");
+  }
+};
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int scl_hip_abi_version(void) { return 1; }
+
+const char* scl_hip_last_error(void) { return g_err.c_str(); }
+
+const char* scl_hip_status_message(int status) {
+  switch (status) {
+    case SCL_OK: return "";
+    case SCL_ERR_SIZE_MISMATCH: return "Vec sizes mismatch";
+    case SCL_ERR_ZERO_INVERSE: return "0 not invertible modulo prime";
+    case SCL_ERR_BAD_ARG: return "bad argument";
+    case SCL_ERR_HIP: return "HIP runtime error";
+    case SCL_ERR_NO_DEVICE: return "no HIP device";
+    case SCL_ERR_ERROR_DETECTED: return "error detected during recovery";
+    case SCL_ERR_NOT_ENOUGH_SHARES: return "not enough shares provided to detect errors";
+    case SCL_ERR_MATMUL_DIMS: return "matmul: this->cols() != that->rows()";
+    case SCL_ERR_VANDERMONDE_XS: return "|xs| != number of rows";
+    case SCL_ERR_INVALID_RANGE: return "invalid range";
+    default: return "unknown status";
+  }
+}
+
+int scl_hip_limbs(int field) { return field == SCL_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : -1; }
+
+const char* scl_hip_field_name(int field) {
+  switch (field) {
+    case SCL_M61: return "Mersenne61";
+    case SCL_M127: return "Mersenne127";
+    case SCL_MONT128: return "Mont128";
+    case SCL_GF2_128: return "GF(2^128)";
+    default: return "";
+  }
+}
+
+// ---- plumbing ------------------------------------------------------------------------------------------
+int scl_hip_device_count(int* count) {
+  if (!count) return fail(SCL_ERR_BAD_ARG, "count is NULL");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(SCL_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  return SCL_OK;
+}
+int scl_hip_set_device(int device) {
+  HIP_TRY(hipSetDevice(device));
+  return SCL_OK;
+}
+int scl_hip_malloc(void** dev, size_t bytes) {
+  if (!dev) return fail(SCL_ERR_BAD_ARG, "dev is NULL");
+  HIP_TRY(hipMalloc(dev, bytes ? bytes : 16));
+  return SCL_OK;
+}
+int scl_hip_free(void* dev) {
+  HIP_TRY(hipFree(dev));
+  return SCL_OK;
+}
+int scl_hip_memcpy_h2d(void* dev, const void* host, size_t bytes, void* stream) {
+  HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, S(stream)));
+  return SCL_OK;
+}
+int scl_hip_memcpy_d2h(void* host, const void* dev, size_t bytes, void* stream) {
+  HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, S(stream)));
+  HIP_TRY(hipStreamSynchronize(S(stream)));
+  return SCL_OK;
+}
+int scl_hip_memset(void* dev, int value, size_t bytes, void* stream) {
+  HIP_TRY(hipMemsetAsync(dev, value, bytes, S(stream)));
+  return SCL_OK;
+}
+int scl_hip_stream_create(void** stream) {
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return SCL_OK;
+}
+int scl_hip_stream_destroy(void* stream) {
+  HIP_TRY(hipStreamDestroy(S(stream)));
+  return SCL_OK;
+}
+int scl_hip_stream_sync(void* stream) {
+  HIP_TRY(hipStreamSynchronize(S(stream)));
+  return SCL_OK;
+}
+
+struct SclTimer {
+  hipEvent_t a, b;
+};
+int scl_hip_timer_create(void** timer) {
+  SclTimer* t = new SclTimer;
+  hipError_t e = hipEventCreate(&t->a);
+  if (e == hipSuccess) e = hipEventCreate(&t->b);
+  if (e != hipSuccess) {
+    delete t;
+    return fail(SCL_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+  }
+  *timer = t;
+  return SCL_OK;
+}
+int scl_hip_timer_destroy(void* timer) {
+  SclTimer* t = static_cast<SclTimer*>(timer);
+  if (!t) return SCL_OK;
+  (void)hipEventDestroy(t->a);
+  (void)hipEventDestroy(t->b);
+  delete t;
+  return SCL_OK;
+}
+int scl_hip_timer_start(void* timer, void* stream) {
+  HIP_TRY(hipEventRecord(static_cast<SclTimer*>(timer)->a, S(stream)));
+  return SCL_OK;
+}
+int scl_hip_timer_stop(void* timer, void* stream) {
+  HIP_TRY(hipEventRecord(static_cast<SclTimer*>(timer)->b, S(stream)));
+  return SCL_OK;
+}
+int scl_hip_timer_elapsed_ms(void* timer, float* ms) {
+  SclTimer* t = static_cast<SclTimer*>(timer);
+  HIP_TRY(hipEventSynchronize(t->b));
+  HIP_TRY(hipEventElapsedTime(ms, t->a, t->b));
+  return SCL_OK;
+}
+
+int scl_hip_set_tuning(const char* key, long value) {
+  if (!key) return fail(SCL_ERR_BAD_ARG, "key is NULL");
+  const std::string k(key);
+  if (k == "max_blocks") g_max_blocks = value;
+  else if (k == "nontemporal") g_nontemporal = value;
+  else if (k == "force_scalar") g_force_scalar = value;
+  else if (k == "force_table") g_force_table = value;
+  else return fail(SCL_ERR_BAD_ARG, "unknown tuning key " + k);
+  return SCL_OK;
+}
+
+int scl_hip_mont128_set_prime(const uint64_t p[2]) { return mont_set(((u128)p[1] << 64) | p[0]); }
+int scl_hip_mont128_get_prime(uint64_t p[2]) {
+  const Mont128::Ctx c = mont_ctx();
+  p[0] = (u64)c.p;
+  p[1] = (u64)(c.p >> 64);
+  return SCL_OK;
+}
+
+// ---- element-wise ---------------------------------------------------------------------------------------
+int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
+  if (op < 0 || op > 5) return fail(SCL_ERR_BAD_ARG, "unknown element-wise op");
+  const bool binary = (op == SCL_OP_ADD || op == SCL_OP_SUB || op == SCL_OP_MUL || op == SCL_OP_DIV);
+  if (n == 0) return SCL_OK;
+  if (!dst || !a || (binary && !b)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({dst, a, binary ? b : nullptr}));
+    unsigned* flag = nullptr;
+    const bool needs_flag = (op == SCL_OP_INV || op == SCL_OP_DIV);
+    if (needs_flag) {
+      void* sc;
+      SCL_TRY(scratch(64, &sc));
+      flag = static_cast<unsigned*>(sc);
+      HIP_TRY(hipMemsetAsync(flag, 0, 4, S(stream)));
+    }
+    const int vec = vec_width<F>({dst, a, binary ? b : nullptr}, {});
+    const bool nt = g_nontemporal.load() != 0;
+    const int rc_ = split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
+      constexpr int VEC = decltype(V)::value;
+      u64* d = dst + first * F::LIMBS;
+      const u64* pa = a + first * F::LIMBS;
+      const u64* pb = binary ? b + first * F::LIMBS : nullptr;
+      const dim3 g(grid_for(npacks)), blk(BLOCK);
+#define EW_CASE(OP)                                                                                             \
+  case OP:                                                                                                      \
+    if (nt) hipLaunchKernelGGL((k_ew<F, OP, VEC, true>), g, blk, 0, S(stream), ctx, d, pa, pb, npacks, flag);   \
+    else hipLaunchKernelGGL((k_ew<F, OP, VEC, false>), g, blk, 0, S(stream), ctx, d, pa, pb, npacks, flag);     \
+    break;
+      switch (op) {
+        EW_CASE(0) EW_CASE(1) EW_CASE(2) EW_CASE(3) EW_CASE(4) EW_CASE(5)
+      }
+#undef EW_CASE
+      LAUNCH_CHECK();
+      return SCL_OK;
+    });
+    SCL_TRY(rc_);
+    if (needs_flag) {
+      unsigned h = 0;
+      HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, S(stream)));
+      HIP_TRY(hipStreamSynchronize(S(stream)));
+      if (h) return fail(SCL_ERR_ZERO_INVERSE, scl_hip_status_message(SCL_ERR_ZERO_INVERSE));
+    }
+    return SCL_OK;
+  });
+}
+
+int scl_hip_scalar_mul(int field, uint64_t* dst, const uint64_t* a, const uint64_t* scalar_host, size_t n,
+                       void* stream) {
+  if (n == 0) return SCL_OK;
+  if (!dst || !a || !scalar_host) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({dst, a}));
+    Table<F> sc;
+    sc.v[0] = F::ld(scalar_host);
+    const int vec = vec_width<F>({dst, a}, {});
+    return split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
+      constexpr int VEC = decltype(V)::value;
+      hipLaunchKernelGGL((k_scalar_mul<F, VEC, true>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx,
+                         dst + first * F::LIMBS, a + first * F::LIMBS, sc, npacks);
+      LAUNCH_CHECK();
+      return SCL_OK;
+    });
+  });
+}
+
+static int reduce_impl(int field, uint64_t* out_host, const uint64_t* a, const uint64_t* b, size_t n, void* stream,
+                       bool is_dot) {
+  if (!out_host) return fail(SCL_ERR_BAD_ARG, "out is NULL");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    if (n == 0) {
+      F::st(out_host, F::zero());
+      return SCL_OK;
+    }
+    if (!a || (is_dot && !b)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+    SCL_TRY(check_align<F>({a, b}));
+    const int vec = vec_width<F>({a, b}, {});
+    const unsigned maxg = 1024;
+    void* sc;
+    SCL_TRY(scratch((size_t)2 * (maxg + 1) * 16, &sc));
+    u64* partial = static_cast<u64*>(sc);
+    unsigned used = 0;
+    SCL_TRY((split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
+      constexpr int VEC = decltype(V)::value;
+      unsigned g = grid_for(npacks);
+      if (g > maxg) g = maxg;
+      if (is_dot)
+        hipLaunchKernelGGL((k_dot<F, VEC>), dim3(g), dim3(BLOCK), 0, S(stream), ctx, partial + (size_t)used * F::LIMBS,
+                           a + first * F::LIMBS, b + first * F::LIMBS, npacks);
+      else
+        hipLaunchKernelGGL((k_sum<F, VEC>), dim3(g), dim3(BLOCK), 0, S(stream), ctx, partial + (size_t)used * F::LIMBS,
+                           a + first * F::LIMBS, npacks);
+      LAUNCH_CHECK();
+      used += g;
+      return SCL_OK;
+    })));
+    std::vector<u64> host((size_t)used * F::LIMBS);
+    HIP_TRY(hipMemcpyAsync(host.data(), partial, host.size() * 8, hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    typename F::E tot = F::zero();
+    for (unsigned i = 0; i < used; ++i) tot = F::add(ctx, tot, F::ld(host.data() + (size_t)i * F::LIMBS));
+    F::st(out_host, tot);
+    return SCL_OK;
+  });
+}
+
+int scl_hip_sum(int field, uint64_t* out_host, const uint64_t* a, size_t n, void* stream) {
+  return reduce_impl(field, out_host, a, nullptr, n, stream, false);
+}
+int scl_hip_dot(int field, uint64_t* out_host, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
+  return reduce_impl(field, out_host, a, b, n, stream, true);
+}
+
+int scl_hip_equals(int field, int* equal_host, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
+  const int L = scl_hip_limbs(field);
+  if (L < 0) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
+  if (!equal_host) return fail(SCL_ERR_BAD_ARG, "equal is NULL");
+  if (n == 0) {
+    *equal_host = 1;
+    return SCL_OK;
+  }
+  if (!a || !b) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  void* sc;
+  SCL_TRY(scratch(64, &sc));
+  unsigned long long* cnt = static_cast<unsigned long long*>(sc);
+  HIP_TRY(hipMemsetAsync(cnt, 0, 8, S(stream)));
+  const size_t words = n * (size_t)L;
+  hipLaunchKernelGGL(k_count_diff, dim3(grid_for(words)), dim3(BLOCK), 0, S(stream), cnt, a, b, words);
+  LAUNCH_CHECK();
+  unsigned long long h = 0;
+  HIP_TRY(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, S(stream)));
+  HIP_TRY(hipStreamSynchronize(S(stream)));
+  *equal_host = (h == 0);
+  return SCL_OK;
+}
+
+// ---- randomness ----------------------------------------------------------------------------------------------
+int scl_hip_prg_blocks(unsigned char* dst, size_t nblocks, const unsigned char* seed, size_t seed_len,
+                       uint64_t counter0, void* stream) {
+  if (nblocks == 0) return SCL_OK;
+  if (!dst) return fail(SCL_ERR_BAD_ARG, "dst is NULL");
+  if (!aligned16(dst)) return fail(SCL_ERR_BAD_ARG, "dst not 16-byte aligned");
+  AesKey key;
+  make_aes_key(seed, seed_len, key);
+  hipLaunchKernelGGL(k_prg_blocks, dim3(grid_for(nblocks)), dim3(BLOCK), 0, S(stream), reinterpret_cast<u64*>(dst),
+                     key, (u64)counter0, nblocks);
+  LAUNCH_CHECK();
+  return SCL_OK;
+}
+
+int scl_hip_from_bytes(int field, uint64_t* dst, const unsigned char* src, size_t n, void* stream) {
+  if (n == 0) return SCL_OK;
+  if (!dst || !src) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({dst}));
+    hipLaunchKernelGGL((k_from_bytes<F>), dim3(grid_for(n)), dim3(BLOCK), 0, S(stream), ctx, dst, src, n);
+    LAUNCH_CHECK();
+    return SCL_OK;
+  });
+}
+
+int scl_hip_vector_random(int field, uint64_t* dst, size_t n, const unsigned char* seed, size_t seed_len,
+                          uint64_t counter0, void* stream) {
+  if (n == 0) return SCL_OK;
+  if (!dst) return fail(SCL_ERR_BAD_ARG, "dst is NULL");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({dst}));
+    AesKey key;
+    make_aes_key(seed, seed_len, key);
+    const size_t work = F::LIMBS == 1 ? (n + 1) / 2 : n;
+    hipLaunchKernelGGL((k_vector_random<F>), dim3(grid_for(work)), dim3(BLOCK), 0, S(stream), ctx, dst, key,
+                       (u64)counter0, n);
+    LAUNCH_CHECK();
+    return SCL_OK;
+  });
+}
+
+// ---- Shamir -----------------------------------------------------------------------------------------------------
+int scl_hip_lagrange_basis(int field, uint64_t* lambda_host, const uint64_t* alphas_host, size_t m,
+                           const uint64_t* x_host) {
+  if (m == 0) return SCL_OK;
+  if (!lambda_host) return fail(SCL_ERR_BAD_ARG, "lambda is NULL");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    std::vector<typename F::E> nodes, out(m);
+    if (alphas_host) load_host<F>(alphas_host, m, nodes);
+    else default_nodes<F>(ctx, m, nodes);
+    const typename F::E x = x_host ? F::ld(x_host) : F::zero();
+    SCL_TRY(lagrange<F>(ctx, nodes, x, out.data()));
+    for (size_t i = 0; i < m; ++i) F::st(lambda_host + i * F::LIMBS, out[i]);
+    return SCL_OK;
+  });
+}
+
+int scl_hip_shamir_recover(int field, uint64_t* out, const uint64_t* shares, size_t stride,
+                           const uint64_t* lambda_host, size_t m, size_t N, void* stream) {
+  if (N == 0) return SCL_OK;
+  if (!out || !shares || !lambda_host) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (m == 0) return fail(SCL_ERR_BAD_ARG, "recover: need at least one share");
+  if (stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "share_stride < N");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({out, shares}));
+    const int vec = vec_width<F>({out, shares}, {stride});
+    const bool nt = g_nontemporal.load() != 0;
+    const bool fixed = (m <= FIXED_M_MAX) && (F::TAG <= 1) && !g_force_table.load();
+    if (m > (size_t)BigTable<F>::CAP) return fail(SCL_ERR_BAD_ARG, "recover: more shares than the table kernels hold (256 for M61, 128 for 128-bit fields)");
+    Table<F> lam;
+    BigTable<F> big;
+    if (fixed) {
+      for (size_t i = 0; i < m; ++i) lam.v[i] = F::ld(lambda_host + i * F::LIMBS);
+    } else {
+      for (size_t i = 0; i < m; ++i) big.v[i] = F::ld(lambda_host + i * F::LIMBS);
+    }
+    return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+      constexpr int VEC = decltype(V)::value;
+      u64* o = out + first * F::LIMBS;
+      const u64* sh = shares + first * F::LIMBS;
+      if (fixed) {
+        if constexpr (F::TAG <= 1) {
+          SCL_TRY((RecoverFixed<F, FIXED_M_MAX>::template run<VEC>(ctx, o, sh, stride, lam, (int)m, npacks, S(stream))));
+        }
+      } else if (nt) {
+        hipLaunchKernelGGL((k_recover_table<F, VEC, true>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx, o,
+                           sh, stride, big, (int)m, npacks);
+      } else {
+        hipLaunchKernelGGL((k_recover_table<F, VEC, false>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx, o,
+                           sh, stride, big, (int)m, npacks);
+      }
+      LAUNCH_CHECK();
+      return SCL_OK;
+    });
+  });
+}
+
+
+int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets,
+                         const uint64_t* coeffs, size_t coeff_stride, size_t N, size_t t, size_t n,
+                         const uint64_t* alphas_host, void* stream) {
+  if (N == 0 || n == 0) return SCL_OK;
+  if (!shares || !secrets || (t > 0 && !coeffs)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (t > 48) return fail(SCL_ERR_BAD_ARG, "share: t > 48 not supported");
+  if (share_stride < N || (t > 0 && coeff_stride < N)) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({shares, secrets, coeffs}));
+    BigTable<F> al;
+    SCL_TRY(alpha_table<F>(ctx, alphas_host, n, al));
+    const int vec = vec_width<F>({shares, secrets, coeffs}, {share_stride, t ? coeff_stride : 0});
+    return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+      constexpr int VEC = decltype(V)::value;
+      u64* sh = shares + first * F::LIMBS;
+      const u64* se = secrets + first * F::LIMBS;
+      const u64* co = coeffs ? coeffs + first * F::LIMBS : nullptr;
+      const dim3 g(grid_for(npacks)), blk(BLOCK);
+#define SHARE_LAUNCH(TREG)                                                                                     \
+  hipLaunchKernelGGL((k_share<F, VEC, TREG>), g, blk, 0, S(stream), ctx, sh, share_stride, se, co, coeff_stride, \
+                     al, (int)t, (int)n, npacks)
+      if (t <= 4) SHARE_LAUNCH(4);
+      else if (t <= 16) SHARE_LAUNCH(16);
+      else SHARE_LAUNCH(48);
+#undef SHARE_LAUNCH
+      LAUNCH_CHECK();
+      return SCL_OK;
+    });
+  });
+}
+
+int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N,
+                             size_t t, size_t n, const unsigned char* seed, size_t seed_len, uint64_t first_secret,
+                             void* stream) {
+  if (N == 0 || n == 0) return SCL_OK;
+  if (!shares || !secrets) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (t > 48) return fail(SCL_ERR_BAD_ARG, "share: t > 48 not supported");
+  if (share_stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({shares, secrets}));
+    BigTable<F> al;
+    SCL_TRY(alpha_table<F>(ctx, nullptr, n, al));
+    AesKey key;
+    make_aes_key(seed, seed_len, key);
+    const int vec = vec_width<F>({shares, secrets}, {share_stride});
+    return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+      constexpr int VEC = decltype(V)::value;
+      u64* sh = shares + first * F::LIMBS;
+      const u64* se = secrets + first * F::LIMBS;
+      const dim3 g(grid_for(npacks)), blk(BLOCK);
+#define SHAREP_LAUNCH(TREG)                                                                                   \
+  hipLaunchKernelGGL((k_share_prg<F, VEC, TREG>), g, blk, 0, S(stream), ctx, sh, share_stride, se, key,         \
+                     (u64)(first_secret + first), al, (int)t, (int)n, npacks)
+      if (t <= 4) SHAREP_LAUNCH(4);
+      else if (t <= 16) SHAREP_LAUNCH(16);
+      else SHAREP_LAUNCH(48);
+#undef SHAREP_LAUNCH
+      LAUNCH_CHECK();
+      return SCL_OK;
+    });
+  });
+}
+
+int scl_hip_shamir_recover_detect(int field, uint64_t* out, unsigned char* status, const uint64_t* shares,
+                                  size_t stride, size_t m, size_t N, size_t t, size_t d, const uint64_t* alphas_host,
+                                  const uint64_t* x_host, size_t* num_bad_host, void* stream) {
+  // shamir.h:122-124: both the shares and the alphas must number at least d+t
+  if (m < d + t) return fail(SCL_ERR_NOT_ENOUGH_SHARES, scl_hip_status_message(SCL_ERR_NOT_ENOUGH_SHARES));
+  if (num_bad_host) *num_bad_host = 0;
+  if (N == 0) return SCL_OK;
+  if (!out || !status || !shares) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "share_stride < N");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({out, shares}));
+    std::vector<typename F::E> alphas;
+    if (alphas_host) load_host<F>(alphas_host, m, alphas);
+    else default_nodes<F>(ctx, m, alphas);
+    const size_t d1 = d + 1;
+    const size_t nchk = (d + t > d1) ? d + t - d1 : 0;  // checks i = d+1 .. d+t-1 (shamir.h:129)
+    std::vector<typename F::E> ns(alphas.begin(), alphas.begin() + d1), L((nchk + 1) * d1);
+    for (size_t r = 0; r < nchk; ++r) SCL_TRY(lagrange<F>(ctx, ns, alphas[d1 + r], L.data() + r * d1));
+    SCL_TRY(lagrange<F>(ctx, ns, x_host ? F::ld(x_host) : F::zero(), L.data() + nchk * d1));
+    std::vector<u64> Ll(L.size() * F::LIMBS);
+    for (size_t i = 0; i < L.size(); ++i) F::st(Ll.data() + i * F::LIMBS, L[i]);
+    const size_t lbytes = Ll.size() * 8;
+    if (lbytes > 150 * 1024) return fail(SCL_ERR_BAD_ARG, "recover_detect: (t)(d+1) table exceeds LDS");
+    void* sc;
+    SCL_TRY(scratch(lbytes + 64, &sc));
+    unsigned long long* cnt = static_cast<unsigned long long*>(sc);
+    u64* L_dev = reinterpret_cast<u64*>(static_cast<unsigned char*>(sc) + 64);
+    HIP_TRY(hipMemsetAsync(cnt, 0, 8, S(stream)));
+    HIP_TRY(hipMemcpyAsync(L_dev, Ll.data(), lbytes, hipMemcpyHostToDevice, S(stream)));
+    if (lbytes > 48 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recover_detect<F>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbytes));
+    hipLaunchKernelGGL((k_recover_detect<F>), dim3(grid_for(N)), dim3(BLOCK), lbytes, S(stream), ctx, out, status,
+                       shares, stride, L_dev, (int)d1, (int)nchk, N, cnt);
+    LAUNCH_CHECK();
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    if (num_bad_host) *num_bad_host = (size_t)h;
+    if (h) return fail(SCL_ERR_ERROR_DETECTED, scl_hip_status_message(SCL_ERR_ERROR_DETECTED));
+    return SCL_OK;
+  });
+}
+
+// ---- additive ------------------------------------------------------------------------------------------------------
+int scl_hip_additive_share(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets,
+                           const uint64_t* rnd, size_t rnd_stride, size_t N, size_t n, void* stream) {
+  if (n == 0) return fail(SCL_ERR_BAD_ARG, "additive share: n must be >= 1");  // additive.h:46 underflows
+  if (N == 0) return SCL_OK;
+  if (!shares || !secrets || (n > 1 && !rnd)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (share_stride < N || (n > 1 && rnd_stride < N)) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({shares, secrets, rnd}));
+    const int vec = vec_width<F>({shares, secrets, rnd}, {share_stride, n > 1 ? rnd_stride : 0});
+    return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+      constexpr int VEC = decltype(V)::value;
+      hipLaunchKernelGGL((k_additive_share<F, VEC>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx,
+                         shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS,
+                         rnd ? rnd + first * F::LIMBS : nullptr, rnd_stride, (int)n, npacks);
+      LAUNCH_CHECK();
+      return SCL_OK;
+    });
+  });
+}
+
+int scl_hip_additive_share_prg(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N,
+                               size_t n, const unsigned char* seed, size_t seed_len, uint64_t first_secret,
+                               void* stream) {
+  if (n == 0) return fail(SCL_ERR_BAD_ARG, "additive share: n must be >= 1");
+  if (N == 0) return SCL_OK;
+  if (!shares || !secrets) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (share_stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({shares, secrets}));
+    AesKey key;
+    make_aes_key(seed, seed_len, key);
+    const int vec = vec_width<F>({shares, secrets}, {share_stride});
+    return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+      constexpr int VEC = decltype(V)::value;
+      hipLaunchKernelGGL((k_additive_share_prg<F, VEC>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx,
+                         shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS, key,
+                         (u64)(first_secret + first), (int)n, npacks);
+      LAUNCH_CHECK();
+      return SCL_OK;
+    });
+  });
+}
+
+int scl_hip_additive_recover(int field, uint64_t* out, const uint64_t* shares, size_t stride, size_t n, size_t N,
+                             void* stream) {
+  if (N == 0) return SCL_OK;
+  if (!out || !shares) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "share_stride < N");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({out, shares}));
+    const int vec = vec_width<F>({out, shares}, {stride});
+    const bool nt = g_nontemporal.load() != 0;
+    return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+      constexpr int VEC = decltype(V)::value;
+      if (nt)
+        hipLaunchKernelGGL((k_additive_recover<F, VEC, true>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx,
+                           out + first * F::LIMBS, shares + first * F::LIMBS, stride, (int)n, npacks);
+      else
+        hipLaunchKernelGGL((k_additive_recover<F, VEC, false>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx,
+                           out + first * F::LIMBS, shares + first * F::LIMBS, stride, (int)n, npacks);
+      LAUNCH_CHECK();
+      return SCL_OK;
+    });
+  });
+}
+
+// ---- matrices --------------------------------------------------------------------------------------------------------
+int scl_hip_vandermonde(int field, uint64_t* V_dev, size_t n, size_t m, const uint64_t* xs_host, void* stream) {
+  if (n == 0 || m == 0) return SCL_OK;
+  if (!V_dev) return fail(SCL_ERR_BAD_ARG, "V is NULL");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({V_dev}));
+    std::vector<typename F::E> xs;
+    if (xs_host) load_host<F>(xs_host, n, xs);
+    else default_nodes<F>(ctx, n, xs);
+    // V(i,0) = 1, V(i,j) = V(i,j-1) * xs[i]  (matrix.h:444-460)
+    std::vector<u64> host(n * m * F::LIMBS);
+    for (size_t i = 0; i < n; ++i) {
+      typename F::E v = F::one(ctx);
+      for (size_t j = 0; j < m; ++j) {
+        if (j) v = F::mul(ctx, v, xs[i]);
+        F::st(host.data() + (i * m + j) * F::LIMBS, v);
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(V_dev, host.data(), host.size() * 8, hipMemcpyHostToDevice, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));  // host staging buffer dies with this frame
+    return SCL_OK;
+  });
+}
+
+int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t lda, const uint64_t* B, size_t ldb,
+                   size_t M, size_t K, size_t N, void* stream) {
+  if (M == 0 || N == 0) return SCL_OK;
+  if (!C || (K && (!A || !B))) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (ldc < N || (K && (lda < K || ldb < N))) return fail(SCL_ERR_MATMUL_DIMS, scl_hip_status_message(SCL_ERR_MATMUL_DIMS));
+  if (M > (1u << 20) || K > (1u << 20)) return fail(SCL_ERR_BAD_ARG, "matmul: M or K too large");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({C, A, B}));
+    const size_t esz = F::LIMBS * 8;
+    const size_t kk = K ? K : 1;
+    size_t rows_per_tile = (48 * 1024) / (kk * esz);
+    if (rows_per_tile == 0) return fail(SCL_ERR_BAD_ARG, "matmul: K too large for the LDS tile");
+    if (rows_per_tile > M) rows_per_tile = M;
+    const size_t tiles = (M + rows_per_tile - 1) / rows_per_tile;
+    unsigned gx = grid_for(N);
+    const size_t shmem = rows_per_tile * kk * esz;
+    hipLaunchKernelGGL((k_matmul<F, 4>), dim3(gx, (unsigned)tiles), dim3(BLOCK), shmem, S(stream), ctx, C, ldc, A, lda,
+                       B, ldb, (int)M, (int)K, N, (int)rows_per_tile);
+    LAUNCH_CHECK();
+    return SCL_OK;
+  });
+}
+
+// ---- layout ------------------------------------------------------------------------------------------------------------
+static int transpose_impl(int field, uint64_t* dst, const uint64_t* src, size_t stride, size_t N, size_t n,
+                          void* stream, bool to_soa) {
+  const int L = scl_hip_limbs(field);
+  if (L < 0) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
+  if (N == 0 || n == 0) return SCL_OK;
+  if (!dst || !src) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
+  size_t tile = (32 * 1024) / (n * (size_t)L * 8);
+  if (tile == 0) return fail(SCL_ERR_BAD_ARG, "transpose: n too large");
+  if (tile > 1024) tile = 1024;
+  if (tile >= 64) tile &= ~(size_t)63;
+  const size_t ntiles = (N + tile - 1) / tile;
+  const unsigned g = (unsigned)(ntiles < 8192 ? ntiles : 8192);
+  const size_t shmem = tile * n * (size_t)L * 8;
+#define TR_LAUNCH(LL, SOA) \
+  hipLaunchKernelGGL((k_transpose<LL, SOA>), dim3(g), dim3(BLOCK), shmem, S(stream), dst, src, stride, N, (int)n, (int)tile)
+  if (L == 1) {
+    if (to_soa) TR_LAUNCH(1, true);
+    else TR_LAUNCH(1, false);
+  } else {
+    if (to_soa) TR_LAUNCH(2, true);
+    else TR_LAUNCH(2, false);
+  }
+#undef TR_LAUNCH
+  LAUNCH_CHECK();
+  return SCL_OK;
+}
+
+int scl_hip_aos_to_soa(int field, uint64_t* soa, size_t stride, const uint64_t* aos, size_t N, size_t n, void* stream) {
+  return transpose_impl(field, soa, aos, stride, N, n, stream, true);
+}
+int scl_hip_soa_to_aos(int field, uint64_t* aos, const uint64_t* soa, size_t stride, size_t N, size_t n, void* stream) {
+  return transpose_impl(field, aos, soa, stride, N, n, stream, false);
+}
+
+// ---- roofline probe -------------------------------------------------------------------------------------------------------
+int scl_hip_stream_copy(void* dst, const void* src, size_t bytes, void* stream) {
+  if (bytes == 0) return SCL_OK;
+  if (!dst || !src || !aligned16(dst) || !aligned16(src) || (bytes & 15))
+    return fail(SCL_ERR_BAD_ARG, "stream_copy: 16-byte aligned buffers and sizes only");
+  const size_t n16 = bytes / 16;
+  hipLaunchKernelGGL(k_copy16, dim3(grid_for(n16)), dim3(BLOCK), 0, S(stream), static_cast<u64x2*>(dst),
+                     static_cast<const u64x2*>(src), n16);
+  LAUNCH_CHECK();
+  return SCL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,336 @@
+// csrc/field.hpp -- per-lane finite-field arithmetic for the MI355X engine.
+//
+// One struct per field with the same static interface, usable from device
+// kernels and from the host-side table builders (Lagrange basis, Vandermonde,
+// reduction epilogues).  All values are canonical (in [0,p)) between calls;
+// because every residue has a unique canonical representative, any evaluation
+// order / lazy reduction here is bit-identical to the reference's
+// reduce-after-every-step code (SURVEY.md section 8a note C).
+//
+// What each field follows in the reference (paths relative to /root/reference):
+//   M61   include/scl/math/fields/mersenne61.h:29-49, src/scl/math/fields/mersenne61.cc:33-100
+//   M127  include/scl/math/fields/mersenne127.h:29-49, src/scl/math/fields/mersenne127.cc:33-128
+//   add/sub/neg  src/scl/math/fields/small_ff.h:28-56
+//   MONT128  new 2-limb Montgomery field, modelled on include/scl/math/fields/ff_ops_gmp.h:44-260
+//   GF2_128  new binary field (not in the reference)
+//
+// Interface (F = field struct):
+//   F::E                  element type            F::LIMBS   uint64 limbs per element
+//   F::Ctx                per-launch field parameters (empty for the Mersenne fields)
+//   F::add/sub/mul/neg(ctx,..)   canonical in, canonical out
+//   F::inv(ctx,a)         Fermat inverse; inv(0) = 0 (callers flag the zero)
+//   F::one(ctx), F::from_u64(ctx,v) (v small, < p), F::from_le_word(ctx, raw) (FF::read: "% p")
+//   F::Acc                lazy dot-product accumulator: acc_zero, mac(acc,a,b), acc_add(acc,a),
+//                         acc_fold(ctx,acc) -> canonical; good for >= F::ACC_TERMS terms
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SCL_HD __host__ __device__ __forceinline__
+#else
+#define SCL_HD inline __attribute__((always_inline))
+#endif
+
+namespace sclhip {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+struct W256 {
+  u128 hi, lo;
+};
+
+// 128 x 128 -> 256 bits from four 64 x 64 -> 128 products
+SCL_HD W256 mulwide(u128 x, u128 y) {
+  const u64 x0 = (u64)x, x1 = (u64)(x >> 64), y0 = (u64)y, y1 = (u64)(y >> 64);
+  const u128 p00 = (u128)x0 * y0, p01 = (u128)x0 * y1, p10 = (u128)x1 * y0, p11 = (u128)x1 * y1;
+  const u128 mid = (p00 >> 64) + (u64)p01 + (u64)p10;  // < 3 * 2^64
+  W256 r;
+  r.lo = (u128)(u64)p00 | (mid << 64);
+  r.hi = p11 + (p01 >> 64) + (p10 >> 64) + (mid >> 64);
+  return r;
+}
+
+SCL_HD u128 bswap128(u128 v) {
+  return ((u128)__builtin_bswap64((u64)v) << 64) | __builtin_bswap64((u64)(v >> 64));
+}
+
+// ------------------------------------------------------------------ Mersenne61
+struct M61 {
+  typedef u64 E;
+  struct Ctx {};
+  enum { LIMBS = 1, ACC_TERMS = 64, TAG = 0 };
+  static constexpr u64 P = 0x1FFFFFFFFFFFFFFFull;
+
+  static SCL_HD E zero() { return 0; }
+  static SCL_HD E one(const Ctx&) { return 1; }
+  static SCL_HD E from_u64(const Ctx&, u64 v) { return v; }
+  static SCL_HD bool is_zero(E a) { return a == 0; }
+  static SCL_HD bool eq(E a, E b) { return a == b; }
+  static SCL_HD E ld(const u64* p) { return p[0]; }
+  static SCL_HD void st(u64* p, E v) { p[0] = v; }
+
+  static SCL_HD E add(const Ctx&, E a, E b) {
+    const u64 t = a + b;
+    return t >= P ? t - P : t;
+  }
+  static SCL_HD E sub(const Ctx&, E a, E b) { return a >= b ? a - b : a + P - b; }
+  static SCL_HD E neg(const Ctx&, E a) { return a ? P - a : 0; }
+  // z < 2^125 -> canonical
+  static SCL_HD E reduce_product(u128 z) {
+    const u64 r = (u64)(z >> 61) + ((u64)z & P);
+    return r >= P ? r - P : r;
+  }
+  static SCL_HD E mul(const Ctx&, E a, E b) { return reduce_product((u128)a * b); }
+  static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
+  // FF::read = native little-endian u64 "% p" (mersenne61.cc:86-90)
+  static SCL_HD E from_le_word(const Ctx&, u64 w) {
+    const u64 r = (w & P) + (w >> 61);
+    return r >= P ? r - P : r;
+  }
+
+  struct Acc {
+    u128 v;
+  };
+  static SCL_HD Acc acc_zero() { return Acc{0}; }
+  static SCL_HD void mac(const Ctx&, Acc& acc, E a, E b) { acc.v += (u128)a * b; }  // product < 2^122
+  static SCL_HD void acc_add(const Ctx&, Acc& acc, E a) { acc.v += a; }
+  // any 128-bit value -> canonical: sum the three 61-bit digits (2^61 = 1 mod p), fold once more
+  static SCL_HD E fold128(u128 z) {
+    const u64 lo = (u64)z, hi = (u64)(z >> 64);
+    const u64 s = (lo & P) + (((lo >> 61) | (hi << 3)) & P) + (hi >> 58);
+    const u64 r = (s & P) + (s >> 61);
+    return r >= P ? r - P : r;
+  }
+  static SCL_HD E acc_fold(const Ctx&, const Acc& acc) { return fold128(acc.v); }
+
+  // x^(2^k) * y
+  static SCL_HD E sqn_mul(const Ctx& c, E x, int k, E y) {
+    for (int i = 0; i < k; ++i) x = sqr(c, x);
+    return mul(c, x, y);
+  }
+  // Fermat: a^(p-2), p-2 = 2^61-3 = (2^59-1)*4 + 1
+  static SCL_HD E inv(const Ctx& c, E a) {
+    const E x2 = sqn_mul(c, a, 1, a);      // 2^2-1
+    const E x4 = sqn_mul(c, x2, 2, x2);    // 2^4-1
+    const E x8 = sqn_mul(c, x4, 4, x4);
+    const E x16 = sqn_mul(c, x8, 8, x8);
+    const E x32 = sqn_mul(c, x16, 16, x16);
+    const E x48 = sqn_mul(c, x32, 16, x16);
+    const E x56 = sqn_mul(c, x48, 8, x8);
+    const E x58 = sqn_mul(c, x56, 2, x2);
+    const E x59 = sqn_mul(c, x58, 1, a);
+    return sqn_mul(c, x59, 2, a);
+  }
+};
+
+// ----------------------------------------------------------------- Mersenne127
+struct M127 {
+  typedef u128 E;
+  struct Ctx {};
+  enum { LIMBS = 2, ACC_TERMS = 1 << 30, TAG = 1 };
+  static SCL_HD u128 P() { return (((u128)0x7FFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFFFFull; }
+
+  static SCL_HD E zero() { return 0; }
+  static SCL_HD E one(const Ctx&) { return 1; }
+  static SCL_HD E from_u64(const Ctx&, u64 v) { return v; }
+  static SCL_HD bool is_zero(E a) { return a == 0; }
+  static SCL_HD bool eq(E a, E b) { return a == b; }
+  static SCL_HD E ld(const u64* p) { return ((u128)p[1] << 64) | p[0]; }
+  static SCL_HD void st(u64* p, E v) {
+    p[0] = (u64)v;
+    p[1] = (u64)(v >> 64);
+  }
+
+  static SCL_HD E add(const Ctx&, E a, E b) {
+    const u128 t = a + b;  // < 2^128
+    return t >= P() ? t - P() : t;
+  }
+  static SCL_HD E sub(const Ctx&, E a, E b) { return a >= b ? a - b : a + P() - b; }
+  static SCL_HD E neg(const Ctx&, E a) { return a ? P() - a : 0; }
+  // a*b as an un-normalised value < 2^128 congruent to the product (mersenne127.cc:87-93)
+  static SCL_HD u128 mul_lazy(E a, E b) {
+    const W256 z = mulwide(a, b);
+    return ((z.hi << 1) | (z.lo >> 127)) + (z.lo & P());
+  }
+  static SCL_HD E mul(const Ctx&, E a, E b) {
+    const u128 t = mul_lazy(a, b);
+    return t >= P() ? t - P() : t;
+  }
+  static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
+  // FF::read = 16-byte little-endian load "% p" (mersenne127.cc:114-118)
+  static SCL_HD E from_le_word(const Ctx&, u128 w) {
+    const u128 r = (w & P()) + (w >> 127);
+    return r >= P() ? r - P() : r;
+  }
+
+  struct Acc {
+    u128 lo;
+    u64 hi;
+  };
+  static SCL_HD Acc acc_zero() { return Acc{0, 0}; }
+  static SCL_HD void acc_add_raw(Acc& acc, u128 a) {
+    const u128 t = acc.lo + a;
+    acc.hi += (t < a);
+    acc.lo = t;
+  }
+  static SCL_HD void acc_add(const Ctx&, Acc& acc, E a) { acc_add_raw(acc, a); }
+  static SCL_HD void mac(const Ctx&, Acc& acc, E a, E b) { acc_add_raw(acc, mul_lazy(a, b)); }
+  // hi*2^128 + lo = 2*hi + lo (mod p)
+  static SCL_HD E acc_fold(const Ctx&, const Acc& acc) {
+    const u128 v = (acc.lo & P()) + (acc.lo >> 127) + ((u128)acc.hi << 1);
+    const u128 r = (v & P()) + (v >> 127);
+    return r >= P() ? r - P() : r;
+  }
+
+  static SCL_HD E sqn_mul(const Ctx& c, E x, int k, E y) {
+    for (int i = 0; i < k; ++i) x = sqr(c, x);
+    return mul(c, x, y);
+  }
+  // Fermat: p-2 = 2^127-3 = (2^125-1)*4 + 1
+  static SCL_HD E inv(const Ctx& c, E a) {
+    const E x2 = sqn_mul(c, a, 1, a);
+    const E x4 = sqn_mul(c, x2, 2, x2);
+    const E x8 = sqn_mul(c, x4, 4, x4);
+    const E x16 = sqn_mul(c, x8, 8, x8);
+    const E x32 = sqn_mul(c, x16, 16, x16);
+    const E x64 = sqn_mul(c, x32, 32, x32);
+    const E x96 = sqn_mul(c, x64, 32, x32);
+    const E x112 = sqn_mul(c, x96, 16, x16);
+    const E x120 = sqn_mul(c, x112, 8, x8);
+    const E x124 = sqn_mul(c, x120, 4, x4);
+    const E x125 = sqn_mul(c, x124, 1, a);
+    return sqn_mul(c, x125, 2, a);
+  }
+};
+
+// --------------------------------------------------------------------- MONT128
+// Elements are Montgomery residues x*R mod p, R = 2^128 (ff_ops_gmp.h keeps its
+// values the same way).  PARITY UNPINNED: no such field in the reference.
+struct Mont128 {
+  typedef u128 E;
+  struct Ctx {
+    u128 p, mc, one, r2;  // modulus, -p^-1 mod R, R mod p, R^2 mod p
+  };
+  enum { LIMBS = 2, ACC_TERMS = 1 << 30, TAG = 2 };
+
+  static SCL_HD E zero() { return 0; }
+  static SCL_HD E one(const Ctx& c) { return c.one; }
+  static SCL_HD bool is_zero(E a) { return a == 0; }
+  static SCL_HD bool eq(E a, E b) { return a == b; }
+  static SCL_HD E ld(const u64* p) { return ((u128)p[1] << 64) | p[0]; }
+  static SCL_HD void st(u64* p, E v) {
+    p[0] = (u64)v;
+    p[1] = (u64)(v >> 64);
+  }
+  static SCL_HD E add(const Ctx& c, E a, E b) {
+    const u128 t = a + b;
+    return (t < a || t >= c.p) ? t - c.p : t;
+  }
+  static SCL_HD E sub(const Ctx& c, E a, E b) { return a >= b ? a - b : a - b + c.p; }
+  static SCL_HD E neg(const Ctx& c, E a) { return a ? c.p - a : 0; }
+  // REDC of a 256-bit T < p*R
+  static SCL_HD E redc(const Ctx& c, const W256& t) {
+    const u128 m = t.lo * c.mc;
+    const W256 mp = mulwide(m, c.p);
+    const u128 lo = t.lo + mp.lo;  // == 0 mod R
+    const u128 hi = t.hi + mp.hi;
+    const bool c1 = hi < t.hi;
+    const u128 hi2 = hi + (lo < t.lo ? 1 : 0);
+    const bool c2 = hi2 < hi;
+    return (c1 || c2 || hi2 >= c.p) ? hi2 - c.p : hi2;
+  }
+  static SCL_HD E mul(const Ctx& c, E a, E b) { return redc(c, mulwide(a, b)); }
+  static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
+  static SCL_HD E to_mont(const Ctx& c, u128 x) { return mul(c, x, c.r2); }
+  static SCL_HD u128 from_mont(const Ctx& c, E a) { return mul(c, a, 1); }
+  static SCL_HD E from_u64(const Ctx& c, u64 v) { return to_mont(c, v); }
+  // fromBytes of the gmp family is BIG-endian (ff_ops_gmp.h:279-290); raw is the LE load
+  static SCL_HD E from_le_word(const Ctx& c, u128 raw) { return to_mont(c, bswap128(raw)); }
+
+  struct Acc {
+    u128 v;
+  };
+  static SCL_HD Acc acc_zero() { return Acc{0}; }
+  static SCL_HD void mac(const Ctx& c, Acc& acc, E a, E b) { acc.v = add(c, acc.v, mul(c, a, b)); }
+  static SCL_HD void acc_add(const Ctx& c, Acc& acc, E a) { acc.v = add(c, acc.v, a); }
+  static SCL_HD E acc_fold(const Ctx&, const Acc& acc) { return acc.v; }
+
+  static SCL_HD E inv(const Ctx& c, E a) {  // a^(p-2), square-and-multiply MSB first
+    const u128 e = c.p - 2;
+    E r = c.one;
+    for (int i = 127; i >= 0; --i) {
+      r = sqr(c, r);
+      if ((e >> i) & 1) r = mul(c, r, a);
+    }
+    return r;
+  }
+};
+
+// ------------------------------------------------------------------- GF(2^128)
+// GF(2)[x]/(x^128 + x^7 + x^2 + x + 1); bit i of the little-endian word = coeff of x^i.
+// PARITY UNPINNED: no such field in the reference.
+struct Gf128 {
+  typedef u128 E;
+  struct Ctx {};
+  enum { LIMBS = 2, ACC_TERMS = 1 << 30, TAG = 3 };
+
+  static SCL_HD E zero() { return 0; }
+  static SCL_HD E one(const Ctx&) { return 1; }
+  static SCL_HD E from_u64(const Ctx&, u64 v) { return v; }
+  static SCL_HD bool is_zero(E a) { return a == 0; }
+  static SCL_HD bool eq(E a, E b) { return a == b; }
+  static SCL_HD E ld(const u64* p) { return ((u128)p[1] << 64) | p[0]; }
+  static SCL_HD void st(u64* p, E v) {
+    p[0] = (u64)v;
+    p[1] = (u64)(v >> 64);
+  }
+  static SCL_HD E add(const Ctx&, E a, E b) { return a ^ b; }
+  static SCL_HD E sub(const Ctx&, E a, E b) { return a ^ b; }
+  static SCL_HD E neg(const Ctx&, E a) { return a; }
+  // multiply by x^4 with reduction
+  static SCL_HD E mulx4(E a) {
+    const u64 t = (u64)(a >> 124);  // the 4 bits leaving the top
+    return (a << 4) ^ (u128)((t << 7) ^ (t << 2) ^ (t << 1) ^ t);
+  }
+  static SCL_HD E mulx(E a) {
+    const u64 t = (u64)(a >> 127);
+    return (a << 1) ^ (u128)(t * 0x87);
+  }
+  // 4-bit windows over b, branch-free: tab = {a, a*x, a*x^2, a*x^3}
+  static SCL_HD E mul(const Ctx&, E a, E b) {
+    const E a1 = mulx(a), a2 = mulx(a1), a3 = mulx(a2);
+    E r = 0;
+    for (int k = 31; k >= 0; --k) {
+      r = mulx4(r);
+      const u32 nib = (u32)(b >> (4 * k)) & 15u;
+      r ^= (nib & 1 ? a : (E)0) ^ (nib & 2 ? a1 : (E)0) ^ (nib & 4 ? a2 : (E)0) ^ (nib & 8 ? a3 : (E)0);
+    }
+    return r;
+  }
+  static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
+  static SCL_HD E from_le_word(const Ctx&, u128 w) { return w; }
+
+  struct Acc {
+    u128 v;
+  };
+  static SCL_HD Acc acc_zero() { return Acc{0}; }
+  static SCL_HD void mac(const Ctx& c, Acc& acc, E a, E b) { acc.v ^= mul(c, a, b); }
+  static SCL_HD void acc_add(const Ctx&, Acc& acc, E a) { acc.v ^= a; }
+  static SCL_HD E acc_fold(const Ctx&, const Acc& acc) { return acc.v; }
+
+  static SCL_HD E inv(const Ctx& c, E a) {  // a^(2^128-2) = prod_{i=1..127} a^(2^i)
+    E r = 1, sq = a;
+    for (int i = 1; i < 128; ++i) {
+      sq = sqr(c, sq);
+      r = mul(c, r, sq);
+    }
+    return a == 0 ? (E)0 : r;
+  }
+};
+
+}  // namespace sclhip

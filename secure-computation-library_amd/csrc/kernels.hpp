@@ -1,0 +1,709 @@
+// csrc/kernels.hpp -- HIP kernels (gfx950) for the SCL field / secret-sharing hot path.
+//
+// Data layout in HBM: SoA share matrices, row i = party i's share vector
+// (u64 limbs, little-endian), so lane s reads shares[i][s] coalesced; one thread
+// handles VEC consecutive secrets through 16-byte loads (M61: 2 x u64, 128-bit
+// fields: 1 element).  Lagrange / alpha tables are wave-uniform: kernel
+// arguments (scalar loads) for small tables, LDS for large ones.  There is no
+// cross-lane traffic on the per-secret paths; sum/dot reduce through LDS.
+//
+// All of these are HBM-bound streaming kernels except inverse, the PRG-driven
+// kernels (AES) and matmul; DESIGN.md has the per-kernel roofline accounting.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "field.hpp"
+
+namespace sclhip {
+
+constexpr int BLOCK = 256;
+constexpr int FIXED_M_MAX = 16;  // recover kernels with lambda in kernel arguments
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+// ---- 16-byte (or 8-byte) pack loads/stores ---------------------------------------------------
+template <class F, int VEC>
+struct Pack {
+  typename F::E v[VEC];
+};
+
+template <bool NT, class T>
+__device__ __forceinline__ T ldg(const T* p) {
+  if constexpr (NT)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+template <bool NT, class T>
+__device__ __forceinline__ void stg(T* p, T v) {
+  if constexpr (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+
+// p points at the first limb of element index e (already multiplied out by the caller)
+template <class F, int VEC, bool NT>
+__device__ __forceinline__ Pack<F, VEC> load_pack(const u64* p) {
+  Pack<F, VEC> r;
+  if constexpr (F::LIMBS == 1 && VEC == 2) {
+    const u64x2 w = ldg<NT>(reinterpret_cast<const u64x2*>(p));
+    r.v[0] = w.x;
+    r.v[1] = w.y;
+  } else if constexpr (F::LIMBS == 1 && VEC == 1) {
+    r.v[0] = ldg<NT>(p);
+  } else {
+    static_assert(VEC == 1, "128-bit fields use one element per lane");
+    const u64x2 w = ldg<NT>(reinterpret_cast<const u64x2*>(p));
+    r.v[0] = ((u128)w.y << 64) | w.x;
+  }
+  return r;
+}
+
+template <class F, int VEC, bool NT>
+__device__ __forceinline__ void store_pack(u64* p, const Pack<F, VEC>& r) {
+  if constexpr (F::LIMBS == 1 && VEC == 2) {
+    u64x2 w;
+    w.x = r.v[0];
+    w.y = r.v[1];
+    stg<NT>(reinterpret_cast<u64x2*>(p), w);
+  } else if constexpr (F::LIMBS == 1 && VEC == 1) {
+    stg<NT>(p, r.v[0]);
+  } else {
+    u64x2 w;
+    w.x = (u64)r.v[0];
+    w.y = (u64)(r.v[0] >> 64);
+    stg<NT>(reinterpret_cast<u64x2*>(p), w);
+  }
+}
+
+template <class F>
+struct Table {  // small kernel-argument table (wave-uniform, scalar loads)
+  typename F::E v[FIXED_M_MAX];
+};
+
+// Large table: 2 KiB of kernel arguments, copied into LDS by the block.  Bounds the party count
+// of the table-driven kernels: 256 for Mersenne61, 128 for the 128-bit fields.
+template <class F>
+struct BigTable {
+  enum { CAP = F::LIMBS == 1 ? 256 : 128 };
+  typename F::E v[CAP];
+};
+
+#define SCL_GRID_STRIDE(q, npacks) \
+  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < (npacks); q += (size_t)gridDim.x * BLOCK)
+
+// ---- element-wise --------------------------------------------------------------------------
+// Vector::add/subtract/multiplyEntryWise, FF::negate/invert/operator/ (vector.h:199-245, ff.h:203-246)
+template <class F, int OP, int VEC, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_ew(typename F::Ctx ctx, u64* dst, const u64* a, const u64* b,
+                                              size_t npacks, unsigned* zero_flag) {
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> x = load_pack<F, VEC, NT>(a + off), y, r;
+    if constexpr (OP == 0 || OP == 1 || OP == 2 || OP == 5) y = load_pack<F, VEC, NT>(b + off);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if constexpr (OP == 0) r.v[v] = F::add(ctx, x.v[v], y.v[v]);
+      if constexpr (OP == 1) r.v[v] = F::sub(ctx, x.v[v], y.v[v]);
+      if constexpr (OP == 2) r.v[v] = F::mul(ctx, x.v[v], y.v[v]);
+      if constexpr (OP == 3) r.v[v] = F::neg(ctx, x.v[v]);
+      if constexpr (OP == 4) {
+        if (F::is_zero(x.v[v])) atomicOr(zero_flag, 1u);
+        r.v[v] = F::inv(ctx, x.v[v]);
+      }
+      if constexpr (OP == 5) {
+        if (F::is_zero(y.v[v])) atomicOr(zero_flag, 1u);
+        r.v[v] = F::mul(ctx, x.v[v], F::inv(ctx, y.v[v]));
+      }
+    }
+    store_pack<F, VEC, NT>(dst + off, r);
+  }
+}
+
+// Vector::scalarMultiply (vector.h:274-301)
+template <class F, int VEC, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_scalar_mul(typename F::Ctx ctx, u64* dst, const u64* a,
+                                                      Table<F> scalar, size_t npacks) {
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> x = load_pack<F, VEC, NT>(a + off);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) x.v[v] = F::mul(ctx, scalar.v[0], x.v[v]);
+    store_pack<F, VEC, NT>(dst + off, x);
+  }
+}
+
+// ---- block reduction of canonical elements through LDS --------------------------------------
+template <class F>
+__device__ __forceinline__ typename F::E block_reduce_add(const typename F::Ctx& ctx, typename F::E x) {
+  __shared__ typename F::E red[BLOCK];
+  red[threadIdx.x] = x;
+  __syncthreads();
+#pragma unroll
+  for (int s = BLOCK / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = F::add(ctx, red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  return red[0];
+}
+
+// Vector::sum (vector.h:261-267): per-block partial sums -> partial[blockIdx]
+template <class F, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_sum(typename F::Ctx ctx, u64* partial, const u64* a, size_t npacks) {
+  typename F::Acc acc = F::acc_zero();
+  int terms = 0;
+  typename F::E run = F::zero();
+  SCL_GRID_STRIDE(q, npacks) {
+    const Pack<F, VEC> x = load_pack<F, VEC, false>(a + q * VEC * F::LIMBS);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) F::acc_add(ctx, acc, x.v[v]);
+    terms += VEC;
+    if (terms + VEC > F::ACC_TERMS) {
+      run = F::add(ctx, run, F::acc_fold(ctx, acc));
+      acc = F::acc_zero();
+      terms = 0;
+    }
+  }
+  run = F::add(ctx, run, F::acc_fold(ctx, acc));
+  const typename F::E tot = block_reduce_add<F>(ctx, run);
+  if (threadIdx.x == 0) F::st(partial + (size_t)blockIdx.x * F::LIMBS, tot);
+}
+
+// Vector::dot / innerProd (vector.h:45-52, 252-255)
+template <class F, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_dot(typename F::Ctx ctx, u64* partial, const u64* a, const u64* b,
+                                               size_t npacks) {
+  typename F::Acc acc = F::acc_zero();
+  int terms = 0;
+  typename F::E run = F::zero();
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    const Pack<F, VEC> x = load_pack<F, VEC, false>(a + off), y = load_pack<F, VEC, false>(b + off);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) F::mac(ctx, acc, x.v[v], y.v[v]);
+    terms += VEC;
+    if (terms + VEC > F::ACC_TERMS) {
+      run = F::add(ctx, run, F::acc_fold(ctx, acc));
+      acc = F::acc_zero();
+      terms = 0;
+    }
+  }
+  run = F::add(ctx, run, F::acc_fold(ctx, acc));
+  const typename F::E tot = block_reduce_add<F>(ctx, run);
+  if (threadIdx.x == 0) F::st(partial + (size_t)blockIdx.x * F::LIMBS, tot);
+}
+
+// Vector::equals (vector.h:558-570): counts mismatching limbs
+__global__ __launch_bounds__(BLOCK) void k_count_diff(unsigned long long* count, const u64* a, const u64* b,
+                                                      size_t nwords) {
+  unsigned long long local = 0;
+  SCL_GRID_STRIDE(q, nwords) local += (a[q] != b[q]);
+  if (local) atomicAdd(count, local);
+}
+
+// ---- Shamir reconstruct ----------------------------------------------------------------------
+// shamirRecoverP with a hoisted basis (shamir.h:81-104, lagrange.h:54-71, vector.h:45-52):
+// out[s] = sum_i lambda[i] * shares[i][s].  M rows fully unrolled, lambda in scalar registers,
+// all M loads issued before the first multiply.
+template <class F, int VEC, int M, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_recover_fixed(typename F::Ctx ctx, u64* out, const u64* shares,
+                                                         size_t stride, Table<F> lam, size_t npacks) {
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> x[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) x[i] = load_pack<F, VEC, NT>(shares + (size_t)i * stride * F::LIMBS + off);
+    Pack<F, VEC> r;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      typename F::Acc acc = F::acc_zero();
+#pragma unroll
+      for (int i = 0; i < M; ++i) F::mac(ctx, acc, lam.v[i], x[i].v[v]);
+      r.v[v] = F::acc_fold(ctx, acc);
+    }
+    store_pack<F, VEC, NT>(out + off, r);
+  }
+}
+
+// Any m <= BigTable::CAP: lambda staged in LDS, rows consumed 8 at a time.
+template <class F, int VEC, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_recover_table(typename F::Ctx ctx, u64* out, const u64* shares,
+                                                         size_t stride, BigTable<F> tab, int m, size_t npacks) {
+  __shared__ typename F::E lam[BigTable<F>::CAP];
+  for (int i = threadIdx.x; i < m; i += BLOCK) lam[i] = tab.v[i];
+  __syncthreads();
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    typename F::Acc acc[VEC];
+    typename F::E run[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc[v] = F::acc_zero();
+      run[v] = F::zero();
+    }
+    int i = 0, terms = 0;
+    for (; i + 8 <= m; i += 8) {
+      Pack<F, VEC> x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = load_pack<F, VEC, NT>(shares + (size_t)(i + j) * stride * F::LIMBS + off);
+      if (terms + 8 > F::ACC_TERMS) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          run[v] = F::add(ctx, run[v], F::acc_fold(ctx, acc[v]));
+          acc[v] = F::acc_zero();
+        }
+        terms = 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const typename F::E l = lam[i + j];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) F::mac(ctx, acc[v], l, x[j].v[v]);
+      }
+      terms += 8;
+    }
+    for (; i < m; ++i) {
+      const Pack<F, VEC> x = load_pack<F, VEC, NT>(shares + (size_t)i * stride * F::LIMBS + off);
+      if (terms + 1 > F::ACC_TERMS) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          run[v] = F::add(ctx, run[v], F::acc_fold(ctx, acc[v]));
+          acc[v] = F::acc_zero();
+        }
+        terms = 0;
+      }
+      const typename F::E l = lam[i];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) F::mac(ctx, acc[v], l, x.v[v]);
+      terms += 1;
+    }
+    Pack<F, VEC> r;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) r.v[v] = F::add(ctx, run[v], F::acc_fold(ctx, acc[v]));
+    store_pack<F, VEC, NT>(out + off, r);
+  }
+}
+
+// ---- Shamir share ----------------------------------------------------------------------------
+// Horner over TREG+1 register-resident coefficients (poly.h:56-64); only k <= t take part.
+template <class F, int VEC, int TREG>
+__device__ __forceinline__ void horner_rows(const typename F::Ctx& ctx, const Pack<F, VEC> (&c)[TREG + 1], int t,
+                                            const typename F::E* alpha_lds, int n, u64* shares, size_t stride,
+                                            size_t off) {
+  for (int i = 0; i < n; ++i) {
+    const typename F::E x = alpha_lds[i];
+    Pack<F, VEC> y;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) y.v[v] = F::zero();
+#pragma unroll
+    for (int k = TREG; k >= 0; --k) {
+      if (k <= t) {  // wave-uniform
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) y.v[v] = F::add(ctx, F::mul(ctx, y.v[v], x), c[k].v[v]);
+      }
+    }
+    store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
+  }
+}
+
+// shamirSecretShare with explicit coefficients (shamir.h:51-68): c_0 = secret, c_k = coeffs[k-1]
+template <class F, int VEC, int TREG>
+__global__ __launch_bounds__(BLOCK) void k_share(typename F::Ctx ctx, u64* shares, size_t stride,
+                                                 const u64* secrets, const u64* coeffs, size_t cstride,
+                                                 BigTable<F> tab, int t, int n, size_t npacks) {
+  __shared__ typename F::E alpha[BigTable<F>::CAP];
+  for (int i = threadIdx.x; i < n; i += BLOCK) alpha[i] = tab.v[i];
+  __syncthreads();
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> c[TREG + 1];
+    c[0] = load_pack<F, VEC, true>(secrets + off);
+#pragma unroll
+    for (int k = 1; k <= TREG; ++k) {
+      if (k <= t) c[k] = load_pack<F, VEC, true>(coeffs + (size_t)(k - 1) * cstride * F::LIMBS + off);
+    }
+    horner_rows<F, VEC, TREG>(ctx, c, t, alpha, n, shares, stride, off);
+  }
+}
+
+// ---- AES-128 for util::PRG (src/scl/util/prg.cc) ------------------------------------------------
+// One 256-entry T-table (SubBytes+MixColumns of one byte) in LDS, other three by rotation.
+struct AesKey {
+  u32 rk[44];    // 11 round keys, little-endian column words
+  u32 te0[256];  // te0[x] = (2S, S, S, 3S) as bytes 0..3, S = sbox[x]
+};
+
+__device__ __forceinline__ u32 rotl32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
+
+// block = AES( LE64(counter) || LE64(0x0123456789ABCDEF) ) (prg.h:34-43, prg.cc:82-84)
+__device__ __forceinline__ void aes_ctr_block(const u32* te0, const u32* rk, u64 counter, u64& out_lo, u64& out_hi) {
+  u32 s0 = (u32)counter ^ rk[0], s1 = (u32)(counter >> 32) ^ rk[1], s2 = 0x89ABCDEFu ^ rk[2],
+      s3 = 0x01234567u ^ rk[3];
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    const u32 t0 = te0[s0 & 255] ^ rotl32(te0[(s1 >> 8) & 255], 8) ^ rotl32(te0[(s2 >> 16) & 255], 16) ^
+                   rotl32(te0[s3 >> 24], 24) ^ rk[4 * r + 0];
+    const u32 t1 = te0[s1 & 255] ^ rotl32(te0[(s2 >> 8) & 255], 8) ^ rotl32(te0[(s3 >> 16) & 255], 16) ^
+                   rotl32(te0[s0 >> 24], 24) ^ rk[4 * r + 1];
+    const u32 t2 = te0[s2 & 255] ^ rotl32(te0[(s3 >> 8) & 255], 8) ^ rotl32(te0[(s0 >> 16) & 255], 16) ^
+                   rotl32(te0[s1 >> 24], 24) ^ rk[4 * r + 2];
+    const u32 t3 = te0[s3 & 255] ^ rotl32(te0[(s0 >> 8) & 255], 8) ^ rotl32(te0[(s1 >> 16) & 255], 16) ^
+                   rotl32(te0[s2 >> 24], 24) ^ rk[4 * r + 3];
+    s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+  }
+  // last round: SubBytes + ShiftRows only; S = byte 1 of te0
+#define SCL_SB(x) ((te0[(x)] >> 8) & 255u)
+  const u32 o0 = (SCL_SB(s0 & 255) | (SCL_SB((s1 >> 8) & 255) << 8) | (SCL_SB((s2 >> 16) & 255) << 16) |
+                  (SCL_SB(s3 >> 24) << 24)) ^ rk[40];
+  const u32 o1 = (SCL_SB(s1 & 255) | (SCL_SB((s2 >> 8) & 255) << 8) | (SCL_SB((s3 >> 16) & 255) << 16) |
+                  (SCL_SB(s0 >> 24) << 24)) ^ rk[41];
+  const u32 o2 = (SCL_SB(s2 & 255) | (SCL_SB((s3 >> 8) & 255) << 8) | (SCL_SB((s0 >> 16) & 255) << 16) |
+                  (SCL_SB(s1 >> 24) << 24)) ^ rk[42];
+  const u32 o3 = (SCL_SB(s3 & 255) | (SCL_SB((s0 >> 8) & 255) << 8) | (SCL_SB((s1 >> 16) & 255) << 16) |
+                  (SCL_SB(s2 >> 24) << 24)) ^ rk[43];
+#undef SCL_SB
+  out_lo = (u64)o0 | ((u64)o1 << 32);
+  out_hi = (u64)o2 | ((u64)o3 << 32);
+}
+
+#define SCL_AES_PROLOGUE(key)                                            \
+  __shared__ u32 te0[256];                                               \
+  __shared__ u32 rks[44];                                                \
+  te0[threadIdx.x] = (key).te0[threadIdx.x];                             \
+  if (threadIdx.x < 44) rks[threadIdx.x] = (key).rk[threadIdx.x];        \
+  __syncthreads();
+
+// PRG::next as raw counter-addressed blocks (prg.cc:124-146)
+__global__ __launch_bounds__(BLOCK) void k_prg_blocks(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
+  SCL_AES_PROLOGUE(key)
+  SCL_GRID_STRIDE(q, nblocks) {
+    u64x2 w;
+    u64 lo, hi;
+    aes_ctr_block(te0, rks, counter0 + q, lo, hi);
+    w.x = lo;
+    w.y = hi;
+    *reinterpret_cast<u64x2*>(dst + 2 * q) = w;
+  }
+}
+
+// FF::read over a byte buffer (ff.h:63-67)
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_from_bytes(typename F::Ctx ctx, u64* dst, const unsigned char* src,
+                                                      size_t n) {
+  SCL_GRID_STRIDE(q, n) {
+    if constexpr (F::LIMBS == 1) {
+      u64 w;
+      __builtin_memcpy(&w, src + 8 * q, 8);
+      dst[q] = F::from_le_word(ctx, w);
+    } else {
+      u64 w[2];
+      __builtin_memcpy(w, src + 16 * q, 16);
+      F::st(dst + 2 * q, F::from_le_word(ctx, ((u128)w[1] << 64) | w[0]));
+    }
+  }
+}
+
+// Vector::random(n, prg) for a PRG at counter0 (vector.h:507-519): element e = bytes [e*bs,(e+1)*bs)
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_vector_random(typename F::Ctx ctx, u64* dst, AesKey key, u64 counter0,
+                                                         size_t n) {
+  SCL_AES_PROLOGUE(key)
+  if constexpr (F::LIMBS == 1) {
+    const size_t nb = (n + 1) / 2;
+    SCL_GRID_STRIDE(q, nb) {
+      u64 lo, hi;
+      aes_ctr_block(te0, rks, counter0 + q, lo, hi);
+      dst[2 * q] = F::from_le_word(ctx, lo);
+      if (2 * q + 1 < n) dst[2 * q + 1] = F::from_le_word(ctx, hi);
+    }
+  } else {
+    SCL_GRID_STRIDE(q, n) {
+      u64 lo, hi;
+      aes_ctr_block(te0, rks, counter0 + q, lo, hi);
+      F::st(dst + 2 * q, F::from_le_word(ctx, ((u128)hi << 64) | lo));
+    }
+  }
+}
+
+// shamirSecretShare driven by the reference PRG discipline (SURVEY.md section 8a note P):
+// secret s draws Vector::random(t+1) from counters [s*B, (s+1)*B), B = ceil((t+1)*byteSize/16);
+// c_0's draw is discarded and replaced by the secret (shamir.h:56-57).
+template <class F, int VEC, int TREG>
+__global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* shares, size_t stride,
+                                                     const u64* secrets, AesKey key, u64 first_secret,
+                                                     BigTable<F> tab, int t, int n, size_t npacks) {
+  SCL_AES_PROLOGUE(key)
+  __shared__ typename F::E alpha[BigTable<F>::CAP];
+  for (int i = threadIdx.x; i < n; i += BLOCK) alpha[i] = tab.v[i];
+  __syncthreads();
+  const u64 B = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1);
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> c[TREG + 1];
+    c[0] = load_pack<F, VEC, true>(secrets + off);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const u64 ctr0 = (first_secret + q * VEC + v) * B;
+      if constexpr (F::LIMBS == 1) {
+        // block j holds coefficients 2j (low 8 bytes) and 2j+1 (high 8 bytes)
+#pragma unroll
+        for (int j = 0; j <= TREG / 2; ++j) {
+          if (2 * j <= t) {
+            u64 lo, hi;
+            aes_ctr_block(te0, rks, ctr0 + j, lo, hi);
+            if (j > 0) c[2 * j].v[v] = F::from_le_word(ctx, lo);
+            if (2 * j + 1 <= TREG && 2 * j + 1 <= t) c[2 * j + 1].v[v] = F::from_le_word(ctx, hi);
+          }
+        }
+      } else {
+        // block k holds coefficient k; block 0 (c_0's draw) is never needed
+#pragma unroll
+        for (int k = 1; k <= TREG; ++k) {
+          if (k <= t) {
+            u64 lo, hi;
+            aes_ctr_block(te0, rks, ctr0 + k, lo, hi);
+            c[k].v[v] = F::from_le_word(ctx, ((u128)hi << 64) | lo);
+          }
+        }
+      }
+    }
+    horner_rows<F, VEC, TREG>(ctx, c, t, alpha, n, shares, stride, off);
+  }
+}
+
+// ---- additive ----------------------------------------------------------------------------------
+// additiveShare with explicit randomness (additive.h:41-53)
+template <class F, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_additive_share(typename F::Ctx ctx, u64* shares, size_t stride,
+                                                          const u64* secrets, const u64* rnd, size_t rstride, int n,
+                                                          size_t npacks) {
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> last = load_pack<F, VEC, true>(secrets + off);
+    for (int i = 0; i + 1 < n; ++i) {
+      const Pack<F, VEC> r = load_pack<F, VEC, true>(rnd + (size_t)i * rstride * F::LIMBS + off);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) last.v[v] = F::sub(ctx, last.v[v], r.v[v]);
+      store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, r);
+    }
+    store_pack<F, VEC, true>(shares + (size_t)(n - 1) * stride * F::LIMBS + off, last);
+  }
+}
+
+// PRG-driven: share i < n-1 of secret s = FF::random on counter s*(n-1)+i (ff.h:72-76: one block each)
+template <class F, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_additive_share_prg(typename F::Ctx ctx, u64* shares, size_t stride,
+                                                              const u64* secrets, AesKey key, u64 first_secret, int n,
+                                                              size_t npacks) {
+  SCL_AES_PROLOGUE(key)
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> last = load_pack<F, VEC, true>(secrets + off);
+    for (int i = 0; i + 1 < n; ++i) {
+      Pack<F, VEC> r;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        u64 lo, hi;
+        aes_ctr_block(te0, rks, (first_secret + q * VEC + v) * (u64)(n - 1) + i, lo, hi);
+        if constexpr (F::LIMBS == 1)
+          r.v[v] = F::from_le_word(ctx, lo);
+        else
+          r.v[v] = F::from_le_word(ctx, ((u128)hi << 64) | lo);
+        last.v[v] = F::sub(ctx, last.v[v], r.v[v]);
+      }
+      store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, r);
+    }
+    store_pack<F, VEC, true>(shares + (size_t)(n - 1) * stride * F::LIMBS + off, last);
+  }
+}
+
+// reconstruct = Vector::sum per secret (vector.h:261-267)
+template <class F, int VEC, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_additive_recover(typename F::Ctx ctx, u64* out, const u64* shares,
+                                                            size_t stride, int n, size_t npacks) {
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    typename F::Acc acc[VEC];
+    typename F::E run[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc[v] = F::acc_zero();
+      run[v] = F::zero();
+    }
+    int terms = 0;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+      Pack<F, VEC> x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = load_pack<F, VEC, NT>(shares + (size_t)(i + j) * stride * F::LIMBS + off);
+      if (terms + 4 > F::ACC_TERMS) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          run[v] = F::add(ctx, run[v], F::acc_fold(ctx, acc[v]));
+          acc[v] = F::acc_zero();
+        }
+        terms = 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) F::acc_add(ctx, acc[v], x[j].v[v]);
+      terms += 4;
+    }
+    for (; i < n; ++i) {
+      const Pack<F, VEC> x = load_pack<F, VEC, NT>(shares + (size_t)i * stride * F::LIMBS + off);
+      if (terms + 1 > F::ACC_TERMS) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          run[v] = F::add(ctx, run[v], F::acc_fold(ctx, acc[v]));
+          acc[v] = F::acc_zero();
+        }
+        terms = 0;
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) F::acc_add(ctx, acc[v], x.v[v]);
+      terms += 1;
+    }
+    Pack<F, VEC> r;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) r.v[v] = F::add(ctx, run[v], F::acc_fold(ctx, acc[v]));
+    store_pack<F, VEC, NT>(out + off, r);
+  }
+}
+
+// ---- error-detecting recovery ---------------------------------------------------------------------
+// shamirRecoverD (shamir.h:116-139): rows 0..nchk-1 of L re-derive share d+1+r from the first d+1
+// shares, row nchk evaluates at x.  L is [(nchk+1)][d+1] row-major.
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_recover_detect(typename F::Ctx ctx, u64* out, unsigned char* status,
+                                                          const u64* shares, size_t stride, const u64* L_dev, int d1,
+                                                          int nchk, size_t N, unsigned long long* bad_count) {
+  extern __shared__ unsigned char smem_raw[];
+  typename F::E* L = reinterpret_cast<typename F::E*>(smem_raw);
+  for (int i = threadIdx.x; i < (nchk + 1) * d1; i += BLOCK) L[i] = F::ld(L_dev + (size_t)i * F::LIMBS);
+  __syncthreads();
+  unsigned long long local_bad = 0;
+  SCL_GRID_STRIDE(s, N) {
+    bool bad = false;
+    typename F::E result = F::zero();
+    for (int r = 0; r <= nchk; ++r) {
+      typename F::E run = F::zero();
+      typename F::Acc acc = F::acc_zero();
+      int terms = 0;
+      for (int k = 0; k < d1; ++k) {
+        if (terms + 1 > F::ACC_TERMS) {
+          run = F::add(ctx, run, F::acc_fold(ctx, acc));
+          acc = F::acc_zero();
+          terms = 0;
+        }
+        F::mac(ctx, acc, L[r * d1 + k], F::ld(shares + ((size_t)k * stride + s) * F::LIMBS));
+        ++terms;
+      }
+      const typename F::E y = F::add(ctx, run, F::acc_fold(ctx, acc));
+      if (r < nchk) {
+        const typename F::E got = F::ld(shares + ((size_t)(d1 + r) * stride + s) * F::LIMBS);
+        bad |= !F::eq(y, got);
+      } else {
+        result = y;
+      }
+    }
+    status[s] = bad ? 1 : 0;
+    F::st(out + s * F::LIMBS, bad ? F::zero() : result);
+    local_bad += bad;
+  }
+  if (local_bad) atomicAdd(bad_count, local_bad);
+}
+
+// ---- matrices ---------------------------------------------------------------------------------------
+// Matrix::multiply (matrix.h:477-495): C[M x N] = A[M x K] * B[K x N].  One thread per column j,
+// RM rows of A at a time (A tile in LDS, wave-uniform reads), B streamed coalesced.
+template <class F, int RM>
+__global__ __launch_bounds__(BLOCK) void k_matmul(typename F::Ctx ctx, u64* C, size_t ldc, const u64* A, size_t lda,
+                                                  const u64* B, size_t ldb, int M, int K, size_t N, int rows_per_tile) {
+  extern __shared__ unsigned char smem_raw[];
+  typename F::E* As = reinterpret_cast<typename F::E*>(smem_raw);
+  const int row0 = blockIdx.y * rows_per_tile;
+  const int rows = min(rows_per_tile, M - row0);
+  for (int i = threadIdx.x; i < rows * K; i += BLOCK)
+    As[i] = F::ld(A + ((size_t)(row0 + i / K) * lda + (i % K)) * F::LIMBS);
+  __syncthreads();
+  SCL_GRID_STRIDE(j, N) {
+    for (int r0 = 0; r0 < rows; r0 += RM) {
+      typename F::Acc acc[RM];
+      typename F::E run[RM];
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        acc[r] = F::acc_zero();
+        run[r] = F::zero();
+      }
+      int terms = 0;
+      for (int k = 0; k < K; ++k) {
+        const typename F::E b = F::ld(B + ((size_t)k * ldb + j) * F::LIMBS);
+        if (terms + 1 > F::ACC_TERMS) {
+#pragma unroll
+          for (int r = 0; r < RM; ++r) {
+            run[r] = F::add(ctx, run[r], F::acc_fold(ctx, acc[r]));
+            acc[r] = F::acc_zero();
+          }
+          terms = 0;
+        }
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+          const int rr = (r0 + r < rows) ? r0 + r : rows - 1;  // clamp: duplicates are discarded below
+          F::mac(ctx, acc[r], As[rr * K + k], b);
+        }
+        ++terms;
+      }
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        if (r0 + r < rows)
+          F::st(C + ((size_t)(row0 + r0 + r) * ldc + j) * F::LIMBS, F::add(ctx, run[r], F::acc_fold(ctx, acc[r])));
+      }
+    }
+  }
+}
+
+// ---- layout ----------------------------------------------------------------------------------------------
+// AoS [N][n] (reference Vector per secret) <-> SoA [n][stride], staged through LDS so that both the
+// global reads and the global writes are contiguous.  Tile = TS secrets x n parties.
+template <int LIMBS, bool TO_SOA>
+__global__ __launch_bounds__(BLOCK) void k_transpose(u64* dst, const u64* src, size_t stride, size_t N, int n,
+                                                     int tile_secrets) {
+  extern __shared__ unsigned char smem_raw[];
+  u64* tile = reinterpret_cast<u64*>(smem_raw);  // [tile_secrets][n] elements, AoS order
+  const size_t ntiles = (N + tile_secrets - 1) / tile_secrets;
+  for (size_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const size_t s0 = tix * tile_secrets;
+    const int ts = (int)min((size_t)tile_secrets, N - s0);
+    const int words = ts * n * LIMBS;
+    if constexpr (TO_SOA) {
+      const u64* a = src + s0 * n * LIMBS;
+      for (int w = threadIdx.x; w < words; w += BLOCK) tile[w] = a[w];
+      __syncthreads();
+      for (int e = threadIdx.x; e < ts * n; e += BLOCK) {
+        const int i = e / ts, s = e % ts;
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l) dst[((size_t)i * stride + s0 + s) * LIMBS + l] = tile[(s * n + i) * LIMBS + l];
+      }
+    } else {
+      for (int e = threadIdx.x; e < ts * n; e += BLOCK) {
+        const int i = e / ts, s = e % ts;
+#pragma unroll
+        for (int l = 0; l < LIMBS; ++l) tile[(s * n + i) * LIMBS + l] = src[((size_t)i * stride + s0 + s) * LIMBS + l];
+      }
+      __syncthreads();
+      u64* a = dst + s0 * n * LIMBS;
+      for (int w = threadIdx.x; w < words; w += BLOCK) a[w] = tile[w];
+    }
+    __syncthreads();
+  }
+}
+
+// ---- roofline probe ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_copy16(u64x2* dst, const u64x2* src, size_t n16) {
+  SCL_GRID_STRIDE(q, n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + q), dst + q);
+}
+
+}  // namespace sclhip

@@ -1,0 +1,337 @@
+"""scl_amd -- Python harness over libscl_hip.so, the MI355X-native finite-field /
+secret-sharing engine behind SCL's API (include/scl_hip.h is the boundary).
+
+This module is plumbing: it hands torch device buffers (`data_ptr()`) and the
+current HIP stream to the C ABI.  All arithmetic runs in the HIP kernels of
+csrc/; there is no CPU or torch fallback -- if the extension is missing the
+import fails, and if no GPU is present every batch call raises SclError.
+
+Conventions: an element tensor has dtype int64 (the bits of the uint64 limbs)
+and trailing dimension `limbs(field)`; a share matrix is SoA `[party][secret][limb]`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch  # imported BEFORE the extension so both share torch's libamdhip64 (same SONAME)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libscl_hip.so")
+if not os.path.exists(_SO):
+    raise ImportError(
+        f"{_SO} is missing: build the HIP extension first "
+        "(python -c 'import __graft_entry__ as g; g.build()' or make -C secure-computation-library_amd/csrc)")
+lib = C.CDLL(_SO)
+
+M61, M127, MONT128, GF2_128 = 0, 1, 2, 3
+ADD, SUB, MUL, NEG, INV, DIV = range(6)
+OK, ERR_SIZE_MISMATCH, ERR_ZERO_INVERSE, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_ERROR_DETECTED, \
+    ERR_NOT_ENOUGH_SHARES, ERR_MATMUL_DIMS, ERR_VANDERMONDE_XS, ERR_INVALID_RANGE = range(11)
+
+lib.scl_hip_last_error.restype = C.c_char_p
+lib.scl_hip_status_message.restype = C.c_char_p
+lib.scl_hip_field_name.restype = C.c_char_p
+
+_u64p = C.POINTER(C.c_uint64)
+
+
+class SclError(RuntimeError):
+    """status + the message the reference would put in its C++ exception"""
+
+    def __init__(self, status: int, detail: str):
+        self.status = status
+        self.reference_message = lib.scl_hip_status_message(status).decode()
+        super().__init__(f"[{status}] {self.reference_message}" + (f" ({detail})" if detail and detail != self.reference_message else ""))
+
+
+def _chk(status: int):
+    if status != OK:
+        raise SclError(status, lib.scl_hip_last_error().decode())
+
+
+def limbs(field: int) -> int:
+    n = lib.scl_hip_limbs(field)
+    if n < 0:
+        raise SclError(ERR_BAD_ARG, "unknown field tag")
+    return n
+
+
+def field_name(field: int) -> str:
+    return lib.scl_hip_field_name(field).decode()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor):
+    if not t.is_cuda:
+        raise SclError(ERR_BAD_ARG, "tensor is not on the GPU")
+    if not t.is_contiguous():
+        raise SclError(ERR_BAD_ARG, "tensor is not contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _host(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _hp(a: np.ndarray):
+    return a.ctypes.data_as(_u64p)
+
+
+def to_device(a, device="cuda") -> torch.Tensor:
+    """numpy uint64 (..., limbs) -> int64 device tensor"""
+    return torch.from_numpy(_host(a).view(np.int64)).to(device)
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+def empty(field: int, *shape, device="cuda") -> torch.Tensor:
+    return torch.empty(*shape, limbs(field), dtype=torch.int64, device=device)
+
+
+def set_tuning(key: str, value: int):
+    _chk(lib.scl_hip_set_tuning(key.encode(), C.c_long(value)))
+
+
+def set_mont128_prime(p: int):
+    a = np.array([p & (2 ** 64 - 1), p >> 64], dtype=np.uint64)
+    _chk(lib.scl_hip_mont128_set_prime(_hp(a)))
+
+
+# ---- element-wise: scl::math::Vector<FF> ------------------------------------------------------------
+def ew(field, op, a, b=None, out=None):
+    L = limbs(field)
+    if b is not None and b.shape != a.shape:
+        raise SclError(ERR_SIZE_MISMATCH, "")  # Vector::ensureCompatible
+    if out is None:
+        out = torch.empty_like(a)
+    n = a.numel() // L
+    _chk(lib.scl_hip_ew(field, op, _dev(out), _dev(a), _dev(b) if b is not None else None, C.c_size_t(n), _stream()))
+    return out
+
+
+def scalar_mul(field, a, scalar, out=None):
+    L = limbs(field)
+    if out is None:
+        out = torch.empty_like(a)
+    s = _host(scalar).reshape(L)
+    _chk(lib.scl_hip_scalar_mul(field, _dev(out), _dev(a), _hp(s), C.c_size_t(a.numel() // L), _stream()))
+    return out
+
+
+def vsum(field, a) -> np.ndarray:
+    L = limbs(field)
+    out = np.zeros(L, dtype=np.uint64)
+    _chk(lib.scl_hip_sum(field, _hp(out), _dev(a), C.c_size_t(a.numel() // L), _stream()))
+    return out
+
+
+def dot(field, a, b) -> np.ndarray:
+    L = limbs(field)
+    if b.shape != a.shape:
+        raise SclError(ERR_SIZE_MISMATCH, "")
+    out = np.zeros(L, dtype=np.uint64)
+    _chk(lib.scl_hip_dot(field, _hp(out), _dev(a), _dev(b), C.c_size_t(a.numel() // L), _stream()))
+    return out
+
+
+def equals(field, a, b) -> bool:
+    if a.shape != b.shape:
+        return False  # Vector::equals (vector.h:559-561)
+    eq = C.c_int(0)
+    _chk(lib.scl_hip_equals(field, C.byref(eq), _dev(a), _dev(b), C.c_size_t(a.numel() // limbs(field)), _stream()))
+    return bool(eq.value)
+
+
+# ---- randomness: scl::util::PRG ------------------------------------------------------------------------
+def prg_blocks(nblocks: int, seed: bytes, counter0: int = 0, device="cuda") -> torch.Tensor:
+    out = torch.empty(max(nblocks, 1) * 16, dtype=torch.uint8, device=device)
+    _chk(lib.scl_hip_prg_blocks(_dev(out), C.c_size_t(nblocks), seed, C.c_size_t(len(seed)), C.c_uint64(counter0),
+                                _stream()))
+    return out[: nblocks * 16]
+
+
+def from_bytes(field, raw: torch.Tensor) -> torch.Tensor:
+    L = limbs(field)
+    n = raw.numel() // (8 * L)
+    out = empty(field, n, device=raw.device)
+    _chk(lib.scl_hip_from_bytes(field, _dev(out), _dev(raw), C.c_size_t(n), _stream()))
+    return out
+
+
+def vector_random(field, n: int, seed: bytes, counter0: int = 0, device="cuda") -> torch.Tensor:
+    out = empty(field, n, device=device)
+    _chk(lib.scl_hip_vector_random(field, _dev(out), C.c_size_t(n), seed, C.c_size_t(len(seed)),
+                                   C.c_uint64(counter0), _stream()))
+    return out
+
+
+# ---- Shamir: scl::ss -----------------------------------------------------------------------------------------
+def lagrange_basis(field, m: int, alphas=None, x=None) -> np.ndarray:
+    L = limbs(field)
+    out = np.zeros((m, L), dtype=np.uint64)
+    al = _host(alphas).reshape(m, L) if alphas is not None else None
+    xx = _host(x).reshape(L) if x is not None else None
+    _chk(lib.scl_hip_lagrange_basis(field, _hp(out), _hp(al) if al is not None else None, C.c_size_t(m),
+                                    _hp(xx) if xx is not None else None))
+    return out
+
+
+def shamir_share(field, secrets, coeffs, n: int, alphas=None, out=None):
+    """secrets [N][L]; coeffs [t][N][L] (c_1..c_t) -> shares [n][N][L]"""
+    L = limbs(field)
+    N = secrets.shape[0]
+    t = 0 if coeffs is None else coeffs.shape[0]
+    if coeffs is not None and coeffs.shape[1] != N:
+        raise SclError(ERR_SIZE_MISMATCH, "")
+    if out is None:
+        out = empty(field, n, N, device=secrets.device)
+    al = _host(alphas).reshape(n, L) if alphas is not None else None
+    _chk(lib.scl_hip_shamir_share(field, _dev(out), C.c_size_t(N), _dev(secrets),
+                                  _dev(coeffs) if t else None, C.c_size_t(N), C.c_size_t(N), C.c_size_t(t),
+                                  C.c_size_t(n), _hp(al) if al is not None else None, _stream()))
+    return out
+
+
+def shamir_share_prg(field, secrets, t: int, n: int, seed: bytes, first_secret: int = 0, out=None):
+    N = secrets.shape[0]
+    if out is None:
+        out = empty(field, n, N, device=secrets.device)
+    _chk(lib.scl_hip_shamir_share_prg(field, _dev(out), C.c_size_t(N), _dev(secrets), C.c_size_t(N), C.c_size_t(t),
+                                      C.c_size_t(n), seed, C.c_size_t(len(seed)), C.c_uint64(first_secret),
+                                      _stream()))
+    return out
+
+
+def shamir_recover(field, shares, lam=None, out=None):
+    """shares [m][N][L] -> out [N][L]; lam defaults to the basis for nodes 1..m at x=0"""
+    L = limbs(field)
+    m, N = shares.shape[0], shares.shape[1]
+    if lam is None:
+        lam = lagrange_basis(field, m)
+    lam = _host(lam).reshape(m, L)
+    if out is None:
+        out = empty(field, N, device=shares.device)
+    _chk(lib.scl_hip_shamir_recover(field, _dev(out), _dev(shares), C.c_size_t(N), _hp(lam), C.c_size_t(m),
+                                    C.c_size_t(N), _stream()))
+    return out
+
+
+def shamir_recover_detect(field, shares, t: int, d: int | None = None, alphas=None, x=None):
+    """-> (out [N][L], status uint8 [N], num_bad); raises nothing for detected errors (see status)"""
+    L = limbs(field)
+    m, N = shares.shape[0], shares.shape[1]
+    d = t if d is None else d
+    out = empty(field, N, device=shares.device)
+    status = torch.empty(max(N, 1), dtype=torch.uint8, device=shares.device)
+    al = _host(alphas).reshape(m, L) if alphas is not None else None
+    xx = _host(x).reshape(L) if x is not None else None
+    bad = C.c_size_t(0)
+    st = lib.scl_hip_shamir_recover_detect(field, _dev(out), _dev(status), _dev(shares), C.c_size_t(N), C.c_size_t(m),
+                                           C.c_size_t(N), C.c_size_t(t), C.c_size_t(d),
+                                           _hp(al) if al is not None else None, _hp(xx) if xx is not None else None,
+                                           C.byref(bad), _stream())
+    if st not in (OK, ERR_ERROR_DETECTED):
+        _chk(st)
+    return out, status[:N], bad.value
+
+
+# ---- additive ----------------------------------------------------------------------------------------------------
+def additive_share(field, secrets, rnd, n: int, out=None):
+    N = secrets.shape[0]
+    if out is None:
+        out = empty(field, n, N, device=secrets.device)
+    _chk(lib.scl_hip_additive_share(field, _dev(out), C.c_size_t(N), _dev(secrets),
+                                    _dev(rnd) if rnd is not None else None, C.c_size_t(N), C.c_size_t(N),
+                                    C.c_size_t(n), _stream()))
+    return out
+
+
+def additive_share_prg(field, secrets, n: int, seed: bytes, first_secret: int = 0, out=None):
+    N = secrets.shape[0]
+    if out is None:
+        out = empty(field, n, N, device=secrets.device)
+    _chk(lib.scl_hip_additive_share_prg(field, _dev(out), C.c_size_t(N), _dev(secrets), C.c_size_t(N), C.c_size_t(n),
+                                        seed, C.c_size_t(len(seed)), C.c_uint64(first_secret), _stream()))
+    return out
+
+
+def additive_recover(field, shares, out=None):
+    n, N = shares.shape[0], shares.shape[1]
+    if out is None:
+        out = empty(field, N, device=shares.device)
+    _chk(lib.scl_hip_additive_recover(field, _dev(out), _dev(shares), C.c_size_t(N), C.c_size_t(n), C.c_size_t(N),
+                                      _stream()))
+    return out
+
+
+# ---- matrices ---------------------------------------------------------------------------------------------------------
+def vandermonde(field, n: int, m: int, xs=None, device="cuda"):
+    L = limbs(field)
+    out = empty(field, n, m, device=device)
+    x = _host(xs).reshape(n, L) if xs is not None else None
+    _chk(lib.scl_hip_vandermonde(field, _dev(out), C.c_size_t(n), C.c_size_t(m), _hp(x) if x is not None else None,
+                                 _stream()))
+    return out
+
+
+def matmul(field, A, B, out=None):
+    M, K = A.shape[0], A.shape[1]
+    if B.shape[0] != K:
+        raise SclError(ERR_MATMUL_DIMS, "")
+    N = B.shape[1]
+    if out is None:
+        out = empty(field, M, N, device=A.device)
+    _chk(lib.scl_hip_matmul(field, _dev(out), C.c_size_t(N), _dev(A), C.c_size_t(K), _dev(B), C.c_size_t(N),
+                            C.c_size_t(M), C.c_size_t(K), C.c_size_t(N), _stream()))
+    return out
+
+
+# ---- layout -----------------------------------------------------------------------------------------------------------
+def aos_to_soa(field, aos):
+    N, n = aos.shape[0], aos.shape[1]
+    out = empty(field, n, N, device=aos.device)
+    _chk(lib.scl_hip_aos_to_soa(field, _dev(out), C.c_size_t(N), _dev(aos), C.c_size_t(N), C.c_size_t(n), _stream()))
+    return out
+
+
+def soa_to_aos(field, soa):
+    n, N = soa.shape[0], soa.shape[1]
+    out = empty(field, N, n, device=soa.device)
+    _chk(lib.scl_hip_soa_to_aos(field, _dev(out), _dev(soa), C.c_size_t(N), C.c_size_t(N), C.c_size_t(n), _stream()))
+    return out
+
+
+def stream_copy(dst: torch.Tensor, src: torch.Tensor):
+    _chk(lib.scl_hip_stream_copy(_dev(dst), _dev(src), C.c_size_t(src.numel() * src.element_size()), _stream()))
+
+
+class Timer:
+    """HIP-event timer on the stream the kernels are launched on (torch's current stream)"""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _chk(lib.scl_hip_timer_create(C.byref(self._h)))
+
+    def start(self):
+        _chk(lib.scl_hip_timer_start(self._h, _stream()))
+
+    def stop(self):
+        _chk(lib.scl_hip_timer_stop(self._h, _stream()))
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float()
+        _chk(lib.scl_hip_timer_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib.scl_hip_timer_destroy(self._h)
+        except Exception:
+            pass

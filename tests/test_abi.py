@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol that
+include/scl_hip.h declares, and its host-only entry points (tables, messages) behave like the
+reference.  No kernels are launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def scl():
+    import scl_amd
+    return scl_amd
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "scl_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(scl_hip_\w+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(scl):
+    names = declared_symbols()
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(scl.lib, n)]
+    assert not missing, missing
+
+
+def test_metadata_and_messages(scl):
+    assert scl.lib.scl_hip_abi_version() == 1
+    assert [scl.limbs(f) for f in range(4)] == [1, 2, 2, 2]
+    # names pinned by test/scl/math/test_mersenne61.cc:28-33, test_mersenne127.cc:28-33
+    assert scl.field_name(0) == "Mersenne61" and scl.field_name(1) == "Mersenne127"
+    msg = lambda s: scl.lib.scl_hip_status_message(s).decode()
+    assert msg(scl.ERR_ZERO_INVERSE) == "0 not invertible modulo prime"
+    assert msg(scl.ERR_SIZE_MISMATCH) == "Vec sizes mismatch"
+    assert msg(scl.ERR_ERROR_DETECTED) == "error detected during recovery"
+    assert msg(scl.ERR_NOT_ENOUGH_SHARES) == "not enough shares provided to detect errors"
+    assert msg(scl.ERR_MATMUL_DIMS) == "matmul: this->cols() != that->rows()"
+    assert msg(scl.ERR_VANDERMONDE_XS) == "|xs| != number of rows"
+    assert msg(scl.ERR_INVALID_RANGE) == "invalid range"
+
+
+@pytest.mark.parametrize("f", [O.M61, O.M127, O.MONT128, O.GF2_128])
+def test_host_lagrange_basis_matches_oracle(scl, f):
+    """the hoisted basis (host table code in csrc/capi.hip, Fermat inverses) == the oracle's
+    per-factor Euclid divisions (lagrange.h:54-71)"""
+    port = O.Port()
+    L = O.LIMBS[f]
+    for m in (1, 2, 4, 10, 40, 128):
+        if f in (O.MONT128, O.GF2_128) and m > 40:
+            continue
+        nodes = O.from_ints(list(range(1, m + 1)), L) if f == O.GF2_128 else np.stack(
+            [port.from_int(f, i + 1) for i in range(m)])
+        want = port.lagrange_basis(f, nodes, port.from_int(f, 0))
+        assert np.array_equal(scl.lagrange_basis(f, m), want), (f, m)
+    nodes = port.vector_random(f, b"nodes", 9)
+    x = port.vector_random(f, b"x", 1)[0]
+    assert np.array_equal(scl.lagrange_basis(f, 9, nodes, x), port.lagrange_basis(f, nodes, x))
+    nodes[3] = nodes[7]
+    with pytest.raises(scl.SclError) as ei:
+        scl.lagrange_basis(f, 9, nodes, x)
+    assert ei.value.status == scl.ERR_ZERO_INVERSE
+
+
+def test_mont128_prime_roundtrip(scl):
+    p = np.zeros(2, dtype=np.uint64)
+    scl.lib.scl_hip_mont128_get_prime(p.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert O.to_ints(p.reshape(1, 2))[0] == 2 ** 128 - 159
+    with pytest.raises(scl.SclError):
+        scl.set_mont128_prime(2 ** 100)  # even
+
+
+def test_batch_calls_fail_loudly_without_a_gpu(scl):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cnt = C.c_int(-1)
+    st = scl.lib.scl_hip_device_count(C.byref(cnt))
+    assert st != 0 or cnt.value == 0
+    # a device pointer is required: host tensors are rejected, nothing is computed on the CPU
+    a = torch.zeros(4, 1, dtype=torch.int64)
+    with pytest.raises(scl.SclError):
+        scl.ew(O.M61, O.ADD, a, a)
