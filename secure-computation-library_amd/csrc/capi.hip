@@ -53,8 +53,10 @@ std::atomic<long> g_force_table{0};
 
 unsigned grid_for(size_t work_items) {
   size_t blocks = (work_items + BLOCK - 1) / BLOCK;
+  // Measured on MI355X (profiles/r1_tune_m61.txt): one pack per thread with no grid-stride wrap is the
+  // fastest geometry for every streaming kernel here; "max_blocks" caps it for experiments.
   long cap = g_max_blocks.load();
-  if (cap <= 0) cap = 256 * 16;  // 256 CUs x 16 blocks; grid-stride covers the rest
+  if (cap <= 0) cap = 0x7fffffff;
   if (blocks > (size_t)cap) blocks = (size_t)cap;
   if (blocks == 0) blocks = 1;
   return (unsigned)blocks;
@@ -699,6 +701,34 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
     BigTable<F> al;
     SCL_TRY(alpha_table<F>(ctx, alphas_host, n, al));
     const int vec = vec_width<F>({shares, secrets, coeffs}, {share_stride, t ? coeff_stride : 0});
+    if constexpr (F::TAG <= 1) {
+      // Small-node path: every power alpha_i^k (as an integer, no reduction) stays below 2^29.
+      SmallVdm sv;
+      bool small = !g_force_table.load() && t >= 1 && t <= (size_t)SmallVdm::TMAX && n * (t + 1) <= (size_t)SmallVdm::CAP;
+      const u128 lim = (u128)1 << 29;
+      for (size_t i = 0; small && i < n; ++i) {
+        const u128 a = al.v[i];
+        u128 pw = 1;
+        for (size_t k = 0; k <= t; ++k) {
+          if (pw >= lim) { small = false; break; }
+          sv.v[i * (t + 1) + k] = (u32)pw;
+          if (k < t) {
+            if (a >= lim) { small = false; break; }
+            pw *= a;  // < 2^58
+          }
+        }
+      }
+      if (small) {
+        return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+          constexpr int VEC = decltype(V)::value;
+          hipLaunchKernelGGL((k_share_small<F, VEC>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream),
+                             shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS,
+                             coeffs + first * F::LIMBS, coeff_stride, sv, (int)t, (int)n, npacks);
+          LAUNCH_CHECK();
+          return SCL_OK;
+        });
+      }
+    }
     return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;
       u64* sh = shares + first * F::LIMBS;

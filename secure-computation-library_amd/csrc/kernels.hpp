@@ -328,6 +328,95 @@ __global__ __launch_bounds__(BLOCK) void k_share(typename F::Ctx ctx, u64* share
   }
 }
 
+// Vandermonde-row formulation for SMALL nodes (the default nodes 1..n): share_i = sum_k c_k * V[i][k]
+// with V[i][k] = alpha_i^k < 2^29 held as u32 in LDS.  A 61/127-bit coefficient times a 29-bit
+// constant is one v_mad_u64_u32 per 32-bit limb, accumulated lazily per limb (<= 7 terms cannot
+// overflow 64 bits) and folded once per share -- about half the multiplier work of Horner with
+// full-width nodes, which is what lets the (10,3) share kernel run at the HBM rate.
+struct SmallVdm {
+  enum { CAP = 512, TMAX = 7 };
+  u32 v[CAP];  // row-major [n][t+1]
+};
+
+template <class F>
+struct SmallAcc;
+
+template <>
+struct SmallAcc<M61> {
+  u64 a0, a1;
+  __device__ __forceinline__ void init() { a0 = a1 = 0; }
+  __device__ __forceinline__ void mac(u64 c, u32 v) {
+    a0 += (u64)(u32)c * v;          // c_lo * v < 2^61
+    a1 += (u64)(u32)(c >> 32) * v;  // c_hi < 2^29, * v < 2^58
+  }
+  // c0 + a0 + a1*2^32 mod p, with 2^61 = 1: a1*2^32 = (a1 >> 29) + ((a1 & (2^29-1)) << 32)
+  __device__ __forceinline__ u64 fold(u64 c0) const {
+    const u64 P = M61::P;
+    const u64 s = (a0 & P) + (a0 >> 61) + c0 + (a1 >> 29) + ((a1 & 0x1FFFFFFFull) << 32);  // < 2^63
+    const u64 r = (s & P) + (s >> 61);
+    return r >= P ? r - P : r;
+  }
+};
+
+template <>
+struct SmallAcc<M127> {
+  u64 a[4];
+  __device__ __forceinline__ void init() { a[0] = a[1] = a[2] = a[3] = 0; }
+  __device__ __forceinline__ void mac(u128 c, u32 v) {
+    a[0] += (u64)(u32)c * v;
+    a[1] += (u64)(u32)(c >> 32) * v;
+    a[2] += (u64)(u32)(c >> 64) * v;
+    a[3] += (u64)(u32)(c >> 96) * v;
+  }
+  // c0 + sum_j a_j 2^(32j) mod p: assemble a 192-bit value, then hi*2^128 = 2*hi (mod p)
+  __device__ __forceinline__ u128 fold(u128 c0) const {
+    M127::Acc acc = M127::acc_zero();
+    M127::acc_add_raw(acc, c0);
+    M127::acc_add_raw(acc, (u128)a[0]);
+    M127::acc_add_raw(acc, (u128)a[1] << 32);
+    M127::acc_add_raw(acc, (u128)a[2] << 64);
+    M127::acc_add_raw(acc, (u128)a[3] << 96);  // low 32 bits of a3 land in bits 96..127
+    acc.hi += (u64)(a[3] >> 32);                // the rest of a3 is a multiple of 2^128
+    return M127::acc_fold(M127::Ctx{}, acc);
+  }
+};
+
+template <class F, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_share_small(u64* shares, size_t stride, const u64* secrets,
+                                                       const u64* coeffs, size_t cstride, SmallVdm tab, int t, int n,
+                                                       size_t npacks) {
+  __shared__ u32 V[SmallVdm::CAP];
+  for (int i = threadIdx.x; i < n * (t + 1); i += BLOCK) V[i] = tab.v[i];
+  __syncthreads();
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> c[SmallVdm::TMAX + 1];
+    c[0] = load_pack<F, VEC, true>(secrets + off);
+#pragma unroll
+    for (int k = 1; k <= SmallVdm::TMAX; ++k) {
+      if (k <= t) c[k] = load_pack<F, VEC, true>(coeffs + (size_t)(k - 1) * cstride * F::LIMBS + off);
+    }
+    for (int i = 0; i < n; ++i) {
+      const u32* row = V + i * (t + 1);
+      SmallAcc<F> acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v].init();
+#pragma unroll
+      for (int k = 1; k <= SmallVdm::TMAX; ++k) {
+        if (k <= t) {
+          const u32 w = row[k];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v].mac(c[k].v[v], w);
+        }
+      }
+      Pack<F, VEC> y;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) y.v[v] = acc[v].fold(c[0].v[v]);  // V[i][0] = 1
+      store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
+    }
+  }
+}
+
 // ---- AES-128 for util::PRG (src/scl/util/prg.cc) ------------------------------------------------
 // One 256-entry T-table (SubBytes+MixColumns of one byte) in LDS, other three by rotation.
 struct AesKey {

@@ -239,6 +239,12 @@ def test_shamir_share_recover_vs_oracle(scl, port, f, n, t, N):
     dco = dev(scl, np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2)))) if t else None
     got2 = scl.shamir_share(f, dev(scl, secrets), dco, n)
     assert np.array_equal(host(scl, got2), want2)
+    # the Horner kernel (used for large / arbitrary nodes) on the same inputs
+    scl.set_tuning("force_table", 1)
+    try:
+        assert np.array_equal(host(scl, scl.shamir_share(f, dev(scl, secrets), dco, n)), want2)
+    finally:
+        scl.set_tuning("force_table", 0)
     # reconstruct from all n shares (reference semantics) and from the first t+1
     lam = scl.lagrange_basis(f, n)
     assert np.array_equal(lam, port.lagrange_basis(f, O.from_ints(list(range(1, n + 1)), L) if f == O.GF2_128 else
@@ -251,6 +257,31 @@ def test_shamir_share_recover_vs_oracle(scl, port, f, n, t, N):
     # oracle's per-secret recompute-the-basis path gives the same values
     if f != O.GF2_128:
         assert np.array_equal(host(scl, rec), port.shamir_recover(f, np.ascontiguousarray(np.transpose(want2, (1, 0, 2)))))
+
+
+@pytest.mark.parametrize("f", ALL_FIELDS)
+def test_share_with_explicit_nodes(scl, port, f):
+    """nodes 42..48 (test_shamir.cc:81-109), worst-case small nodes, and arbitrary field elements"""
+    L, N, t = O.LIMBS[f], 333, 3
+    secrets = rand_elems(port, f, N, b"xs")
+    coeffs = rand_elems(port, f, t * N, b"xc").reshape(N, t, L)
+    if N > 3:  # p-1 everywhere in one column: the lazy per-limb accumulators at their bound
+        secrets[0] = port.from_int(f, -1)
+        coeffs[0] = port.from_int(f, -1)
+    dco = dev(scl, np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2))))
+    node_sets = [np.stack([port.from_int(f, v) for v in range(42, 49)]),
+                 np.stack([port.from_int(f, v) for v in (812, 1, 811, 3)]),   # 812^3 just below 2^29
+                 np.stack([port.from_int(f, v) for v in (813, 2)]),           # 813^3 just above 2^29
+                 rand_elems(port, f, 5, b"nodes")]
+    if f == O.GF2_128:
+        node_sets = [O.from_ints(list(range(42, 49)), L), rand_elems(port, f, 5, b"nodes")]
+    for nodes in node_sets:
+        want = soa(np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)]))
+        got = scl.shamir_share(f, dev(scl, secrets), dco, nodes.shape[0], alphas=nodes)
+        assert np.array_equal(host(scl, got), want)
+        if nodes.shape[0] > t:
+            lam = scl.lagrange_basis(f, nodes.shape[0], nodes)
+            assert np.array_equal(host(scl, scl.shamir_recover(f, got, lam)), secrets)
 
 
 @pytest.mark.parametrize("f", [O.M61, O.M127])
