@@ -62,6 +62,18 @@ unsigned grid_for(size_t work_items) {
   return (unsigned)blocks;
 }
 
+// PRG kernels carry a 32 KiB replicated AES table per block: a fixed grid of resident blocks that
+// grid-strides amortises filling it.
+std::atomic<long> g_aes_blocks{0};
+unsigned grid_aes(size_t work_items) {
+  size_t blocks = (work_items + BLOCK - 1) / BLOCK;
+  long cap = g_aes_blocks.load();
+  if (cap <= 0) cap = AES_GRID_CAP;
+  if (blocks > (size_t)cap) blocks = (size_t)cap;
+  if (blocks == 0) blocks = 1;
+  return (unsigned)blocks;
+}
+
 // ---- Mont128 process-wide modulus ---------------------------------------------------------------
 std::mutex g_mont_mu;
 Mont128::Ctx g_mont = {0, 0, 0, 0};
@@ -254,6 +266,26 @@ int check_align(std::initializer_list<const void*> ptrs) {
   return SCL_OK;
 }
 
+// Small-node test: every power alpha_i^k, k <= t, as an integer (no reduction) stays below 2^29.
+template <class F>
+bool small_vandermonde(const BigTable<F>& al, size_t n, size_t t, SmallVdm& sv) {
+  if (g_force_table.load() || t > (size_t)SmallVdm::TMAX || n * (t + 1) > (size_t)SmallVdm::CAP) return false;
+  const u128 lim = (u128)1 << 29;
+  for (size_t i = 0; i < n; ++i) {
+    const u128 a = al.v[i];
+    u128 pw = 1;
+    for (size_t k = 0; k <= t; ++k) {
+      if (pw >= lim) return false;
+      sv.v[i * (t + 1) + k] = (u32)pw;
+      if (k < t) {
+        if (a >= lim) return false;
+        pw *= a;  // < 2^58
+      }
+    }
+  }
+  return true;
+}
+
 template <class F>
 int alpha_table(const typename F::Ctx& ctx, const u64* alphas_host, size_t n, BigTable<F>& tab) {
   if (n > (size_t)BigTable<F>::CAP)
@@ -435,6 +467,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "nontemporal") g_nontemporal = value;
   else if (k == "force_scalar") g_force_scalar = value;
   else if (k == "force_table") g_force_table = value;
+  else if (k == "aes_blocks") g_aes_blocks = value;
   else return fail(SCL_ERR_BAD_ARG, "unknown tuning key " + k);
   return SCL_OK;
 }
@@ -594,7 +627,7 @@ int scl_hip_prg_blocks(unsigned char* dst, size_t nblocks, const unsigned char* 
   if (!aligned16(dst)) return fail(SCL_ERR_BAD_ARG, "dst not 16-byte aligned");
   AesKey key;
   make_aes_key(seed, seed_len, key);
-  hipLaunchKernelGGL(k_prg_blocks, dim3(grid_for(nblocks)), dim3(BLOCK), 0, S(stream), reinterpret_cast<u64*>(dst),
+  hipLaunchKernelGGL(k_prg_blocks, dim3(grid_aes((nblocks + 3) / 4)), dim3(BLOCK), 0, S(stream), reinterpret_cast<u64*>(dst),
                      key, (u64)counter0, nblocks);
   LAUNCH_CHECK();
   return SCL_OK;
@@ -621,8 +654,8 @@ int scl_hip_vector_random(int field, uint64_t* dst, size_t n, const unsigned cha
     SCL_TRY(check_align<F>({dst}));
     AesKey key;
     make_aes_key(seed, seed_len, key);
-    const size_t work = F::LIMBS == 1 ? (n + 1) / 2 : n;
-    hipLaunchKernelGGL((k_vector_random<F>), dim3(grid_for(work)), dim3(BLOCK), 0, S(stream), ctx, dst, key,
+    const size_t work = ((F::LIMBS == 1 ? (n + 1) / 2 : n) + 3) / 4;
+    hipLaunchKernelGGL((k_vector_random<F>), dim3(grid_aes(work)), dim3(BLOCK), 0, S(stream), ctx, dst, key,
                        (u64)counter0, n);
     LAUNCH_CHECK();
     return SCL_OK;
@@ -702,22 +735,8 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
     SCL_TRY(alpha_table<F>(ctx, alphas_host, n, al));
     const int vec = vec_width<F>({shares, secrets, coeffs}, {share_stride, t ? coeff_stride : 0});
     if constexpr (F::TAG <= 1) {
-      // Small-node path: every power alpha_i^k (as an integer, no reduction) stays below 2^29.
       SmallVdm sv;
-      bool small = !g_force_table.load() && t >= 1 && t <= (size_t)SmallVdm::TMAX && n * (t + 1) <= (size_t)SmallVdm::CAP;
-      const u128 lim = (u128)1 << 29;
-      for (size_t i = 0; small && i < n; ++i) {
-        const u128 a = al.v[i];
-        u128 pw = 1;
-        for (size_t k = 0; k <= t; ++k) {
-          if (pw >= lim) { small = false; break; }
-          sv.v[i * (t + 1) + k] = (u32)pw;
-          if (k < t) {
-            if (a >= lim) { small = false; break; }
-            pw *= a;  // < 2^58
-          }
-        }
-      }
+      const bool small = t >= 1 && small_vandermonde<F>(al, n, t, sv);
       if (small) {
         return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
           constexpr int VEC = decltype(V)::value;
@@ -763,11 +782,41 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
     AesKey key;
     make_aes_key(seed, seed_len, key);
     const int vec = vec_width<F>({shares, secrets}, {share_stride});
+    if constexpr (F::TAG <= 1) {
+      SmallVdm sv;
+      if (t >= 1 && small_vandermonde<F>(al, n, t, sv)) {
+        return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+          constexpr int VEC = decltype(V)::value;
+          const int nblk = F::LIMBS == 1 ? (int)(t / 2 + 1) : (int)t;
+#define SPS_CASE(NB)                                                                                          \
+  case NB:                                                                                                    \
+    hipLaunchKernelGGL((k_share_prg_small<F, VEC, NB>), dim3(grid_aes(npacks)), dim3(BLOCK), 0, S(stream),    \
+                       shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS, key,              \
+                       (u64)(first_secret + first), sv, (int)t, (int)n, npacks);                              \
+    break;
+          switch (nblk) {
+            SPS_CASE(1) SPS_CASE(2) SPS_CASE(3) SPS_CASE(4)
+            default:
+              if constexpr (F::LIMBS == 2) {
+                switch (nblk) {
+                  SPS_CASE(5) SPS_CASE(6) SPS_CASE(7)
+                  default: return fail(SCL_ERR_BAD_ARG, "share_prg: internal block count");
+                }
+              } else {
+                return fail(SCL_ERR_BAD_ARG, "share_prg: internal block count");
+              }
+          }
+#undef SPS_CASE
+          LAUNCH_CHECK();
+          return SCL_OK;
+        });
+      }
+    }
     return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;
       u64* sh = shares + first * F::LIMBS;
       const u64* se = secrets + first * F::LIMBS;
-      const dim3 g(grid_for(npacks)), blk(BLOCK);
+      const dim3 g(grid_aes(npacks)), blk(BLOCK);
 #define SHAREP_LAUNCH(TREG)                                                                                   \
   hipLaunchKernelGGL((k_share_prg<F, VEC, TREG>), g, blk, 0, S(stream), ctx, sh, share_stride, se, key,         \
                      (u64)(first_secret + first), al, (int)t, (int)n, npacks)
@@ -863,7 +912,7 @@ int scl_hip_additive_share_prg(int field, uint64_t* shares, size_t share_stride,
     const int vec = vec_width<F>({shares, secrets}, {share_stride});
     return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;
-      hipLaunchKernelGGL((k_additive_share_prg<F, VEC>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx,
+      hipLaunchKernelGGL((k_additive_share_prg<F, VEC>), dim3(grid_aes(npacks)), dim3(BLOCK), 0, S(stream), ctx,
                          shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS, key,
                          (u64)(first_secret + first), (int)n, npacks);
       LAUNCH_CHECK();

@@ -382,6 +382,29 @@ struct SmallAcc<M127> {
 };
 
 template <class F, int VEC>
+__device__ __forceinline__ void small_rows(const Pack<F, VEC> (&c)[SmallVdm::TMAX + 1], const u32* V, int t, int n,
+                                           u64* shares, size_t stride, size_t off) {
+  for (int i = 0; i < n; ++i) {
+    const u32* row = V + i * (t + 1);
+    SmallAcc<F> acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v].init();
+#pragma unroll
+    for (int k = 1; k <= SmallVdm::TMAX; ++k) {
+      if (k <= t) {
+        const u32 w = row[k];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v].mac(c[k].v[v], w);
+      }
+    }
+    Pack<F, VEC> y;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) y.v[v] = acc[v].fold(c[0].v[v]);  // V[i][0] = 1
+    store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
+  }
+}
+
+template <class F, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_share_small(u64* shares, size_t stride, const u64* secrets,
                                                        const u64* coeffs, size_t cstride, SmallVdm tab, int t, int n,
                                                        size_t npacks) {
@@ -396,84 +419,134 @@ __global__ __launch_bounds__(BLOCK) void k_share_small(u64* shares, size_t strid
     for (int k = 1; k <= SmallVdm::TMAX; ++k) {
       if (k <= t) c[k] = load_pack<F, VEC, true>(coeffs + (size_t)(k - 1) * cstride * F::LIMBS + off);
     }
-    for (int i = 0; i < n; ++i) {
-      const u32* row = V + i * (t + 1);
-      SmallAcc<F> acc[VEC];
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v].init();
-#pragma unroll
-      for (int k = 1; k <= SmallVdm::TMAX; ++k) {
-        if (k <= t) {
-          const u32 w = row[k];
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) acc[v].mac(c[k].v[v], w);
-        }
-      }
-      Pack<F, VEC> y;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) y.v[v] = acc[v].fold(c[0].v[v]);  // V[i][0] = 1
-      store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
-    }
+    small_rows<F, VEC>(c, V, t, n, shares, stride, off);
   }
 }
 
 // ---- AES-128 for util::PRG (src/scl/util/prg.cc) ------------------------------------------------
-// One 256-entry T-table (SubBytes+MixColumns of one byte) in LDS, other three by rotation.
+// One 256-entry T-table (SubBytes+MixColumns of one byte), the other three by rotation.  In LDS the
+// table is replicated 32 times, entry x of copy c at word x*32 + c, and lane l reads copy l & 31:
+// every ds_read_b32 of a wave then touches 32 distinct banks per half-wave -- conflict-free for
+// arbitrary (data-dependent) indices, where a single shared copy costs ~3.5 LDS cycles per read.
 struct AesKey {
-  u32 rk[44];    // 11 round keys, little-endian column words
+  u32 rk[44];    // 11 round keys, little-endian column words (wave-uniform: scalar loads)
   u32 te0[256];  // te0[x] = (2S, S, S, 3S) as bytes 0..3, S = sbox[x]
 };
+
+constexpr int AES_LDS_WORDS = 256 * 32;
+constexpr int AES_GRID_CAP = 256 * 4;  // 4 x 34 KiB blocks per CU; the PRG kernels grid-stride
 
 __device__ __forceinline__ u32 rotl32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
 
 // block = AES( LE64(counter) || LE64(0x0123456789ABCDEF) ) (prg.h:34-43, prg.cc:82-84)
-__device__ __forceinline__ void aes_ctr_block(const u32* te0, const u32* rk, u64 counter, u64& out_lo, u64& out_hi) {
-  u32 s0 = (u32)counter ^ rk[0], s1 = (u32)(counter >> 32) ^ rk[1], s2 = 0x89ABCDEFu ^ rk[2],
-      s3 = 0x01234567u ^ rk[3];
+// tl = te0 + (lane & 31): the lane's private copy, entries 32 words apart
+__device__ __forceinline__ void aes_ctr_block(const u32* tl, const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) {
+#define SCL_T(x) tl[(x) << 5]
+  u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2 = 0x89ABCDEFu ^ key.rk[2],
+      s3 = 0x01234567u ^ key.rk[3];
 #pragma unroll
   for (int r = 1; r < 10; ++r) {
-    const u32 t0 = te0[s0 & 255] ^ rotl32(te0[(s1 >> 8) & 255], 8) ^ rotl32(te0[(s2 >> 16) & 255], 16) ^
-                   rotl32(te0[s3 >> 24], 24) ^ rk[4 * r + 0];
-    const u32 t1 = te0[s1 & 255] ^ rotl32(te0[(s2 >> 8) & 255], 8) ^ rotl32(te0[(s3 >> 16) & 255], 16) ^
-                   rotl32(te0[s0 >> 24], 24) ^ rk[4 * r + 1];
-    const u32 t2 = te0[s2 & 255] ^ rotl32(te0[(s3 >> 8) & 255], 8) ^ rotl32(te0[(s0 >> 16) & 255], 16) ^
-                   rotl32(te0[s1 >> 24], 24) ^ rk[4 * r + 2];
-    const u32 t3 = te0[s3 & 255] ^ rotl32(te0[(s0 >> 8) & 255], 8) ^ rotl32(te0[(s1 >> 16) & 255], 16) ^
-                   rotl32(te0[s2 >> 24], 24) ^ rk[4 * r + 3];
+    const u32 t0 = SCL_T(s0 & 255) ^ rotl32(SCL_T((s1 >> 8) & 255), 8) ^ rotl32(SCL_T((s2 >> 16) & 255), 16) ^
+                   rotl32(SCL_T(s3 >> 24), 24) ^ key.rk[4 * r + 0];
+    const u32 t1 = SCL_T(s1 & 255) ^ rotl32(SCL_T((s2 >> 8) & 255), 8) ^ rotl32(SCL_T((s3 >> 16) & 255), 16) ^
+                   rotl32(SCL_T(s0 >> 24), 24) ^ key.rk[4 * r + 1];
+    const u32 t2 = SCL_T(s2 & 255) ^ rotl32(SCL_T((s3 >> 8) & 255), 8) ^ rotl32(SCL_T((s0 >> 16) & 255), 16) ^
+                   rotl32(SCL_T(s1 >> 24), 24) ^ key.rk[4 * r + 2];
+    const u32 t3 = SCL_T(s3 & 255) ^ rotl32(SCL_T((s0 >> 8) & 255), 8) ^ rotl32(SCL_T((s1 >> 16) & 255), 16) ^
+                   rotl32(SCL_T(s2 >> 24), 24) ^ key.rk[4 * r + 3];
     s0 = t0; s1 = t1; s2 = t2; s3 = t3;
   }
   // last round: SubBytes + ShiftRows only; S = byte 1 of te0
-#define SCL_SB(x) ((te0[(x)] >> 8) & 255u)
+#define SCL_SB(x) ((SCL_T(x) >> 8) & 255u)
   const u32 o0 = (SCL_SB(s0 & 255) | (SCL_SB((s1 >> 8) & 255) << 8) | (SCL_SB((s2 >> 16) & 255) << 16) |
-                  (SCL_SB(s3 >> 24) << 24)) ^ rk[40];
+                  (SCL_SB(s3 >> 24) << 24)) ^ key.rk[40];
   const u32 o1 = (SCL_SB(s1 & 255) | (SCL_SB((s2 >> 8) & 255) << 8) | (SCL_SB((s3 >> 16) & 255) << 16) |
-                  (SCL_SB(s0 >> 24) << 24)) ^ rk[41];
+                  (SCL_SB(s0 >> 24) << 24)) ^ key.rk[41];
   const u32 o2 = (SCL_SB(s2 & 255) | (SCL_SB((s3 >> 8) & 255) << 8) | (SCL_SB((s0 >> 16) & 255) << 16) |
-                  (SCL_SB(s1 >> 24) << 24)) ^ rk[42];
+                  (SCL_SB(s1 >> 24) << 24)) ^ key.rk[42];
   const u32 o3 = (SCL_SB(s3 & 255) | (SCL_SB((s0 >> 8) & 255) << 8) | (SCL_SB((s1 >> 16) & 255) << 16) |
-                  (SCL_SB(s2 >> 24) << 24)) ^ rk[43];
+                  (SCL_SB(s2 >> 24) << 24)) ^ key.rk[43];
 #undef SCL_SB
+#undef SCL_T
   out_lo = (u64)o0 | ((u64)o1 << 32);
   out_hi = (u64)o2 | ((u64)o3 << 32);
 }
 
-#define SCL_AES_PROLOGUE(key)                                            \
-  __shared__ u32 te0[256];                                               \
-  __shared__ u32 rks[44];                                                \
-  te0[threadIdx.x] = (key).te0[threadIdx.x];                             \
-  if (threadIdx.x < 44) rks[threadIdx.x] = (key).rk[threadIdx.x];        \
-  __syncthreads();
+// NB independent blocks in lockstep, one round at a time: 16*NB table reads are in flight per round,
+// which is what hides the LDS latency at the 4 waves/SIMD the 32 KiB table allows.  The round loop
+// is kept rolled so the body stays small in the instruction cache.
+template <int NB>
+__device__ __forceinline__ void aes_ctr_multi(const u32* tl, const AesKey& key, const u64 (&ctr)[NB], u64 (&lo)[NB],
+                                              u64 (&hi)[NB]) {
+#define SCL_T(x) tl[(x) << 5]
+  u32 s[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    s[b][0] = (u32)ctr[b] ^ key.rk[0];
+    s[b][1] = (u32)(ctr[b] >> 32) ^ key.rk[1];
+    s[b][2] = 0x89ABCDEFu ^ key.rk[2];
+    s[b][3] = 0x01234567u ^ key.rk[3];
+  }
+#pragma unroll 1
+  for (int r = 1; r < 10; ++r) {
+    const u32 k0 = key.rk[4 * r], k1 = key.rk[4 * r + 1], k2 = key.rk[4 * r + 2], k3 = key.rk[4 * r + 3];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const u32 s0 = s[b][0], s1 = s[b][1], s2 = s[b][2], s3 = s[b][3];
+      s[b][0] = SCL_T(s0 & 255) ^ rotl32(SCL_T((s1 >> 8) & 255), 8) ^ rotl32(SCL_T((s2 >> 16) & 255), 16) ^
+                rotl32(SCL_T(s3 >> 24), 24) ^ k0;
+      s[b][1] = SCL_T(s1 & 255) ^ rotl32(SCL_T((s2 >> 8) & 255), 8) ^ rotl32(SCL_T((s3 >> 16) & 255), 16) ^
+                rotl32(SCL_T(s0 >> 24), 24) ^ k1;
+      s[b][2] = SCL_T(s2 & 255) ^ rotl32(SCL_T((s3 >> 8) & 255), 8) ^ rotl32(SCL_T((s0 >> 16) & 255), 16) ^
+                rotl32(SCL_T(s1 >> 24), 24) ^ k2;
+      s[b][3] = SCL_T(s3 & 255) ^ rotl32(SCL_T((s0 >> 8) & 255), 8) ^ rotl32(SCL_T((s1 >> 16) & 255), 16) ^
+                rotl32(SCL_T(s2 >> 24), 24) ^ k3;
+    }
+  }
+#define SCL_SB(x) ((SCL_T(x) >> 8) & 255u)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const u32 s0 = s[b][0], s1 = s[b][1], s2 = s[b][2], s3 = s[b][3];
+    const u32 o0 = (SCL_SB(s0 & 255) | (SCL_SB((s1 >> 8) & 255) << 8) | (SCL_SB((s2 >> 16) & 255) << 16) |
+                    (SCL_SB(s3 >> 24) << 24)) ^ key.rk[40];
+    const u32 o1 = (SCL_SB(s1 & 255) | (SCL_SB((s2 >> 8) & 255) << 8) | (SCL_SB((s3 >> 16) & 255) << 16) |
+                    (SCL_SB(s0 >> 24) << 24)) ^ key.rk[41];
+    const u32 o2 = (SCL_SB(s2 & 255) | (SCL_SB((s3 >> 8) & 255) << 8) | (SCL_SB((s0 >> 16) & 255) << 16) |
+                    (SCL_SB(s1 >> 24) << 24)) ^ key.rk[42];
+    const u32 o3 = (SCL_SB(s3 & 255) | (SCL_SB((s0 >> 8) & 255) << 8) | (SCL_SB((s1 >> 16) & 255) << 16) |
+                    (SCL_SB(s2 >> 24) << 24)) ^ key.rk[43];
+    lo[b] = (u64)o0 | ((u64)o1 << 32);
+    hi[b] = (u64)o2 | ((u64)o3 << 32);
+  }
+#undef SCL_SB
+#undef SCL_T
+}
 
-// PRG::next as raw counter-addressed blocks (prg.cc:124-146)
+#define SCL_AES_PROLOGUE(key)                                                              \
+  __shared__ u32 te0_lds[AES_LDS_WORDS];                                                   \
+  for (int e_ = threadIdx.x; e_ < AES_LDS_WORDS; e_ += BLOCK) te0_lds[e_] = (key).te0[e_ >> 5]; \
+  __syncthreads();                                                                         \
+  const u32* te0 = te0_lds + (threadIdx.x & 31);
+
+// PRG::next as raw counter-addressed blocks (prg.cc:124-146); each lane computes 4 blocks a grid
+// stride apart so that every store instruction is a contiguous 1 KiB per wave.
 __global__ __launch_bounds__(BLOCK) void k_prg_blocks(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
   SCL_AES_PROLOGUE(key)
-  SCL_GRID_STRIDE(q, nblocks) {
-    u64x2 w;
-    u64 lo, hi;
-    aes_ctr_block(te0, rks, counter0 + q, lo, hi);
-    w.x = lo;
-    w.y = hi;
-    *reinterpret_cast<u64x2*>(dst + 2 * q) = w;
+  const size_t G = (size_t)gridDim.x * BLOCK;
+  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nblocks; q += 4 * G) {
+    u64 ctr[4], lo[4], hi[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ctr[b] = counter0 + q + b * G;
+    aes_ctr_multi<4>(te0, key, ctr, lo, hi);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (q + b * G < nblocks) {
+        u64x2 w;
+        w.x = lo[b];
+        w.y = hi[b];
+        *reinterpret_cast<u64x2*>(dst + 2 * (q + b * G)) = w;
+      }
+    }
   }
 }
 
@@ -499,26 +572,71 @@ template <class F>
 __global__ __launch_bounds__(BLOCK) void k_vector_random(typename F::Ctx ctx, u64* dst, AesKey key, u64 counter0,
                                                          size_t n) {
   SCL_AES_PROLOGUE(key)
-  if constexpr (F::LIMBS == 1) {
-    const size_t nb = (n + 1) / 2;
-    SCL_GRID_STRIDE(q, nb) {
-      u64 lo, hi;
-      aes_ctr_block(te0, rks, counter0 + q, lo, hi);
-      dst[2 * q] = F::from_le_word(ctx, lo);
-      if (2 * q + 1 < n) dst[2 * q + 1] = F::from_le_word(ctx, hi);
-    }
-  } else {
-    SCL_GRID_STRIDE(q, n) {
-      u64 lo, hi;
-      aes_ctr_block(te0, rks, counter0 + q, lo, hi);
-      F::st(dst + 2 * q, F::from_le_word(ctx, ((u128)hi << 64) | lo));
+  const size_t G = (size_t)gridDim.x * BLOCK;
+  const size_t nb = F::LIMBS == 1 ? (n + 1) / 2 : n;  // AES blocks needed
+  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nb; q += 4 * G) {
+    u64 ctr[4], lo[4], hi[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ctr[b] = counter0 + q + b * G;
+    aes_ctr_multi<4>(te0, key, ctr, lo, hi);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const size_t blk = q + b * G;
+      if (blk < nb) {
+        if constexpr (F::LIMBS == 1) {
+          if (2 * blk + 1 < n) {
+            u64x2 w;
+            w.x = F::from_le_word(ctx, lo[b]);
+            w.y = F::from_le_word(ctx, hi[b]);
+            *reinterpret_cast<u64x2*>(dst + 2 * blk) = w;
+          } else {
+            dst[2 * blk] = F::from_le_word(ctx, lo[b]);
+          }
+        } else {
+          F::st(dst + 2 * blk, F::from_le_word(ctx, ((u128)hi[b] << 64) | lo[b]));
+        }
+      }
     }
   }
 }
 
-// shamirSecretShare driven by the reference PRG discipline (SURVEY.md section 8a note P):
-// secret s draws Vector::random(t+1) from counters [s*B, (s+1)*B), B = ceil((t+1)*byteSize/16);
+// Coefficients of secret (first_secret + q*VEC + v) under the reference PRG discipline (SURVEY.md
+// section 8a note P): Vector::random(t+1) from counters [s*B, (s+1)*B), B = ceil((t+1)*byteSize/16);
 // c_0's draw is discarded and replaced by the secret (shamir.h:56-57).
+template <class F, int VEC, int TREG>
+__device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, VEC> (&c)[TREG + 1], const u32* te0,
+                                           const AesKey& key, u64 first_secret, size_t q, int t) {
+  const u64 B = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const u64 ctr0 = (first_secret + q * VEC + v) * B;
+    if constexpr (F::LIMBS == 1) {
+      // block j holds coefficients 2j (low 8 bytes) and 2j+1 (high 8 bytes)
+#pragma unroll
+      for (int j = 0; j <= TREG / 2; ++j) {
+        if (2 * j <= t) {
+          u64 lo, hi;
+          aes_ctr_block(te0, key, ctr0 + j, lo, hi);
+          if (j > 0) c[2 * j].v[v] = F::from_le_word(ctx, lo);
+          if (2 * j + 1 <= TREG && 2 * j + 1 <= t) c[2 * j + 1].v[v] = F::from_le_word(ctx, hi);
+        }
+      }
+    } else {
+      // block k holds coefficient k; block 0 (c_0's draw) is never needed
+#pragma unroll
+      for (int k = 1; k <= TREG; ++k) {
+        if (k <= t) {
+          u64 lo, hi;
+          aes_ctr_block(te0, key, ctr0 + k, lo, hi);
+          c[k].v[v] = F::from_le_word(ctx, ((u128)hi << 64) | lo);
+        }
+      }
+    }
+  }
+}
+
+// shamirSecretShare(secret_s, t, n, prg) for a whole batch, bit-identical to the per-secret calls on
+// ONE PRG (shamir.h:51-68); Horner evaluation at the default nodes 1..n.
 template <class F, int VEC, int TREG>
 __global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* shares, size_t stride,
                                                      const u64* secrets, AesKey key, u64 first_secret,
@@ -527,38 +645,55 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* s
   __shared__ typename F::E alpha[BigTable<F>::CAP];
   for (int i = threadIdx.x; i < n; i += BLOCK) alpha[i] = tab.v[i];
   __syncthreads();
-  const u64 B = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1);
   SCL_GRID_STRIDE(q, npacks) {
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> c[TREG + 1];
     c[0] = load_pack<F, VEC, true>(secrets + off);
+    prg_coeffs<F, VEC, TREG>(ctx, c, te0, key, first_secret, q, t);
+    horner_rows<F, VEC, TREG>(ctx, c, t, alpha, n, shares, stride, off);
+  }
+}
+
+// Same, small-node Vandermonde evaluation (see k_share_small) for t <= SmallVdm::TMAX.  NBLK = AES
+// blocks per secret that carry a used coefficient: t/2+1 for M61 (block j = c_2j, c_2j+1), t for the
+// 128-bit fields (block k = c_k, block 0 skipped).  All VEC*NBLK blocks of a lane run in lockstep.
+template <class F, int VEC, int NBLK>
+__global__ __launch_bounds__(BLOCK) void k_share_prg_small(u64* shares, size_t stride, const u64* secrets, AesKey key,
+                                                           u64 first_secret, SmallVdm tab, int t, int n,
+                                                           size_t npacks) {
+  SCL_AES_PROLOGUE(key)
+  __shared__ u32 V[SmallVdm::CAP];
+  for (int i = threadIdx.x; i < n * (t + 1); i += BLOCK) V[i] = tab.v[i];
+  __syncthreads();
+  const typename F::Ctx ctx{};
+  const u64 B = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1);
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> c[SmallVdm::TMAX + 1];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const u64 ctr0 = (first_secret + q * VEC + v) * B;
-      if constexpr (F::LIMBS == 1) {
-        // block j holds coefficients 2j (low 8 bytes) and 2j+1 (high 8 bytes)
+    for (int k = 1; k <= SmallVdm::TMAX; ++k)
 #pragma unroll
-        for (int j = 0; j <= TREG / 2; ++j) {
-          if (2 * j <= t) {
-            u64 lo, hi;
-            aes_ctr_block(te0, rks, ctr0 + j, lo, hi);
-            if (j > 0) c[2 * j].v[v] = F::from_le_word(ctx, lo);
-            if (2 * j + 1 <= TREG && 2 * j + 1 <= t) c[2 * j + 1].v[v] = F::from_le_word(ctx, hi);
-          }
-        }
-      } else {
-        // block k holds coefficient k; block 0 (c_0's draw) is never needed
+      for (int v = 0; v < VEC; ++v) c[k].v[v] = F::zero();
+    c[0] = load_pack<F, VEC, true>(secrets + off);
+    u64 ctr[VEC * NBLK], lo[VEC * NBLK], hi[VEC * NBLK];
 #pragma unroll
-        for (int k = 1; k <= TREG; ++k) {
-          if (k <= t) {
-            u64 lo, hi;
-            aes_ctr_block(te0, rks, ctr0 + k, lo, hi);
-            c[k].v[v] = F::from_le_word(ctx, ((u128)hi << 64) | lo);
-          }
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j)
+        ctr[v * NBLK + j] = (first_secret + q * VEC + v) * B + j + (F::LIMBS == 1 ? 0 : 1);
+    aes_ctr_multi<VEC * NBLK>(te0, key, ctr, lo, hi);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) {
+        if constexpr (F::LIMBS == 1) {
+          if (j > 0) c[2 * j].v[v] = F::from_le_word(ctx, lo[v * NBLK + j]);
+          if (2 * j + 1 <= SmallVdm::TMAX) c[2 * j + 1].v[v] = F::from_le_word(ctx, hi[v * NBLK + j]);
+        } else {
+          c[j + 1].v[v] = F::from_le_word(ctx, ((u128)hi[v * NBLK + j] << 64) | lo[v * NBLK + j]);
         }
       }
-    }
-    horner_rows<F, VEC, TREG>(ctx, c, t, alpha, n, shares, stride, off);
+    small_rows<F, VEC>(c, V, t, n, shares, stride, off);
   }
 }
 
@@ -595,7 +730,7 @@ __global__ __launch_bounds__(BLOCK) void k_additive_share_prg(typename F::Ctx ct
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         u64 lo, hi;
-        aes_ctr_block(te0, rks, (first_secret + q * VEC + v) * (u64)(n - 1) + i, lo, hi);
+        aes_ctr_block(te0, key, (first_secret + q * VEC + v) * (u64)(n - 1) + i, lo, hi);
         if constexpr (F::LIMBS == 1)
           r.v[v] = F::from_le_word(ctx, lo);
         else

@@ -37,8 +37,6 @@ for t in (0, 1, 2, 3, 4):
     print(f"share n={n} t={t}: {ms:.3f} ms  {((1 + t) + n) * E * N / ms / 1e6:.0f} GB/s  {N / ms / 1e6:.1f} Gsecrets/s")
 ms = timeit(lambda: scl.shamir_share_prg(f, secrets, 3, n, b"seed", out=shares), reps=3)
 print(f"share_prg n={n} t=3: {ms:.3f} ms  {(1 + n) * E * N / ms / 1e6:.0f} GB/s  {N / ms / 1e6:.1f} Gsecrets/s")
-ms = timeit(lambda: shares.zero_())
-print(f"torch zero_ {shares.numel() * 8 / ms / 1e6:.0f} GB/s write-only")
 out = scl.empty(f, N)
 ms = timeit(lambda: scl.shamir_recover(f, shares, out=out))
 print(f"recover n={n}: {(n + 1) * E * N / ms / 1e6:.0f} GB/s")
@@ -52,3 +50,11 @@ ms = timeit(lambda: scl.ew(f, 4, shares[0], None, out=shares[2]), reps=3)
 print(f"ew inv: {2 * E * N / ms / 1e6:.0f} GB/s  {N / ms / 1e6:.2f} Ginv/s")
 ms = timeit(lambda: scl.vector_random(f, N, b"x"), reps=3)
 print(f"vector_random: {N * E / 16 / ms / 1e6:.2f} G AES blocks/s")
+ms = timeit(lambda: scl.prg_blocks(N // 2, b"x"), reps=3)
+print(f"prg_blocks: {N / 2 / ms / 1e6:.2f} G AES blocks/s  {N * 8 / ms / 1e6:.0f} GB/s written")
+ms = timeit(lambda: scl.additive_share_prg(f, secrets, 3, b"x", out=shares[:3]), reps=3)
+print(f"additive_share_prg n=3: {N / ms / 1e6:.2f} Gsecrets/s")
+ms = timeit(lambda: shares.zero_())
+print(f"torch zero_ {shares.numel() * 8 / ms / 1e6:.0f} GB/s write-only")
+ms = timeit(lambda: scl.vsum(f, shares))
+print(f"vsum (read-only): {shares.numel() * 8 / ms / 1e6:.0f} GB/s")
