@@ -135,13 +135,15 @@ int scl_hip_shamir_share(int field, uint64_t* shares_dev, size_t share_stride,
                          size_t coeff_stride, size_t N, size_t t, size_t n,
                          const uint64_t* alphas_host, void* stream);
 /* The same driven by the reference's PRG discipline: bit-identical to calling
- * shamirSecretShare(secret_s, t, n, prg) for s = first_secret .. first_secret+N-1 on ONE PRG
- * seeded with `seed` (secret s uses counters [s*B, (s+1)*B), B = ceil((t+1)*byteSize/16);
- * the draw for c_0 is made and discarded, shamir.h:56-57). */
+ * shamirSecretShare(secret_s, t, n, prg) for s = 0..N-1 on a PRG seeded with `seed` whose block
+ * counter stands at counter0 when the batch begins (secret s draws Vector::random(t+1) from blocks
+ * [counter0 + s*B, counter0 + (s+1)*B), B = ceil((t+1)*byteSize/16); the draw for c_0 is made and
+ * discarded, shamir.h:56-57).  A shard that starts at secret index f of a longer run passes
+ * counter0 = f*B.  The PRG has consumed N*B blocks afterwards. */
 int scl_hip_shamir_share_prg(int field, uint64_t* shares_dev, size_t share_stride,
                              const uint64_t* secrets_dev, size_t N, size_t t, size_t n,
                              const unsigned char* seed_host, size_t seed_len,
-                             uint64_t first_secret, void* stream);
+                             uint64_t counter0, void* stream);
 /* Batched shamirRecoverP (shamir.h:81-104) with the basis hoisted out of the per-secret
  * call: out[s] = sum_{i<m} lambda[i] * shares[i][s]. */
 int scl_hip_shamir_recover(int field, uint64_t* out_dev, const uint64_t* shares_dev,
@@ -163,11 +165,12 @@ int scl_hip_shamir_recover_detect(int field, uint64_t* out_dev, unsigned char* s
 int scl_hip_additive_share(int field, uint64_t* shares_dev, size_t share_stride,
                            const uint64_t* secrets_dev, const uint64_t* rnd_dev, size_t rnd_stride,
                            size_t N, size_t n, void* stream);
-/* PRG-driven: secret s, share i < n-1 is FF::random on counter (first_secret+s)*(n-1)+i. */
+/* PRG-driven: share i < n-1 of secret s is FF::random on block counter0 + s*(n-1) + i (one whole
+ * AES block per element, ff.h:72-76); N*(n-1) blocks are consumed. */
 int scl_hip_additive_share_prg(int field, uint64_t* shares_dev, size_t share_stride,
                                const uint64_t* secrets_dev, size_t N, size_t n,
                                const unsigned char* seed_host, size_t seed_len,
-                               uint64_t first_secret, void* stream);
+                               uint64_t counter0, void* stream);
 /* reconstruct = Vector::sum per secret (vector.h:261-267): out[s] = sum_i shares[i][s] */
 int scl_hip_additive_recover(int field, uint64_t* out_dev, const uint64_t* shares_dev,
                              size_t share_stride, size_t n, size_t N, void* stream);

@@ -1,4 +1,4 @@
-// csrc/field.hpp -- per-lane finite-field arithmetic for the MI355X engine.
+// include/scl_hip/detail/field.hpp -- per-lane finite-field arithmetic for the MI355X engine.
 //
 // One struct per field with the same static interface, usable from device
 // kernels and from the host-side table builders (Lagrange basis, Vandermonde,
@@ -217,6 +217,24 @@ struct Mont128 {
     u128 p, mc, one, r2;  // modulus, -p^-1 mod R, R mod p, R^2 mod p
   };
   enum { LIMBS = 2, ACC_TERMS = 1 << 30, TAG = 2 };
+
+  // parameters for an odd modulus p >= 3 (host side)
+  static inline Ctx make_ctx(u128 p) {
+    Ctx c;
+    c.p = p;
+    u128 inv = p;  // correct to 3 bits for odd p; each Newton step doubles that
+    for (int i = 0; i < 7; ++i) inv *= 2 - p * inv;
+    c.mc = (u128)0 - inv;
+    u128 r = 1 % p;
+    c.one = 0;
+    for (int i = 0; i < 256; ++i) {
+      const u128 t = r + r;
+      r = (t < r || t >= p) ? t - p : t;
+      if (i == 127) c.one = r;
+    }
+    c.r2 = r;
+    return c;
+  }
 
   static SCL_HD E zero() { return 0; }
   static SCL_HD E one(const Ctx& c) { return c.one; }

@@ -1,0 +1,135 @@
+// include/scl_hip/hip/device.h -- device-resident containers for the batch API.
+//
+// The reference keeps every value in host std::vector and works one secret per call
+// (include/scl/ss/shamir.h:52-68).  At 10^8 secrets the data has to live in HBM, so the batch API
+// is expressed over two RAII buffers: DeviceVector<T> (N elements) and ShareMatrix<T> (SoA
+// [party][secret]).  Both talk to libscl_hip.so through the C ABI only.
+#ifndef SCL_HIP_HIP_DEVICE_H
+#define SCL_HIP_HIP_DEVICE_H
+
+#include <cstddef>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "../detail/call.h"
+
+namespace scl::hip {
+
+using detail::check;
+
+/// Raw device allocation (move-only).
+class DeviceBuffer {
+ public:
+  DeviceBuffer() = default;
+  explicit DeviceBuffer(std::size_t bytes) : m_bytes(bytes) {
+    if (bytes) check(scl_hip_malloc(&m_ptr, bytes));
+  }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  DeviceBuffer(DeviceBuffer&& o) noexcept : m_ptr(o.m_ptr), m_bytes(o.m_bytes) {
+    o.m_ptr = nullptr;
+    o.m_bytes = 0;
+  }
+  DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
+    if (this != &o) {
+      release();
+      m_ptr = o.m_ptr;
+      m_bytes = o.m_bytes;
+      o.m_ptr = nullptr;
+      o.m_bytes = 0;
+    }
+    return *this;
+  }
+  ~DeviceBuffer() { release(); }
+
+  void* get() const { return m_ptr; }
+  std::size_t bytes() const { return m_bytes; }
+
+ private:
+  void release() {
+    if (m_ptr) (void)scl_hip_free(m_ptr);
+    m_ptr = nullptr;
+  }
+  void* m_ptr = nullptr;
+  std::size_t m_bytes = 0;
+};
+
+/// N field elements in HBM.  T is an scl::math::FF<FIELD>.
+template <typename T>
+class DeviceVector {
+ public:
+  static constexpr int FIELD_TAG = T::Field::TAG;
+  static constexpr std::size_t LIMBS = T::byteSize() / 8;
+
+  DeviceVector() = default;
+  explicit DeviceVector(std::size_t n) : m_buf(n * T::byteSize()), m_size(n) {}
+
+  /// upload (element image = the C ABI's little-endian limbs)
+  explicit DeviceVector(const std::vector<T>& host) : DeviceVector(host.size()) {
+    if (!host.empty()) {
+      std::vector<std::uint64_t> limbs(host.size() * LIMBS);
+      for (std::size_t i = 0; i < host.size(); ++i)
+        host[i].toLimbs(limbs.data() + i * LIMBS);
+      check(scl_hip_memcpy_h2d(m_buf.get(), limbs.data(), limbs.size() * 8, nullptr));
+      check(scl_hip_stream_sync(nullptr));
+    }
+  }
+
+  std::vector<T> toHost() const {
+    std::vector<std::uint64_t> limbs(m_size * LIMBS);
+    if (m_size) check(scl_hip_memcpy_d2h(limbs.data(), m_buf.get(), limbs.size() * 8, nullptr));
+    std::vector<T> out;
+    out.reserve(m_size);
+    for (std::size_t i = 0; i < m_size; ++i)
+      out.emplace_back(T::fromLimbs(limbs.data() + i * LIMBS));
+    return out;
+  }
+
+  std::size_t size() const { return m_size; }
+  std::uint64_t* data() { return static_cast<std::uint64_t*>(m_buf.get()); }
+  const std::uint64_t* data() const { return static_cast<const std::uint64_t*>(m_buf.get()); }
+
+ private:
+  DeviceBuffer m_buf;
+  std::size_t m_size = 0;
+};
+
+/// n share vectors of N secrets each, SoA [party][secret], row stride = N.
+template <typename T>
+class ShareMatrix {
+ public:
+  static constexpr std::size_t LIMBS = T::byteSize() / 8;
+
+  ShareMatrix() = default;
+  ShareMatrix(std::size_t parties, std::size_t secrets)
+      : m_buf(parties * secrets * T::byteSize()), m_parties(parties), m_secrets(secrets) {}
+
+  std::size_t parties() const { return m_parties; }
+  std::size_t secrets() const { return m_secrets; }
+  std::size_t stride() const { return m_secrets; }
+  std::uint64_t* data() { return static_cast<std::uint64_t*>(m_buf.get()); }
+  const std::uint64_t* data() const { return static_cast<const std::uint64_t*>(m_buf.get()); }
+  /// party i's share vector (device pointer)
+  const std::uint64_t* row(std::size_t i) const { return data() + i * m_secrets * LIMBS; }
+
+  /// the shares of secret s as the reference returns them: one host Vector of n elements
+  std::vector<T> sharesOf(std::size_t s) const {
+    std::vector<T> out;
+    out.reserve(m_parties);
+    std::uint64_t limbs[LIMBS];
+    for (std::size_t i = 0; i < m_parties; ++i) {
+      check(scl_hip_memcpy_d2h(limbs, row(i) + s * LIMBS, sizeof limbs, nullptr));
+      out.emplace_back(T::fromLimbs(limbs));
+    }
+    return out;
+  }
+
+ private:
+  DeviceBuffer m_buf;
+  std::size_t m_parties = 0, m_secrets = 0;
+};
+
+}  // namespace scl::hip
+
+#endif

@@ -1,0 +1,270 @@
+// include/scl_hip/math/ff.h -- scl::math::FF<FIELD> / Fp<BITS>, the scalar value type.
+//
+// Same surface as the reference's include/scl/math/ff.h:36-346 and fp.h:34-64 (names, operators,
+// exception text).  A single element is host data in the reference and stays host data here; the
+// per-element arithmetic comes from the one field implementation shared with the device kernels
+// (detail/field.hpp), so a scalar computed on the host and a lane computed on the GPU agree by
+// construction.  Everything batch-shaped (Vector, Matrix, ss::*) goes through the C ABI.
+//
+// Field plug-in boundary: the reference extends fields by specialising ff::add/... for a traits
+// struct (include/scl/math/fields/ff_ops.h:35-118, worked example test/scl/gf7.cc:26-103).  Here a
+// field is a traits struct naming its device implementation: { ValueType, NAME, BYTE_SIZE, BIT_SIZE,
+// TAG (scl_field), Impl (struct in detail/field.hpp) }.
+#ifndef SCL_HIP_MATH_FF_H
+#define SCL_HIP_MATH_FF_H
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <ostream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+
+#include "../detail/call.h"
+#include "../detail/field.hpp"
+#include "../util/prg.h"
+
+namespace scl::math {
+
+namespace ff {
+
+struct Mersenne61 {  // include/scl/math/fields/mersenne61.h:29-49
+  using ValueType = std::uint64_t;
+  using Impl = sclhip::M61;
+  constexpr static const char* NAME = "Mersenne61";
+  constexpr static std::size_t BYTE_SIZE = 8;
+  constexpr static std::size_t BIT_SIZE = 61;
+  constexpr static int TAG = SCL_M61;
+};
+
+struct Mersenne127 {  // include/scl/math/fields/mersenne127.h:29-49
+  using ValueType = __uint128_t;
+  using Impl = sclhip::M127;
+  constexpr static const char* NAME = "Mersenne127";
+  constexpr static std::size_t BYTE_SIZE = 16;
+  constexpr static std::size_t BIT_SIZE = 127;
+  constexpr static int TAG = SCL_M127;
+};
+
+struct Mont128 {  // plug-in: generic 128-bit prime, Montgomery form (not in the reference)
+  using ValueType = __uint128_t;
+  using Impl = sclhip::Mont128;
+  constexpr static const char* NAME = "Mont128";
+  constexpr static std::size_t BYTE_SIZE = 16;
+  constexpr static std::size_t BIT_SIZE = 128;
+  constexpr static int TAG = SCL_MONT128;
+};
+
+struct GF2_128 {  // plug-in: GF(2^128) (not in the reference)
+  using ValueType = __uint128_t;
+  using Impl = sclhip::Gf128;
+  constexpr static const char* NAME = "GF(2^128)";
+  constexpr static std::size_t BYTE_SIZE = 16;
+  constexpr static std::size_t BIT_SIZE = 128;
+  constexpr static int TAG = SCL_GF2_128;
+};
+
+namespace detail {
+
+template <typename FIELD>
+inline typename FIELD::Impl::Ctx context() {
+  if constexpr (FIELD::TAG == SCL_MONT128) {
+    std::uint64_t p[2];
+    scl::hip::detail::check(scl_hip_mont128_get_prime(p));
+    static thread_local __uint128_t cached_p = 0;
+    static thread_local sclhip::Mont128::Ctx cached;
+    const __uint128_t pp = ((__uint128_t)p[1] << 64) | p[0];
+    if (pp != cached_p) {
+      cached = sclhip::Mont128::make_ctx(pp);
+      cached_p = pp;
+    }
+    return cached;
+  } else {
+    return typename FIELD::Impl::Ctx{};
+  }
+}
+
+// big-endian hex, no "0x"; bits shifted past the value type are dropped (include/scl/util/str.h:49-76)
+template <typename V>
+inline V parseHex(const std::string& s) {
+  if (s.size() % 2) throw std::invalid_argument("odd-length hex string");
+  V t = 0;
+  for (char c : s) {
+    unsigned d;
+    if (c >= '0' && c <= '9') d = c - '0';
+    else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+    else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+    else throw std::invalid_argument("encountered invalid hex character");
+    t = (V)(t << 4) + d;
+  }
+  return t;
+}
+
+inline std::string hex64(std::uint64_t v) {
+  std::stringstream ss;
+  ss << std::hex << v;
+  return ss.str();
+}
+
+}  // namespace detail
+}  // namespace ff
+
+template <typename FIELD>
+class FF final {
+  using Impl = typename FIELD::Impl;
+  using V = typename FIELD::ValueType;
+
+ public:
+  using Field = FIELD;
+
+  constexpr static std::size_t byteSize() { return FIELD::BYTE_SIZE; }
+  constexpr static std::size_t bitSize() { return FIELD::BIT_SIZE; }
+  constexpr static const char* name() { return FIELD::NAME; }
+
+  /// FF::read (ff.h:63-67): byteSize() bytes, reduced into the field
+  static FF read(const unsigned char* src) {
+    V raw;
+    std::memcpy(&raw, src, sizeof raw);
+    return fromRaw(Impl::from_le_word(ctx(), raw));
+  }
+
+  /// FF::random (ff.h:72-76): one prg.next(byteSize()) -- a whole AES block per element
+  static FF random(util::PRG& prg) {
+    unsigned char buffer[FIELD::BYTE_SIZE];
+    prg.next(buffer, FIELD::BYTE_SIZE);
+    return read(buffer);
+  }
+
+  /// hex string, reduced mod p (mersenne61.cc:42-46)
+  static FF fromString(const std::string& hexstr) {
+    const V raw = ff::detail::parseHex<V>(hexstr);
+    if constexpr (FIELD::TAG == SCL_MONT128)
+      return fromRaw(Impl::to_mont(ctx(), raw));
+    else
+      return fromRaw(Impl::from_le_word(ctx(), raw));
+  }
+
+  static FF zero() { return FF(); }
+  static FF one() { return FF(1); }
+
+  /// FF(int): negative values wrap to p - |v| (mersenne61.cc:37-40)
+  explicit FF(int value) {
+    const auto c = ctx();
+    const std::uint64_t mag = value < 0 ? (std::uint64_t)(-(std::int64_t)value) : (std::uint64_t)value;
+    m_value = Impl::from_u64(c, mag);
+    if (value < 0) m_value = Impl::neg(c, m_value);
+  }
+  FF() : m_value(Impl::zero()) {}
+
+  FF& operator+=(const FF& o) { m_value = Impl::add(ctx(), m_value, o.m_value); return *this; }
+  FF& operator-=(const FF& o) { m_value = Impl::sub(ctx(), m_value, o.m_value); return *this; }
+  FF& operator*=(const FF& o) { m_value = Impl::mul(ctx(), m_value, o.m_value); return *this; }
+  FF& operator/=(const FF& o) { return *this *= o.inverse(); }  // ff.h:203-205
+  friend FF operator+(FF a, const FF& b) { return a += b; }
+  friend FF operator-(FF a, const FF& b) { return a -= b; }
+  friend FF operator*(FF a, const FF& b) { return a *= b; }
+  friend FF operator/(FF a, const FF& b) { return a /= b; }
+  FF& operator++() { return *this += one(); }
+  friend FF operator++(FF& e, int) { FF t(e); ++e; return t; }
+  FF& operator--() { return *this -= one(); }
+  friend FF operator--(FF& e, int) { FF t(e); --e; return t; }
+
+  FF& negate() { m_value = Impl::neg(ctx(), m_value); return *this; }
+  FF negated() const { FF r(*this); return r.negate(); }
+  friend FF operator-(const FF& e) { return e.negated(); }
+
+  /// throws std::logic_error("0 not invertible modulo prime") on zero (test_ff.cc:168-171)
+  FF& invert() {
+    if (Impl::is_zero(m_value)) scl::hip::detail::raise(SCL_ERR_ZERO_INVERSE);
+    m_value = Impl::inv(ctx(), m_value);
+    return *this;
+  }
+  FF inverse() const { FF r(*this); return r.invert(); }
+
+  bool equal(const FF& o) const { return Impl::eq(m_value, o.m_value); }
+  friend bool operator==(const FF& a, const FF& b) { return a.equal(b); }
+  friend bool operator!=(const FF& a, const FF& b) { return !a.equal(b); }
+
+  /// Mersenne61: std::hex of the word; Mersenne127: the top word (if non-zero) then the low word
+  /// without zero padding -- the reference's formatting (src/scl/util/str.cc:23-39), kept as is.
+  std::string toString() const {
+    if constexpr (FIELD::TAG == SCL_M61) {
+      return ff::detail::hex64(m_value);
+    } else {
+      V v = m_value;
+      if constexpr (FIELD::TAG == SCL_MONT128) v = Impl::from_mont(ctx(), v);
+      const auto top = (std::uint64_t)(v >> 64), bot = (std::uint64_t)v;
+      if (v == 0) return "0";
+      std::string s;
+      if (top) s = ff::detail::hex64(top);
+      if (FIELD::TAG == SCL_M127 || !top) return s + ff::detail::hex64(bot);
+      std::string b = ff::detail::hex64(bot);
+      return s + std::string(16 - b.size(), '0') + b;
+    }
+  }
+  friend std::ostream& operator<<(std::ostream& os, const FF& e) { return os << e.toString(); }
+
+  /// FF::write (ff.h:300-302).  Mersenne fields: the canonical little-endian word.  Mont128 follows
+  /// the reference's Montgomery family (ff_ops_gmp.h:298-314): out of Montgomery form, big-endian.
+  void write(unsigned char* dest) const {
+    if constexpr (FIELD::TAG == SCL_MONT128) {
+      const V v = sclhip::bswap128(Impl::from_mont(ctx(), m_value));
+      std::memcpy(dest, &v, sizeof v);
+    } else {
+      std::memcpy(dest, &m_value, sizeof m_value);
+    }
+  }
+
+  /// the limb image the C ABI and the kernels use (internal representation, little-endian limbs)
+  void toLimbs(std::uint64_t* dest) const { std::memcpy(dest, &m_value, sizeof m_value); }
+  static FF fromLimbs(const std::uint64_t* src) {
+    FF e;
+    std::memcpy(&e.m_value, src, sizeof e.m_value);
+    return e;
+  }
+
+  V value() const { return m_value; }
+  V& value() { return m_value; }
+
+ private:
+  static typename Impl::Ctx ctx() { return ff::detail::context<FIELD>(); }
+  static FF fromRaw(V v) {
+    FF e;
+    e.m_value = v;
+    return e;
+  }
+  V m_value;
+};
+
+/// exp(base, e): square-and-multiply over the bits of e (ff.h:329-346)
+template <typename F>
+FF<F> exp(const FF<F>& base, std::size_t e) {
+  FF<F> r = FF<F>::one();
+  if (e == 0) return r;
+  for (int i = 63 - __builtin_clzll((unsigned long long)e); i >= 0; --i) {
+    r *= r;
+    if ((e >> i) & 1) r *= base;
+  }
+  return r;
+}
+
+namespace ff_detail {
+template <std::size_t BITS, bool SMALL = (BITS <= 61)>
+struct Select {
+  using Field = ff::Mersenne61;
+};
+template <std::size_t BITS>
+struct Select<BITS, false> {
+  using Field = ff::Mersenne127;
+};
+}  // namespace ff_detail
+
+/// Fp<BITS>: 1..61 bits -> Mersenne61, 62..127 -> Mersenne127 (fp.h:34-64)
+template <std::size_t BITS>
+  requires(BITS > 0 && BITS < 128)
+using Fp = FF<typename ff_detail::Select<BITS>::Field>;
+
+}  // namespace scl::math
+
+#endif

@@ -1,0 +1,203 @@
+// include/scl_hip/math/matrix.h -- scl::math::Matrix<T> (include/scl/math/matrix.h:52-968).
+//
+// Row-major host storage like the reference.  The data-parallel members -- multiply(Matrix),
+// multiply(Vector), the entry-wise family -- run on the GPU behind the C ABI (scl_hip_matmul,
+// scl_hip_ew); vandermonde / hyperInvertible build their O(n*m) tables through the library's host
+// table code.  invert() is a small dense Gauss-Jordan on scalars and stays host work, as in the
+// reference ("invert/solveLinearSystem host-side only").
+#ifndef SCL_HIP_MATH_MATRIX_H
+#define SCL_HIP_MATH_MATRIX_H
+
+#include <iomanip>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lagrange.h"
+#include "vector.h"
+
+namespace scl::math {
+
+template <typename ELEMENT>
+class Matrix {
+  static constexpr std::size_t L = ELEMENT::byteSize() / 8;
+  static constexpr int TAG = ELEMENT::Field::TAG;
+
+ public:
+  using ValueType = ELEMENT;
+
+  static Matrix random(std::size_t n, std::size_t m, util::PRG& prg) {
+    return Matrix(n, m, Vector<ELEMENT>::random(n * m, prg).toStlVector());
+  }
+
+  /// V(i, j) = xs[i]^j (matrix.h:444-460)
+  static Matrix vandermonde(std::size_t n, std::size_t m, const Vector<ELEMENT>& xs) {
+    if (xs.size() != n) hip::detail::raise(SCL_ERR_VANDERMONDE_XS);
+    hip::DeviceVector<ELEMENT> v(n * m);
+    std::vector<std::uint64_t> x(n * L + 1);
+    for (std::size_t i = 0; i < n; ++i) xs[i].toLimbs(x.data() + i * L);
+    hip::check(scl_hip_vandermonde(TAG, v.data(), n, m, x.data(), nullptr));
+    return Matrix(n, m, v.toHost());
+  }
+  /// default nodes 1..n (matrix.h:102-104)
+  static Matrix vandermonde(std::size_t n, std::size_t m) { return vandermonde(n, m, Vector<ELEMENT>::range(1, n + 1)); }
+
+  /// row i = Lagrange basis of nodes 1..m evaluated at -i (matrix.h:462-475)
+  static Matrix hyperInvertible(std::size_t n, std::size_t m) {
+    Matrix him(n, m);
+    const auto vs = Vector<ELEMENT>::range(1, m + 1);
+    for (std::size_t i = 0; i < n; ++i) {
+      const auto r = computeLagrangeBasis(vs, -static_cast<int>(i));
+      for (std::size_t j = 0; j < m; ++j) him(i, j) = r[j];
+    }
+    return him;
+  }
+
+  static Matrix fromVector(std::size_t n, std::size_t m, const std::vector<ELEMENT>& vec) {
+    if (vec.size() != n * m) throw std::invalid_argument("invalid dimensions");
+    return Matrix(n, m, vec);
+  }
+
+  static Matrix identity(std::size_t n) {
+    Matrix id(n);
+    for (std::size_t i = 0; i < n; ++i) id(i, i) = ELEMENT(1);
+    return id;
+  }
+
+  Matrix() : m_rows(0), m_cols(0) {}
+  explicit Matrix(std::size_t n, std::size_t m) : m_rows(n), m_cols(m), m_values(n * m) {
+    if (n == 0 || m == 0) throw std::invalid_argument("n or m cannot be 0");
+  }
+  explicit Matrix(std::size_t n) : Matrix(n, n) {}
+
+  std::size_t rows() const { return m_rows; }
+  std::size_t cols() const { return m_cols; }
+  ELEMENT& operator()(std::size_t r, std::size_t c) { return m_values[r * m_cols + c]; }
+  ELEMENT operator()(std::size_t r, std::size_t c) const { return m_values[r * m_cols + c]; }
+
+  Matrix add(const Matrix& o) const { return entrywise(o, &Vector<ELEMENT>::add); }
+  Matrix subtract(const Matrix& o) const { return entrywise(o, &Vector<ELEMENT>::subtract); }
+  Matrix multiplyEntryWise(const Matrix& o) const { return entrywise(o, &Vector<ELEMENT>::multiplyEntryWise); }
+  Matrix& addInPlace(const Matrix& o) { return *this = add(o); }
+  Matrix& subtractInPlace(const Matrix& o) { return *this = subtract(o); }
+  Matrix& multiplyEntryWiseInPlace(const Matrix& o) { return *this = multiplyEntryWise(o); }
+  Matrix scalarMultiply(const ELEMENT& s) const {
+    return Matrix(m_rows, m_cols, Vector<ELEMENT>(m_values).scalarMultiply(s).toStlVector());
+  }
+  Matrix& scalarMultiplyInPlace(const ELEMENT& s) { return *this = scalarMultiply(s); }
+
+  /// C = this * other on the GPU (matrix.h:477-495)
+  Matrix multiply(const Matrix& o) const {
+    if (cols() != o.rows()) hip::detail::raise(SCL_ERR_MATMUL_DIMS);
+    hip::DeviceVector<ELEMENT> a(m_values), b(o.m_values), c(rows() * o.cols());
+    hip::check(scl_hip_matmul(TAG, c.data(), o.cols(), a.data(), cols(), b.data(), o.cols(), rows(), cols(), o.cols(),
+                              nullptr));
+    return Matrix(rows(), o.cols(), c.toHost());
+  }
+
+  /// matrix-vector product (matrix.h:497-513)
+  Vector<ELEMENT> multiply(const Vector<ELEMENT>& v) const {
+    if (cols() != v.size()) throw std::invalid_argument("matmul: this->cols() != vec.size()");
+    hip::DeviceVector<ELEMENT> a(m_values), b(v.toStlVector()), c(rows());
+    hip::check(scl_hip_matmul(TAG, c.data(), 1, a.data(), cols(), b.data(), 1, rows(), cols(), 1, nullptr));
+    return Vector<ELEMENT>(c.toHost());
+  }
+
+  Matrix transpose() const {
+    Matrix t(m_cols, m_rows);
+    for (std::size_t i = 0; i < m_rows; ++i)
+      for (std::size_t j = 0; j < m_cols; ++j) t(j, i) = (*this)(i, j);
+    return t;
+  }
+
+  Matrix& resize(std::size_t new_rows, std::size_t new_cols) {
+    if (new_rows * new_cols != m_rows * m_cols) throw std::invalid_argument("cannot resize matrix");
+    m_rows = new_rows;
+    m_cols = new_cols;
+    return *this;
+  }
+
+  bool isSquare() const { return m_rows == m_cols; }
+
+  bool isIdentity() const {
+    if (!isSquare()) return false;
+    bool ok = true;
+    for (std::size_t i = 0; i < m_rows; ++i)
+      for (std::size_t j = 0; j < m_cols; ++j) ok &= (*this)(i, j) == (i == j ? ELEMENT{1} : ELEMENT{0});
+    return ok;
+  }
+
+  /// Gauss-Jordan inverse of a square matrix (matrix.h:830-850)
+  Matrix invert() const {
+    if (!isSquare()) throw std::invalid_argument("cannot invert non-square matrix");
+    const std::size_t n = m_rows;
+    Matrix a = *this, inv = identity(n);
+    for (std::size_t col = 0; col < n; ++col) {
+      std::size_t piv = col;
+      while (piv < n && a(piv, col) == ELEMENT{}) ++piv;
+      if (piv == n) continue;  // singular: the reference returns whatever the reduction leaves
+      if (piv != col)
+        for (std::size_t j = 0; j < n; ++j) {
+          std::swap(a.m_values[piv * n + j], a.m_values[col * n + j]);
+          std::swap(inv.m_values[piv * n + j], inv.m_values[col * n + j]);
+        }
+      const ELEMENT s = a(col, col).inverse();
+      for (std::size_t j = 0; j < n; ++j) {
+        a(col, j) *= s;
+        inv(col, j) *= s;
+      }
+      for (std::size_t r = 0; r < n; ++r) {
+        if (r == col) continue;
+        const ELEMENT f = a(r, col);
+        if (f == ELEMENT{}) continue;
+        for (std::size_t j = 0; j < n; ++j) {
+          a(r, j) -= f * a(col, j);
+          inv(r, j) -= f * inv(col, j);
+        }
+      }
+    }
+    return inv;
+  }
+
+  bool equals(const Matrix& o) const {
+    if (rows() != o.rows() || cols() != o.cols()) return false;
+    return Vector<ELEMENT>(m_values).equals(Vector<ELEMENT>(o.m_values));
+  }
+  friend bool operator==(const Matrix& l, const Matrix& r) { return l.equals(r); }
+  friend bool operator!=(const Matrix& l, const Matrix& r) { return !l.equals(r); }
+
+  std::string toString() const {
+    if (!(m_rows && m_cols)) return "[ EMPTY MATRIX ]";
+    std::vector<std::size_t> width(m_cols, 0);
+    for (std::size_t j = 0; j < m_cols; ++j)
+      for (std::size_t i = 0; i < m_rows; ++i) width[j] = std::max(width[j], (*this)(i, j).toString().size());
+    std::stringstream ss;
+    ss << "\n";
+    for (std::size_t i = 0; i < m_rows; ++i) {
+      ss << "[";
+      for (std::size_t j = 0; j < m_cols; ++j) ss << std::setfill(' ') << std::setw((int)width[j] + 1) << (*this)(i, j).toString() << " ";
+      ss << "]";
+      if (i + 1 < m_rows) ss << "\n";
+    }
+    return ss.str();
+  }
+  friend std::ostream& operator<<(std::ostream& os, const Matrix& m) { return os << m.toString(); }
+
+  const std::vector<ELEMENT>& values() const { return m_values; }
+
+ private:
+  Matrix(std::size_t r, std::size_t c, std::vector<ELEMENT> v) : m_rows(r), m_cols(c), m_values(std::move(v)) {}
+
+  Matrix entrywise(const Matrix& o, Vector<ELEMENT> (Vector<ELEMENT>::*op)(const Vector<ELEMENT>&) const) const {
+    if (rows() != o.rows() || cols() != o.cols()) throw std::invalid_argument("incompatible matrices");
+    return Matrix(m_rows, m_cols, (Vector<ELEMENT>(m_values).*op)(Vector<ELEMENT>(o.m_values)).toStlVector());
+  }
+
+  std::size_t m_rows, m_cols;
+  std::vector<ELEMENT> m_values;
+};
+
+}  // namespace scl::math
+
+#endif

@@ -1,0 +1,15 @@
+// include/scl_hip/scl.h -- umbrella header: the hot-path surface of <scl/scl.h> on the MI355X engine.
+#ifndef SCL_HIP_SCL_H
+#define SCL_HIP_SCL_H
+
+#include "hip/device.h"
+#include "math/ff.h"
+#include "math/lagrange.h"
+#include "math/matrix.h"
+#include "math/poly.h"
+#include "math/vector.h"
+#include "ss/additive.h"
+#include "ss/shamir.h"
+#include "util/prg.h"
+
+#endif

@@ -1,0 +1,180 @@
+// include/scl_hip/ss/shamir.h -- scl::ss Shamir sharing (include/scl/ss/shamir.h:51-155) on the GPU.
+//
+// The reference works one secret per call and returns a heap Vector of n shares; those signatures
+// are kept (they run the same kernels with N = 1, through the C ABI).  The batch forms in scl::ss
+// take many secrets at once and keep the shares in HBM as a ShareMatrix (SoA [party][secret]).
+// Results are bit-identical to the per-secret reference calls driven by the same PRG.
+#ifndef SCL_HIP_SS_SHAMIR_H
+#define SCL_HIP_SS_SHAMIR_H
+
+#include <cstdint>
+#include <vector>
+
+#include "../hip/device.h"
+#include "../math/lagrange.h"
+#include "../math/vector.h"
+#include "../util/prg.h"
+
+namespace scl::ss {
+
+namespace shamir_detail {
+template <typename T>
+constexpr std::size_t limbs() {
+  return T::byteSize() / 8;
+}
+/// AES blocks one shamirSecretShare call draws: Vector::random(t+1) = ceil((t+1)*byteSize/16)
+template <typename T>
+std::uint64_t blocksPerSecret(std::size_t t) {
+  return ((t + 1) * T::byteSize() + 15) / 16;
+}
+template <typename T>
+std::vector<std::uint64_t> toLimbs(const math::Vector<T>& v) {
+  std::vector<std::uint64_t> out(v.size() * limbs<T>() + 1);
+  for (std::size_t i = 0; i < v.size(); ++i) v[i].toLimbs(out.data() + i * limbs<T>());
+  return out;
+}
+}  // namespace shamir_detail
+
+// ------------------------------------------------------------------------------------------- batch
+/// shamirSecretShare for a whole batch: secret s is shared exactly as the reference's
+/// shamirSecretShare(secrets[s], t, n, prg) would on this PRG, in order.  The PRG is advanced.
+template <typename T>
+hip::ShareMatrix<T> shamirSecretShare(const hip::DeviceVector<T>& secrets, std::size_t t, std::size_t n,
+                                      util::PRG& prg) {
+  hip::ShareMatrix<T> shares(n, secrets.size());
+  const auto seed = prg.Seed();
+  hip::check(scl_hip_shamir_share_prg(T::Field::TAG, shares.data(), shares.stride(), secrets.data(), secrets.size(), t,
+                                      n, seed.data(), seed.size(), prg.counter(), nullptr));
+  prg.advance(secrets.size() * shamir_detail::blocksPerSecret<T>(t));
+  return shares;
+}
+
+/// the same with caller-provided coefficient vectors c_1..c_t (each of secrets.size() elements)
+template <typename T>
+hip::ShareMatrix<T> shamirSecretShare(const hip::DeviceVector<T>& secrets,
+                                      const std::vector<hip::DeviceVector<T>>& coefficients, std::size_t n) {
+  const std::size_t N = secrets.size(), t = coefficients.size();
+  hip::DeviceVector<T> packed(t * N);
+  for (std::size_t k = 0; k < t; ++k) {
+    if (coefficients[k].size() != N) hip::detail::raise(SCL_ERR_SIZE_MISMATCH);
+    hip::check(scl_hip_stream_copy(packed.data() + k * N * shamir_detail::limbs<T>(), coefficients[k].data(),
+                                   N * T::byteSize(), nullptr));
+  }
+  hip::ShareMatrix<T> shares(n, N);
+  hip::check(scl_hip_shamir_share(T::Field::TAG, shares.data(), shares.stride(), secrets.data(), packed.data(), N, N, t,
+                                  n, nullptr, nullptr));
+  hip::check(scl_hip_stream_sync(nullptr));
+  return shares;
+}
+
+namespace shamir_detail {
+/// out[s] = sum_{i < parties} lambda[i] * shares[i][s]
+template <typename T>
+hip::DeviceVector<T> recoverWithBasis(const hip::ShareMatrix<T>& shares, const math::Vector<T>& lambda) {
+  if (lambda.size() < shares.parties()) hip::detail::raise(SCL_ERR_SIZE_MISMATCH);
+  const auto lam = toLimbs(lambda);
+  hip::DeviceVector<T> out(shares.secrets());
+  hip::check(scl_hip_shamir_recover(T::Field::TAG, out.data(), shares.data(), shares.stride(), lam.data(),
+                                    shares.parties(), shares.secrets(), nullptr));
+  return out;
+}
+}  // namespace shamir_detail
+
+/// shamirRecoverP for every secret of a share matrix: basis for `alphas` at `x`, computed once
+/// (the reference recomputes it -- n(n-1) field inversions -- for every secret, shamir.h:85)
+template <typename T>
+hip::DeviceVector<T> shamirRecoverP(const hip::ShareMatrix<T>& shares, const math::Vector<T>& alphas, const T& x) {
+  return shamir_detail::recoverWithBasis(shares, math::computeLagrangeBasis(alphas, x));
+}
+
+template <typename T>
+hip::DeviceVector<T> shamirRecoverP(const hip::ShareMatrix<T>& shares) {
+  return shamirRecoverP(shares, math::Vector<T>::range(1, shares.parties() + 1), T{});
+}
+
+/// batch shamirRecoverD(shares, t): returns the values; `bad` (optional) receives the indices of the
+/// secrets for which the reference would throw "error detected during recovery"
+template <typename T>
+hip::DeviceVector<T> shamirRecoverD(const hip::ShareMatrix<T>& shares, std::size_t t,
+                                    std::vector<std::size_t>* bad = nullptr) {
+  hip::DeviceVector<T> out(shares.secrets());
+  hip::DeviceBuffer status(shares.secrets() ? shares.secrets() : 1);
+  std::size_t nbad = 0;
+  const int st = scl_hip_shamir_recover_detect(T::Field::TAG, out.data(), static_cast<unsigned char*>(status.get()),
+                                               shares.data(), shares.stride(), shares.parties(), shares.secrets(), t,
+                                               t, nullptr, nullptr, &nbad, nullptr);
+  if (st != SCL_OK && st != SCL_ERR_ERROR_DETECTED) hip::detail::raise(st);
+  if (st == SCL_ERR_ERROR_DETECTED && bad == nullptr) hip::detail::raise(st);
+  if (bad) {
+    bad->clear();
+    std::vector<unsigned char> h(shares.secrets());
+    if (!h.empty()) hip::check(scl_hip_memcpy_d2h(h.data(), status.get(), h.size(), nullptr));
+    for (std::size_t i = 0; i < h.size(); ++i)
+      if (h[i]) bad->push_back(i);
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------- per-secret (reference)
+/// shamirSecretShare(secret, t, n, prg) (shamir.h:51-68)
+template <typename T>
+math::Vector<T> shamirSecretShare(const T& secret, std::size_t t, std::size_t n, util::PRG& prg) {
+  hip::DeviceVector<T> one(std::vector<T>{secret});
+  const auto m = shamirSecretShare(one, t, n, prg);
+  return math::Vector<T>(m.sharesOf(0));
+}
+
+namespace shamir_detail {
+template <typename T>
+hip::ShareMatrix<T> upload(const math::Vector<T>& shares, std::size_t count) {
+  hip::ShareMatrix<T> m(count, 1);
+  std::vector<std::uint64_t> l(count * limbs<T>() + 1);
+  for (std::size_t i = 0; i < count; ++i) shares[i].toLimbs(l.data() + i * limbs<T>());
+  if (count) hip::check(scl_hip_memcpy_h2d(m.data(), l.data(), count * T::byteSize(), nullptr));
+  hip::check(scl_hip_stream_sync(nullptr));
+  return m;
+}
+}  // namespace shamir_detail
+
+/// shamirRecoverP(shares, alphas, x) (shamir.h:81-87): the basis is taken over ALL alphas and paired
+/// with the shares in order, as innerProd does there
+template <typename T>
+T shamirRecoverP(const math::Vector<T>& shares, const math::Vector<T>& alphas, const T& x) {
+  const auto m = shamir_detail::upload(shares, shares.size());
+  return shamir_detail::recoverWithBasis(m, math::computeLagrangeBasis(alphas, x)).toHost()[0];
+}
+
+/// shamirRecoverP(shares) (shamir.h:99-104): nodes 1..size, x = 0
+template <typename T>
+T shamirRecoverP(const math::Vector<T>& shares) {
+  return shamirRecoverP(shares, math::Vector<T>::range(1, shares.size() + 1), T{});
+}
+
+/// shamirRecoverD(shares, alphas, t, d, x) (shamir.h:116-139)
+template <typename T>
+T shamirRecoverD(const math::Vector<T>& shares, const math::Vector<T>& alphas, std::size_t t, std::size_t d,
+                 const T& x) {
+  if (shares.size() < d + t || alphas.size() < d + t) hip::detail::raise(SCL_ERR_NOT_ENOUGH_SHARES);
+  const std::size_t m = d + t;  // shares d+t .. are never looked at
+  const auto sm = shamir_detail::upload(shares, m);
+  const auto al = shamir_detail::toLimbs(alphas.subVector(m));
+  std::uint64_t xl[shamir_detail::limbs<T>()];
+  x.toLimbs(xl);
+  hip::DeviceVector<T> out(1);
+  hip::DeviceBuffer status(1);
+  std::size_t nbad = 0;
+  hip::check(scl_hip_shamir_recover_detect(T::Field::TAG, out.data(), static_cast<unsigned char*>(status.get()),
+                                           sm.data(), 1, m, 1, t, d, al.data(), xl, &nbad, nullptr));
+  return out.toHost()[0];
+}
+
+/// shamirRecoverD(shares, t) (shamir.h:150-155): n = 2t+1 nodes 1..n, d = t, x = 0
+template <typename T>
+T shamirRecoverD(const math::Vector<T>& shares, std::size_t t) {
+  const std::size_t n = 2 * t + 1;
+  return shamirRecoverD(shares, math::Vector<T>::range(1, n + 1), t, t, T{});
+}
+
+}  // namespace scl::ss
+
+#endif

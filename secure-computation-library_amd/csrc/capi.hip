@@ -15,7 +15,7 @@
 #include <vector>
 
 #include "../../include/scl_hip.h"
-#include "field.hpp"
+#include "../../include/scl_hip/detail/field.hpp"
 #include "kernels.hpp"
 
 using namespace sclhip;
@@ -80,18 +80,7 @@ Mont128::Ctx g_mont = {0, 0, 0, 0};
 
 int mont_set(u128 p) {
   if (!(p & 1) || p < 3) return fail(SCL_ERR_BAD_ARG, "mont128: modulus must be odd and >= 3");
-  Mont128::Ctx c;
-  c.p = p;
-  u128 inv = p;  // 3 correct bits; Newton doubles them
-  for (int i = 0; i < 7; ++i) inv *= 2 - p * inv;
-  c.mc = (u128)0 - inv;
-  u128 r = 1 % p;
-  for (int i = 0; i < 256; ++i) {
-    const u128 t = r + r;
-    r = (t < r || t >= p) ? t - p : t;
-    if (i == 127) c.one = r;
-  }
-  c.r2 = r;
+  const Mont128::Ctx c = Mont128::make_ctx(p);
   std::lock_guard<std::mutex> lk(g_mont_mu);
   g_mont = c;
   return SCL_OK;
@@ -768,7 +757,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
 }
 
 int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N,
-                             size_t t, size_t n, const unsigned char* seed, size_t seed_len, uint64_t first_secret,
+                             size_t t, size_t n, const unsigned char* seed, size_t seed_len, uint64_t counter0,
                              void* stream) {
   if (N == 0 || n == 0) return SCL_OK;
   if (!shares || !secrets) return fail(SCL_ERR_BAD_ARG, "NULL operand");
@@ -782,6 +771,7 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
     AesKey key;
     make_aes_key(seed, seed_len, key);
     const int vec = vec_width<F>({shares, secrets}, {share_stride});
+    const u64 blocks_per_secret = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1);  // ceil((t+1)*byteSize/16)
     if constexpr (F::TAG <= 1) {
       SmallVdm sv;
       if (t >= 1 && small_vandermonde<F>(al, n, t, sv)) {
@@ -792,7 +782,7 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
   case NB:                                                                                                    \
     hipLaunchKernelGGL((k_share_prg_small<F, VEC, NB>), dim3(grid_aes(npacks)), dim3(BLOCK), 0, S(stream),    \
                        shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS, key,              \
-                       (u64)(first_secret + first), sv, (int)t, (int)n, npacks);                              \
+                       (u64)(counter0 + first * blocks_per_secret), sv, (int)t, (int)n, npacks);                              \
     break;
           switch (nblk) {
             SPS_CASE(1) SPS_CASE(2) SPS_CASE(3) SPS_CASE(4)
@@ -819,7 +809,7 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
       const dim3 g(grid_aes(npacks)), blk(BLOCK);
 #define SHAREP_LAUNCH(TREG)                                                                                   \
   hipLaunchKernelGGL((k_share_prg<F, VEC, TREG>), g, blk, 0, S(stream), ctx, sh, share_stride, se, key,         \
-                     (u64)(first_secret + first), al, (int)t, (int)n, npacks)
+                     (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks)
       if (t <= 4) SHAREP_LAUNCH(4);
       else if (t <= 16) SHAREP_LAUNCH(16);
       else SHAREP_LAUNCH(48);
@@ -898,7 +888,7 @@ int scl_hip_additive_share(int field, uint64_t* shares, size_t share_stride, con
 }
 
 int scl_hip_additive_share_prg(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N,
-                               size_t n, const unsigned char* seed, size_t seed_len, uint64_t first_secret,
+                               size_t n, const unsigned char* seed, size_t seed_len, uint64_t counter0,
                                void* stream) {
   if (n == 0) return fail(SCL_ERR_BAD_ARG, "additive share: n must be >= 1");
   if (N == 0) return SCL_OK;
@@ -914,7 +904,7 @@ int scl_hip_additive_share_prg(int field, uint64_t* shares, size_t share_stride,
       constexpr int VEC = decltype(V)::value;
       hipLaunchKernelGGL((k_additive_share_prg<F, VEC>), dim3(grid_aes(npacks)), dim3(BLOCK), 0, S(stream), ctx,
                          shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS, key,
-                         (u64)(first_secret + first), (int)n, npacks);
+                         (u64)(counter0 + first * (n - 1)), (int)n, npacks);
       LAUNCH_CHECK();
       return SCL_OK;
     });

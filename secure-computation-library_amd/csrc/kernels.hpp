@@ -13,7 +13,7 @@
 
 #include <hip/hip_runtime.h>
 
-#include "field.hpp"
+#include "../../include/scl_hip/detail/field.hpp"
 
 namespace sclhip {
 
@@ -600,16 +600,16 @@ __global__ __launch_bounds__(BLOCK) void k_vector_random(typename F::Ctx ctx, u6
   }
 }
 
-// Coefficients of secret (first_secret + q*VEC + v) under the reference PRG discipline (SURVEY.md
+// Coefficients of secret q*VEC + v of a batch whose first draw starts at block counter0, under the reference PRG discipline (SURVEY.md
 // section 8a note P): Vector::random(t+1) from counters [s*B, (s+1)*B), B = ceil((t+1)*byteSize/16);
 // c_0's draw is discarded and replaced by the secret (shamir.h:56-57).
 template <class F, int VEC, int TREG>
 __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, VEC> (&c)[TREG + 1], const u32* te0,
-                                           const AesKey& key, u64 first_secret, size_t q, int t) {
+                                           const AesKey& key, u64 counter0, size_t q, int t) {
   const u64 B = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1);
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
-    const u64 ctr0 = (first_secret + q * VEC + v) * B;
+    const u64 ctr0 = counter0 + (q * VEC + v) * B;
     if constexpr (F::LIMBS == 1) {
       // block j holds coefficients 2j (low 8 bytes) and 2j+1 (high 8 bytes)
 #pragma unroll
@@ -639,7 +639,7 @@ __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, V
 // ONE PRG (shamir.h:51-68); Horner evaluation at the default nodes 1..n.
 template <class F, int VEC, int TREG>
 __global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* shares, size_t stride,
-                                                     const u64* secrets, AesKey key, u64 first_secret,
+                                                     const u64* secrets, AesKey key, u64 counter0,
                                                      BigTable<F> tab, int t, int n, size_t npacks) {
   SCL_AES_PROLOGUE(key)
   __shared__ typename F::E alpha[BigTable<F>::CAP];
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* s
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> c[TREG + 1];
     c[0] = load_pack<F, VEC, true>(secrets + off);
-    prg_coeffs<F, VEC, TREG>(ctx, c, te0, key, first_secret, q, t);
+    prg_coeffs<F, VEC, TREG>(ctx, c, te0, key, counter0, q, t);
     horner_rows<F, VEC, TREG>(ctx, c, t, alpha, n, shares, stride, off);
   }
 }
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* s
 // 128-bit fields (block k = c_k, block 0 skipped).  All VEC*NBLK blocks of a lane run in lockstep.
 template <class F, int VEC, int NBLK>
 __global__ __launch_bounds__(BLOCK) void k_share_prg_small(u64* shares, size_t stride, const u64* secrets, AesKey key,
-                                                           u64 first_secret, SmallVdm tab, int t, int n,
+                                                           u64 counter0, SmallVdm tab, int t, int n,
                                                            size_t npacks) {
   SCL_AES_PROLOGUE(key)
   __shared__ u32 V[SmallVdm::CAP];
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg_small(u64* shares, size_t s
     for (int v = 0; v < VEC; ++v)
 #pragma unroll
       for (int j = 0; j < NBLK; ++j)
-        ctr[v * NBLK + j] = (first_secret + q * VEC + v) * B + j + (F::LIMBS == 1 ? 0 : 1);
+        ctr[v * NBLK + j] = counter0 + (q * VEC + v) * B + j + (F::LIMBS == 1 ? 0 : 1);
     aes_ctr_multi<VEC * NBLK>(te0, key, ctr, lo, hi);
 #pragma unroll
     for (int v = 0; v < VEC; ++v)
@@ -716,10 +716,10 @@ __global__ __launch_bounds__(BLOCK) void k_additive_share(typename F::Ctx ctx, u
   }
 }
 
-// PRG-driven: share i < n-1 of secret s = FF::random on counter s*(n-1)+i (ff.h:72-76: one block each)
+// PRG-driven: share i < n-1 of secret s = FF::random on counter counter0 + s*(n-1)+i (ff.h:72-76: one block each)
 template <class F, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_additive_share_prg(typename F::Ctx ctx, u64* shares, size_t stride,
-                                                              const u64* secrets, AesKey key, u64 first_secret, int n,
+                                                              const u64* secrets, AesKey key, u64 counter0, int n,
                                                               size_t npacks) {
   SCL_AES_PROLOGUE(key)
   SCL_GRID_STRIDE(q, npacks) {
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(BLOCK) void k_additive_share_prg(typename F::Ctx ct
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         u64 lo, hi;
-        aes_ctr_block(te0, key, (first_secret + q * VEC + v) * (u64)(n - 1) + i, lo, hi);
+        aes_ctr_block(te0, key, counter0 + (q * VEC + v) * (u64)(n - 1) + i, lo, hi);
         if constexpr (F::LIMBS == 1)
           r.v[v] = F::from_le_word(ctx, lo);
         else

@@ -199,12 +199,21 @@ def shamir_share(field, secrets, coeffs, n: int, alphas=None, out=None):
     return out
 
 
-def shamir_share_prg(field, secrets, t: int, n: int, seed: bytes, first_secret: int = 0, out=None):
+def blocks_per_secret(field, t: int) -> int:
+    """AES blocks one shamirSecretShare call consumes: ceil((t+1)*byteSize/16)"""
+    return ((t + 1) * 8 * limbs(field) + 15) // 16
+
+
+def shamir_share_prg(field, secrets, t: int, n: int, seed: bytes, first_secret: int = 0, out=None, counter0=None):
+    """first_secret: index of secrets[0] in a longer single-PRG run (counter0 = first_secret * B);
+    counter0 overrides it with an explicit PRG block counter"""
     N = secrets.shape[0]
+    if counter0 is None:
+        counter0 = first_secret * blocks_per_secret(field, t)
     if out is None:
         out = empty(field, n, N, device=secrets.device)
     _chk(lib.scl_hip_shamir_share_prg(field, _dev(out), C.c_size_t(N), _dev(secrets), C.c_size_t(N), C.c_size_t(t),
-                                      C.c_size_t(n), seed, C.c_size_t(len(seed)), C.c_uint64(first_secret),
+                                      C.c_size_t(n), seed, C.c_size_t(len(seed)), C.c_uint64(counter0),
                                       _stream()))
     return out
 
@@ -253,12 +262,14 @@ def additive_share(field, secrets, rnd, n: int, out=None):
     return out
 
 
-def additive_share_prg(field, secrets, n: int, seed: bytes, first_secret: int = 0, out=None):
+def additive_share_prg(field, secrets, n: int, seed: bytes, first_secret: int = 0, out=None, counter0=None):
     N = secrets.shape[0]
+    if counter0 is None:
+        counter0 = first_secret * (n - 1)
     if out is None:
         out = empty(field, n, N, device=secrets.device)
     _chk(lib.scl_hip_additive_share_prg(field, _dev(out), C.c_size_t(N), _dev(secrets), C.c_size_t(N), C.c_size_t(n),
-                                        seed, C.c_size_t(len(seed)), C.c_uint64(first_secret), _stream()))
+                                        seed, C.c_size_t(len(seed)), C.c_uint64(counter0), _stream()))
     return out
 
 

@@ -1,0 +1,84 @@
+"""Multi-GPU plumbing: one process per GPU over torch.distributed (backend "nccl" = RCCL on xGMI).
+
+Two things only:
+
+* sharding -- secrets are independent, so a batch splits along the secret axis with no data-path
+  collective; `shard_bounds` also gives the PRG counter origin (`first_secret`) that keeps every
+  rank bit-identical to the single-PRG reference run (SURVEY.md section 8a note P).
+* the "open" step -- every party sends its share vector to every party, then reconstructs
+  (reference: Network::send + Network::recv, include/scl/net/network.h:148-185, exercised by
+  test/scl/protocol/beaver.h:43-55).  Parties map onto ranks; one all-gather of each rank's
+  `[parties_per_rank][chunk]` slab per chunk, overlapped with the reconstruct kernel of the
+  previous chunk on the compute stream.
+
+The collective/layout code is device-agnostic (it runs on CPU tensors over gloo in the tests);
+the arithmetic is always the HIP kernels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(N: int, rank: int, world: int) -> tuple[int, int]:
+    """contiguous split of [0, N): (first_secret, count); the first N % world ranks get one extra"""
+    base, rem = divmod(N, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def party_slab(n: int, rank: int, world: int) -> tuple[int, int]:
+    """parties owned by `rank` when n parties are dealt in contiguous blocks of ceil(n/world)"""
+    per = -(-n // world)
+    first = min(rank * per, n)
+    return first, max(0, min(per, n - first))
+
+
+def parties_per_rank(n: int, world: int) -> int:
+    return -(-n // world)
+
+
+def open_shares(local: torch.Tensor, n: int, group=None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """All-gather of party slabs.  local: [parties_per_rank(n)][N][L] (rows past this rank's party
+    count are padding).  Returns [n][N][L] with party p = rank*per + j at row p."""
+    world = dist.get_world_size(group)
+    per = parties_per_rank(n, world)
+    if local.shape[0] != per:
+        raise ValueError(f"local slab must have {per} party rows (pad the last rank)")
+    gathered = out if out is not None else torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype,
+                                                        device=local.device)
+    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    return gathered[:n]
+
+
+def open_and_reconstruct(field: int, local: torch.Tensor, n: int, lam, chunk: int = 1 << 24, group=None,
+                         recover=None) -> torch.Tensor:
+    """The MPC 'open': gather all n parties' shares of N secrets and reconstruct on every rank.
+    Chunked over the secret axis; the all-gather of chunk k+1 (RCCL, its own stream) overlaps the
+    reconstruct kernel of chunk k.  `recover(field, shares[n][c][L], lam, out)` defaults to the HIP
+    kernel; tests inject a checker to exercise the collective on CPU."""
+    if recover is None:
+        from . import shamir_recover as recover  # the HIP path; raises without a GPU
+    world = dist.get_world_size(group)
+    per = parties_per_rank(n, world)
+    N, L = local.shape[1], local.shape[2]
+    out = torch.empty((N, L), dtype=local.dtype, device=local.device)
+    bufs = [torch.empty((world * per, min(chunk, N), L), dtype=local.dtype, device=local.device) for _ in range(2)]
+    pending = None
+    starts = list(range(0, N, chunk))
+    for k, s0 in enumerate(starts):
+        c = min(chunk, N - s0)
+        buf = bufs[k % 2][:, :c] if c == bufs[k % 2].shape[1] else torch.empty((world * per, c, L), dtype=local.dtype,
+                                                                                device=local.device)
+        work = dist.all_gather_into_tensor(buf, local[:, s0:s0 + c].contiguous(), group=group, async_op=True)
+        if pending is not None:
+            pwork, pbuf, ps0, pc = pending
+            pwork.wait()
+            recover(field, pbuf[:n], lam, out[ps0:ps0 + pc])
+        pending = (work, buf, s0, c)
+    if pending is not None:
+        pwork, pbuf, ps0, pc = pending
+        pwork.wait()
+        recover(field, pbuf[:n], lam, out[ps0:ps0 + pc])
+    return out

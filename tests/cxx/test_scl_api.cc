@@ -1,0 +1,428 @@
+// tests/cxx/test_scl_api.cc -- the reference's own tests for the hot path, restated against the C++
+// mirror (include/scl_hip/), so that they read like test/scl/math/test_ff.cc, test_vector.cc,
+// test_poly.cc, test_matrix.cc, test/scl/ss/test_shamir.cc, test_additive.cc and
+// test/scl/util/test_prg.cc.  Known-answer values come from the real reference
+// (tests/golden/golden_v1.json).
+//
+//   test_scl_api --host-only   scalar FF / Polynomial / hex / Lagrange-table cases (no GPU needed)
+//   test_scl_api               everything (needs a GPU: Vector, Matrix, PRG and ss:: run HIP kernels)
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include <scl_hip/scl.h>
+
+using namespace scl;
+
+static int g_fail = 0, g_checks = 0;
+#define REQUIRE(...)                                                         \
+  do {                                                                       \
+    ++g_checks;                                                              \
+    if (!(__VA_ARGS__)) {                                                           \
+      ++g_fail;                                                              \
+      std::printf("  FAILED %s:%d: %s\n", __FILE__, __LINE__, #__VA_ARGS__);       \
+    }                                                                        \
+  } while (0)
+#define REQUIRE_THROWS_MSG(expr, Type, msg)                                  \
+  do {                                                                       \
+    ++g_checks;                                                              \
+    bool ok_ = false;                                                        \
+    try {                                                                    \
+      (void)(expr);                                                          \
+    } catch (const Type& e_) {                                               \
+      ok_ = std::string(e_.what()) == (msg);                                 \
+      if (!ok_) std::printf("  wrong message '%s'\n", e_.what());            \
+    } catch (...) {                                                          \
+    }                                                                        \
+    if (!ok_) {                                                              \
+      ++g_fail;                                                              \
+      std::printf("  FAILED %s:%d: %s should throw %s(\"%s\")\n", __FILE__, __LINE__, #expr, #Type, msg); \
+    }                                                                        \
+  } while (0)
+
+struct Case {
+  const char* name;
+  bool needs_gpu;
+  std::function<void()> fn;
+};
+static std::vector<Case>& cases() {
+  static std::vector<Case> c;
+  return c;
+}
+struct Reg {
+  Reg(const char* n, bool g, std::function<void()> f) { cases().push_back({n, g, std::move(f)}); }
+};
+#define TEST_CASE(id, name, gpu) \
+  static void id();              \
+  static Reg reg_##id(name, gpu, id); \
+  static void id()
+
+using F61 = math::Fp<61>;
+using F127 = math::Fp<127>;
+
+// ---------------------------------------------------------------------------- scalars (host)
+template <typename FF>
+static void field_identities(const char* seed_tag) {
+  // test/scl/math/test_ff.cc:64-227 -- identities on pseudo-random operands.  Operands come from
+  // FF::fromString over a simple counter hash so that this case needs no PRG (no GPU).
+  std::uint64_t st = 0x9E3779B97F4A7C15ull ^ (std::uint64_t)seed_tag[0];
+  auto next = [&]() {
+    char buf[33];
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    std::uint64_t a = st;
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    std::snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)a, (unsigned long long)st);
+    return FF::fromString(buf);
+  };
+  const FF zero = FF::zero(), one = FF::one();
+  for (int rep = 0; rep < 50; ++rep) {
+    FF a = next(), b = next(), c = next();
+    if (a == zero) a = one;
+    if (b == zero) b = one;
+    REQUIRE(a + b == b + a);
+    REQUIRE(a * b == b * a);
+    REQUIRE(c * (a + b) == c * a + c * b);
+    REQUIRE((a + b) + c == a + (b + c));
+    REQUIRE(a * a.inverse() == one);
+    REQUIRE(a - a == zero);
+    REQUIRE(-(a - b) == b - a);
+    REQUIRE(a / b == (b / a).inverse());
+    REQUIRE(a + zero == a);
+    REQUIRE(a * one == a);
+    REQUIRE(a * zero == zero);
+    REQUIRE(-a + a == zero);
+    unsigned char buf[FF::byteSize()];
+    a.write(buf);
+    REQUIRE(FF::read(buf) == a);
+    REQUIRE(math::exp(a, 0) == one);
+    REQUIRE(math::exp(a, 1) == a);
+    REQUIRE(math::exp(a, 5) == a * a * a * a * a);
+    FF d = a;
+    REQUIRE(d++ == a);
+    REQUIRE(d == a + one);
+    REQUIRE(--d == a);
+  }
+  REQUIRE_THROWS_MSG(zero.inverse(), std::logic_error, "0 not invertible modulo prime");  // test_ff.cc:168-171
+  REQUIRE(FF(-1) + one == zero);
+  REQUIRE(FF(-5) == zero - FF(5));
+}
+
+TEST_CASE(ff_mersenne61, "FF<Mersenne61> identities + metadata", false) {
+  field_identities<F61>("a");
+  REQUIRE(std::string(F61::name()) == "Mersenne61");  // test_mersenne61.cc:28-33
+  REQUIRE(F61::bitSize() == 61);
+  REQUIRE(F61::byteSize() == 8);
+  REQUIRE(F61::fromString("7b") == F61(0x7b));        // :41-47
+  REQUIRE(F61(0x41621e).toString() == "41621e");
+  REQUIRE(F61::fromString("1fffffffffffffff") == F61(0));  // p == 0
+  REQUIRE_THROWS_MSG(F61::fromString("abc"), std::invalid_argument, "odd-length hex string");
+  REQUIRE_THROWS_MSG(F61::fromString("zz"), std::invalid_argument, "encountered invalid hex character");
+  std::stringstream ss;
+  ss << F61(255);
+  REQUIRE(ss.str() == "ff");
+}
+
+TEST_CASE(ff_mersenne127, "FF<Mersenne127> identities + metadata", false) {
+  field_identities<F127>("b");
+  REQUIRE(std::string(F127::name()) == "Mersenne127");  // test_mersenne127.cc:28-33
+  REQUIRE(F127::bitSize() == 127);
+  REQUIRE(F127::byteSize() == 16);
+  REQUIRE(F127::fromString("80000000000000000000000000000000") == F127(1));  // :41-42: 2^127 = 1
+  const auto v = F127::fromString("58797a14d0653d22a05c11c60e1aacf4");     // :44-45
+  REQUIRE(v.toString() == "58797a14d0653d22a05c11c60e1aacf4");
+  REQUIRE((std::is_same_v<math::Fp<62>, F127>));  // fp.h:34-43 selection
+  REQUIRE((std::is_same_v<math::Fp<1>, F61>));
+}
+
+TEST_CASE(ff_plugins, "plug-in fields: Mont128, GF(2^128) identities", false) {
+  field_identities<math::FF<math::ff::Mont128>>("c");
+  using G = math::FF<math::ff::GF2_128>;
+  G a = G::fromString("0123456789abcdeffedcba9876543210"), b = G::fromString("ffeeddccbbaa99887766554433221100");
+  REQUIRE(a + a == G::zero());
+  REQUIRE(a * b == b * a);
+  REQUIRE(a * a.inverse() == G::one());
+  REQUIRE((a + b) * a == a * a + b * a);
+  // x^127 * x = x^128 = x^7 + x^2 + x + 1
+  REQUIRE(G::fromString("80000000000000000000000000000000") * G(2) == G(0x87));
+}
+
+TEST_CASE(poly_host, "Polynomial: create / evaluate / arithmetic", false) {
+  using P = math::Polynomial<F61>;
+  // test/scl/math/test_poly.cc:64-71: 4 + 5x + x^2 at 5 = 54
+  const auto p = P::create({F61(4), F61(5), F61(1)});
+  REQUIRE(p.evaluate(F61(5)) == F61(54));
+  REQUIRE(p.degree() == 2);
+  // trailing zeros are trimmed (poly.h:178-198)
+  REQUIRE(P::create({F61(1), F61(2), F61(0), F61(0)}).degree() == 1);
+  REQUIRE(P::create({F61(0), F61(0)}).isZero());
+  const auto q = P::create({F61(1), F61(1)});
+  const auto pq = p.multiply(q);  // (4+5x+x^2)(1+x) = 4 + 9x + 6x^2 + x^3
+  REQUIRE(pq[0] == F61(4));
+  REQUIRE(pq[1] == F61(9));
+  REQUIRE(pq[2] == F61(6));
+  REQUIRE(pq[3] == F61(1));
+  const auto qr = pq.divide(q);
+  REQUIRE(qr[1].isZero());
+  REQUIRE(qr[0].evaluate(F61(7)) == p.evaluate(F61(7)));
+  REQUIRE(p.add(q).evaluate(F61(3)) == p.evaluate(F61(3)) + q.evaluate(F61(3)));
+  REQUIRE(p.subtract(p).isZero());
+}
+
+TEST_CASE(lagrange_host, "computeLagrangeBasis (host table code)", false) {
+  // closed form for nodes 1..n at 0: (-1)^(i-1) C(n,i)   
+  const auto lb = math::computeLagrangeBasis(math::Vector<F61>::range(1, 11), 0);
+  const int want[10] = {10, -45, 120, -210, 252, -210, 120, -45, 10, -1};
+  for (int i = 0; i < 10; ++i) REQUIRE(lb[i] == F61(want[i]));
+  REQUIRE_THROWS_MSG(math::computeLagrangeBasis(math::Vector<F61>{F61(1), F61(2), F61(2)}, 0), std::logic_error,
+                     "0 not invertible modulo prime");
+  REQUIRE_THROWS_MSG(math::Vector<F61>::range(3, 1), std::invalid_argument, "invalid range");
+  REQUIRE(math::Vector<F61>::range(2, 2).empty());
+}
+
+TEST_CASE(matrix_host, "Matrix: identity / transpose / invert on scalars", false) {
+  using M = math::Matrix<F61>;
+  auto m = M::fromVector(2, 2, {F61(1), F61(2), F61(3), F61(4)});
+  REQUIRE(m.transpose()(0, 1) == F61(3));
+  REQUIRE(M::identity(3).isIdentity());
+  const auto inv = m.invert();
+  // m * m^-1 = I checked entry by entry with scalars (test_matrix.cc:326-331 uses multiply)
+  REQUIRE(m(0, 0) * inv(0, 0) + m(0, 1) * inv(1, 0) == F61(1));
+  REQUIRE(m(0, 0) * inv(0, 1) + m(0, 1) * inv(1, 1) == F61(0));
+  REQUIRE(m(1, 0) * inv(0, 0) + m(1, 1) * inv(1, 0) == F61(0));
+  REQUIRE(m(1, 0) * inv(0, 1) + m(1, 1) * inv(1, 1) == F61(1));
+  REQUIRE_THROWS_MSG(M(0, 2), std::invalid_argument, "n or m cannot be 0");
+  REQUIRE_THROWS_MSG(M::fromVector(2, 2, {F61(1)}), std::invalid_argument, "invalid dimensions");
+  REQUIRE_THROWS_MSG(M(2, 3).invert(), std::invalid_argument, "cannot invert non-square matrix");
+}
+
+// ---------------------------------------------------------------------------- GPU-backed
+TEST_CASE(prg_gpu, "util::PRG stream", true) {
+  // test/scl/util/test_prg.cc:49-125 (determinism, reset, seed truncation) + known answers
+  auto prg = util::PRG::create("shamir passive");
+  const auto b = prg.next(32);
+  const unsigned char want[32] = {0x96, 0x5e, 0xf3, 0x3d, 0x3c, 0x2c, 0xdc, 0x34, 0x67, 0x66, 0x2f, 0xf2, 0x20, 0x77, 0xce, 0xde,
+                                  0x04, 0x8c, 0xd9, 0xa3, 0x69, 0xc0, 0xf7, 0xec, 0x8b, 0x1e, 0x76, 0xf3, 0x6b, 0xae, 0xc7, 0x1a};
+  REQUIRE(std::memcmp(b.data(), want, 32) == 0);
+  auto z = util::PRG::create();
+  const auto zb = z.next(16);
+  const unsigned char zw[16] = {0x77, 0x27, 0xa8, 0x00, 0x4e, 0xa0, 0xc9, 0x70, 0x84, 0x41, 0x89, 0x3d, 0x28, 0x08, 0xca, 0x94};
+  REQUIRE(std::memcmp(zb.data(), zw, 16) == 0);
+  prg.reset();
+  REQUIRE(prg.next(32) == b);
+  // next(n) burns whole blocks: 8 bytes then 8 bytes come from blocks 0 and 1
+  prg.reset();
+  const auto p0 = prg.next(8), p1 = prg.next(8);
+  REQUIRE(std::memcmp(p0.data(), want, 8) == 0);
+  REQUIRE(std::memcmp(p1.data(), want + 16, 8) == 0);
+  // seeds longer than 16 bytes are truncated (test_prg.cc:115-125)
+  auto l1 = util::PRG::create("0123456789abcdefXYZ"), l2 = util::PRG::create("0123456789abcdef");
+  REQUIRE(l1.next(64) == l2.next(64));
+  std::vector<unsigned char> small(4);
+  REQUIRE_THROWS_MSG(prg.next(small, 5), std::invalid_argument, "n exceeds buffer.size()");
+}
+
+TEST_CASE(vector_gpu, "Vector<FF> members", true) {
+  using Vec = math::Vector<F61>;
+  // test/scl/math/test_vector.cc:39-203
+  const Vec v0{F61(1), F61(2), F61(3)}, v1{F61(2), F61(123), F61(5)};
+  REQUIRE(v0.dot(v1) == F61(263));  // :81-84
+  REQUIRE(v0.add(v1) == Vec{F61(3), F61(125), F61(8)});
+  REQUIRE(v1.subtract(v0) == Vec{F61(1), F61(121), F61(2)});
+  REQUIRE(v0.multiplyEntryWise(v1) == Vec{F61(2), F61(246), F61(15)});
+  REQUIRE(v0.scalarMultiply(F61(2)) == Vec{F61(2), F61(4), F61(6)});
+  REQUIRE(v0.sum() == F61(6));
+  REQUIRE(v0 != v1);
+  REQUIRE(!(v0 == Vec{F61(1), F61(2)}));
+  REQUIRE_THROWS_MSG(v0.add(Vec{F61(1)}), std::invalid_argument, "Vec sizes mismatch");
+  REQUIRE_THROWS_MSG(v0.dot(Vec{F61(1)}), std::invalid_argument, "Vec sizes mismatch");
+  REQUIRE_THROWS_MSG(v0.subVector(2, 1), std::logic_error, "invalid range");
+  REQUIRE(v0.subVector(1, 3) == Vec{F61(2), F61(3)});
+  REQUIRE(Vec::range(1, 4) == v0);
+  REQUIRE(v0.toString() == "[1, 2, 3]");
+  REQUIRE(Vec{}.toString() == "[ EMPTY VECTOR ]");
+  Vec w = v0;
+  w.addInPlace(v1).subtractInPlace(v1);
+  REQUIRE(w == v0);
+  // Vector::random: known answer from the reference
+  auto prg = util::PRG::create("shamir passive");
+  const auto r = Vec::random(4, prg);
+  REQUIRE(r[0] == F61::fromString("14dc2c3c3df35e97"));
+  REQUIRE(r[1] == F61::fromString("1ece7720f22f666d"));
+  REQUIRE(r[2] == F61::fromString("0cf7c069a3d98c0b"));
+  REQUIRE(r[3] == F61::fromString("1ac7ae6bf3761e8b"));
+  REQUIRE(prg.counter() == 2);  // 32 bytes = 2 blocks
+  // a bigger vector: sum/dot against scalar loops
+  auto prg2 = util::PRG::create("big");
+  const auto a = Vec::random(5000, prg2), b = Vec::random(5000, prg2);
+  F61 s, d;
+  for (std::size_t i = 0; i < a.size(); ++i) {
+    s += a[i];
+    d += a[i] * b[i];
+  }
+  REQUIRE(a.sum() == s);
+  REQUIRE(a.dot(b) == d);
+  REQUIRE((math::innerProd<F61>(a.begin(), a.end(), b.begin())) == d);
+}
+
+TEST_CASE(matrix_gpu, "Matrix multiply / vandermonde", true) {
+  using M = math::Matrix<F61>;
+  // test/scl/math/test_matrix.cc:367-395
+  const auto v = M::vandermonde(3, 3);
+  const int want[9] = {1, 1, 1, 1, 2, 4, 1, 3, 9};
+  for (int i = 0; i < 9; ++i) REQUIRE(v(i / 3, i % 3) == F61(want[i]));
+  REQUIRE_THROWS_MSG(M::vandermonde(3, 3, math::Vector<F61>{F61(1)}), std::invalid_argument, "|xs| != number of rows");
+  // :175-205 style small integer products
+  const auto a = M::fromVector(2, 2, {F61(1), F61(2), F61(3), F61(4)});
+  const auto b = M::fromVector(2, 2, {F61(5), F61(6), F61(7), F61(8)});
+  const auto c = a.multiply(b);
+  REQUIRE(c == M::fromVector(2, 2, {F61(19), F61(22), F61(43), F61(50)}));
+  REQUIRE_THROWS_MSG(a.multiply(M(3, 2)), std::invalid_argument, "matmul: this->cols() != that->rows()");
+  REQUIRE(a.multiply(a.invert()).isIdentity());  // :326-331
+  REQUIRE(a.multiply(math::Vector<F61>{F61(1), F61(1)}) == math::Vector<F61>{F61(3), F61(7)});
+  REQUIRE(a.add(b) == M::fromVector(2, 2, {F61(6), F61(8), F61(10), F61(12)}));
+  // :342-365 -- Vandermonde evaluation then interpolation through the inverse
+  auto prg = util::PRG::create("vdm");
+  const std::size_t n = 10, t = 3;
+  const auto coeff = math::Vector<F61>::random(t + 1, prg);
+  const auto points = M::vandermonde(n, t + 1).multiply(coeff);
+  const auto poly = math::Polynomial<F61>::create(coeff);
+  for (std::size_t i = 0; i < n; ++i) REQUIRE(points[i] == poly.evaluate(F61((int)i + 1)));
+  const auto back = M::vandermonde(t + 1, t + 1).invert().multiply(points.subVector(t + 1));
+  REQUIRE(back == coeff);
+  // hyper-invertible: every square sub-matrix invertible; spot-check one
+  const auto him = M::hyperInvertible(3, 3);
+  REQUIRE(him.multiply(him.invert()).isIdentity());
+}
+
+TEST_CASE(shamir_gpu, "ss::shamir*", true) {
+  // test/scl/ss/test_shamir.cc:34-40
+  {
+    auto prg = util::PRG::create("shamir passive");
+    const auto shares = ss::shamirSecretShare(F61(123), 3, 4, prg);
+    REQUIRE(shares.size() == 4);
+    REQUIRE(shares[0] == F61::fromString("068de5f6897f1180"));  // values from the reference
+    REQUIRE(shares[1] == F61::fromString("07b963480f75f1e3"));
+    REQUIRE(shares[2] == F61::fromString("04308e7c46a958eb"));
+    REQUIRE(shares[3] == F61::fromString("1ca17e1ae3ddfdde"));
+    REQUIRE(ss::shamirRecoverP(shares) == F61(123));
+  }
+  {
+    auto prg = util::PRG::create("shamir passive");
+    const auto shares = ss::shamirSecretShare(F127(123), 3, 4, prg);
+    REQUIRE(shares[0] == F127::fromString("68cb89a3b5d99924eddf871da5480cd8"));
+    REQUIRE(shares[3] == F127::fromString("7009444c16f85b3b6d51f54c483ec2f8"));
+    REQUIRE(ss::shamirRecoverP(shares) == F127(123));
+  }
+  // :42-66 t=5, n=100, nodes 4..9 at x=0 and x=27
+  {
+    auto prg = util::PRG::create("shamir recons");
+    const auto shares = ss::shamirSecretShare(F61(123), 5, 100, prg);
+    REQUIRE(shares.size() == 100);
+    const math::Vector<F61> nodes{F61(4), F61(5), F61(6), F61(7), F61(8), F61(9)};
+    const auto lb_0 = math::computeLagrangeBasis(nodes, 0);
+    const auto r_0 = math::innerProd<F61>(shares.begin() + 3, shares.begin() + 9, lb_0.begin());
+    REQUIRE(r_0 == F61(123));
+    REQUIRE(shares.subVector(3, 9).dot(lb_0) == r_0);
+    const auto lb_27 = math::computeLagrangeBasis(nodes, 27);
+    REQUIRE(math::innerProd<F61>(shares.begin() + 3, shares.begin() + 9, lb_27.begin()) == shares[26]);
+    REQUIRE(ss::shamirRecoverP(shares.subVector(3, 9), nodes, F61(27)) == shares[26]);
+  }
+  // :68-79 detection
+  {
+    auto prg = util::PRG::create("shamir detect");
+    auto shares = ss::shamirSecretShare(F61(123), 4, 9, prg);
+    REQUIRE(ss::shamirRecoverD(shares, 4) == F61(123));
+    shares[2] = F61(4);
+    REQUIRE_THROWS_MSG(ss::shamirRecoverD(shares, 4), std::logic_error, "error detected during recovery");
+    REQUIRE_THROWS_MSG(ss::shamirRecoverD(shares.subVector(5), 4), std::logic_error,
+                       "not enough shares provided to detect errors");
+  }
+  // :81-109 other nodes and evaluation points
+  {
+    auto prg = util::PRG::create("shamir detect2");
+    auto c = math::Vector<F61>::random(4, prg);
+    c[0] = F61(123);
+    const auto p = math::Polynomial<F61>::create(c);
+    std::vector<F61> sh;
+    for (int i = 0; i < 7; ++i) sh.push_back(p.evaluate(F61(i + 42)));
+    const math::Vector<F61> shares(sh);
+    const auto alphas = math::Vector<F61>::range(42, 50);
+    REQUIRE(ss::shamirRecoverD(shares, alphas, 3, 3, F61(0)) == F61(123));
+    REQUIRE(ss::shamirRecoverD(shares, alphas, 3, 3, alphas[0]) == shares[0]);
+  }
+  // batch == the per-secret calls on one PRG, in order
+  {
+    const std::size_t N = 1000, n = 10, t = 3;
+    std::vector<F61> secrets;
+    for (std::size_t s = 0; s < N; ++s) secrets.emplace_back((int)(s * 7919 + 1));
+    auto prg_b = util::PRG::create("batch"), prg_s = util::PRG::create("batch");
+    const hip::DeviceVector<F61> dsec(secrets);
+    const auto m = ss::shamirSecretShare(dsec, t, n, prg_b);
+    for (std::size_t s : {std::size_t(0), std::size_t(1), std::size_t(499), N - 1}) {
+      // replay the sequential PRG up to secret s
+      auto prg = util::PRG::create("batch");
+      prg.advance(2 * s);
+      const auto one = ss::shamirSecretShare(secrets[s], t, n, prg);
+      REQUIRE(math::Vector<F61>(m.sharesOf(s)) == one);
+    }
+    REQUIRE(prg_b.counter() == 2 * N);
+    const auto rec = ss::shamirRecoverP(m).toHost();
+    REQUIRE(math::Vector<F61>(rec) == math::Vector<F61>(secrets));
+    std::vector<std::size_t> bad;
+    (void)prg_s;
+    auto prg_d = util::PRG::create("batch-d");
+    const auto md = ss::shamirSecretShare(dsec, 4, 9, prg_d);
+    const auto recd = ss::shamirRecoverD(md, 4, &bad).toHost();
+    REQUIRE(bad.empty());
+    REQUIRE(math::Vector<F61>(recd) == math::Vector<F61>(secrets));
+  }
+}
+
+TEST_CASE(additive_gpu, "ss::additiveShare", true) {
+  // test/scl/ss/test_additive.cc:26-41
+  auto prg = util::PRG::create();
+  const auto shares = ss::additiveShare(F61(12345), 3, prg);
+  REQUIRE(shares.size() == 3);
+  REQUIRE(shares[0] == F61::fromString("10c9a04e00a8277a"));  // from the reference
+  REQUIRE(shares[1] == F61::fromString("0e0c7bcabdee0f5b"));
+  REQUIRE(shares[2] == F61::fromString("0129e3e74169f963"));
+  REQUIRE(shares.sum() == F61(12345));
+  auto prg2 = util::PRG::create("add");
+  const auto x = ss::additiveShare(F61(55), 10, prg2), y = ss::additiveShare(F61(11), 10, prg2);
+  REQUIRE(x.size() == 10);
+  REQUIRE(x.sum() == F61(55));
+  REQUIRE(x.add(y).sum() == F61(66));  // additive homomorphism
+  REQUIRE(ss::additiveShare(F61(9), 1, prg2) == math::Vector<F61>{F61(9)});
+  // batch
+  std::vector<F61> secrets;
+  for (int s = 0; s < 300; ++s) secrets.emplace_back(s * 31 + 5);
+  auto prg3 = util::PRG::create("add-batch");
+  const auto m = ss::additiveShare(hip::DeviceVector<F61>(secrets), 3, prg3);
+  REQUIRE(prg3.counter() == 600);
+  REQUIRE(math::Vector<F61>(ss::additiveRecover(m).toHost()) == math::Vector<F61>(secrets));
+  auto prg4 = util::PRG::create("add-batch");
+  prg4.advance(2 * 7);
+  REQUIRE(math::Vector<F61>(m.sharesOf(7)) == ss::additiveShare(secrets[7], 3, prg4));
+}
+
+int main(int argc, char** argv) {
+  const bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
+  int ran = 0;
+  for (const auto& c : cases()) {
+    if (host_only && c.needs_gpu) continue;
+    const int before = g_fail;
+    try {
+      c.fn();
+    } catch (const std::exception& e) {
+      ++g_fail;
+      std::printf("  EXCEPTION in '%s': %s\n", c.name, e.what());
+    }
+    std::printf("[%s] %s\n", g_fail == before ? " ok " : "FAIL", c.name);
+    ++ran;
+  }
+  std::printf("%d cases, %d checks, %d failures\n", ran, g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}

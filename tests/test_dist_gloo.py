@@ -1,0 +1,108 @@
+"""world_size-2 (and 3) gloo runs on CPU of the multi-GPU plumbing: secret-axis sharding with PRG
+counter origins, and the all-gather 'open' step's layout.  The HIP kernels cannot run here, so the
+reconstruct step is injected: the CPU oracle acts as the checker of what the collective assembled."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(fn, world, *args):
+    port = _free_port()
+    mp.spawn(_entry, args=(fn, world, port) + args, nprocs=world, join=True)
+
+
+def _entry(rank, fn, world, port, *args):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fn(rank, world, *args)
+    finally:
+        dist.destroy_process_group()
+
+
+def _soa(aos):
+    return np.ascontiguousarray(np.transpose(aos, (1, 0, 2)))
+
+
+def _open_worker(rank, world, field, n, t, N, chunk):
+    from scl_amd import dist as sd
+    port = O.Port()
+    L = O.LIMBS[field]
+    secrets = port.vector_random(field, b"open-secrets", N)
+    full = _soa(port.shamir_share(field, b"open-seed", secrets, t, n))  # [n][N][L], same on every rank
+    per = sd.parties_per_rank(n, world)
+    first, cnt = sd.party_slab(n, rank, world)
+    local = np.zeros((per, N, L), dtype=np.uint64)
+    local[:cnt] = full[first:first + cnt]
+    lt = torch.from_numpy(local.view(np.int64))
+    got = sd.open_shares(lt, n).numpy().view(np.uint64)
+    assert np.array_equal(got, full)
+    nodes = np.stack([port.from_int(field, i + 1) for i in range(n)])
+    lam = port.lagrange_basis(field, nodes, port.from_int(field, 0))
+    calls = []
+
+    def checker(f, shares, lam_, out):  # stands in for the HIP kernel: oracle on the gathered chunk
+        sh = shares.numpy().view(np.uint64)
+        assert sh.shape[0] == n
+        rec = port.shamir_recover_lambda(f, np.ascontiguousarray(np.transpose(sh, (1, 0, 2))), lam_)
+        out.copy_(torch.from_numpy(rec.view(np.int64)))
+        calls.append(sh.shape[1])
+
+    out = sd.open_and_reconstruct(field, lt, n, lam, chunk=chunk, recover=checker)
+    assert np.array_equal(out.numpy().view(np.uint64), secrets)
+    assert sum(calls) == N and len(calls) == -(-N // chunk)
+
+
+@pytest.mark.parametrize("world,field,n,t,N,chunk", [(2, O.M61, 10, 3, 1000, 256), (2, O.M127, 5, 2, 77, 1 << 20),
+                                                     (3, O.M61, 40, 13, 300, 128)])
+def test_open_all_gather_layout(world, field, n, t, N, chunk):
+    _run(_open_worker, world, field, n, t, N, chunk)
+
+
+def _shard_worker(rank, world, field, n, t, N):
+    """each rank shares its own slice with first_secret = its origin; concatenated == the one-PRG run"""
+    from scl_amd import dist as sd
+    port = O.Port()
+    L = O.LIMBS[field]
+    secrets = port.vector_random(field, b"shard-secrets", N)
+    first, cnt = sd.shard_bounds(N, rank, world)
+    # the rank's slice under the reference PRG discipline: coefficients from blocks [s*B, (s+1)*B)
+    B = (t + 2) // 2 if L == 1 else t + 1
+    elems = port.from_bytes(field, port.prg_blocks(b"shard-seed", first * B, cnt * B)).reshape(cnt, -1, L)
+    mine = port.shamir_share_coeffs(field, secrets[first:first + cnt], np.ascontiguousarray(elems[:, 1:t + 1]), n)
+    pieces = [None] * world
+    dist.all_gather_object(pieces, (first, cnt, mine))
+    assert sorted(p[0] for p in pieces) == [sd.shard_bounds(N, r, world)[0] for r in range(world)]
+    assert sum(p[1] for p in pieces) == N
+    whole = np.concatenate([p[2] for p in sorted(pieces, key=lambda p: p[0])])
+    assert np.array_equal(whole, port.shamir_share(field, b"shard-seed", secrets, t, n))
+
+
+@pytest.mark.parametrize("world,N", [(2, 101), (3, 10)])
+def test_sharded_prg_origins_reproduce_the_single_prg_run(world, N):
+    _run(_shard_worker, world, O.M61, 10, 3, N)
+
+
+def test_shard_bounds_cover_everything():
+    from scl_amd import dist as sd
+    for N in (0, 1, 7, 8, 100_000_000):
+        for world in (1, 2, 4, 8):
+            spans = [sd.shard_bounds(N, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == N
+            for (a, c), (b, _) in zip(spans, spans[1:]):
+                assert a + c == b
+    assert [sd.party_slab(40, r, 8) for r in range(8)] == [(5 * r, 5) for r in range(8)]
+    assert [sd.party_slab(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 3), (9, 1)]
