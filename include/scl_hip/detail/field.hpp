@@ -93,6 +93,20 @@ struct M61 {
     return r >= P ? r - P : r;
   }
 
+  // y*x + c for a small constant x < 2^32, LAZY: inputs y, c < 2^62 (not necessarily canonical),
+  // result < 2^61 + 4 and congruent to y*x + c.  Two 32x32->64 multiplies, one fold:
+  //   y*x = h*2^32 + lo32(l),  l = yl*x,  h = yh*x + (l >> 32);   h*2^32 = (h >> 29) + ((h & (2^29-1)) << 32) mod p
+  enum { SMALL_BITS = 32 };
+  static SCL_HD u64 muladd_small_lazy(u64 y, u32 x, u64 c) {
+    const u64 l = (u64)(u32)y * x;
+    const u64 h = (u64)(u32)(y >> 32) * x + (l >> 32);              // < 2^62 + 2^32
+    const u64 v = (u64)(u32)l | ((h & 0x1FFFFFFFull) << 32);         // < 2^61
+    const u64 s = v + (h >> 29) + c;                                 // < 2^63
+    return (s & P) + (s >> 61);
+  }
+  static SCL_HD E canon(u64 r) { return r >= P ? r - P : r; }       // r < 2^61 + P
+  static SCL_HD E muladd_small(const Ctx&, E y, u32 x, E c) { return canon(muladd_small_lazy(y, x, c)); }
+
   struct Acc {
     u128 v;
   };
@@ -167,6 +181,24 @@ struct M127 {
     const u128 r = (w & P()) + (w >> 127);
     return r >= P() ? r - P() : r;
   }
+
+  // y*x + c for a small constant x < 2^32, LAZY: y any u128 (congruent value), c < 2^127; result
+  // < 2^127 + 2^34, congruent to y*x + c.  A 4-limb multiply chain (4 mads) gives 160 bits, one fold.
+  enum { SMALL_BITS = 32 };
+  static SCL_HD u128 muladd_small_lazy(u128 y, u32 x, u128 c) {
+    const u64 t0 = (u64)(u32)y * x;
+    const u64 t1 = (u64)(u32)(y >> 32) * x + (t0 >> 32);
+    const u64 t2 = (u64)(u32)(y >> 64) * x + (t1 >> 32);
+    const u64 t3 = (u64)(u32)(y >> 96) * x + (t2 >> 32);  // bits 96..159 of the product
+    const u128 low = (u128)(u32)t0 | ((u128)(u32)t1 << 32) | ((u128)(u32)t2 << 64) | ((u128)(t3 & 0x7FFFFFFFull) << 96);
+    const u128 s = low + c;  // < 2^128
+    return (s & P()) + (s >> 127) + (t3 >> 31);
+  }
+  static SCL_HD E canon(u128 r) {  // r < 2^127 + 2^34
+    const u128 f = (r & P()) + (r >> 127);
+    return f >= P() ? f - P() : f;
+  }
+  static SCL_HD E muladd_small(const Ctx&, E y, u32 x, E c) { return canon(muladd_small_lazy(y, x, c)); }
 
   struct Acc {
     u128 lo;
@@ -264,6 +296,10 @@ struct Mont128 {
   }
   static SCL_HD E mul(const Ctx& c, E a, E b) { return redc(c, mulwide(a, b)); }
   static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
+  enum { SMALL_BITS = 0 };  // Montgomery residues are never small
+  static SCL_HD E muladd_small(const Ctx& c, E y, u32, E a) { return add(c, y, a); }
+  static SCL_HD E muladd_small_lazy(E y, u32, E) { return y; }
+  static SCL_HD E canon(E r) { return r; }
   static SCL_HD E to_mont(const Ctx& c, u128 x) { return mul(c, x, c.r2); }
   static SCL_HD u128 from_mont(const Ctx& c, E a) { return mul(c, a, 1); }
   static SCL_HD E from_u64(const Ctx& c, u64 v) { return to_mont(c, v); }
@@ -331,6 +367,23 @@ struct Gf128 {
     return r;
   }
   static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
+  // y*x + c for a small polynomial x (< 2^16, wave-uniform on the GPU): shift-xor per set bit of x,
+  // then the <= 16 overflow bits are reduced with x^128 = x^7 + x^2 + x + 1.
+  enum { SMALL_BITS = 16 };
+  static SCL_HD E canon(E r) { return r; }
+  static SCL_HD E muladd_small_lazy(E y, u32 x, E c) { return muladd_small(Ctx{}, y, x, c); }
+  static SCL_HD E muladd_small(const Ctx&, E y, u32 x, E c) {
+    u128 lo = 0;
+    u64 ovf = 0;
+    const u64 ytop = (u64)(y >> 64);
+    while (x) {
+      const int b = __builtin_ctz(x);
+      x &= x - 1;
+      lo ^= y << b;
+      ovf ^= b ? (ytop >> (64 - b)) : 0;  // bits of y shifted past bit 127 (b <= 15)
+    }
+    return lo ^ c ^ (u128)((ovf << 7) ^ (ovf << 2) ^ (ovf << 1) ^ ovf);
+  }
   static SCL_HD E from_le_word(const Ctx&, u128 w) { return w; }
 
   struct Acc {

@@ -275,6 +275,15 @@ bool small_vandermonde(const BigTable<F>& al, size_t n, size_t t, SmallVdm& sv) 
   return true;
 }
 
+// every node below 2^SMALL_BITS as an integer / bit pattern -> the Horner kernels' small-constant form
+template <class F>
+bool small_nodes(const BigTable<F>& al, size_t n) {
+  if (F::SMALL_BITS == 0 || g_force_table.load() > 1) return false;
+  for (size_t i = 0; i < n; ++i)
+    if ((u128)al.v[i] >> F::SMALL_BITS) return false;
+  return true;
+}
+
 template <class F>
 int alpha_table(const typename F::Ctx& ctx, const u64* alphas_host, size_t n, BigTable<F>& tab) {
   if (n > (size_t)BigTable<F>::CAP)
@@ -688,6 +697,14 @@ int scl_hip_shamir_recover(int field, uint64_t* out, const uint64_t* shares, siz
     } else {
       for (size_t i = 0; i < m; ++i) big.v[i] = F::ld(lambda_host + i * F::LIMBS);
     }
+    if constexpr (F::TAG == 3) {
+      if (!g_force_table.load()) {  // GF(2^128): nibble-table kernel
+        hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
+                           (int)m, N);
+        LAUNCH_CHECK();
+        return SCL_OK;
+      }
+    }
     return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;
       u64* o = out + first * F::LIMBS;
@@ -722,6 +739,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
     SCL_TRY(check_align<F>({shares, secrets, coeffs}));
     BigTable<F> al;
     SCL_TRY(alpha_table<F>(ctx, alphas_host, n, al));
+    const bool smallx = small_nodes<F>(al, n);
     const int vec = vec_width<F>({shares, secrets, coeffs}, {share_stride, t ? coeff_stride : 0});
     if constexpr (F::TAG <= 1) {
       SmallVdm sv;
@@ -743,9 +761,15 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
       const u64* se = secrets + first * F::LIMBS;
       const u64* co = coeffs ? coeffs + first * F::LIMBS : nullptr;
       const dim3 g(grid_for(npacks)), blk(BLOCK);
-#define SHARE_LAUNCH(TREG)                                                                                     \
-  hipLaunchKernelGGL((k_share<F, VEC, TREG>), g, blk, 0, S(stream), ctx, sh, share_stride, se, co, coeff_stride, \
-                     al, (int)t, (int)n, npacks)
+#define SHARE_LAUNCH(TREG)                                                                                        \
+  do {                                                                                                            \
+    if (smallx)                                                                                                   \
+      hipLaunchKernelGGL((k_share<F, VEC, TREG, true>), g, blk, 0, S(stream), ctx, sh, share_stride, se, co,      \
+                         coeff_stride, al, (int)t, (int)n, npacks);                                               \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_share<F, VEC, TREG, false>), g, blk, 0, S(stream), ctx, sh, share_stride, se, co,     \
+                         coeff_stride, al, (int)t, (int)n, npacks);                                               \
+  } while (0)
       if (t <= 4) SHARE_LAUNCH(4);
       else if (t <= 16) SHARE_LAUNCH(16);
       else SHARE_LAUNCH(48);
@@ -768,6 +792,7 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
     SCL_TRY(check_align<F>({shares, secrets}));
     BigTable<F> al;
     SCL_TRY(alpha_table<F>(ctx, nullptr, n, al));
+    const bool smallx = small_nodes<F>(al, n);
     AesKey key;
     make_aes_key(seed, seed_len, key);
     const int vec = vec_width<F>({shares, secrets}, {share_stride});
@@ -807,9 +832,15 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
       u64* sh = shares + first * F::LIMBS;
       const u64* se = secrets + first * F::LIMBS;
       const dim3 g(grid_aes(npacks)), blk(BLOCK);
-#define SHAREP_LAUNCH(TREG)                                                                                   \
-  hipLaunchKernelGGL((k_share_prg<F, VEC, TREG>), g, blk, 0, S(stream), ctx, sh, share_stride, se, key,         \
-                     (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks)
+#define SHAREP_LAUNCH(TREG)                                                                                      \
+  do {                                                                                                           \
+    if (smallx)                                                                                                  \
+      hipLaunchKernelGGL((k_share_prg<F, VEC, TREG, true>), g, blk, 0, S(stream), ctx, sh, share_stride, se,     \
+                         key, (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks);          \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_share_prg<F, VEC, TREG, false>), g, blk, 0, S(stream), ctx, sh, share_stride, se,    \
+                         key, (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks);          \
+  } while (0)
       if (t <= 4) SHAREP_LAUNCH(4);
       else if (t <= 16) SHAREP_LAUNCH(16);
       else SHAREP_LAUNCH(48);

@@ -286,36 +286,113 @@ __global__ __launch_bounds__(BLOCK) void k_recover_table(typename F::Ctx ctx, u6
   }
 }
 
+// GF(2^128) reconstruct.  Multiplying by the wave-uniform constant lambda_i is a 4-bit-window table
+// walk: T_i[j] = j(x) * lambda_i for the 16 nibble values (256 B per party = one LDS bank row, so a
+// ds_read_b128 with data-dependent nibbles is conflict-free).  The x^4 shifts are shared across
+// parties: for nibble position k (high to low)  r = r * x^4  ^  XOR_i T_i[nib_k(s_i)].
+__global__ __launch_bounds__(BLOCK) void k_recover_gf128(u64* out, const u64* shares, size_t stride,
+                                                         BigTable<Gf128> tab, int m, size_t N) {
+  __shared__ u128 T[BigTable<Gf128>::CAP * 16];
+  for (int e = threadIdx.x; e < m * 16; e += BLOCK) {
+    const u128 l0 = tab.v[e >> 4];
+    const u128 l1 = Gf128::mulx(l0), l2 = Gf128::mulx(l1), l3 = Gf128::mulx(l2);
+    const int j = e & 15;
+    T[e] = (j & 1 ? l0 : (u128)0) ^ (j & 2 ? l1 : (u128)0) ^ (j & 4 ? l2 : (u128)0) ^ (j & 8 ? l3 : (u128)0);
+  }
+  __syncthreads();
+  constexpr int G = 8;
+  SCL_GRID_STRIDE(s, N) {
+    u128 total = 0;
+    for (int i0 = 0; i0 < m; i0 += G) {
+      u32 w[G][4];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        if (i0 + j < m) {  // wave-uniform
+          const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(shares + ((size_t)(i0 + j) * stride + s) * 2));
+          w[j][0] = (u32)v.x;
+          w[j][1] = (u32)(v.x >> 32);
+          w[j][2] = (u32)v.y;
+          w[j][3] = (u32)(v.y >> 32);
+        }
+      }
+      u128 r = 0;
+#pragma unroll
+      for (int k = 31; k >= 0; --k) {
+        r = Gf128::mulx4(r);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          if (i0 + j < m) {
+            const u32 nib = (w[j][k >> 3] >> (4 * (k & 7))) & 15u;
+            r ^= T[(i0 + j) * 16 + nib];
+          }
+        }
+      }
+      total ^= r;
+    }
+    u64x2 o;
+    o.x = (u64)total;
+    o.y = (u64)(total >> 64);
+    __builtin_nontemporal_store(o, reinterpret_cast<u64x2*>(out + s * 2));
+  }
+}
+
 // ---- Shamir share ----------------------------------------------------------------------------
 // Horner over TREG+1 register-resident coefficients (poly.h:56-64); only k <= t take part.
-template <class F, int VEC, int TREG>
+// SMALLX: every node is a small integer (< 2^F::SMALL_BITS; true for the default nodes 1..n), held as
+// u32 in LDS, and y*x + c uses the field's cheap small-constant form.
+template <class F, int VEC, int TREG, bool SMALLX>
 __device__ __forceinline__ void horner_rows(const typename F::Ctx& ctx, const Pack<F, VEC> (&c)[TREG + 1], int t,
-                                            const typename F::E* alpha_lds, int n, u64* shares, size_t stride,
-                                            size_t off) {
+                                            const typename F::E* alpha_lds, const u32* alpha32_lds, int n,
+                                            u64* shares, size_t stride, size_t off) {
   for (int i = 0; i < n; ++i) {
-    const typename F::E x = alpha_lds[i];
     Pack<F, VEC> y;
+    if constexpr (SMALLX) {
+      const u32 x = alpha32_lds[i];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) y.v[v] = F::zero();
+      for (int k = TREG; k >= 0; --k) {
+        if (k == t) {  // wave-uniform
+          y = c[k];
+        } else if (k < t) {
 #pragma unroll
-    for (int k = TREG; k >= 0; --k) {
-      if (k <= t) {  // wave-uniform
+          for (int v = 0; v < VEC; ++v) y.v[v] = F::muladd_small_lazy(y.v[v], x, c[k].v[v]);  // canonical once, below
+        }
+      }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) y.v[v] = F::add(ctx, F::mul(ctx, y.v[v], x), c[k].v[v]);
+      for (int v = 0; v < VEC; ++v) y.v[v] = F::canon(y.v[v]);
+    } else {
+      const typename F::E x = alpha_lds[i];
+#pragma unroll
+      for (int k = TREG; k >= 0; --k) {
+        if (k == t) {
+          y = c[k];
+        } else if (k < t) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) y.v[v] = F::add(ctx, F::mul(ctx, y.v[v], x), c[k].v[v]);
+        }
       }
     }
     store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
   }
 }
 
+// node table of a Horner kernel: full elements, or u32 images when SMALLX
+template <class F, bool SMALLX>
+__device__ __forceinline__ void stage_nodes(const BigTable<F>& tab, int n, typename F::E* alpha, u32* alpha32) {
+  for (int i = threadIdx.x; i < n; i += BLOCK) {
+    if constexpr (SMALLX) alpha32[i] = (u32)tab.v[i];
+    else alpha[i] = tab.v[i];
+  }
+  __syncthreads();
+}
+
 // shamirSecretShare with explicit coefficients (shamir.h:51-68): c_0 = secret, c_k = coeffs[k-1]
-template <class F, int VEC, int TREG>
+template <class F, int VEC, int TREG, bool SMALLX>
 __global__ __launch_bounds__(BLOCK) void k_share(typename F::Ctx ctx, u64* shares, size_t stride,
                                                  const u64* secrets, const u64* coeffs, size_t cstride,
                                                  BigTable<F> tab, int t, int n, size_t npacks) {
-  __shared__ typename F::E alpha[BigTable<F>::CAP];
-  for (int i = threadIdx.x; i < n; i += BLOCK) alpha[i] = tab.v[i];
-  __syncthreads();
+  __shared__ typename F::E alpha[SMALLX ? 1 : BigTable<F>::CAP];
+  __shared__ u32 alpha32[SMALLX ? BigTable<F>::CAP : 1];
+  stage_nodes<F, SMALLX>(tab, n, alpha, alpha32);
   SCL_GRID_STRIDE(q, npacks) {
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> c[TREG + 1];
@@ -324,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) void k_share(typename F::Ctx ctx, u64* share
     for (int k = 1; k <= TREG; ++k) {
       if (k <= t) c[k] = load_pack<F, VEC, true>(coeffs + (size_t)(k - 1) * cstride * F::LIMBS + off);
     }
-    horner_rows<F, VEC, TREG>(ctx, c, t, alpha, n, shares, stride, off);
+    horner_rows<F, VEC, TREG, SMALLX>(ctx, c, t, alpha, alpha32, n, shares, stride, off);
   }
 }
 
@@ -637,20 +714,20 @@ __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, V
 
 // shamirSecretShare(secret_s, t, n, prg) for a whole batch, bit-identical to the per-secret calls on
 // ONE PRG (shamir.h:51-68); Horner evaluation at the default nodes 1..n.
-template <class F, int VEC, int TREG>
+template <class F, int VEC, int TREG, bool SMALLX>
 __global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* shares, size_t stride,
                                                      const u64* secrets, AesKey key, u64 counter0,
                                                      BigTable<F> tab, int t, int n, size_t npacks) {
   SCL_AES_PROLOGUE(key)
-  __shared__ typename F::E alpha[BigTable<F>::CAP];
-  for (int i = threadIdx.x; i < n; i += BLOCK) alpha[i] = tab.v[i];
-  __syncthreads();
+  __shared__ typename F::E alpha[SMALLX ? 1 : BigTable<F>::CAP];
+  __shared__ u32 alpha32[SMALLX ? BigTable<F>::CAP : 1];
+  stage_nodes<F, SMALLX>(tab, n, alpha, alpha32);
   SCL_GRID_STRIDE(q, npacks) {
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> c[TREG + 1];
     c[0] = load_pack<F, VEC, true>(secrets + off);
     prg_coeffs<F, VEC, TREG>(ctx, c, te0, key, counter0, q, t);
-    horner_rows<F, VEC, TREG>(ctx, c, t, alpha, n, shares, stride, off);
+    horner_rows<F, VEC, TREG, SMALLX>(ctx, c, t, alpha, alpha32, n, shares, stride, off);
   }
 }
 

@@ -149,6 +149,72 @@ TEST_CASE(ff_plugins, "plug-in fields: Mont128, GF(2^128) identities", false) {
   REQUIRE(G::fromString("80000000000000000000000000000000") * G(2) == G(0x87));
 }
 
+TEST_CASE(small_forms, "detail/field.hpp: small-constant and lazy forms == generic mul/add", false) {
+  // the device kernels' shortcuts (muladd_small, lazy accumulators) against plain mul/add on the host
+  std::uint64_t st = 88172645463325252ull;
+  auto rnd = [&]() {
+    st ^= st << 13;
+    st ^= st >> 7;
+    st ^= st << 17;
+    return st;
+  };
+  using namespace sclhip;
+  for (int rep = 0; rep < 20000; ++rep) {
+    const u32 x = rep < 64 ? (u32)(0xFFFFFFFFu >> (rep % 32)) : (u32)rnd();
+    {
+      const M61::Ctx c{};
+      const u64 y = rep == 0 ? M61::P - 1 : rnd() % M61::P, a = rep == 1 ? M61::P - 1 : rnd() % M61::P;
+      REQUIRE(M61::muladd_small(c, y, x, a) == M61::add(c, M61::mul(c, y, (u64)x), a));
+      // lazy chain: three steps without intermediate canonicalisation, worst-case inputs included
+      {
+        u64 lz = y, want = y;
+        for (int i = 0; i < 3; ++i) {
+          lz = M61::muladd_small_lazy(lz, x, a);
+          want = M61::add(c, M61::mul(c, want, (u64)x), a);
+        }
+        REQUIRE(M61::canon(lz) == want);
+      }
+      M61::Acc acc = M61::acc_zero();
+      u64 want = 0;
+      for (int i = 0; i < 64; ++i) {
+        const u64 p = i & 1 ? M61::P - 1 : y, q = i & 2 ? M61::P - 1 : a;
+        M61::mac(c, acc, p, q);
+        want = M61::add(c, want, M61::mul(c, p, q));
+      }
+      REQUIRE(M61::acc_fold(c, acc) == want);
+      REQUIRE(M61::from_le_word(c, rnd() | (rep < 3 ? ~0ull : 0)) < M61::P);
+    }
+    {
+      const M127::Ctx c{};
+      const u128 P = M127::P();
+      const u128 y = rep == 0 ? P - 1 : (((u128)rnd() << 64) | rnd()) % P, a = rep == 1 ? P - 1 : (((u128)rnd() << 64) | rnd()) % P;
+      REQUIRE(M127::muladd_small(c, y, x, a) == M127::add(c, M127::mul(c, y, (u128)x), a));
+      {
+        u128 lz = y, want = y;
+        for (int i = 0; i < 3; ++i) {
+          lz = M127::muladd_small_lazy(lz, x, a);
+          want = M127::add(c, M127::mul(c, want, (u128)x), a);
+        }
+        REQUIRE(M127::canon(lz) == want);
+      }
+      M127::Acc acc = M127::acc_zero();
+      u128 want = 0;
+      for (int i = 0; i < 40; ++i) {
+        const u128 p = i & 1 ? P - 1 : y, q = i & 2 ? P - 1 : a;
+        M127::mac(c, acc, p, q);
+        want = M127::add(c, want, M127::mul(c, p, q));
+      }
+      REQUIRE(M127::acc_fold(c, acc) == want);
+    }
+    {
+      const Gf128::Ctx c{};
+      const u128 y = ((u128)rnd() << 64) | rnd(), a = ((u128)rnd() << 64) | rnd();
+      const u32 xs = x & 0xFFFF;
+      REQUIRE(Gf128::muladd_small(c, y, xs, a) == Gf128::add(c, Gf128::mul(c, y, (u128)xs), a));
+    }
+  }
+}
+
 TEST_CASE(poly_host, "Polynomial: create / evaluate / arithmetic", false) {
   using P = math::Polynomial<F61>;
   // test/scl/math/test_poly.cc:64-71: 4 + 5x + x^2 at 5 = 54

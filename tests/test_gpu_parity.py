@@ -239,12 +239,15 @@ def test_shamir_share_recover_vs_oracle(scl, port, f, n, t, N):
     dco = dev(scl, np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2)))) if t else None
     got2 = scl.shamir_share(f, dev(scl, secrets), dco, n)
     assert np.array_equal(host(scl, got2), want2)
-    # the Horner kernel (used for large / arbitrary nodes) on the same inputs
-    scl.set_tuning("force_table", 1)
-    try:
-        assert np.array_equal(host(scl, scl.shamir_share(f, dev(scl, secrets), dco, n)), want2)
-    finally:
-        scl.set_tuning("force_table", 0)
+    # the Horner kernels on the same inputs: 1 = small-constant nodes, 2 = full-width nodes
+    for mode in (1, 2):
+        scl.set_tuning("force_table", mode)
+        try:
+            assert np.array_equal(host(scl, scl.shamir_share(f, dev(scl, secrets), dco, n)), want2), mode
+            if f != O.GF2_128:
+                assert np.array_equal(host(scl, scl.shamir_share_prg(f, dev(scl, secrets), t, n, seed)), want), mode
+        finally:
+            scl.set_tuning("force_table", 0)
     # reconstruct from all n shares (reference semantics) and from the first t+1
     lam = scl.lagrange_basis(f, n)
     assert np.array_equal(lam, port.lagrange_basis(f, O.from_ints(list(range(1, n + 1)), L) if f == O.GF2_128 else
