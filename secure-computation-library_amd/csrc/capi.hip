@@ -17,6 +17,7 @@
 #include "../../include/scl_hip.h"
 #include "../../include/scl_hip/detail/field.hpp"
 #include "kernels.hpp"
+#include "share_mfma.hpp"
 
 using namespace sclhip;
 
@@ -50,6 +51,7 @@ std::atomic<long> g_max_blocks{0};
 std::atomic<long> g_nontemporal{1};
 std::atomic<long> g_force_scalar{0};
 std::atomic<long> g_force_table{0};
+std::atomic<long> g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
 
 unsigned grid_for(size_t work_items) {
   size_t blocks = (work_items + BLOCK - 1) / BLOCK;
@@ -298,6 +300,77 @@ int alpha_table(const typename F::Ctx& ctx, const u64* alphas_host, size_t n, Bi
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
+// ---- MFMA share path (Mersenne61): limb planes of the Vandermonde matrix, cached per device ----------
+struct MfmaTable {
+  int device, n, t, KS, MT;
+  std::vector<u64> alphas;
+  void* dev;
+};
+std::mutex g_mfma_mu;
+std::vector<MfmaTable> g_mfma_tables;  // immutable once built; never freed (a handful of (n,t) pairs)
+
+int mfma_table(const BigTable<M61>& al, size_t n, size_t t, int KS, int MT, const unsigned char** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mfma_mu);
+  for (const MfmaTable& e : g_mfma_tables) {
+    if (e.device == dev && e.n == (int)n && e.t == (int)t && e.KS == KS && e.MT == MT &&
+        std::equal(e.alphas.begin(), e.alphas.end(), al.v)) {
+      *out = static_cast<const unsigned char*>(e.dev);
+      return SCL_OK;
+    }
+  }
+  const int ROWB = mf_rowb(KS);
+  std::vector<unsigned char> host(mf_a_bytes(KS, MT), 0);
+  const M61::Ctx ctx{};
+  for (size_t i = 0; i < n; ++i) {
+    u64 v = 1;  // alpha_i^k, Matrix::vandermonde (matrix.h:444-460)
+    for (size_t k = 0; k <= t; ++k) {
+      if (k) v = M61::mul(ctx, v, al.v[i]);
+      for (int l = 0; l < MF_LIMBS; ++l)
+        host[((size_t)(l * MT + (int)(i / 32)) * 32 + (i % 32)) * ROWB + k] = (unsigned char)((v >> (7 * l)) & 127);
+    }
+  }
+  MfmaTable e{dev, (int)n, (int)t, KS, MT, std::vector<u64>(al.v, al.v + n), nullptr};
+  HIP_TRY(hipMalloc(&e.dev, host.size()));
+  HIP_TRY(hipMemcpy(e.dev, host.data(), host.size(), hipMemcpyHostToDevice));
+  g_mfma_tables.push_back(e);
+  *out = static_cast<const unsigned char*>(e.dev);
+  return SCL_OK;
+}
+
+template <int KS, int MT>
+int launch_share_mfma(u64* shares, size_t stride, const u64* secrets, const u64* coeffs, size_t cstride,
+                      const unsigned char* tab, int t, int n, size_t N, hipStream_t st) {
+  const size_t shmem = mf_a_bytes(KS, MT) + mf_b_bytes(KS, MT);
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_mfma_m61<KS, MT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr_set = true;
+  }
+  const size_t cols = (size_t)2 * (4 / MT) * 32;
+  const size_t nblocks = (N + cols - 1) / cols;
+  const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);  // one 8-wave workgroup per CU, grid-strided
+  hipLaunchKernelGGL((k_share_mfma_m61<KS, MT>), dim3(grid), dim3(512), shmem, st, shares, stride, secrets, coeffs,
+                     cstride, tab, t, n, N);
+  HIP_TRY(hipGetLastError());
+  return SCL_OK;
+}
+
+int share_mfma(const BigTable<M61>& al, u64* shares, size_t stride, const u64* secrets, const u64* coeffs,
+               size_t cstride, size_t N, size_t t, size_t n, hipStream_t st) {
+  const int KS = t + 1 <= 32 ? 1 : 2;
+  const int MT = n <= 32 ? 1 : n <= 64 ? 2 : 4;
+  const unsigned char* tab = nullptr;
+  SCL_TRY(mfma_table(al, n, t, KS, MT, &tab));
+#define MF_CASE(ks, mt) \
+  if (KS == ks && MT == mt) return launch_share_mfma<ks, mt>(shares, stride, secrets, coeffs, cstride, tab, (int)t, (int)n, N, st);
+  MF_CASE(1, 1) MF_CASE(1, 2) MF_CASE(1, 4) MF_CASE(2, 1) MF_CASE(2, 2) MF_CASE(2, 4)
+#undef MF_CASE
+  return fail(SCL_ERR_BAD_ARG, "share_mfma: unsupported shape");
+}
+
 // Runs body(VEC-tag, first_element, npacks) for the vectorisable head and the scalar tail of [0,N).
 template <class F, class Body>
 int split_vec(int vec, size_t N, Body&& body) {
@@ -466,6 +539,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "force_scalar") g_force_scalar = value;
   else if (k == "force_table") g_force_table = value;
   else if (k == "aes_blocks") g_aes_blocks = value;
+  else if (k == "mfma") g_mfma = value;
   else return fail(SCL_ERR_BAD_ARG, "unknown tuning key " + k);
   return SCL_OK;
 }
@@ -741,6 +815,17 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
     SCL_TRY(alpha_table<F>(ctx, alphas_host, n, al));
     const bool smallx = small_nodes<F>(al, n);
     const int vec = vec_width<F>({shares, secrets, coeffs}, {share_stride, t ? coeff_stride : 0});
+    if constexpr (F::TAG == 0) {
+      // dense-contraction path on the matrix cores for large (n, t); "mfma" tuning: 1 forces, -1 disables
+      const long mode = g_mfma.load();
+      SmallVdm probe;
+      const bool eligible = n <= 128 && t >= 1 && t <= 63;
+      // measured on MI355X (profiles/r1_probe_mfma.txt): the matrix-core path wins from about
+      // n*(t+1) >= 1024 multiply-adds per secret ((64,21): 2.7x, (128,42): 2.9x; (40,13): 0.7x)
+      if (eligible && (mode > 0 || (mode == 0 && n * (t + 1) >= 1024 && !small_vandermonde<F>(al, n, t, probe) &&
+                                    !g_force_table.load())))
+        return share_mfma(al, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, S(stream));
+    }
     if constexpr (F::TAG <= 1) {
       SmallVdm sv;
       const bool small = t >= 1 && small_vandermonde<F>(al, n, t, sv);

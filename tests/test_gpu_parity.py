@@ -287,6 +287,34 @@ def test_share_with_explicit_nodes(scl, port, f):
             assert np.array_equal(host(scl, scl.shamir_recover(f, got, lam)), secrets)
 
 
+@pytest.mark.parametrize("n,t,N", [(128, 42, 300), (40, 13, 257), (10, 3, 1000), (33, 8, 31), (64, 31, 65), (65, 32, 96),
+                                   (5, 1, 7), (128, 48, 129), (1, 1, 40), (32, 31, 64)])
+def test_share_on_matrix_cores_vs_oracle(scl, port, n, t, N):
+    """the i8-limb MFMA formulation of V * C (csrc/share_mfma.hpp) == per-secret Horner in the oracle"""
+    f, L = O.M61, 1
+    secrets = rand_elems(port, f, N, b"mf-s")
+    coeffs = rand_elems(port, f, t * N, b"mf-c").reshape(N, t, L)
+    secrets[0] = port.from_int(f, -1)          # p-1 everywhere: every 7-bit limb at its maximum
+    coeffs[0] = port.from_int(f, -1)
+    coeffs[N - 1] = port.from_int(f, 0)
+    dco = dev(scl, np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2))))
+    want = soa(port.shamir_share_coeffs(f, secrets, coeffs, n))
+    scl.set_tuning("mfma", 1)
+    try:
+        got = scl.shamir_share(f, dev(scl, secrets), dco, n)
+        assert np.array_equal(host(scl, got), want)
+        # arbitrary (full-width) nodes too
+        nodes = rand_elems(port, f, n, b"mf-nodes")
+        want2 = soa(np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)]))
+        got2 = scl.shamir_share(f, dev(scl, secrets), dco, n, alphas=nodes)
+        assert np.array_equal(host(scl, got2), want2)
+    finally:
+        scl.set_tuning("mfma", 0)
+    # and the path chosen automatically agrees with the forced VALU path
+    auto = scl.shamir_share(f, dev(scl, secrets), dco, n)
+    assert np.array_equal(host(scl, auto), want)
+
+
 @pytest.mark.parametrize("f", [O.M61, O.M127])
 def test_recover_fixed_and_table_kernels_agree(scl, port, f):
     L = O.LIMBS[f]
