@@ -327,8 +327,9 @@ int mfma_table(const BigTable<M61>& al, size_t n, size_t t, int KS, int MT, cons
     u64 v = 1;  // alpha_i^k, Matrix::vandermonde (matrix.h:444-460)
     for (size_t k = 0; k <= t; ++k) {
       if (k) v = M61::mul(ctx, v, al.v[i]);
+      const u64 digits = mf_recode(v);  // 8 signed base-256 digits, one per byte
       for (int l = 0; l < MF_LIMBS; ++l)
-        host[((size_t)(l * MT + (int)(i / 32)) * 32 + (i % 32)) * ROWB + k] = (unsigned char)((v >> (7 * l)) & 127);
+        host[((size_t)(l * MT + (int)(i / 32)) * 32 + (i % 32)) * ROWB + k] = (unsigned char)(digits >> (8 * l));
     }
   }
   MfmaTable e{dev, (int)n, (int)t, KS, MT, std::vector<u64>(al.v, al.v + n), nullptr};
@@ -821,8 +822,8 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
       SmallVdm probe;
       const bool eligible = n <= 128 && t >= 1 && t <= 63;
       // measured on MI355X (profiles/r1_probe_mfma.txt): the matrix-core path wins from about
-      // n*(t+1) >= 1024 multiply-adds per secret ((64,21): 2.7x, (128,42): 2.9x; (40,13): 0.7x)
-      if (eligible && (mode > 0 || (mode == 0 && n * (t + 1) >= 1024 && !small_vandermonde<F>(al, n, t, probe) &&
+      // n*(t+1) >= 512 multiply-adds per secret ((40,13): 1.0x, (64,21): 3.5x, (128,42): 3.6x over Horner)
+      if (eligible && (mode > 0 || (mode == 0 && n * (t + 1) >= 512 && !small_vandermonde<F>(al, n, t, probe) &&
                                     !g_force_table.load())))
         return share_mfma(al, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, S(stream));
     }

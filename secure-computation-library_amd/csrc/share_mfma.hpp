@@ -5,20 +5,25 @@
 // test/scl/math/test_matrix.cc:342-365).  For large (n, t) -- BASELINE configs[4]: n=128, t=42, i.e.
 // 5 504 modular multiply-adds per secret -- the VALU Horner kernel is compute-bound far below HBM.
 //
-// Formulation: every 61-bit value is split into 9 limbs of 7 bits (signed-i8-safe).  With
-// V = sum_l V_l 2^(7l) and C = sum_m C_m 2^(7m),
-//     V*C = sum_{d=0..16} 2^(7d) E_d,   E_d = sum_{l+m=d} V_l * C_m      (exact in int32: < 9*64*127^2 < 2^24)
+// Formulation: every 61-bit value x is recoded into 8 SIGNED base-256 digits, x = sum_i d_i 2^(8i) with
+// d_i in [-128, 127]: the digits are the bytes of (x + 0x8080808080808080) with their top bits flipped
+// (the +0x80 per byte makes the natural carries do the recoding).  With V = sum_l V_l 2^(8l) and
+// C = sum_m C_m 2^(8m),
+//     V*C = sum_{d=0..14} 2^(8d) E_d,   E_d = sum_{l+m=d} V_l * C_m      (|E_d| <= 8*64*128^2 < 2^24, exact in int32)
 // Each V_l * C_m is an i8 GEMM on v_mfma_i32_32x32x32_i8; all (l, m) pairs of one diagonal d accumulate
-// into the SAME accumulator tile, so the VALU only sees 17 int32 tiles per 32x32 output tile.  They are
-// recombined by Horner in d: adjacent diagonals pair up in 32 bits, three pairs make a 64-bit word of 6
-// diagonals, and the three words are placed by rotations in the 61-bit ring (2^84 = 2^23 mod 2^61 - 1).
+// into the SAME accumulator tile, so the VALU only sees 15 int32 tiles per 32x32 output tile.  Four
+// diagonals form one 32-bit-aligned word T_a = sum_b E_{4a+b} 2^(8b) (three v_mad_i64_i32), and the four
+// words are placed by rotations in the 61-bit ring (2^64 = 8, 2^96 = 2^35 mod 2^61 - 1).  A bias keeps the
+// words positive and is removed as one precomputed constant at the end.
 //
 // Work split: M = evaluation points (tiles of 32, MT = 1, 2 or 4 tiles), N = secrets (tiles of 32),
 // K = coefficients (KS = 1 or 2 steps of 32).  A workgroup is two groups of 4 waves; within a group wave
-// w owns the output tile (N-tile w / MT, M-tile w % MT) of the group's 4/MT N-tiles.  V's limb planes live in LDS for the whole
-// kernel (rows padded to a stride that makes ds_read_b128 fragment loads conflict-free); the block's
-// coefficient limbs are staged into LDS once per block.  k-slot order is the byte order of the LDS rows for both operands,
-// which makes the contraction independent of the instruction's internal k permutation.
+// w owns the output tile (N-tile w / MT, M-tile w % MT) of the group's 4/MT N-tiles, so that on every
+// SIMD one wave's recombination (VALU) runs under the other wave's MFMAs.  V's digit planes live in LDS
+// for the whole kernel (rows padded to a stride that makes ds_read_b128 fragment loads conflict-free);
+// the block's coefficient digits are staged into LDS once per block while the next block's coefficients
+// are already in flight from HBM.  k-slot order is the byte order of the LDS rows for both operands, which
+// makes the contraction independent of the instruction's internal k permutation.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -30,80 +35,83 @@ namespace sclhip {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int MF_LIMBS = 9;  // ceil(61 / 7)
+constexpr int MF_LIMBS = 8;  // signed base-256 digits of a 61-bit value
 constexpr int MF_PAD = 16;   // row padding (bytes): row stride/4 is then 4 * odd -> conflict-free b128 reads
+constexpr u64 MF_RECODE = 0x8080808080808080ull;
 
 __host__ __device__ constexpr int mf_rowb(int KS) { return KS * 32 + MF_PAD; }
 __host__ __device__ constexpr size_t mf_a_bytes(int KS, int MT) { return (size_t)MF_LIMBS * MT * 32 * mf_rowb(KS); }
 __host__ __device__ constexpr size_t mf_b_bytes(int KS, int MT) { return (size_t)MF_LIMBS * 2 * (4 / MT) * 32 * mf_rowb(KS); }
 
-// rotate left by s in the 61-bit ring: x * 2^s mod (2^61 - 1) for x < 2^61 (the all-ones pattern maps to itself = 0)
+// signed digits of x (x < 2^61) as the 8 bytes of the result (two's complement i8 each)
+__host__ __device__ inline u64 mf_recode(u64 x) { return (x + MF_RECODE) ^ MF_RECODE; }
+
+// rotate left by s in the 61-bit ring: x * 2^s mod (2^61 - 1) for x < 2^61
 __device__ __forceinline__ u64 rotl61(u64 x, int s) { return ((x << s) & M61::P) | (x >> (61 - s)); }
 
-// One loop trip of the diagonal recombination: the two diagonals d = 2Q+1 and d = 2Q (Q = 8: only d = 16).
-// Everything here is straight-line with compile-time offsets and shift counts: MFMA chains into two
-// accumulator tiles, then  pairword = E_{2Q+1} * 2^7 + E_{2Q}  (fits 32 bits),  W = W * 2^14 + pairword,
-// and when a 6-diagonal chunk is complete (Q = 6, 3, 0) it is rotated into place in the 61-bit ring.
-template <int Q, int KS, int MT, int COLS>
-__device__ __forceinline__ void mf_pair(const unsigned char* arow, const unsigned char* brow, u64 (&S)[16], u64 (&W)[16]) {
+// Word bias: every T_a gets 2^50 added (|T_a| < 2^49); the total bias
+//   2^50 (1 + 2^32 + 2^64 + 2^96) = 2^50 + 2^21 + 2^53 + 2^24   (mod 2^61 - 1)
+// is subtracted once at the end.
+constexpr u64 MF_WORD_BIAS = 1ull << 50;
+constexpr u64 MF_TOTAL_BIAS = (1ull << 50) + (1ull << 21) + (1ull << 53) + (1ull << 24);
+
+// One loop trip: the four diagonals d = 4A .. 4A+3 (A = 3: d = 12, 13, 14) -> the word T_A, rotated into S.
+// Everything is straight-line with compile-time offsets: MFMA chains into up to four accumulator tiles, then
+//   T = E_{4A} + E_{4A+1} 2^8 + E_{4A+2} 2^16 + E_{4A+3} 2^24 + 2^50      (signed 64-bit multiply-adds)
+template <int A, int KS, int MT, int COLS>
+__device__ __forceinline__ void mf_word(const unsigned char* arow, const unsigned char* brow, u64 (&S)[16]) {
   constexpr int ROWB = mf_rowb(KS);
   constexpr int L = MF_LIMBS;
-  v16i acc0, acc1;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    acc0[e] = 0;
-    acc1[e] = 0;
-  }
-  constexpr int D0 = 2 * Q, D1 = 2 * Q + 1;
+  constexpr int DMAX = 2 * (L - 1);
+  v16i acc[4];
+  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int l = 0; l < L; ++l) {
-    constexpr int dummy = 0;
-    (void)dummy;
-    const int m0 = D0 - l, m1 = D1 - l;
-    if (m0 >= 0 && m0 < L) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const v4i a = *reinterpret_cast<const v4i*>(arow + (size_t)l * MT * 32 * ROWB + ks * 32);
-        const v4i b = *reinterpret_cast<const v4i*>(brow + (size_t)m0 * COLS * ROWB + ks * 32);
-        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc0, 0, 0, 0);
-      }
-    }
-    if (D1 <= 2 * (L - 1) && m1 >= 0 && m1 < L) {
+    for (int j = 0; j < 4; ++j) {
+      const int d = 4 * A + j, m = d - l;
+      if (d <= DMAX && m >= 0 && m < L) {
+        const int l_first = d > L - 1 ? d - (L - 1) : 0;  // the chain's first MFMA takes the inline-constant 0 as C
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const v4i a = *reinterpret_cast<const v4i*>(arow + (size_t)l * MT * 32 * ROWB + ks * 32);
-        const v4i b = *reinterpret_cast<const v4i*>(brow + (size_t)m1 * COLS * ROWB + ks * 32);
-        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc1, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+          const v4i a = *reinterpret_cast<const v4i*>(arow + (size_t)l * MT * 32 * ROWB + ks * 32);
+          const v4i b = *reinterpret_cast<const v4i*>(brow + (size_t)m * COLS * ROWB + ks * 32);
+          acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, (l == l_first && ks == 0) ? zero : acc[j], 0, 0, 0);
+        }
       }
     }
   }
+  // multipliers kept opaque so that the products stay v_mad_i64_i32 (one instruction each) instead of being
+  // strength-reduced into sign-extend + 64-bit shift + 64-bit add
+  int m8 = 256, m16 = 65536, m24 = 16777216, m0 = 1;
+  asm volatile("" : "+s"(m8), "+s"(m16), "+s"(m24), "+s"(m0));
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const u32 pw = ((u32)acc1[e] << 7) + (u32)acc0[e];
-    if constexpr (Q % 3 == 2) W[e] = pw;  // first pair-word of a chunk (Q = 8, 5, 2)
-    else W[e] = (W[e] << 14) + pw;
-    if constexpr (Q == 6) S[e] = rotl61(W[e], 23);        // 2^84 = 2^23 (mod p)
-    if constexpr (Q == 3) S[e] += rotl61(W[e], 42);
-    if constexpr (Q == 0) S[e] += W[e];
+    long long T = (long long)acc[0][e] * m0 + (long long)MF_WORD_BIAS;
+    T = (long long)acc[1][e] * m8 + T;
+    T = (long long)acc[2][e] * m16 + T;
+    if (4 * A + 3 <= DMAX) T = (long long)acc[3][e] * m24 + T;
+    const u64 w = (u64)T;  // 0 < w < 2^51
+    if constexpr (A == 3) S[e] = rotl61(w, 35);   // 2^96
+    if constexpr (A == 2) S[e] += w << 3;         // 2^64
+    if constexpr (A == 1) S[e] += rotl61(w, 32);  // 2^32
+    if constexpr (A == 0) S[e] += w;
   }
 }
 
-// A table layout (host-built, see mfma_table in capi.hip): [limb l][m-tile][row 0..31][mf_rowb] bytes,
-// byte k of a row = limb l of V[mtile*32 + row][k] (0 for k > t or row >= n).
-//
-// 8 waves per workgroup: waves 0-3 and waves 4-7 work on two different groups of N-tiles against the same
-// V planes, so that on every SIMD one wave's recombination (VALU) runs under the other wave's MFMAs.
+// A table layout (host-built, see mfma_table in capi.hip): [digit l][m-tile][row 0..31][mf_rowb] bytes,
+// byte k of a row = signed digit l of V[mtile*32 + row][k] (0 for k > t or row >= n).
 template <int KS, int MT>
 __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stride, const u64* secrets,
                                                         const u64* coeffs, size_t cstride,
                                                         const unsigned char* Atab, int t, int n, size_t N) {
   constexpr int ROWB = mf_rowb(KS);
-  constexpr int NBLK = 4 / MT;            // N-tiles per 4-wave group
-  constexpr int COLS = 2 * NBLK * 32;     // secrets per workgroup iteration (two groups)
-  constexpr int KG = KS * 8;              // groups of four k-slots
+  constexpr int NBLK = 4 / MT;         // N-tiles per 4-wave group
+  constexpr int COLS = 2 * NBLK * 32;  // secrets per workgroup iteration (two groups)
+  constexpr int KG = KS * 8;           // groups of four k-slots
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;
-  unsigned char* Bs = smem + mf_a_bytes(KS, MT);  // [limb][2*NBLK n-tiles][32 cols][ROWB]
+  unsigned char* Bs = smem + mf_a_bytes(KS, MT);  // [digit][2*NBLK n-tiles * 32 cols][ROWB]
 
   {
     const uint4* src = reinterpret_cast<const uint4*>(Atab);
@@ -140,18 +148,30 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
   for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const size_t s_base = blk * COLS;
     __syncthreads();  // everyone is done reading the previous iteration's Bs (and As is in place)
-    // ---- split this block's coefficients into 7-bit limbs: Bs[m][ntile*32 + col][k] ----
+    // ---- recode this block's coefficients into signed digits: Bs[digit][ntile*32 + col][k] ----
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int e = threadIdx.x + it * 512;
       if (e < COLS * KG) {
         const int col = e % COLS, kg = e / COLS;
         unsigned char* dst = Bs + (size_t)col * ROWB + 4 * kg;
+        u32 lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u64 u = mf_recode(creg[it][j]);  // 0 stays 0: padded k-slots contribute nothing
+          lo[j] = (u32)u;
+          hi[j] = (u32)(u >> 32);
+        }
 #pragma unroll
         for (int m = 0; m < MF_LIMBS; ++m) {
-          const u32 word = (u32)((creg[it][0] >> (7 * m)) & 127) | ((u32)((creg[it][1] >> (7 * m)) & 127) << 8) |
-                           ((u32)((creg[it][2] >> (7 * m)) & 127) << 16) | ((u32)((creg[it][3] >> (7 * m)) & 127) << 24);
-          *reinterpret_cast<u32*>(dst + (size_t)m * COLS * ROWB) = word;
+          // byte (m & 3) of the four values -> one 32-bit word, gathered with byte permutes:
+          // v_perm_b32(s0, s1, sel): selector bytes 0-3 pick from s1, 4-7 from s0, 0x0c gives zero
+          const u32* src = m < 4 ? lo : hi;
+          const u32 b = m & 3;
+          const u32 sel = 0x0c0c0000u | ((4 + b) << 8) | b;  // result byte0 = s1[b], byte1 = s0[b]
+          const u32 p01 = __builtin_amdgcn_perm(src[1], src[0], sel);
+          const u32 p23 = __builtin_amdgcn_perm(src[3], src[2], sel);
+          *reinterpret_cast<u32*>(dst + (size_t)m * COLS * ROWB) = p01 | (p23 << 16);
         }
       }
     }
@@ -161,29 +181,21 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
     const unsigned char* brow = Bs + ((size_t)nt * 32 + r) * ROWB + 16 * h;
     const unsigned char* arow = As + ((size_t)mt * 32 + r) * ROWB + 16 * h;
 
-    // Nine trips, one per pair of diagonals (high to low).  The loop is kept rolled -- with an opaque trip
-    // variable so that it is not unrolled and constant-folded back -- because fully unrolled the compiler
-    // interleaves many diagonals, keeps their accumulator tiles live and spills.
-    u64 S[16], W[16];
+    // Four trips, one per 32-bit word of diagonals (high to low).  The loop is kept rolled -- with an opaque
+    // trip variable so that it is not unrolled and constant-folded back -- because fully unrolled the compiler
+    // interleaves all diagonals, keeps their accumulator tiles live and spills.
+    u64 S[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      S[e] = 0;
-      W[e] = 0;
-    }
-    int q = MF_LIMBS - 1;
-    asm volatile("" : "+s"(q));
+    for (int e = 0; e < 16; ++e) S[e] = 0;
+    int a = 3;
+    asm volatile("" : "+s"(a));
 #pragma unroll 1
-    for (; q >= 0; --q) {
-      switch (q) {
-        case 8: mf_pair<8, KS, MT, COLS>(arow, brow, S, W); break;
-        case 7: mf_pair<7, KS, MT, COLS>(arow, brow, S, W); break;
-        case 6: mf_pair<6, KS, MT, COLS>(arow, brow, S, W); break;
-        case 5: mf_pair<5, KS, MT, COLS>(arow, brow, S, W); break;
-        case 4: mf_pair<4, KS, MT, COLS>(arow, brow, S, W); break;
-        case 3: mf_pair<3, KS, MT, COLS>(arow, brow, S, W); break;
-        case 2: mf_pair<2, KS, MT, COLS>(arow, brow, S, W); break;
-        case 1: mf_pair<1, KS, MT, COLS>(arow, brow, S, W); break;
-        default: mf_pair<0, KS, MT, COLS>(arow, brow, S, W); break;
+    for (; a >= 0; --a) {
+      switch (a) {
+        case 3: mf_word<3, KS, MT, COLS>(arow, brow, S); break;
+        case 2: mf_word<2, KS, MT, COLS>(arow, brow, S); break;
+        case 1: mf_word<1, KS, MT, COLS>(arow, brow, S); break;
+        default: mf_word<0, KS, MT, COLS>(arow, brow, S); break;
       }
     }
     // ---- fold and store: element e of the lane is row (e&3) + 8*(e>>2) + 4*h, column r of the tile ----
@@ -196,7 +208,8 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
       for (int e = 0; e < 16; ++e) {
         const int i = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (i < n) {
-          u64 v = (S[e] & P) + (S[e] >> 61);  // S < 3 * 2^61
+          const u64 sum = S[e] + (P - MF_TOTAL_BIAS);  // < 2^63
+          u64 v = (sum & P) + (sum >> 61);
           v = v >= P ? v - P : v;
           __builtin_nontemporal_store(v, colp + (size_t)i * row_stride);
         }
