@@ -359,6 +359,36 @@ int launch_share_mfma(u64* shares, size_t stride, const u64* secrets, const u64*
   return SCL_OK;
 }
 
+// C[M x N] = A[M x K] * B[K x N] over Mersenne61 on the matrix cores: A's digit planes are built on the
+// device into a stream-ordered temporary, B's rows play the role of the coefficient rows.
+template <int KS, int MT>
+int matmul_mfma_impl(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M, size_t K,
+                     size_t N, hipStream_t st) {
+  void* tab = nullptr;
+  const size_t bytes = mf_a_bytes(KS, MT);
+  HIP_TRY(hipMallocAsync(&tab, bytes, st));
+  HIP_TRY(hipMemsetAsync(tab, 0, bytes, st));
+  hipLaunchKernelGGL((k_mfma_planes_from_matrix<KS, MT>), dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, st,
+                     static_cast<unsigned char*>(tab), A, lda, (int)M, (int)K);
+  int rc = hipGetLastError() == hipSuccess ? SCL_OK : fail(SCL_ERR_HIP, "k_mfma_planes_from_matrix launch failed");
+  if (rc == SCL_OK)
+    rc = launch_share_mfma<KS, MT>(C, ldc, B, B + ldb, ldb, static_cast<const unsigned char*>(tab), (int)K - 1, (int)M, N,
+                                   st);
+  (void)hipFreeAsync(tab, st);
+  return rc;
+}
+
+int matmul_mfma(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M, size_t K, size_t N,
+                hipStream_t st) {
+  const int KS = K <= 32 ? 1 : 2;
+  const int MT = M <= 32 ? 1 : M <= 64 ? 2 : 4;
+#define MM_CASE(ks, mt) \
+  if (KS == ks && MT == mt) return matmul_mfma_impl<ks, mt>(C, ldc, A, lda, B, ldb, M, K, N, st);
+  MM_CASE(1, 1) MM_CASE(1, 2) MM_CASE(1, 4) MM_CASE(2, 1) MM_CASE(2, 2) MM_CASE(2, 4)
+#undef MM_CASE
+  return fail(SCL_ERR_BAD_ARG, "matmul_mfma: unsupported shape");
+}
+
 int share_mfma(const BigTable<M61>& al, u64* shares, size_t stride, const u64* secrets, const u64* coeffs,
                size_t cstride, size_t N, size_t t, size_t n, hipStream_t st) {
   const int KS = t + 1 <= 32 ? 1 : 2;
@@ -1086,6 +1116,12 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({C, A, B}));
+    if constexpr (F::TAG == 0) {
+      // small left factor, long right factor (Vandermonde evaluation, share generation): matrix cores
+      const long mode = g_mfma.load();
+      if (M <= 128 && K >= 1 && K <= 64 && (mode > 0 || (mode == 0 && M * K >= 512 && N >= 4096)))
+        return matmul_mfma(C, ldc, A, lda, B, ldb, M, K, N, S(stream));
+    }
     const size_t esz = F::LIMBS * 8;
     const size_t kk = K ? K : 1;
     size_t rows_per_tile = (48 * 1024) / (kk * esz);

@@ -218,4 +218,20 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
   }
 }
 
+// Digit planes of an arbitrary row-major matrix A[M x K] (device memory) in the A-table layout above, so
+// that Matrix::multiply (matrix.h:477-495) with a small left factor runs on the same kernel.  `tab` must be
+// zero-filled beforehand (padding rows / k-slots).
+template <int KS, int MT>
+__global__ __launch_bounds__(256) void k_mfma_planes_from_matrix(unsigned char* tab, const u64* A, size_t lda, int M,
+                                                                 int K) {
+  constexpr int ROWB = mf_rowb(KS);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < M * K; e += gridDim.x * 256) {
+    const int i = e / K, k = e % K;
+    const u64 digits = mf_recode(A[(size_t)i * lda + k]);
+#pragma unroll
+    for (int l = 0; l < MF_LIMBS; ++l)
+      tab[((size_t)(l * MT + i / 32) * 32 + (i % 32)) * ROWB + k] = (unsigned char)(digits >> (8 * l));
+  }
+}
+
 }  // namespace sclhip

@@ -471,6 +471,23 @@ def test_matmul_vs_oracle(scl, port, f, M, K, N):
     assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), port.matmul(f, A, B))
 
 
+@pytest.mark.parametrize("M,K,N", [(128, 43, 5000), (64, 22, 4099), (100, 64, 300), (1, 1, 70), (33, 5, 129)])
+def test_matmul_on_matrix_cores(scl, port, M, K, N):
+    """Matrix::multiply with a small left factor through the i8-digit MFMA kernel == the oracle's i-k-j loop"""
+    f, L = O.M61, 1
+    A = rand_elems(port, f, M * K, b"mmA").reshape(M, K, L)
+    B = rand_elems(port, f, K * N, b"mmB").reshape(K, N, L)
+    A[0, 0] = port.from_int(f, -1)
+    B[0, 0] = port.from_int(f, -1)
+    want = port.matmul(f, A, B)
+    scl.set_tuning("mfma", 1)
+    try:
+        assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), want)
+    finally:
+        scl.set_tuning("mfma", 0)
+    assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), want)  # automatic choice
+
+
 def test_vandermonde_matmul_is_sharing(scl, port):
     """test_matrix.cc:342-365: V(n, t+1) x coefficient matrix == Shamir shares at nodes 1..n"""
     f, L, n, t, N = O.M61, 1, 10, 3, 500
