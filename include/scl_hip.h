@@ -191,6 +191,17 @@ int scl_hip_aos_to_soa(int field, uint64_t* soa_dev, size_t stride, const uint64
 int scl_hip_soa_to_aos(int field, uint64_t* aos_dev, const uint64_t* soa_dev, size_t stride,
                        size_t N, size_t n, void* stream);
 
+/* ---- wire image: seri::Serializer<Vector<FF>> ------------------------------------------------ */
+/* What `packet << vector` puts on the wire (include/scl/serialization/serializer.h:157-190,
+ * include/scl/math/ff.h:355-391, vector.h:595-629): u32 count (little-endian) followed by count
+ * elements as FF::write emits them.  Buffers must be 4-byte aligned. */
+size_t scl_hip_wire_size(int field, size_t n); /* 4 + n * byteSize */
+int scl_hip_wire_pack(int field, unsigned char* dst_dev, const uint64_t* src_dev, size_t n, void* stream);
+/* Reads the count (synchronous), checks it against nbytes and capacity, then FF::read per element.
+ * *n_host receives the element count. */
+int scl_hip_wire_unpack(int field, uint64_t* dst_dev, size_t capacity, const unsigned char* src_dev,
+                        size_t nbytes, size_t* n_host, void* stream);
+
 /* ---- roofline probe -------------------------------------------------------- */
 /* plain device copy kernel (16 B per lane) used to measure achievable HBM bandwidth */
 int scl_hip_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream);

@@ -19,6 +19,7 @@
 #include <scl/math/matrix.h>
 #include <scl/math/poly.h>
 #include <scl/math/vector.h>
+#include <scl/serialization/serializer.h>
 #include <scl/ss/additive.h>
 #include <scl/ss/shamir.h>
 #include <scl/util/prg.h>
@@ -398,6 +399,28 @@ int sclref_mat_invert(int field, const std::uint64_t* A, std::size_t n, std::uin
   DISPATCH(field, {
     auto m = loadMat<F>(A, n, n);
     storeMat<F>(out, m.invert());
+  });
+  return 0;
+}
+
+// seri::Serializer<math::Vector<F>> wire image (what net::Packet << vector sends)
+int sclref_wire_vector(int field, const std::uint64_t* elems, std::size_t n, unsigned char* out,
+                       std::size_t* outlen) {
+  DISPATCH(field, {
+    const auto v = loadVec<F>(elems, n);
+    using S = scl::seri::Serializer<Vector<F>>;
+    *outlen = S::sizeOf(v);
+    if (out) S::write(v, out);
+  });
+  return 0;
+}
+
+int sclref_unwire_vector(int field, const unsigned char* in, std::uint64_t* elems, std::size_t* n) {
+  DISPATCH(field, {
+    Vector<F> v;
+    scl::seri::Serializer<Vector<F>>::read(v, in);
+    *n = v.size();
+    if (elems) storeVec<F>(elems, v);
   });
   return 0;
 }

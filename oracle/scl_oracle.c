@@ -745,6 +745,35 @@ int sclo_matmul(int field, const uint64_t* A, const uint64_t* B, size_t n, size_
 #undef BODY
 }
 
+size_t sclo_wire_vector(int field, const uint64_t* elems, size_t n, unsigned char* out) {
+  const size_t L = (size_t)sclo_limbs(field), bs = 8 * L;
+  if (out) {
+    const uint32_t cnt = (uint32_t)n;
+    memcpy(out, &cnt, 4);
+    for (size_t i = 0; i < n; ++i) {
+      if (field == SCLO_MONT128) { /* gmp family: out of Montgomery form, big-endian (ff_ops_gmp.h:298-314) */
+        mont128_ensure();
+        u128 v = mont128_from_mont(mont128_ld(elems + i * L));
+        for (int b = 0; b < 16; ++b) out[4 + i * bs + b] = (unsigned char)(v >> (8 * (15 - b)));
+      } else {
+        memcpy(out + 4 + i * bs, elems + i * L, bs); /* ff::toBytes = memcpy of the value (mersenne61.cc:92-95) */
+      }
+    }
+  }
+  return 4 + n * bs;
+}
+
+int sclo_unwire_vector(int field, const unsigned char* in, size_t nbytes, uint64_t* elems, size_t capacity,
+                       size_t* n) {
+  const size_t L = (size_t)sclo_limbs(field), bs = 8 * L;
+  uint32_t cnt;
+  if (nbytes < 4) return SCLO_BAD_ARG;
+  memcpy(&cnt, in, 4);
+  if (4 + (size_t)cnt * bs > nbytes || cnt > capacity) return SCLO_BAD_ARG;
+  *n = cnt;
+  return sclo_from_bytes(field, in + 4, cnt, elems);
+}
+
 int sclo_time_shamir(int field, size_t N, size_t t, size_t n, const unsigned char* seed,
                      size_t seed_len, double* share_s, double* recover_s, uint64_t* mismatches,
                      uint64_t* checksum) {

@@ -94,6 +94,13 @@ int sclo_vandermonde(int field, size_t n, size_t m, const uint64_t* xs, uint64_t
 int sclo_matmul(int field, const uint64_t* A, const uint64_t* B, size_t n, size_t k, size_t m,
                 uint64_t* C);
 
+/* wire image of a vector: seri::Serializer<std::vector<T>> = u32 count (little-endian) followed by
+ * count elements as FF::write emits them (include/scl/serialization/serializer.h:157-190, ff.h:355-391).
+ * wire: returns bytes written (out may be NULL to size).  unwire: FF::read per element (reduces mod p). */
+size_t sclo_wire_vector(int field, const uint64_t* elems, size_t n, unsigned char* out);
+int sclo_unwire_vector(int field, const unsigned char* in, size_t nbytes, uint64_t* elems, size_t capacity,
+                       size_t* n);
+
 /* MONT128 plugin field: choose the modulus (odd, 2^127 < p < 2^128 not required;
  * any odd p >= 3 below 2^128).  Default: p = 2^128 - 159.  Not thread safe. */
 int sclo_mont128_set_prime(const uint64_t p[2]);

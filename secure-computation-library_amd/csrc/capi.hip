@@ -1173,6 +1173,51 @@ int scl_hip_soa_to_aos(int field, uint64_t* aos, const uint64_t* soa, size_t str
   return transpose_impl(field, aos, soa, stride, N, n, stream, false);
 }
 
+// ---- wire image ------------------------------------------------------------------------------------------------------------
+size_t scl_hip_wire_size(int field, size_t n) {
+  const int L = scl_hip_limbs(field);
+  return L < 0 ? 0 : 4 + n * (size_t)L * 8;
+}
+
+int scl_hip_wire_pack(int field, unsigned char* dst, const uint64_t* src, size_t n, void* stream) {
+  if (!dst || (n && !src)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (reinterpret_cast<uintptr_t>(dst) & 3) return fail(SCL_ERR_BAD_ARG, "wire buffer not 4-byte aligned");
+  if (n > 0xFFFFFFFFull) return fail(SCL_ERR_BAD_ARG, "vector too long for the u32 count");  // Vector::SizeType, vector.h:73
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({src}));
+    hipLaunchKernelGGL((k_wire_pack<F>), dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, S(stream), ctx,
+                       reinterpret_cast<u32*>(dst), src, n);
+    LAUNCH_CHECK();
+    return SCL_OK;
+  });
+}
+
+int scl_hip_wire_unpack(int field, uint64_t* dst, size_t capacity, const unsigned char* src, size_t nbytes,
+                        size_t* n_host, void* stream) {
+  if (!src || !n_host) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (reinterpret_cast<uintptr_t>(src) & 3) return fail(SCL_ERR_BAD_ARG, "wire buffer not 4-byte aligned");
+  if (nbytes < 4) return fail(SCL_ERR_BAD_ARG, "wire image shorter than its count");
+  u32 cnt = 0;
+  HIP_TRY(hipMemcpyAsync(&cnt, src, 4, hipMemcpyDeviceToHost, S(stream)));
+  HIP_TRY(hipStreamSynchronize(S(stream)));
+  const int L = scl_hip_limbs(field);
+  if (L < 0) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
+  if (4 + (size_t)cnt * L * 8 > nbytes) return fail(SCL_ERR_BAD_ARG, "wire image truncated");
+  if (cnt > capacity) return fail(SCL_ERR_SIZE_MISMATCH, "destination too small for the wire image");
+  *n_host = cnt;
+  if (cnt == 0) return SCL_OK;
+  if (!dst) return fail(SCL_ERR_BAD_ARG, "dst is NULL");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({dst}));
+    hipLaunchKernelGGL((k_wire_unpack<F>), dim3(grid_for(cnt)), dim3(BLOCK), 0, S(stream), ctx, dst,
+                       reinterpret_cast<const u32*>(src), (size_t)cnt);
+    LAUNCH_CHECK();
+    return SCL_OK;
+  });
+}
+
 // ---- roofline probe -------------------------------------------------------------------------------------------------------
 int scl_hip_stream_copy(void* dst, const void* src, size_t bytes, void* stream) {
   if (bytes == 0) return SCL_OK;

@@ -1002,6 +1002,43 @@ __global__ __launch_bounds__(BLOCK) void k_transpose(u64* dst, const u64* src, s
   }
 }
 
+// ---- wire image --------------------------------------------------------------------------------------
+// seri::Serializer<Vector<FF>> (include/scl/serialization/serializer.h:157-190, ff.h:355-391): u32 count
+// then count elements as FF::write emits them.  The payload starts 4 bytes into the buffer, so it is moved
+// as 32-bit words (buffers must be 4-byte aligned).
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_wire_pack(typename F::Ctx ctx, u32* dst, const u64* src, size_t n) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) dst[0] = (u32)n;
+  SCL_GRID_STRIDE(e, n) {
+    u32* o = dst + 1 + e * (2 * F::LIMBS);
+    if constexpr (F::LIMBS == 1) {
+      const u64 v = src[e];
+      o[0] = (u32)v;
+      o[1] = (u32)(v >> 32);
+    } else {
+      u128 v = F::ld(src + 2 * e);
+      if constexpr (F::TAG == 2) v = bswap128(F::from_mont(ctx, v));  // Montgomery family: value, big-endian
+      o[0] = (u32)v;
+      o[1] = (u32)(v >> 32);
+      o[2] = (u32)(v >> 64);
+      o[3] = (u32)(v >> 96);
+    }
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_wire_unpack(typename F::Ctx ctx, u64* dst, const u32* src, size_t n) {
+  SCL_GRID_STRIDE(e, n) {
+    const u32* in = src + 1 + e * (2 * F::LIMBS);
+    if constexpr (F::LIMBS == 1) {
+      dst[e] = F::from_le_word(ctx, (u64)in[0] | ((u64)in[1] << 32));
+    } else {
+      const u128 raw = (u128)in[0] | ((u128)in[1] << 32) | ((u128)in[2] << 64) | ((u128)in[3] << 96);
+      F::st(dst + 2 * e, F::from_le_word(ctx, raw));
+    }
+  }
+}
+
 // ---- roofline probe ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_copy16(u64x2* dst, const u64x2* src, size_t n16) {
   SCL_GRID_STRIDE(q, n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + q), dst + q);

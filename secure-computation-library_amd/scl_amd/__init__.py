@@ -319,6 +319,27 @@ def soa_to_aos(field, soa):
     return out
 
 
+# ---- wire image: seri::Serializer<Vector<FF>> -------------------------------------------------------------------------
+def wire_pack(field, a: torch.Tensor) -> torch.Tensor:
+    """elements [n][L] -> uint8 device buffer: u32 count || n * byteSize bytes (FF::write images)"""
+    L = limbs(field)
+    n = a.numel() // L
+    lib.scl_hip_wire_size.restype = C.c_size_t
+    out = torch.empty(lib.scl_hip_wire_size(field, C.c_size_t(n)), dtype=torch.uint8, device=a.device)
+    _chk(lib.scl_hip_wire_pack(field, _dev(out), _dev(a) if n else None, C.c_size_t(n), _stream()))
+    return out
+
+
+def wire_unpack(field, raw: torch.Tensor, capacity: int | None = None) -> torch.Tensor:
+    L = limbs(field)
+    cap = (raw.numel() - 4) // (8 * L) if capacity is None else capacity
+    out = empty(field, max(cap, 1), device=raw.device)
+    n = C.c_size_t(0)
+    _chk(lib.scl_hip_wire_unpack(field, _dev(out), C.c_size_t(cap), _dev(raw), C.c_size_t(raw.numel()), C.byref(n),
+                                 _stream()))
+    return out[: n.value]
+
+
 def stream_copy(dst: torch.Tensor, src: torch.Tensor):
     _chk(lib.scl_hip_stream_copy(_dev(dst), _dev(src), C.c_size_t(src.numel() * src.element_size()), _stream()))
 

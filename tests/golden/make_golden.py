@@ -176,6 +176,11 @@ def main():
         V = ref.vandermonde(f, 10, 4)
         Cm = O.from_ints(rnd[50:50 + 4 * 5], L).reshape(4, 5, L)
         fd["vandermonde_eval"] = {"n": 10, "m": 4, "N": 5, "C": hx(Cm), "out": hx(ref.matmul(f, V, Cm))}
+        # ---- wire image (seri::Serializer<Vector<FF>>, test/scl/serialization/test_serializer.cc:106-123) ----
+        wv = O.from_ints([1, 2, 3], L)
+        fd["wire"] = [{"elems": hx(wv), "bytes": ref.wire_vector(f, wv).hex()},
+                      {"elems": hx(a[:40]), "bytes": ref.wire_vector(f, a[:40]).hex()},
+                      {"elems": [], "bytes": ref.wire_vector(f, np.zeros((0, L), np.uint64)).hex()}]
         doc["fields"][name] = fd
 
     path = os.path.join(HERE, "golden_v1.json")

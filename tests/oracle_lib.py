@@ -265,6 +265,33 @@ class _Base:
         self._call("matmul", C.c_int(field), _p(A), _p(B), C.c_size_t(n), C.c_size_t(k), C.c_size_t(m), _p(out))
         return out
 
+    def wire_vector(self, field, elems) -> bytes:
+        L = LIMBS[field]
+        elems = _arr(elems, L).reshape(-1, L)
+        n = elems.shape[0]
+        out = np.zeros(4 + n * 8 * L, dtype=np.uint8)
+        if self.has_err:
+            ln = C.c_size_t(0)
+            self._call("wire_vector", C.c_int(field), _p(elems), C.c_size_t(n), _b(out), C.byref(ln))
+            assert ln.value == out.size
+        else:
+            fn = self._f("wire_vector")
+            fn.restype = C.c_size_t
+            assert fn(C.c_int(field), _p(elems), C.c_size_t(n), _b(out)) == out.size
+        return out.tobytes()
+
+    def unwire_vector(self, field, raw: bytes):
+        L = LIMBS[field]
+        src = np.frombuffer(raw, dtype=np.uint8).copy()
+        cap = max(1, (len(raw) - 4) // (8 * L))
+        out = np.zeros((cap, L), dtype=np.uint64)
+        n = C.c_size_t(0)
+        if self.has_err:
+            self._call("unwire_vector", C.c_int(field), _b(src), _p(out), C.byref(n))
+        else:
+            self._call("unwire_vector", C.c_int(field), _b(src), C.c_size_t(len(raw)), _p(out), C.c_size_t(cap), C.byref(n))
+        return out[: n.value]
+
     def time_shamir(self, field, N, t, n, seed: bytes = b"scl-bench"):
         ss, rs = C.c_double(), C.c_double()
         bad, chk = C.c_uint64(), C.c_uint64()

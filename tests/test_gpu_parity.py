@@ -500,6 +500,32 @@ def test_vandermonde_matmul_is_sharing(scl, port):
     assert scl.equals(f, via_matmul, via_share)
 
 
+# ---------------------------------------------------------------------------------------------- wire image
+@pytest.mark.parametrize("f", ALL_FIELDS)
+def test_wire_image(scl, port, f):
+    """seri::Serializer<Vector<FF>>: u32 count || FF::write images; golden bytes from the reference"""
+    L = O.LIMBS[f]
+    name = {O.M61: "Mersenne61", O.M127: "Mersenne127"}.get(f)
+    if name:
+        for c in GOLD["fields"][name]["wire"]:
+            el = O.from_ints(ints(c["elems"]), L) if c["elems"] else np.zeros((0, L), np.uint64)
+            got = bytes(scl.wire_pack(f, dev(scl, el) if len(el) else scl.empty(f, 0)).cpu().numpy())
+            assert got.hex() == c["bytes"]
+    for n in (0, 1, 2, 1000, 4097):
+        el = rand_elems(port, f, n, b"wire") if n else np.zeros((0, L), np.uint64)
+        raw = scl.wire_pack(f, dev(scl, el) if n else scl.empty(f, 0))
+        assert bytes(raw.cpu().numpy()) == port.wire_vector(f, el)
+        back = scl.wire_unpack(f, raw)
+        assert np.array_equal(host(scl, back), el)
+    # unpack reduces non-canonical words like FF::read does
+    junk = port.prg(b"wire-junk", [8 * L * 50])
+    raw = (50).to_bytes(4, "little") + junk
+    rt = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    assert np.array_equal(host(scl, scl.wire_unpack(f, rt)), port.from_bytes(f, junk))
+    with pytest.raises(scl.SclError):
+        scl.wire_unpack(f, rt[: 4 + 8 * L * 10].clone())  # count says 50, only 10 present
+
+
 # ---------------------------------------------------------------------------------------------- full size properties
 @pytest.mark.parametrize("f,n,t,N", [(O.M61, 10, 3, 10_000_000), (O.M127, 10, 3, 2_000_000)])
 def test_full_size_round_trip(scl, port, f, n, t, N):

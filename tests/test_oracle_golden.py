@@ -165,6 +165,18 @@ def test_vector_matrix(port, f, name):
     eq(port.matmul(f, V, arr(ve["C"], L).reshape(ve["m"], ve["N"], L)), ve["out"])
 
 
+@pytest.mark.parametrize("f,name", FIELDS)
+def test_wire_image(port, f, name):
+    g, L = GOLD["fields"][name], O.LIMBS[f]
+    for c in g["wire"]:
+        el = arr(c["elems"], L) if c["elems"] else np.zeros((0, L), np.uint64)
+        raw = port.wire_vector(f, el)
+        assert raw.hex() == c["bytes"]
+        assert np.array_equal(port.unwire_vector(f, raw), el.reshape(-1, L))
+    # test/scl/serialization/test_serializer.cc:106-123: size = 4 + 3 * byteSize
+    assert len(port.wire_vector(f, O.from_ints([1, 2, 3], L))) == 4 + 3 * 8 * L
+
+
 # ---- known answers held by the reference's own tests for this path ----
 def test_reference_test_suite_kats(port):
     f, L = O.M61, 1
