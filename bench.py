@@ -169,8 +169,20 @@ def main():
     }
     dom = "shamir_share" if share_ms >= rec_ms else "shamir_recover"
     ach = kernels[dom]["GBps"]
+    # HBM traffic per launch of the dominant kernel: PMC counters collected offline with rocprofv3 on this
+    # exact configuration (bench.py cannot read PMCs itself); null for any other configuration.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        c = pmc["config"]
+        if (c["field"], c["n"], c["t"], c["secrets_per_gpu"], c["share_mode"]) == (args.field, n, t, N, args.share_mode):
+            traffic = pmc[dom]["bytes"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                "algorithmic_bytes": kernels[dom]["bytes_per_secret"] * N,
                 "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": ach / copy_gbps}
     total = N * world * args.steps
     line = {
