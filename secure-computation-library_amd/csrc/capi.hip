@@ -344,12 +344,9 @@ template <int KS, int MT>
 int launch_share_mfma(u64* shares, size_t stride, const u64* secrets, const u64* coeffs, size_t cstride,
                       const unsigned char* tab, int t, int n, size_t N, hipStream_t st) {
   const size_t shmem = mf_a_bytes(KS, MT) + mf_b_bytes(KS, MT);
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_mfma_m61<KS, MT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = true;
-  }
+  // per device and cheap: set on every call so that multi-device processes are covered
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_mfma_m61<KS, MT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   const size_t cols = (size_t)2 * (4 / MT) * 32;
   const size_t nblocks = (N + cols - 1) / cols;
   const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);  // one 8-wave workgroup per CU, grid-strided

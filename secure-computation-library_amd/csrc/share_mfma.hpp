@@ -34,6 +34,7 @@ namespace sclhip {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int MF_LIMBS = 8;  // signed base-256 digits of a 61-bit value
 constexpr int MF_PAD = 16;   // row padding (bytes): row stride/4 is then 4 * odd -> conflict-free b128 reads
@@ -143,12 +144,8 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
       }
     }
   };
-  if (blockIdx.x < nblocks) fetch(blockIdx.x);
-
-  for (size_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const size_t s_base = blk * COLS;
-    __syncthreads();  // everyone is done reading the previous iteration's Bs (and As is in place)
-    // ---- recode this block's coefficients into signed digits: Bs[digit][ntile*32 + col][k] ----
+  // recode the coefficients held in creg into signed digits: Bs[digit][ntile*32 + col][k]
+  auto recode = [&]() {
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int e = threadIdx.x + it * 512;
@@ -175,12 +172,28 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
         }
       }
     }
-    __syncthreads();
-    if (blk + gridDim.x < nblocks) fetch(blk + gridDim.x);  // in flight during the MFMA loop below
+  };
 
-    const unsigned char* brow = Bs + ((size_t)nt * 32 + r) * ROWB + 16 * h;
-    const unsigned char* arow = As + ((size_t)mt * 32 + r) * ROWB + 16 * h;
+  const unsigned char* brow = Bs + ((size_t)nt * 32 + r) * ROWB + 16 * h;
+  const unsigned char* arow = As + ((size_t)mt * 32 + r) * ROWB + 16 * h;
 
+  // Software pipeline over blocks (b0 = this workgroup's first block, step = gridDim.x):
+  //   prologue: fetch(b0); recode -> Bs; fetch(b0 + step)
+  //   loop:     MFMA + recombination of block i (reads Bs)           -> S in registers
+  //             barrier; recode block i+1 (its loads landed during the MFMA loop) -> Bs; barrier
+  //             store block i's results; fetch block i+2
+  // so that neither the HBM latency of the coefficient loads nor the completion of the result stores sits
+  // between two MFMA loops (vmcnt is in-order: the loads are waited for a whole MFMA loop after the stores
+  // that precede them were issued).
+  size_t blk = blockIdx.x;
+  if (blk < nblocks) fetch(blk);
+  __syncthreads();  // As is in place
+  if (blk < nblocks) recode();
+  __syncthreads();
+  if (blk + gridDim.x < nblocks) fetch(blk + gridDim.x);
+
+  for (; blk < nblocks; blk += gridDim.x) {
+    const size_t s_base = blk * COLS;
     // Four trips, one per 32-bit word of diagonals (high to low).  The loop is kept rolled -- with an opaque
     // trip variable so that it is not unrolled and constant-folded back -- because fully unrolled the compiler
     // interleaves all diagonals, keeps their accumulator tiles live and spills.
@@ -198,23 +211,47 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
         default: mf_word<0, KS, MT, COLS>(arow, brow, S); break;
       }
     }
-    // ---- fold and store: element e of the lane is row (e&3) + 8*(e>>2) + 4*h, column r of the tile ----
-    const size_t s = s_base + (size_t)nt * 32 + r;
+    __syncthreads();  // every wave is done reading this block's digits
+    if (blk + gridDim.x < nblocks) recode();
+    __syncthreads();
+    // ---- fold and store.  Element e of the lane is row (e&3) + 8*(e>>2) + 4*h, column r of the tile.  A plain
+    // epilogue is 16 dwordx2 stores per lane and is store-ISSUE bound; adjacent lanes (adjacent columns)
+    // therefore trade one value per element pair over DPP (quad_perm 1,0,3,2) so that even lanes hold two
+    // consecutive columns of row(e) and odd lanes two consecutive columns of row(e+1): 8 dwordx4 stores.
+    const size_t s_even = s_base + (size_t)nt * 32 + (r & ~1);  // first of this lane's two columns
     size_t row_stride = stride;
-    asm volatile("" : "+s"(row_stride));  // keep the 16 row addresses out of the loop-invariant set (register pressure)
-    if (s < N) {
-      u64* colp = shares + s;
+    asm volatile("" : "+s"(row_stride));  // keep the row addresses out of the loop-invariant set (register pressure)
+    const bool odd = lane & 1;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (i < n) {
-          const u64 sum = S[e] + (P - MF_TOTAL_BIAS);  // < 2^63
-          u64 v = (sum & P) + (sum >> 61);
-          v = v >= P ? v - P : v;
-          __builtin_nontemporal_store(v, colp + (size_t)i * row_stride);
+    for (int e = 0; e < 16; e += 2) {
+      u64 v[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u64 sum = S[e + j] + (P - MF_TOTAL_BIAS);  // < 2^63
+        const u64 f = (sum & P) + (sum >> 61);
+        v[j] = f >= P ? f - P : f;
+      }
+      const u64 give = odd ? v[0] : v[1];  // what the neighbour needs: its row's value from my column
+      const u32 glo = (u32)give, ghi = (u32)(give >> 32);
+      const u32 tlo = (u32)__builtin_amdgcn_update_dpp(0, (int)glo, 0xB1, 0xF, 0xF, false);
+      const u32 thi = (u32)__builtin_amdgcn_update_dpp(0, (int)ghi, 0xB1, 0xF, 0xF, false);
+      const u64 take = ((u64)thi << 32) | tlo;
+      const u64 keep = odd ? v[1] : v[0];
+      u64x2 out;
+      out.x = odd ? take : keep;  // column r & ~1
+      out.y = odd ? keep : take;  // column (r & ~1) + 1
+      const int i = mt * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * h;
+      if (i < n) {
+        u64* dst = shares + (size_t)i * row_stride + s_even;
+        if (s_even + 1 < N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+          __builtin_nontemporal_store(out, reinterpret_cast<u64x2*>(dst));
+        } else {  // ragged tail or an 8-byte-aligned row: two scalar stores
+          if (s_even < N) dst[0] = out.x;
+          if (s_even + 1 < N) dst[1] = out.y;
         }
       }
     }
+    if (blk + 2 * (size_t)gridDim.x < nblocks) fetch(blk + 2 * (size_t)gridDim.x);
   }
 }
 
