@@ -14,6 +14,7 @@
 // Share matrices are AoS [secret][party], the layout the reference returns
 // (one Vector of n shares per secret, include/scl/ss/shamir.h:52-68).
 
+#include <scl/math/fields/secp256k1_scalar.h>
 #include <scl/math/fp.h>
 #include <scl/math/lagrange.h>
 #include <scl/math/matrix.h>
@@ -35,6 +36,7 @@ namespace {
 
 using F61 = scl::math::Fp<61>;
 using F127 = scl::math::Fp<127>;
+using F256 = scl::math::FF<scl::math::ff::Secp256k1Scalar>;  // field tag 4 (4 limbs, Montgomery form)
 using scl::math::Matrix;
 using scl::math::Vector;
 using scl::util::PRG;
@@ -44,14 +46,19 @@ constexpr std::size_t limbs() {
   return F::byteSize() / 8;
 }
 
+// Elements cross this face as the raw FF::m_value image (what std::vector<FF>::data() holds):
+// the canonical integer for the Mersenne fields, the Montgomery residue limbs for secp256k1_order.
 template <typename F>
 F load(const std::uint64_t* p) {
-  return F::read(reinterpret_cast<const unsigned char*>(p));
+  F e;
+  std::memcpy(&e.value(), p, sizeof(e.value()));
+  return e;
 }
 
 template <typename F>
 void store(std::uint64_t* p, const F& v) {
-  v.write(reinterpret_cast<unsigned char*>(p));
+  const auto raw = v.value();
+  std::memcpy(p, &raw, sizeof(raw));
 }
 
 template <typename F>
@@ -191,6 +198,9 @@ void storeMat(std::uint64_t* p, const Matrix<F>& m) {
     } else if ((field) == 1) {     \
       using F = F127;              \
       __VA_ARGS__;                 \
+    } else if ((field) == 4) {     \
+      using F = F256;              \
+      __VA_ARGS__;                 \
     } else {                       \
       return -2;                   \
     }                              \
@@ -198,10 +208,10 @@ void storeMat(std::uint64_t* p, const Matrix<F>& m) {
 
 extern "C" {
 
-int sclref_limbs(int field) { return field == 0 ? 1 : field == 1 ? 2 : -1; }
+int sclref_limbs(int field) { return field == 0 ? 1 : field == 1 ? 2 : field == 4 ? 4 : -1; }
 
 const char* sclref_field_name(int field) {
-  return field == 0 ? F61::name() : field == 1 ? F127::name() : "";
+  return field == 0 ? F61::name() : field == 1 ? F127::name() : field == 4 ? F256::name() : "";
 }
 
 // returns 0 ok, 1 if the reference threw (message copied to err, NUL terminated)
@@ -230,6 +240,13 @@ int sclref_from_bytes(int field, const unsigned char* src, std::size_t n,
   DISPATCH(field, {
     for (std::size_t i = 0; i < n; ++i)
       store<F>(dst + i * limbs<F>(), F::read(src + i * F::byteSize()));
+  });
+  return 0;
+}
+
+int sclref_to_bytes(int field, const std::uint64_t* src, std::size_t n, unsigned char* dst) {
+  DISPATCH(field, {
+    for (std::size_t i = 0; i < n; ++i) load<F>(src + i * limbs<F>()).write(dst + i * F::byteSize());
   });
   return 0;
 }

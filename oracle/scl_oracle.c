@@ -484,8 +484,127 @@ static inline int gf128_is_zero(u128 v) { return v == 0; }
 #undef FN
 #undef LIMBS
 
+/* ======================================================== secp256k1 group order */
+/* FF<Secp256k1Scalar> (include/scl/math/fields/secp256k1_scalar.h, src/scl/math/fields/secp256k1_scalar.cc:47-135):
+ * 4 x 64-bit limbs, values held in Montgomery form x*2^256 mod p, arithmetic from the mpn Montgomery family
+ * include/scl/math/fields/ff_ops_gmp.h:44-314.  Prime p = the order of the secp256k1 group. */
+typedef struct { uint64_t w[4]; } fe256;
+static const uint64_t SQ_P[4] = {0xBFD25E8CD0364141ULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFEULL, 0xFFFFFFFFFFFFFFFFULL};
+static uint64_t g_sq_mc0 = 0; /* -p^{-1} mod 2^64 (low limb of RedParams::mc, secp256k1_scalar.cc:62-67) */
+static fe256 g_sq_one, g_sq_r2;
+
+static int sq_geq_p(const uint64_t a[4]) {
+  for (int i = 3; i >= 0; --i) {
+    if (a[i] > SQ_P[i]) return 1;
+    if (a[i] < SQ_P[i]) return 0;
+  }
+  return 1;
+}
+static uint64_t sq_add_n(uint64_t* r, const uint64_t* a, const uint64_t* b) {
+  u128 c = 0;
+  for (int i = 0; i < 4; ++i) { c += (u128)a[i] + b[i]; r[i] = (uint64_t)c; c >>= 64; }
+  return (uint64_t)c;
+}
+static uint64_t sq_sub_n(uint64_t* r, const uint64_t* a, const uint64_t* b) {
+  uint64_t borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 d = (u128)a[i] - b[i] - borrow;
+    r[i] = (uint64_t)d;
+    borrow = (uint64_t)(d >> 64) & 1;
+  }
+  return borrow;
+}
+static inline fe256 secpq_add(fe256 a, fe256 b) { /* montyModAdd, ff_ops_gmp.h:128-134 */
+  fe256 r;
+  uint64_t carry = sq_add_n(r.w, a.w, b.w);
+  if (carry || sq_geq_p(r.w)) sq_sub_n(r.w, r.w, SQ_P);
+  return r;
+}
+static inline fe256 secpq_sub(fe256 a, fe256 b) { /* montyModSub, ff_ops_gmp.h:142-148 */
+  fe256 r;
+  if (sq_sub_n(r.w, a.w, b.w)) sq_add_n(r.w, r.w, SQ_P);
+  return r;
+}
+static inline fe256 secpq_neg(fe256 a) { /* montyModNeg: 0 - a, ff_ops_gmp.h:156-162 */
+  fe256 z = {{0, 0, 0, 0}};
+  return secpq_sub(z, a);
+}
+/* montyModMul, ff_ops_gmp.h:174-191: interleaved (CIOS) multiplication, a*b/2^256 mod p */
+static inline fe256 secpq_mul(fe256 a, fe256 b) {
+  uint64_t u[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)a.w[j] * b.w[i] + u[j]; u[j] = (uint64_t)c; c >>= 64; }
+    c += u[4]; u[4] = (uint64_t)c; u[5] = (uint64_t)(c >> 64);
+    const uint64_t q = g_sq_mc0 * u[0];
+    c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)q * SQ_P[j] + u[j]; u[j] = (uint64_t)c; c >>= 64; }
+    c += u[4]; u[4] = (uint64_t)c; u[5] += (uint64_t)(c >> 64);
+    for (int j = 0; j < 5; ++j) u[j] = u[j + 1];
+    u[5] = 0;
+  }
+  fe256 r = {{u[0], u[1], u[2], u[3]}};
+  if (u[4] || sq_geq_p(r.w)) sq_sub_n(r.w, r.w, SQ_P);
+  return r;
+}
+static inline int secpq_is_zero(fe256 v) { return (v.w[0] | v.w[1] | v.w[2] | v.w[3]) == 0; }
+static inline int secpq_inv(fe256* out, fe256 v) { /* montyModInv: a^(p-2), ff_ops_gmp.h:225-260 */
+  if (secpq_is_zero(v)) return SCLO_ZERO_INVERSE;
+  uint64_t e[4] = {SQ_P[0] - 2, SQ_P[1], SQ_P[2], SQ_P[3]};
+  fe256 r = g_sq_one;
+  for (int i = 255; i >= 0; --i) {
+    r = secpq_mul(r, r);
+    if ((e[i / 64] >> (i % 64)) & 1) r = secpq_mul(r, v);
+  }
+  *out = r;
+  return SCLO_OK;
+}
+static inline fe256 secpq_to_mont(fe256 x) { return secpq_mul(x, g_sq_r2); } /* montyIn: x*2^256 mod p */
+static inline fe256 secpq_from_mont(fe256 x) { fe256 one = {{1, 0, 0, 0}}; return secpq_mul(x, one); } /* montyRedc */
+static inline fe256 secpq_from_int(int v) { /* montyInFromInt, ff_ops_gmp.h:108-114 */
+  fe256 x = {{(uint64_t)(v < 0 ? -(int64_t)v : (int64_t)v), 0, 0, 0}};
+  if (v < 0) { fe256 pp = {{SQ_P[0], SQ_P[1], SQ_P[2], SQ_P[3]}}; sq_sub_n(x.w, pp.w, x.w); }
+  return secpq_to_mont(x);
+}
+static inline fe256 secpq_from_bytes(const unsigned char* src) { /* montyFromBytes: big-endian, ff_ops_gmp.h:279-290 */
+  fe256 x;
+  for (int i = 3; i >= 0; --i) {
+    uint64_t w = 0;
+    for (int j = 0; j < 8; ++j) w = (w << 8) | *src++;
+    x.w[i] = w;
+  }
+  return secpq_to_mont(x);
+}
+static inline fe256 secpq_ld(const uint64_t* p) { fe256 r = {{p[0], p[1], p[2], p[3]}}; return r; }
+static inline void secpq_st(uint64_t* p, fe256 v) { memcpy(p, v.w, 32); }
+
+static void secpq_ensure(void) {
+  if (g_sq_mc0) return;
+  uint64_t inv = SQ_P[0]; /* Newton: -p^{-1} mod 2^64 */
+  for (int i = 0; i < 6; ++i) inv *= 2 - SQ_P[0] * inv;
+  g_sq_mc0 = (uint64_t)0 - inv;
+  /* R mod p and R^2 mod p by 512 modular doublings of 1 */
+  fe256 r = {{1, 0, 0, 0}};
+  for (int i = 0; i < 512; ++i) {
+    fe256 t;
+    uint64_t c = sq_add_n(t.w, r.w, r.w);
+    if (c || sq_geq_p(t.w)) sq_sub_n(t.w, t.w, SQ_P);
+    r = t;
+    if (i == 255) g_sq_one = r;
+  }
+  g_sq_r2 = r;
+}
+
+#define FE fe256
+#define FN(name) secpq_##name
+#define LIMBS 4
+#include "scl_oracle_generic.inc"
+#undef FE
+#undef FN
+#undef LIMBS
+
 /* ================================================================ dispatch */
-int sclo_limbs(int field) { return field == SCLO_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : -1; }
+int sclo_limbs(int field) { return field == SCLO_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : field == SCLO_SECP256K1_SCALAR ? 4 : -1; }
 
 const char* sclo_field_name(int field) {
   switch (field) {
@@ -493,6 +612,7 @@ const char* sclo_field_name(int field) {
     case SCLO_M127: return "Mersenne127"; /* mersenne127.h:38 */
     case SCLO_MONT128: return "Mont128";
     case SCLO_GF2_128: return "GF(2^128)";
+    case SCLO_SECP256K1_SCALAR: return "secp256k1_order"; /* secp256k1_scalar.h NAME */
     default: return "";
   }
 }
@@ -517,6 +637,7 @@ const char* sclo_status_message(int status) {
     case SCLO_M127: { BODY(m127_) } break;                 \
     case SCLO_MONT128: { mont128_ensure(); BODY(mont128_) } break; \
     case SCLO_GF2_128: { BODY(gf128_) } break;             \
+    case SCLO_SECP256K1_SCALAR: { secpq_ensure(); BODY(secpq_) } break; \
     default: break;                                        \
   }                                                        \
   return SCLO_BAD_ARG;
@@ -542,7 +663,53 @@ int sclo_from_bytes(int field, const unsigned char* src, size_t n, uint64_t* dst
 
 /* convertTo(string): parse big-endian hex into the value type, then "% p"
  * (mersenne61.cc:42-46, mersenne127.cc:42-46) */
+/* montyFromString (include/scl/math/fields/ff_ops_gmp.h:370-398): an odd-length string gets a leading
+ * "0" (no error), more than 64 digits is an error, and the digits are cut into 16-character limbs FROM
+ * THE LEFT -- the first chunk is the top limb (index (n-1)/16), a short last chunk becomes limb 0 as it
+ * stands.  For lengths that are not a multiple of 16 this is not the usual big-endian reading; restated
+ * as is.  The empty string leaves the element 0. */
+static int hex_parse256(const char* s, fe256* out) {
+  size_t n = strlen(s);
+  fe256 t = {{0, 0, 0, 0}};
+  *out = t;
+  if (n == 0) return SCLO_OK;
+  if (n > 64) return SCLO_BAD_ARG; /* "hex string too large to parse" */
+  char buf[66];
+  if (n % 2) {
+    buf[0] = '0';
+    memcpy(buf + 1, s, n + 1);
+    ++n;
+  } else {
+    memcpy(buf, s, n + 1);
+  }
+  int cidx = (int)((n - 1) / 16);
+  for (size_t i = 0; i < n && cidx >= 0; i += 16) {
+    size_t end = i + 16 < n ? i + 16 : n;
+    uint64_t w = 0;
+    for (size_t j = i; j < end; ++j) {
+      char ch = buf[j];
+      unsigned v;
+      if (ch >= '0' && ch <= '9') v = (unsigned)(ch - '0');
+      else if (ch >= 'a' && ch <= 'f') v = (unsigned)(ch - 'a' + 10);
+      else if (ch >= 'A' && ch <= 'F') v = (unsigned)(ch - 'A' + 10);
+      else return SCLO_BAD_HEX_CHAR;
+      w = (w << 4) | v;
+    }
+    t.w[cidx--] = w;
+  }
+  *out = t;
+  return SCLO_OK;
+}
+
 int sclo_from_hex(int field, const char* hex, uint64_t* dst) {
+  if (field == SCLO_SECP256K1_SCALAR) {
+    fe256 t;
+    int st256 = hex_parse256(hex, &t);
+    if (st256) return st256;
+    secpq_ensure();
+    secpq_st(dst, hex[0] ? secpq_to_mont(t) : t);
+    return SCLO_OK;
+  }
   u128 v;
   int st = hex_parse(hex, &v, field == SCLO_M61 ? 64 : 128);
   if (st) return st;
@@ -559,6 +726,21 @@ int sclo_from_hex(int field, const char* hex, uint64_t* dst) {
  * the top word (if non-zero) then the low word WITHOUT zero padding
  * (src/scl/util/str.cc:23-39) -- reproduced as is. */
 int sclo_to_hex(int field, const uint64_t* a, char* out, size_t outlen) {
+  if (field == SCLO_SECP256K1_SCALAR) { /* montyToString: value out of Montgomery form, hex without leading zeros */
+    secpq_ensure();
+    const fe256 v = secpq_from_mont(secpq_ld(a));
+    char tmp[65];
+    int len = 0, started = 0;
+    for (int i = 3; i >= 0; --i)
+      for (int nib = 15; nib >= 0; --nib) {
+        unsigned d = (unsigned)((v.w[i] >> (4 * nib)) & 15);
+        if (d || started || (i == 0 && nib == 0)) { tmp[len++] = "0123456789abcdef"[d]; started = 1; }
+      }
+    if ((size_t)len + 1 > outlen) return SCLO_BAD_ARG;
+    memcpy(out, tmp, (size_t)len);
+    out[len] = 0;
+    return SCLO_OK;
+  }
   if (field == SCLO_M61) return hex_u64(a[0], out, outlen, 0) < 0 ? SCLO_BAD_ARG : SCLO_OK;
   if (field == SCLO_M127) {
     if (a[0] == 0 && a[1] == 0) return hex_u64(0, out, outlen, 0) < 0 ? SCLO_BAD_ARG : SCLO_OK;
@@ -645,32 +827,9 @@ int sclo_shamir_recover_d(int field, const uint64_t* shares, size_t n, size_t t,
 
 int sclo_lagrange_basis(int field, const uint64_t* nodes, size_t m, const uint64_t* x,
                         uint64_t* out) {
-  switch (field) {
-    case SCLO_M61: {
-      uint64_t* o = (uint64_t*)malloc((m + 1) * 8);
-      if (!o) return SCLO_BAD_ARG;
-      int st = m61_lagrange_basis(nodes, m, x[0], o);
-      if (!st) memcpy(out, o, m * 8);
-      free(o);
-      return st;
-    }
-#define BODY128(P)                                                     \
-  {                                                                    \
-    u128* nd = (u128*)calloc(2 * (m + 1), sizeof(u128));                  \
-    if (!nd) return SCLO_BAD_ARG;                                      \
-    u128* o = nd + (m + 1);                                            \
-    CAT(P, ldv)(nd, nodes, m);                                         \
-    int st = CAT(P, lagrange_basis)(nd, m, CAT(P, ld)(x), o);          \
-    if (!st) for (size_t i = 0; i < m; ++i) CAT(P, st)(out + 2 * i, o[i]); \
-    free(nd);                                                          \
-    return st;                                                         \
-  }
-    case SCLO_M127: BODY128(m127_)
-    case SCLO_MONT128: mont128_ensure(); BODY128(mont128_)
-    case SCLO_GF2_128: BODY128(gf128_)
-#undef BODY128
-    default: return SCLO_BAD_ARG;
-  }
+#define BODY(P) return CAT(P, lagrange_api)(nodes, m, x, out);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
 }
 
 int sclo_additive_share(int field, const unsigned char* seed, size_t seed_len,
@@ -708,28 +867,9 @@ int sclo_scalar_mul(int field, const uint64_t* a, const uint64_t* scalar, size_t
 
 int sclo_poly_eval(int field, const uint64_t* coeffs, size_t ncoeff, const uint64_t* xs,
                    size_t nx, uint64_t* out) {
-  const size_t L = (size_t)sclo_limbs(field);
-  switch (field) {
-    case SCLO_M61: {
-      for (size_t i = 0; i < nx; ++i) out[i] = m61_horner(coeffs, ncoeff, xs[i]);
-      return SCLO_OK;
-    }
-#define BODY128(P)                                                             \
-  {                                                                            \
-    u128* c = (u128*)malloc((ncoeff + 1) * sizeof(u128));                      \
-    if (!c) return SCLO_BAD_ARG;                                               \
-    CAT(P, ldv)(c, coeffs, ncoeff);                                            \
-    for (size_t i = 0; i < nx; ++i)                                            \
-      CAT(P, st)(out + i * L, CAT(P, horner)(c, ncoeff, CAT(P, ld)(xs + i * L))); \
-    free(c);                                                                   \
-    return SCLO_OK;                                                            \
-  }
-    case SCLO_M127: BODY128(m127_)
-    case SCLO_MONT128: mont128_ensure(); BODY128(mont128_)
-    case SCLO_GF2_128: BODY128(gf128_)
-#undef BODY128
-    default: return SCLO_BAD_ARG;
-  }
+#define BODY(P) return CAT(P, poly_eval_api)(coeffs, ncoeff, xs, nx, out);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
 }
 
 int sclo_vandermonde(int field, size_t n, size_t m, const uint64_t* xs, uint64_t* out) {
@@ -751,7 +891,11 @@ size_t sclo_wire_vector(int field, const uint64_t* elems, size_t n, unsigned cha
     const uint32_t cnt = (uint32_t)n;
     memcpy(out, &cnt, 4);
     for (size_t i = 0; i < n; ++i) {
-      if (field == SCLO_MONT128) { /* gmp family: out of Montgomery form, big-endian (ff_ops_gmp.h:298-314) */
+      if (field == SCLO_SECP256K1_SCALAR) { /* montyToBytes: out of Montgomery form, big-endian (ff_ops_gmp.h:298-314) */
+        secpq_ensure();
+        const fe256 v = secpq_from_mont(secpq_ld(elems + i * L));
+        for (int b = 0; b < 32; ++b) out[4 + i * bs + b] = (unsigned char)(v.w[3 - b / 8] >> (8 * (7 - b % 8)));
+      } else if (field == SCLO_MONT128) { /* gmp family: out of Montgomery form, big-endian (ff_ops_gmp.h:298-314) */
         mont128_ensure();
         u128 v = mont128_from_mont(mont128_ld(elems + i * L));
         for (int b = 0; b < 16; ++b) out[4 + i * bs + b] = (unsigned char)(v >> (8 * (15 - b)));

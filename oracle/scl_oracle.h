@@ -6,7 +6,7 @@
  * leg may load it.  Every function cites the reference file:line it follows
  * (paths relative to /root/reference).
  *
- * Parity status: PINNED for Mersenne61 / Mersenne127 / PRG / Shamir / additive
+ * Parity status: PINNED for Mersenne61 / Mersenne127 / secp256k1_order / PRG / Shamir / additive
  * / Lagrange / Vandermonde / matmul -- tests/test_oracle_golden.py checks every
  * function here against golden vectors emitted by the real reference
  * (oracle/_ref, tests/golden/make_golden.py) and, where /root/reference is
@@ -15,8 +15,10 @@
  * has no such fields; they are checked against Python
  * big-integer arithmetic and algebraic identities only.
  *
- * Encoding: an element is 1 (M61) or 2 (M127, MONT128, GF2_128) little-endian
- * uint64 limbs -- the byte image of FF::write (include/scl/math/ff.h:300-302).
+ * Encoding: an element is 1 (M61), 2 (M127, MONT128, GF2_128) or 4 (SECP256K1_SCALAR)
+ * little-endian uint64 limbs -- the in-memory image of FF::m_value: the canonical integer
+ * for the Mersenne fields, the Montgomery residue for MONT128 / SECP256K1_SCALAR (as the
+ * reference keeps its 256-bit fields, secp256k1_scalar.cc:47-135).
  * Values are canonical (in [0,p)) on entry and exit.
  * Share matrices on this face are AoS [secret][party] like the reference's
  * per-secret Vector (include/scl/ss/shamir.h:52-68).
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-enum { SCLO_M61 = 0, SCLO_M127 = 1, SCLO_MONT128 = 2, SCLO_GF2_128 = 3 };
+enum { SCLO_M61 = 0, SCLO_M127 = 1, SCLO_MONT128 = 2, SCLO_GF2_128 = 3, SCLO_SECP256K1_SCALAR = 4 };
 enum { SCLO_ADD = 0, SCLO_SUB = 1, SCLO_MUL = 2, SCLO_NEG = 3, SCLO_INV = 4, SCLO_DIV = 5 };
 /* status codes */
 enum { SCLO_OK = 0, SCLO_ZERO_INVERSE = 1, SCLO_BAD_ARG = 2, SCLO_BAD_HEX_LEN = 3,

@@ -26,6 +26,114 @@ def hx(arr):
     return [format(v, "x") for v in O.to_ints(arr)]
 
 
+def gen_montgomery_field(ref, f):
+    """secp256k1_order = FF<Secp256k1Scalar> (src/scl/math/fields/secp256k1_scalar.cc): elements are the
+    4-limb Montgomery images of FF::m_value, written as hex of the 256-bit little-endian limb integer.
+    Inputs come from FF::read over fixed bytes / FF(int), never from integers assumed to be values."""
+    L = O.LIMBS[f]
+    rng = np.random.default_rng(4141)
+    fd = {"limbs": L}
+    I = lambda v: ref.from_int(f, v)
+    edge = np.stack([I(0), I(1), I(2), I(-1), I(-2), I(2 ** 31 - 1), I(-(2 ** 31 - 1)), I(65536)])
+    rnd = ref.from_bytes(f, rng.bytes(32 * 60))
+    a = np.concatenate([edge, rnd])
+    b = np.concatenate([rnd[::-1], edge[::-1]])
+    zero = I(0)
+    nz = np.stack([x for x in a if not np.array_equal(x, zero)])
+    nzb = np.stack([x for x in b if not np.array_equal(x, zero)])[: nz.shape[0]]
+    fd["ew"] = {"a": hx(a), "b": hx(b), "add": hx(ref.ew(f, O.ADD, a, b)), "sub": hx(ref.ew(f, O.SUB, a, b)),
+                "mul": hx(ref.ew(f, O.MUL, a, b)), "neg": hx(ref.ew(f, O.NEG, a)), "nz": hx(nz), "nzb": hx(nzb),
+                "inv": hx(ref.ew(f, O.INV, nz)), "div": hx(ref.ew(f, O.DIV, nz[: nzb.shape[0]], nzb))}
+    try:
+        ref.ew(f, O.INV, zero.reshape(1, L))
+        fd["inv0_error"] = None
+    except O.OracleError as e:
+        fd["inv0_error"] = e.message
+    ints = [0, 1, -1, 5, -5, 123, 2 ** 31 - 1, -(2 ** 31 - 1), 65536, -65536]
+    fd["from_int"] = {"in": ints, "out": [hx(I(v).reshape(1, L))[0] for v in ints]}
+    raw = b"\x00" * 32 + b"\xff" * 32 + bytes(range(32)) + rng.bytes(32 * 40)
+    fd["from_bytes"] = {"raw": raw.hex(), "out": hx(ref.from_bytes(f, raw))}
+    hexes = ["7b", "41621e", "00", "ffffffffffffffffffffffffffffffff",
+             "fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141",
+             "fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364140",
+             "ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff", "0123456789ABCDEFabcdef"]
+    fh = {"in": hexes, "out": [], "to_hex": [], "errors": {}}
+    for h in hexes:
+        v = ref.from_hex(f, h)
+        fh["out"].append(hx(v.reshape(1, L))[0])
+        fh["to_hex"].append(ref.to_hex(f, v))
+    for bad in ("abc", "zz"):
+        try:
+            ref.from_hex(f, bad)
+            fh["errors"][bad] = None
+        except O.OracleError as e:
+            fh["errors"][bad] = e.message
+    fd["hex"] = fh
+    fd["to_hex"] = {"in": hx(a[:30]), "out": [ref.to_hex(f, a[i]) for i in range(30)]}
+    fd["exp"] = [{"base": hx(a[i].reshape(1, L))[0], "e": e, "out": hx(ref.exp(f, a[i], e).reshape(1, L))[0]}
+                 for i, e in ((9, 0), (10, 1), (11, 2), (12, 65537), (13, 2 ** 63 + 12345))]
+    fd["vector_random"] = [{"seed": s.hex(), "n": n, "out": hx(ref.vector_random(f, s, n))}
+                           for s, n in ((b"shamir passive", 4), (b"", 1), (b"vec", 9))]
+    sh = []
+    for (n, t, N, seed) in ((4, 3, 6, b"shamir passive"), (10, 3, 12, b"scl-bench-c2"), (10, 0, 3, b"t0"),
+                            (40, 13, 4, b"scl-bench-c4"), (7, 6, 3, b"full-degree")):
+        secrets = np.concatenate([I(123).reshape(1, L), ref.from_bytes(f, rng.bytes(32 * (N - 2))), I(-1).reshape(1, L)])
+        shares = ref.shamir_share(f, seed, secrets, t, n)
+        alph = np.stack([I(i + 1) for i in range(n)])
+        sh.append({"n": n, "t": t, "seed": seed.hex(), "secrets": hx(secrets), "shares": hx(shares),
+                   "recovered_all_n": hx(ref.shamir_recover(f, shares)),
+                   "lambda_1_to_n_at_0": hx(ref.lagrange_basis(f, alph, I(0)))})
+    fd["shamir"] = sh
+    lb = []
+    for nodes, x in (([4, 5, 6, 7, 8, 9], 0), ([4, 5, 6, 7, 8, 9], 27), ([1, 2, 3], 2), ([1], 0), ([5, 3, 9, 1 << 20], -7)):
+        nd = np.stack([I(v) for v in nodes])
+        lb.append({"nodes": nodes, "x": x, "out": hx(ref.lagrange_basis(f, nd, I(x)))})
+    fd["lagrange"] = lb
+    try:
+        ref.lagrange_basis(f, np.stack([I(1), I(2), I(2)]), I(0))
+        fd["lagrange_dup_error"] = None
+    except O.OracleError as e:
+        fd["lagrange_dup_error"] = e.message
+    coeffs = np.concatenate([I(123).reshape(1, L), rnd[:3]])
+    xs = np.stack([I(v) for v in range(42, 49)])
+    ys = ref.poly_eval(f, coeffs, xs)
+    fd["poly_eval"] = {"coeffs": hx(coeffs), "xs": hx(xs), "ys": hx(ys)}
+    fd["recover_at"] = [{"alphas": hx(xs), "x": hx(xv.reshape(1, L))[0], "shares": hx(ys),
+                         "out": hx(ref.shamir_recover_at(f, ys.reshape(1, 7, L), xs, xv))[0]}
+                        for xv in (I(0), xs[0], I(1000))]
+    secrets = np.stack([I(123), I(5), I(-1), I(77), I(0), I(9)])
+    shares = ref.shamir_share(f, b"shamir detect", secrets, 4, 9)
+    shares[1, 2] = I(4)
+    shares[2, 5] = I(4)
+    shares[3, 8] = I(4)
+    shares[4, 7] = I(1)
+    out, status = ref.shamir_recover_d(f, shares, 4)
+    fd["recover_d"] = {"t": 4, "n": 9, "shares": hx(shares), "out": hx(out), "status": status.tolist()}
+    ad = []
+    for (n, N, seed) in ((3, 8, b""), (10, 3, b"additive"), (1, 2, b"one")):
+        secrets = np.concatenate([I(12345).reshape(1, L), ref.from_bytes(f, rng.bytes(32 * (N - 1)))])
+        shares = ref.additive_share(f, seed, secrets, n)
+        ad.append({"n": n, "seed": seed.hex(), "secrets": hx(secrets), "shares": hx(shares),
+                   "sum": hx(ref.additive_recover(f, shares))})
+    fd["additive"] = ad
+    fd["dot"] = {"a": hx(a), "b": hx(b), "out": hx(ref.dot(f, a, b).reshape(1, L))[0]}
+    fd["sum"] = {"a": hx(a), "out": hx(ref.sum(f, a).reshape(1, L))[0]}
+    fd["scalar_mul"] = {"a": hx(a), "scalar": hx(b[3].reshape(1, L))[0], "out": hx(ref.scalar_mul(f, a, b[3]))}
+    xs5 = np.stack([I(7), I(-1), I(0), I(1), rnd[5]])
+    fd["vandermonde"] = [{"n": 3, "m": 3, "xs": None, "out": hx(ref.vandermonde(f, 3, 3))},
+                         {"n": 10, "m": 4, "xs": None, "out": hx(ref.vandermonde(f, 10, 4))},
+                         {"n": 5, "m": 6, "xs": hx(xs5), "out": hx(ref.vandermonde(f, 5, 6, xs5))}]
+    A = rnd[:20].reshape(2, 10, L)
+    B = rnd[20:50].reshape(10, 3, L)
+    fd["matmul"] = [{"n": 2, "k": 10, "m": 3, "A": hx(A), "B": hx(B), "C": hx(ref.matmul(f, A, B))}]
+    V = ref.vandermonde(f, 10, 4)
+    Cm = rnd[30:50].reshape(4, 5, L)
+    fd["vandermonde_eval"] = {"n": 10, "m": 4, "N": 5, "C": hx(Cm), "out": hx(ref.matmul(f, V, Cm))}
+    fd["wire"] = [{"elems": hx(a[:12]), "bytes": ref.wire_vector(f, a[:12]).hex()},
+                  {"elems": [], "bytes": ref.wire_vector(f, np.zeros((0, L), np.uint64)).hex()}]
+    return fd
+
+
 def main():
     ref = O.Ref()
     rng = np.random.default_rng(20261003)
@@ -182,6 +290,8 @@ def main():
                       {"elems": hx(a[:40]), "bytes": ref.wire_vector(f, a[:40]).hex()},
                       {"elems": [], "bytes": ref.wire_vector(f, np.zeros((0, L), np.uint64)).hex()}]
         doc["fields"][name] = fd
+
+    doc["fields"]["secp256k1_order"] = gen_montgomery_field(ref, O.SECP256K1_SCALAR)
 
     path = os.path.join(HERE, "golden_v1.json")
     with open(path, "w") as fh_:

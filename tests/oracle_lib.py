@@ -21,9 +21,9 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 PORT_SO = os.path.join(ORACLE_DIR, "_build", "libscl_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libscl_ref.so")
 
-M61, M127, MONT128, GF2_128 = 0, 1, 2, 3
+M61, M127, MONT128, GF2_128, SECP256K1_SCALAR = 0, 1, 2, 3, 4
 ADD, SUB, MUL, NEG, INV, DIV = range(6)
-LIMBS = {M61: 1, M127: 2, MONT128: 2, GF2_128: 2}
+LIMBS = {M61: 1, M127: 2, MONT128: 2, GF2_128: 2, SECP256K1_SCALAR: 4}
 P = {M61: (1 << 61) - 1, M127: (1 << 127) - 1}
 
 u64p = C.POINTER(C.c_uint64)
@@ -137,8 +137,8 @@ class _Base:
 
     def to_hex(self, field, a):
         a = _arr(a, LIMBS[field])
-        buf = C.create_string_buffer(80)
-        self._call("to_hex", C.c_int(field), _p(a), buf, C.c_size_t(80))
+        buf = C.create_string_buffer(96)
+        self._call("to_hex", C.c_int(field), _p(a), buf, C.c_size_t(96))
         return buf.value.decode()
 
     def exp(self, field, base, e: int):

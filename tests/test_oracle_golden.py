@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "golden_v1.json")) as fh:
     GOLD = json.load(fh)
 
-FIELDS = [(O.M61, "Mersenne61"), (O.M127, "Mersenne127")]
+FIELDS = [(O.M61, "Mersenne61"), (O.M127, "Mersenne127"), (O.SECP256K1_SCALAR, "secp256k1_order")]
 
 
 @pytest.fixture(scope="module")
@@ -59,6 +59,8 @@ def test_prg_counter_addressing(port):
 def test_elementwise(port, f, name):
     g, L = GOLD["fields"][name], O.LIMBS[f]
     for key in ("ew", "ew_edge_pairs"):
+        if key not in g:
+            continue
         e = g[key]
         a, b = arr(e["a"], L), arr(e["b"], L)
         eq(port.ew(f, O.ADD, a, b), e["add"])
@@ -84,6 +86,9 @@ def test_conversions(port, f, name):
         eq(v.reshape(1, L), [out])
         assert port.to_hex(f, v) == th
     for bad, msg in g["hex"]["errors"].items():
+        if msg is None:  # the Montgomery family pads an odd-length string instead of rejecting it
+            port.from_hex(f, bad)
+            continue
         with pytest.raises(O.OracleError) as ei:
             port.from_hex(f, bad)
         assert ei.value.message == msg
@@ -104,24 +109,25 @@ def test_shamir(port, f, name):
         shares = port.shamir_share(f, bytes.fromhex(c["seed"]), secrets, t, n)
         eq(shares, c["shares"])
         eq(port.shamir_recover(f, shares), c["recovered_all_n"])
-        lam = port.lagrange_basis(f, O.from_ints(range(1, n + 1), L), port.from_int(f, 0))
+        lam = port.lagrange_basis(f, np.stack([port.from_int(f, i) for i in range(1, n + 1)]), port.from_int(f, 0))
         eq(lam, c["lambda_1_to_n_at_0"])
         eq(port.shamir_recover_lambda(f, shares, lam), c["recovered_all_n"])
         if t < n:
             assert c["recovered_all_n"] == c["secrets"]
         # closed form for nodes 1..n at 0: (-1)^(i-1) C(n,i) mod p
         from math import comb
-        p = O.P[f]
-        assert O.to_ints(lam) == [((-1) ** (i - 1) * comb(n, i)) % p for i in range(1, n + 1)]
+        if f in O.P:
+            p = O.P[f]
+            assert O.to_ints(lam) == [((-1) ** (i - 1) * comb(n, i)) % p for i in range(1, n + 1)]
 
 
 @pytest.mark.parametrize("f,name", FIELDS)
 def test_lagrange_recover_at_detect(port, f, name):
     g, L = GOLD["fields"][name], O.LIMBS[f]
     for c in g["lagrange"]:
-        eq(port.lagrange_basis(f, O.from_ints([v % O.P[f] for v in c["nodes"]], L), port.from_int(f, c["x"])), c["out"])
+        eq(port.lagrange_basis(f, np.stack([port.from_int(f, v) for v in c["nodes"]]), port.from_int(f, c["x"])), c["out"])
     with pytest.raises(O.OracleError) as ei:
-        port.lagrange_basis(f, O.from_ints([1, 2, 2], L), port.from_int(f, 0))
+        port.lagrange_basis(f, np.stack([port.from_int(f, v) for v in (1, 2, 2)]), port.from_int(f, 0))
     assert ei.value.message == g["lagrange_dup_error"]
     pe = g["poly_eval"]
     eq(port.poly_eval(f, arr(pe["coeffs"], L), arr(pe["xs"], L)), pe["ys"])
@@ -174,7 +180,7 @@ def test_wire_image(port, f, name):
         assert raw.hex() == c["bytes"]
         assert np.array_equal(port.unwire_vector(f, raw), el.reshape(-1, L))
     # test/scl/serialization/test_serializer.cc:106-123: size = 4 + 3 * byteSize
-    assert len(port.wire_vector(f, O.from_ints([1, 2, 3], L))) == 4 + 3 * 8 * L
+    assert len(port.wire_vector(f, np.stack([port.from_int(f, v) for v in (1, 2, 3)]))) == 4 + 3 * 8 * L
 
 
 # ---- known answers held by the reference's own tests for this path ----
@@ -224,7 +230,7 @@ def test_reference_test_suite_kats(port):
 @pytest.mark.parametrize("f,name", FIELDS)
 def test_field_identities(port, f, name):
     """test/scl/math/test_ff.cc:64-227 restated: algebraic identities on PRG-seeded operands."""
-    L, p = O.LIMBS[f], O.P[f]
+    L = O.LIMBS[f]
     a = port.vector_random(f, b"ff-a", 50)
     b = port.vector_random(f, b"ff-b", 50)
     c = port.vector_random(f, b"ff-c", 50)
@@ -239,20 +245,24 @@ def test_field_identities(port, f, name):
     assert E(port.ew(f, O.SUB, a, a), zero)
     assert E(port.ew(f, O.NEG, port.ew(f, O.SUB, a, b)), port.ew(f, O.SUB, b, a))
     assert E(port.ew(f, O.DIV, a, b), port.ew(f, O.INV, port.ew(f, O.DIV, b, a)))
-    assert all(v < p for v in O.to_ints(a))
+    if f in O.P:
+        assert all(v < O.P[f] for v in O.to_ints(a))
 
 
 @pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built and /root/reference absent")
 @pytest.mark.parametrize("f,name", FIELDS)
 def test_port_vs_live_reference(port, f, name):
     ref = O.Ref()
-    L, p = O.LIMBS[f], O.P[f]
+    L = O.LIMBS[f]
     rng = np.random.default_rng(7)
-    vals = [int.from_bytes(rng.bytes(16), "little") % p for _ in range(2000)]
-    a, b = O.from_ints(vals, L), O.from_ints(vals[::-1], L)
+    a = ref.from_bytes(f, rng.bytes(8 * L * 2000))
+    b = np.ascontiguousarray(a[::-1])
     for op in (O.ADD, O.SUB, O.MUL, O.NEG):
         assert np.array_equal(port.ew(f, op, a, b), ref.ew(f, op, a, b))
-    nz = O.from_ints([v or 1 for v in vals[:300]], L)
+    nz = a[:300].copy()
+    for i in range(300):
+        if not nz[i].any():
+            nz[i] = ref.from_int(f, 1)
     assert np.array_equal(port.ew(f, O.INV, nz), ref.ew(f, O.INV, nz))
     for (n, t) in ((10, 3), (40, 13), (5, 4)):
         s1 = port.shamir_share(f, b"live", a[:200], t, n)
