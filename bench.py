@@ -25,8 +25,9 @@ for p in (os.path.join(ROOT, "secure-computation-library_amd"), os.path.join(ROO
     if p not in sys.path:
         sys.path.insert(0, p)
 
-FIELD_TAGS = {"m61": 0, "m127": 1, "mont128": 2, "gf2_128": 3}
-FIELD_NAMES = {"m61": "Mersenne61", "m127": "Mersenne127", "mont128": "Mont128", "gf2_128": "GF(2^128)"}
+FIELD_TAGS = {"m61": 0, "m127": 1, "mont128": 2, "gf2_128": 3, "secp256k1": 4}
+FIELD_NAMES = {"m61": "Mersenne61", "m127": "Mersenne127", "mont128": "Mont128", "gf2_128": "GF(2^128)",
+               "secp256k1": "secp256k1_order"}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
 
 
@@ -189,7 +190,7 @@ def main():
         "metric": "shamir_reconstructions_per_sec", "value": total / elapsed, "unit": "reconstructions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64" if L == 1 else "u128", "data": "synthetic",
+        "dtype": {1: "u64", 2: "u128", 4: "u256"}[L], "data": "synthetic",
         "config": {"workload": f"shamir_share+reconstruct n={n} t={t} {FIELD_NAMES[args.field]} "
                                f"{N} secrets/GPU (BASELINE configs[1])" if (n, t, args.field, N) == (10, 3, "m61", 100_000_000)
                    else f"shamir_share+reconstruct n={n} t={t} {FIELD_NAMES[args.field]} {N} secrets/GPU",

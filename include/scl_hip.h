@@ -10,10 +10,14 @@
  *
  * Conventions
  *  - field tags: SCL_M61 = scl::math::ff::Mersenne61 (1 uint64 limb),
- *    SCL_M127 = Mersenne127 (2 limbs, little-endian, 16-byte aligned);
- *    SCL_MONT128 / SCL_GF2_128 are plug-in fields the reference does not have
- *    (2 limbs).  An element's limbs are the byte image of FF::write
- *    (include/scl/math/ff.h:300-302).
+ *    SCL_M127 = Mersenne127 (2 limbs, little-endian, 16-byte aligned),
+ *    SCL_SECP256K1_SCALAR = scl::math::ff::Secp256k1Scalar, the secp256k1 group
+ *    order (4 limbs, 16-byte aligned); SCL_MONT128 / SCL_GF2_128 are plug-in
+ *    fields the reference does not have (2 limbs).  An element's limbs are the
+ *    in-memory image of FF::m_value (what std::vector<FF>::data() holds): the
+ *    canonical integer for the Mersenne fields, the Montgomery residue
+ *    x*2^256 mod p for secp256k1_order exactly as the reference keeps it
+ *    (src/scl/math/fields/secp256k1_scalar.cc:47-135), x*2^128 mod p for MONT128.
  *  - values are canonical (in [0,p)) on entry and on exit.
  *  - "dev" pointers are device (HBM) pointers, "host" pointers are host
  *    memory.  The caller owns every buffer.
@@ -40,7 +44,7 @@
 extern "C" {
 #endif
 
-typedef enum { SCL_M61 = 0, SCL_M127 = 1, SCL_MONT128 = 2, SCL_GF2_128 = 3 } scl_field;
+typedef enum { SCL_M61 = 0, SCL_M127 = 1, SCL_MONT128 = 2, SCL_GF2_128 = 3, SCL_SECP256K1_SCALAR = 4 } scl_field;
 
 typedef enum { SCL_OP_ADD = 0, SCL_OP_SUB = 1, SCL_OP_MUL = 2, SCL_OP_NEG = 3, SCL_OP_INV = 4,
                SCL_OP_DIV = 5 } scl_op;

@@ -73,6 +73,7 @@ struct M61 {
   static SCL_HD bool eq(E a, E b) { return a == b; }
   static SCL_HD E ld(const u64* p) { return p[0]; }
   static SCL_HD void st(u64* p, E v) { p[0] = v; }
+  static SCL_HD u32 low32(E v) { return (u32)v; }
 
   static SCL_HD E add(const Ctx&, E a, E b) {
     const u64 t = a + b;
@@ -154,6 +155,7 @@ struct M127 {
   static SCL_HD E from_u64(const Ctx&, u64 v) { return v; }
   static SCL_HD bool is_zero(E a) { return a == 0; }
   static SCL_HD bool eq(E a, E b) { return a == b; }
+  static SCL_HD u32 low32(E v) { return (u32)v; }
   static SCL_HD E ld(const u64* p) { return ((u128)p[1] << 64) | p[0]; }
   static SCL_HD void st(u64* p, E v) {
     p[0] = (u64)v;
@@ -272,6 +274,7 @@ struct Mont128 {
   static SCL_HD E one(const Ctx& c) { return c.one; }
   static SCL_HD bool is_zero(E a) { return a == 0; }
   static SCL_HD bool eq(E a, E b) { return a == b; }
+  static SCL_HD u32 low32(E v) { return (u32)v; }
   static SCL_HD E ld(const u64* p) { return ((u128)p[1] << 64) | p[0]; }
   static SCL_HD void st(u64* p, E v) {
     p[0] = (u64)v;
@@ -338,6 +341,7 @@ struct Gf128 {
   static SCL_HD E from_u64(const Ctx&, u64 v) { return v; }
   static SCL_HD bool is_zero(E a) { return a == 0; }
   static SCL_HD bool eq(E a, E b) { return a == b; }
+  static SCL_HD u32 low32(E v) { return (u32)v; }
   static SCL_HD E ld(const u64* p) { return ((u128)p[1] << 64) | p[0]; }
   static SCL_HD void st(u64* p, E v) {
     p[0] = (u64)v;
@@ -401,6 +405,152 @@ struct Gf128 {
       r = mul(c, r, sq);
     }
     return a == 0 ? (E)0 : r;
+  }
+};
+
+// --------------------------------------------------------------- secp256k1 group order
+// FF<Secp256k1Scalar> of the reference (include/scl/math/fields/secp256k1_scalar.h,
+// src/scl/math/fields/secp256k1_scalar.cc:47-135): the field Feldman / Pedersen VSS share over.  Four
+// 64-bit limbs holding the Montgomery residue x*2^256 mod p exactly like the reference's m_value, with the
+// arithmetic of its mpn Montgomery family (include/scl/math/fields/ff_ops_gmp.h:44-314).
+struct U256 {
+  u64 w[4];
+};
+
+struct Secp256k1Scalar {
+  typedef U256 E;
+  struct Ctx {};
+  enum { LIMBS = 4, ACC_TERMS = 1 << 30, TAG = 4, SMALL_BITS = 0 };
+
+  static SCL_HD u64 P(int i) {  // p = FFFFFFFF FFFFFFFF FFFFFFFF FFFFFFFE BAAEDCE6 AF48A03B BFD25E8C D0364141
+    return i == 0 ? 0xBFD25E8CD0364141ull : i == 1 ? 0xBAAEDCE6AF48A03Bull : i == 2 ? 0xFFFFFFFFFFFFFFFEull : 0xFFFFFFFFFFFFFFFFull;
+  }
+  static constexpr u64 MC0 = 0x4B0DFF665588B13Full;  // -p^-1 mod 2^64 (low limb of RedParams::mc, secp256k1_scalar.cc:62-67)
+  static SCL_HD E make(u64 a, u64 b, u64 c, u64 d) {
+    E r;
+    r.w[0] = a; r.w[1] = b; r.w[2] = c; r.w[3] = d;
+    return r;
+  }
+  static SCL_HD E zero() { return make(0, 0, 0, 0); }
+  static SCL_HD E one(const Ctx&) { return make(0x402DA1732FC9BEBFull, 0x4551231950B75FC4ull, 1, 0); }  // 2^256 mod p
+  static SCL_HD E r2() { return make(0x896CF21467D7D140ull, 0x741496C20E7CF878ull, 0xE697F5E45BCD07C6ull, 0x9D671CD581C69BC5ull); }  // 2^512 mod p
+  static SCL_HD bool is_zero(const E& a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
+  static SCL_HD bool eq(const E& a, const E& b) {
+    return ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) == 0;
+  }
+  static SCL_HD u32 low32(const E& v) { return (u32)v.w[0]; }
+  static SCL_HD E ld(const u64* p) { return make(p[0], p[1], p[2], p[3]); }
+  static SCL_HD void st(u64* p, const E& v) {
+    p[0] = v.w[0]; p[1] = v.w[1]; p[2] = v.w[2]; p[3] = v.w[3];
+  }
+  static SCL_HD bool geq_p(const E& a) {
+    for (int i = 3; i >= 0; --i) {
+      if (a.w[i] > P(i)) return true;
+      if (a.w[i] < P(i)) return false;
+    }
+    return true;
+  }
+  static SCL_HD u64 add_n(E& r, const E& a, const E& b) {  // returns the carry out
+    u128 c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      c += (u128)a.w[i] + b.w[i];
+      r.w[i] = (u64)c;
+      c >>= 64;
+    }
+    return (u64)c;
+  }
+  static SCL_HD u64 sub_n(E& r, const E& a, const E& b) {  // returns the borrow out
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u128 d = (u128)a.w[i] - b.w[i] - borrow;
+      r.w[i] = (u64)d;
+      borrow = (u64)(d >> 64) & 1;
+    }
+    return borrow;
+  }
+  static SCL_HD E prime() { return make(P(0), P(1), P(2), P(3)); }
+  static SCL_HD E add(const Ctx&, const E& a, const E& b) {  // montyModAdd, ff_ops_gmp.h:128-134
+    E r;
+    const u64 carry = add_n(r, a, b);
+    if (carry || geq_p(r)) sub_n(r, r, prime());
+    return r;
+  }
+  static SCL_HD E sub(const Ctx&, const E& a, const E& b) {  // montyModSub, ff_ops_gmp.h:142-148
+    E r;
+    if (sub_n(r, a, b)) add_n(r, r, prime());
+    return r;
+  }
+  static SCL_HD E neg(const Ctx& c, const E& a) { return sub(c, zero(), a); }  // montyModNeg
+  // montyModMul (ff_ops_gmp.h:174-191): interleaved Montgomery product a*b/2^256 mod p, valid for a < 2^256, b < p
+  static SCL_HD E mul(const Ctx&, const E& a, const E& b) {
+    u64 u[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u128 c = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c += (u128)a.w[j] * b.w[i] + u[j];
+        u[j] = (u64)c;
+        c >>= 64;
+      }
+      c += u[4];
+      u[4] = (u64)c;
+      u[5] = (u64)(c >> 64);
+      const u64 q = MC0 * u[0];
+      c = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c += (u128)q * P(j) + u[j];
+        u[j] = (u64)c;
+        c >>= 64;
+      }
+      c += u[4];
+      u[4] = (u64)c;
+      u[5] += (u64)(c >> 64);
+      u[0] = u[1]; u[1] = u[2]; u[2] = u[3]; u[3] = u[4]; u[4] = u[5]; u[5] = 0;
+    }
+    E r = make(u[0], u[1], u[2], u[3]);
+    if (u[4] || geq_p(r)) sub_n(r, r, prime());
+    return r;
+  }
+  static SCL_HD E sqr(const Ctx& c, const E& a) { return mul(c, a, a); }
+  static SCL_HD E to_mont(const Ctx& c, const E& x) { return mul(c, x, r2()); }            // montyIn
+  static SCL_HD E from_mont(const Ctx& c, const E& a) { return mul(c, a, make(1, 0, 0, 0)); }  // montyRedc
+  static SCL_HD E from_u64(const Ctx& c, u64 v) { return to_mont(c, make(v, 0, 0, 0)); }
+  // fromBytes: 32 BIG-endian bytes -> value -> Montgomery form (montyFromBytes, ff_ops_gmp.h:279-290);
+  // raw = the four little-endian 64-bit words of the byte string in memory order
+  static SCL_HD E from_le_word(const Ctx& c, const E& raw) {
+    return to_mont(c, make(__builtin_bswap64(raw.w[3]), __builtin_bswap64(raw.w[2]), __builtin_bswap64(raw.w[1]),
+                           __builtin_bswap64(raw.w[0])));
+  }
+  // toBytes image (montyToBytes, ff_ops_gmp.h:298-314) as four little-endian words in memory order
+  static SCL_HD E to_be_image(const Ctx& c, const E& a) {
+    const E v = from_mont(c, a);
+    return make(__builtin_bswap64(v.w[3]), __builtin_bswap64(v.w[2]), __builtin_bswap64(v.w[1]), __builtin_bswap64(v.w[0]));
+  }
+  static SCL_HD E muladd_small(const Ctx& c, const E& y, u32, const E& a) { return add(c, y, a); }
+  static SCL_HD E muladd_small_lazy(const E& y, u32, const E&) { return y; }
+  static SCL_HD E canon(const E& r) { return r; }
+
+  struct Acc {
+    E v;
+  };
+  static SCL_HD Acc acc_zero() { return Acc{zero()}; }
+  static SCL_HD void mac(const Ctx& c, Acc& acc, const E& a, const E& b) { acc.v = add(c, acc.v, mul(c, a, b)); }
+  static SCL_HD void acc_add(const Ctx& c, Acc& acc, const E& a) { acc.v = add(c, acc.v, a); }
+  static SCL_HD E acc_fold(const Ctx&, const Acc& acc) { return acc.v; }
+
+  // montyModInv (ff_ops_gmp.h:225-260): a^(p-2) by square-and-multiply from the top bit; inv(0) = 0
+  static SCL_HD E inv(const Ctx& c, const E& a) {
+    const u64 e[4] = {P(0) - 2, P(1), P(2), P(3)};
+    E r = one(c);
+    for (int i = 255; i >= 0; --i) {
+      r = sqr(c, r);
+      if ((e[i >> 6] >> (i & 63)) & 1) r = mul(c, r, a);
+    }
+    return is_zero(a) ? zero() : r;
   }
 };
 

@@ -47,6 +47,15 @@ struct Mersenne127 {  // include/scl/math/fields/mersenne127.h:29-49
   constexpr static int TAG = SCL_M127;
 };
 
+struct Secp256k1Scalar {  // include/scl/math/fields/secp256k1_scalar.h: the order of the secp256k1 group
+  using ValueType = sclhip::U256;  // 4 x 64-bit limbs, Montgomery form like the reference's std::array<mp_limb_t, 4>
+  using Impl = sclhip::Secp256k1Scalar;
+  constexpr static const char* NAME = "secp256k1_order";
+  constexpr static std::size_t BYTE_SIZE = 32;
+  constexpr static std::size_t BIT_SIZE = 256;
+  constexpr static int TAG = SCL_SECP256K1_SCALAR;
+};
+
 struct Mont128 {  // plug-in: generic 128-bit prime, Montgomery form (not in the reference)
   using ValueType = __uint128_t;
   using Impl = sclhip::Mont128;
@@ -101,6 +110,20 @@ inline V parseHex(const std::string& s) {
   return t;
 }
 
+// montyFromString (include/scl/math/fields/ff_ops_gmp.h:370-398): an odd-length string gets a leading "0",
+// more than 64 digits is an error, and the digits are cut into 16-character limbs FROM THE LEFT (first
+// chunk = top limb (n-1)/16; a short last chunk becomes limb 0 as it stands).  Kept as the reference does it.
+inline sclhip::U256 parseHexLimbs(const std::string& str) {
+  sclhip::U256 out = sclhip::Secp256k1Scalar::zero();
+  if (str.empty()) return out;
+  if (str.size() > 64) throw std::invalid_argument("hex string too large to parse");
+  const std::string s = str.size() % 2 ? "0" + str : str;
+  int c = (int)((s.size() - 1) / 16);
+  for (std::size_t i = 0; i < s.size() && c >= 0; i += 16)
+    out.w[c--] = parseHex<std::uint64_t>(s.substr(i, 16).size() % 2 ? "0" + s.substr(i, 16) : s.substr(i, 16));
+  return out;
+}
+
 inline std::string hex64(std::uint64_t v) {
   std::stringstream ss;
   ss << std::hex << v;
@@ -138,11 +161,16 @@ class FF final {
 
   /// hex string, reduced mod p (mersenne61.cc:42-46)
   static FF fromString(const std::string& hexstr) {
+    if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
+      const V limbs = ff::detail::parseHexLimbs(hexstr);
+      return fromRaw(hexstr.empty() ? limbs : Impl::to_mont(ctx(), limbs));
+    } else {
     const V raw = ff::detail::parseHex<V>(hexstr);
     if constexpr (FIELD::TAG == SCL_MONT128)
       return fromRaw(Impl::to_mont(ctx(), raw));
     else
       return fromRaw(Impl::from_le_word(ctx(), raw));
+    }
   }
 
   static FF zero() { return FF(); }
@@ -191,6 +219,19 @@ class FF final {
   std::string toString() const {
     if constexpr (FIELD::TAG == SCL_M61) {
       return ff::detail::hex64(m_value);
+    } else if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
+      // montyToString: the value out of Montgomery form, hex without leading zeros
+      const V v = Impl::from_mont(ctx(), m_value);
+      std::string out;
+      for (int i = 3; i >= 0; --i) {
+        if (out.empty()) {
+          if (v.w[i] || i == 0) out = ff::detail::hex64(v.w[i]);
+        } else {
+          const std::string part = ff::detail::hex64(v.w[i]);
+          out += std::string(16 - part.size(), '0') + part;
+        }
+      }
+      return out;
     } else {
       V v = m_value;
       if constexpr (FIELD::TAG == SCL_MONT128) v = Impl::from_mont(ctx(), v);
@@ -208,7 +249,10 @@ class FF final {
   /// FF::write (ff.h:300-302).  Mersenne fields: the canonical little-endian word.  Mont128 follows
   /// the reference's Montgomery family (ff_ops_gmp.h:298-314): out of Montgomery form, big-endian.
   void write(unsigned char* dest) const {
-    if constexpr (FIELD::TAG == SCL_MONT128) {
+    if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
+      const V v = Impl::to_be_image(ctx(), m_value);  // montyToBytes: value, big-endian
+      std::memcpy(dest, &v, sizeof v);
+    } else if constexpr (FIELD::TAG == SCL_MONT128) {
       const V v = sclhip::bswap128(Impl::from_mont(ctx(), m_value));
       std::memcpy(dest, &v, sizeof v);
     } else {

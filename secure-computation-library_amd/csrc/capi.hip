@@ -105,6 +105,7 @@ int with_field(int field, Fn&& fn) {
     case SCL_M127: return fn(M127{}, M127::Ctx{});
     case SCL_MONT128: return fn(Mont128{}, mont_ctx());
     case SCL_GF2_128: return fn(Gf128{}, Gf128::Ctx{});
+    case SCL_SECP256K1_SCALAR: return fn(Secp256k1Scalar{}, Secp256k1Scalar::Ctx{});
     default: return fail(SCL_ERR_BAD_ARG, "unknown field tag");
   }
 }
@@ -280,10 +281,14 @@ bool small_vandermonde(const BigTable<F>& al, size_t n, size_t t, SmallVdm& sv) 
 // every node below 2^SMALL_BITS as an integer / bit pattern -> the Horner kernels' small-constant form
 template <class F>
 bool small_nodes(const BigTable<F>& al, size_t n) {
-  if (F::SMALL_BITS == 0 || g_force_table.load() > 1) return false;
-  for (size_t i = 0; i < n; ++i)
-    if ((u128)al.v[i] >> F::SMALL_BITS) return false;
-  return true;
+  if constexpr (F::SMALL_BITS == 0) {
+    return false;
+  } else {
+    if (g_force_table.load() > 1) return false;
+    for (size_t i = 0; i < n; ++i)
+      if ((u128)al.v[i] >> F::SMALL_BITS) return false;
+    return true;
+  }
 }
 
 template <class F>
@@ -459,7 +464,7 @@ const char* scl_hip_status_message(int status) {
   }
 }
 
-int scl_hip_limbs(int field) { return field == SCL_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : -1; }
+int scl_hip_limbs(int field) { return field == SCL_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : field == SCL_SECP256K1_SCALAR ? 4 : -1; }
 
 const char* scl_hip_field_name(int field) {
   switch (field) {
@@ -467,6 +472,7 @@ const char* scl_hip_field_name(int field) {
     case SCL_M127: return "Mersenne127";
     case SCL_MONT128: return "Mont128";
     case SCL_GF2_128: return "GF(2^128)";
+    case SCL_SECP256K1_SCALAR: return "secp256k1_order";  // secp256k1_scalar.h NAME
     default: return "";
   }
 }
@@ -662,7 +668,7 @@ static int reduce_impl(int field, uint64_t* out_host, const uint64_t* a, const u
     const int vec = vec_width<F>({a, b}, {});
     const unsigned maxg = 1024;
     void* sc;
-    SCL_TRY(scratch((size_t)2 * (maxg + 1) * 16, &sc));
+    SCL_TRY(scratch((size_t)2 * (maxg + 1) * F::LIMBS * 8, &sc));
     u64* partial = static_cast<u64*>(sc);
     unsigned used = 0;
     SCL_TRY((split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
@@ -754,7 +760,7 @@ int scl_hip_vector_random(int field, uint64_t* dst, size_t n, const unsigned cha
     SCL_TRY(check_align<F>({dst}));
     AesKey key;
     make_aes_key(seed, seed_len, key);
-    const size_t work = ((F::LIMBS == 1 ? (n + 1) / 2 : n) + 3) / 4;
+    const size_t work = F::LIMBS == 4 ? (n + 1) / 2 : ((F::LIMBS == 1 ? (n + 1) / 2 : n) + 3) / 4;
     hipLaunchKernelGGL((k_vector_random<F>), dim3(grid_aes(work)), dim3(BLOCK), 0, S(stream), ctx, dst, key,
                        (u64)counter0, n);
     LAUNCH_CHECK();
@@ -909,7 +915,7 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
     AesKey key;
     make_aes_key(seed, seed_len, key);
     const int vec = vec_width<F>({shares, secrets}, {share_stride});
-    const u64 blocks_per_secret = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1);  // ceil((t+1)*byteSize/16)
+    const u64 blocks_per_secret = ((u64)(t + 1) * F::LIMBS * 8 + 15) / 16;  // ceil((t+1)*byteSize/16)
     if constexpr (F::TAG <= 1) {
       SmallVdm sv;
       if (t >= 1 && small_vandermonde<F>(al, n, t, sv)) {
@@ -1048,7 +1054,7 @@ int scl_hip_additive_share_prg(int field, uint64_t* shares, size_t share_stride,
       constexpr int VEC = decltype(V)::value;
       hipLaunchKernelGGL((k_additive_share_prg<F, VEC>), dim3(grid_aes(npacks)), dim3(BLOCK), 0, S(stream), ctx,
                          shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS, key,
-                         (u64)(counter0 + first * (n - 1)), (int)n, npacks);
+                         (u64)(counter0 + first * (n - 1) * ((F::LIMBS * 8 + 15) / 16)), (int)n, npacks);
       LAUNCH_CHECK();
       return SCL_OK;
     });
@@ -1154,9 +1160,12 @@ static int transpose_impl(int field, uint64_t* dst, const uint64_t* src, size_t 
   if (L == 1) {
     if (to_soa) TR_LAUNCH(1, true);
     else TR_LAUNCH(1, false);
-  } else {
+  } else if (L == 2) {
     if (to_soa) TR_LAUNCH(2, true);
     else TR_LAUNCH(2, false);
+  } else {
+    if (to_soa) TR_LAUNCH(4, true);
+    else TR_LAUNCH(4, false);
   }
 #undef TR_LAUNCH
   LAUNCH_CHECK();

@@ -53,10 +53,17 @@ __device__ __forceinline__ Pack<F, VEC> load_pack(const u64* p) {
     r.v[1] = w.y;
   } else if constexpr (F::LIMBS == 1 && VEC == 1) {
     r.v[0] = ldg<NT>(p);
-  } else {
+  } else if constexpr (F::LIMBS == 2) {
     static_assert(VEC == 1, "128-bit fields use one element per lane");
     const u64x2 w = ldg<NT>(reinterpret_cast<const u64x2*>(p));
     r.v[0] = ((u128)w.y << 64) | w.x;
+  } else {
+    static_assert(VEC == 1 && F::LIMBS == 4, "256-bit fields use one element per lane");
+    const u64x2 w0 = ldg<NT>(reinterpret_cast<const u64x2*>(p)), w1 = ldg<NT>(reinterpret_cast<const u64x2*>(p) + 1);
+    r.v[0].w[0] = w0.x;
+    r.v[0].w[1] = w0.y;
+    r.v[0].w[2] = w1.x;
+    r.v[0].w[3] = w1.y;
   }
   return r;
 }
@@ -70,11 +77,19 @@ __device__ __forceinline__ void store_pack(u64* p, const Pack<F, VEC>& r) {
     stg<NT>(reinterpret_cast<u64x2*>(p), w);
   } else if constexpr (F::LIMBS == 1 && VEC == 1) {
     stg<NT>(p, r.v[0]);
-  } else {
+  } else if constexpr (F::LIMBS == 2) {
     u64x2 w;
     w.x = (u64)r.v[0];
     w.y = (u64)(r.v[0] >> 64);
     stg<NT>(reinterpret_cast<u64x2*>(p), w);
+  } else {
+    u64x2 w0, w1;
+    w0.x = r.v[0].w[0];
+    w0.y = r.v[0].w[1];
+    w1.x = r.v[0].w[2];
+    w1.y = r.v[0].w[3];
+    stg<NT>(reinterpret_cast<u64x2*>(p), w0);
+    stg<NT>(reinterpret_cast<u64x2*>(p) + 1, w1);
   }
 }
 
@@ -84,10 +99,10 @@ struct Table {  // small kernel-argument table (wave-uniform, scalar loads)
 };
 
 // Large table: 2 KiB of kernel arguments, copied into LDS by the block.  Bounds the party count
-// of the table-driven kernels: 256 for Mersenne61, 128 for the 128-bit fields.
+// of the table-driven kernels: 256 for Mersenne61, 128 for the 128-bit fields, 64 for secp256k1_order.
 template <class F>
 struct BigTable {
-  enum { CAP = F::LIMBS == 1 ? 256 : 128 };
+  enum { CAP = 256 / F::LIMBS };
   typename F::E v[CAP];
 };
 
@@ -379,7 +394,7 @@ __device__ __forceinline__ void horner_rows(const typename F::Ctx& ctx, const Pa
 template <class F, bool SMALLX>
 __device__ __forceinline__ void stage_nodes(const BigTable<F>& tab, int n, typename F::E* alpha, u32* alpha32) {
   for (int i = threadIdx.x; i < n; i += BLOCK) {
-    if constexpr (SMALLX) alpha32[i] = (u32)tab.v[i];
+    if constexpr (SMALLX) alpha32[i] = F::low32(tab.v[i]);
     else alpha[i] = tab.v[i];
   }
   __syncthreads();
@@ -599,6 +614,21 @@ __device__ __forceinline__ void aes_ctr_multi(const u32* tl, const AesKey& key, 
 #undef SCL_T
 }
 
+// FF::read over the AES stream: element bytes = F::LIMBS/2 consecutive blocks (128- and 256-bit fields)
+template <class F>
+__device__ __forceinline__ typename F::E elem_from_blocks(const typename F::Ctx& ctx, const u64* lo, const u64* hi) {
+  if constexpr (F::LIMBS == 2) {
+    return F::from_le_word(ctx, ((u128)hi[0] << 64) | lo[0]);
+  } else {
+    typename F::E raw;
+    raw.w[0] = lo[0];
+    raw.w[1] = hi[0];
+    raw.w[2] = lo[1];
+    raw.w[3] = hi[1];
+    return F::from_le_word(ctx, raw);
+  }
+}
+
 #define SCL_AES_PROLOGUE(key)                                                              \
   __shared__ u32 te0_lds[AES_LDS_WORDS];                                                   \
   for (int e_ = threadIdx.x; e_ < AES_LDS_WORDS; e_ += BLOCK) te0_lds[e_] = (key).te0[e_ >> 5]; \
@@ -636,10 +666,14 @@ __global__ __launch_bounds__(BLOCK) void k_from_bytes(typename F::Ctx ctx, u64* 
       u64 w;
       __builtin_memcpy(&w, src + 8 * q, 8);
       dst[q] = F::from_le_word(ctx, w);
-    } else {
+    } else if constexpr (F::LIMBS == 2) {
       u64 w[2];
       __builtin_memcpy(w, src + 16 * q, 16);
       F::st(dst + 2 * q, F::from_le_word(ctx, ((u128)w[1] << 64) | w[0]));
+    } else {
+      typename F::E raw;
+      __builtin_memcpy(raw.w, src + 32 * q, 32);
+      F::st(dst + 4 * q, F::from_le_word(ctx, raw));
     }
   }
 }
@@ -650,12 +684,23 @@ __global__ __launch_bounds__(BLOCK) void k_vector_random(typename F::Ctx ctx, u6
                                                          size_t n) {
   SCL_AES_PROLOGUE(key)
   const size_t G = (size_t)gridDim.x * BLOCK;
-  const size_t nb = F::LIMBS == 1 ? (n + 1) / 2 : n;  // AES blocks needed
-  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nb; q += 4 * G) {
+  constexpr int BPE = F::LIMBS >= 2 ? F::LIMBS / 2 : 1;        // AES blocks per element (wide fields)
+  const size_t nb = F::LIMBS == 1 ? (n + 1) / 2 : n * BPE;    // AES blocks needed
+  // 256-bit fields: q enumerates elements (two blocks each), two elements per trip
+  const size_t units = F::LIMBS == 4 ? n : nb;
+  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < units; q += (F::LIMBS == 4 ? 2 : 4) * G) {
     u64 ctr[4], lo[4], hi[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) ctr[b] = counter0 + q + b * G;
+    for (int b = 0; b < 4; ++b) ctr[b] = counter0 + (F::LIMBS == 4 ? 2 * (q + (b >> 1) * G) + (b & 1) : q + b * G);
     aes_ctr_multi<4>(te0, key, ctr, lo, hi);
+    if constexpr (F::LIMBS == 4) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const size_t e = q + u * G;
+        if (e < n) F::st(dst + 4 * e, elem_from_blocks<F>(ctx, lo + 2 * u, hi + 2 * u));
+      }
+      continue;
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const size_t blk = q + b * G;
@@ -669,7 +714,7 @@ __global__ __launch_bounds__(BLOCK) void k_vector_random(typename F::Ctx ctx, u6
           } else {
             dst[2 * blk] = F::from_le_word(ctx, lo[b]);
           }
-        } else {
+        } else if constexpr (F::LIMBS == 2) {
           F::st(dst + 2 * blk, F::from_le_word(ctx, ((u128)hi[b] << 64) | lo[b]));
         }
       }
@@ -683,7 +728,8 @@ __global__ __launch_bounds__(BLOCK) void k_vector_random(typename F::Ctx ctx, u6
 template <class F, int VEC, int TREG>
 __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, VEC> (&c)[TREG + 1], const u32* te0,
                                            const AesKey& key, u64 counter0, size_t q, int t) {
-  const u64 B = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1);
+  constexpr int BPE = F::LIMBS >= 2 ? F::LIMBS / 2 : 1;  // AES blocks per coefficient (wide fields)
+  const u64 B = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1) * BPE;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     const u64 ctr0 = counter0 + (q * VEC + v) * B;
@@ -699,13 +745,14 @@ __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, V
         }
       }
     } else {
-      // block k holds coefficient k; block 0 (c_0's draw) is never needed
+      // blocks k*BPE .. hold coefficient k; the blocks of c_0's draw are never needed
 #pragma unroll
       for (int k = 1; k <= TREG; ++k) {
         if (k <= t) {
-          u64 lo, hi;
-          aes_ctr_block(te0, key, ctr0 + k, lo, hi);
-          c[k].v[v] = F::from_le_word(ctx, ((u128)hi << 64) | lo);
+          u64 lo[BPE], hi[BPE];
+#pragma unroll
+          for (int b = 0; b < BPE; ++b) aes_ctr_block(te0, key, ctr0 + (u64)k * BPE + b, lo[b], hi[b]);
+          c[k].v[v] = elem_from_blocks<F>(ctx, lo, hi);
         }
       }
     }
@@ -802,16 +849,19 @@ __global__ __launch_bounds__(BLOCK) void k_additive_share_prg(typename F::Ctx ct
   SCL_GRID_STRIDE(q, npacks) {
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> last = load_pack<F, VEC, true>(secrets + off);
+    constexpr int BPE = F::LIMBS >= 2 ? F::LIMBS / 2 : 1;  // FF::random burns ceil(byteSize/16) blocks
     for (int i = 0; i + 1 < n; ++i) {
       Pack<F, VEC> r;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        u64 lo, hi;
-        aes_ctr_block(te0, key, counter0 + (q * VEC + v) * (u64)(n - 1) + i, lo, hi);
+        u64 lo[BPE], hi[BPE];
+        const u64 c0 = counter0 + ((q * VEC + v) * (u64)(n - 1) + i) * BPE;
+#pragma unroll
+        for (int b = 0; b < BPE; ++b) aes_ctr_block(te0, key, c0 + b, lo[b], hi[b]);
         if constexpr (F::LIMBS == 1)
-          r.v[v] = F::from_le_word(ctx, lo);
+          r.v[v] = F::from_le_word(ctx, lo[0]);
         else
-          r.v[v] = F::from_le_word(ctx, ((u128)hi << 64) | lo);
+          r.v[v] = elem_from_blocks<F>(ctx, lo, hi);
         last.v[v] = F::sub(ctx, last.v[v], r.v[v]);
       }
       store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, r);
@@ -1015,13 +1065,20 @@ __global__ __launch_bounds__(BLOCK) void k_wire_pack(typename F::Ctx ctx, u32* d
       const u64 v = src[e];
       o[0] = (u32)v;
       o[1] = (u32)(v >> 32);
-    } else {
+    } else if constexpr (F::LIMBS == 2) {
       u128 v = F::ld(src + 2 * e);
       if constexpr (F::TAG == 2) v = bswap128(F::from_mont(ctx, v));  // Montgomery family: value, big-endian
       o[0] = (u32)v;
       o[1] = (u32)(v >> 32);
       o[2] = (u32)(v >> 64);
       o[3] = (u32)(v >> 96);
+    } else {
+      const typename F::E img = F::to_be_image(ctx, F::ld(src + 4 * e));  // montyToBytes
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[2 * j] = (u32)img.w[j];
+        o[2 * j + 1] = (u32)(img.w[j] >> 32);
+      }
     }
   }
 }
@@ -1032,9 +1089,14 @@ __global__ __launch_bounds__(BLOCK) void k_wire_unpack(typename F::Ctx ctx, u64*
     const u32* in = src + 1 + e * (2 * F::LIMBS);
     if constexpr (F::LIMBS == 1) {
       dst[e] = F::from_le_word(ctx, (u64)in[0] | ((u64)in[1] << 32));
-    } else {
+    } else if constexpr (F::LIMBS == 2) {
       const u128 raw = (u128)in[0] | ((u128)in[1] << 32) | ((u128)in[2] << 64) | ((u128)in[3] << 96);
       F::st(dst + 2 * e, F::from_le_word(ctx, raw));
+    } else {
+      typename F::E raw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) raw.w[j] = (u64)in[2 * j] | ((u64)in[2 * j + 1] << 32);
+      F::st(dst + 4 * e, F::from_le_word(ctx, raw));
     }
   }
 }

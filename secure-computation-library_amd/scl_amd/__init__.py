@@ -25,7 +25,7 @@ if not os.path.exists(_SO):
         "(python -c 'import __graft_entry__ as g; g.build()' or make -C secure-computation-library_amd/csrc)")
 lib = C.CDLL(_SO)
 
-M61, M127, MONT128, GF2_128 = 0, 1, 2, 3
+M61, M127, MONT128, GF2_128, SECP256K1_SCALAR = 0, 1, 2, 3, 4
 ADD, SUB, MUL, NEG, INV, DIV = range(6)
 OK, ERR_SIZE_MISMATCH, ERR_ZERO_INVERSE, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_ERROR_DETECTED, \
     ERR_NOT_ENOUGH_SHARES, ERR_MATMUL_DIMS, ERR_VANDERMONDE_XS, ERR_INVALID_RANGE = range(11)
@@ -265,7 +265,7 @@ def additive_share(field, secrets, rnd, n: int, out=None):
 def additive_share_prg(field, secrets, n: int, seed: bytes, first_secret: int = 0, out=None, counter0=None):
     N = secrets.shape[0]
     if counter0 is None:
-        counter0 = first_secret * (n - 1)
+        counter0 = first_secret * (n - 1) * ((8 * limbs(field) + 15) // 16)  # FF::random burns whole blocks
     if out is None:
         out = empty(field, n, N, device=secrets.device)
     _chk(lib.scl_hip_additive_share_prg(field, _dev(out), C.c_size_t(N), _dev(secrets), C.c_size_t(N), C.c_size_t(n),

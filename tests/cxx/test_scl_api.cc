@@ -137,6 +137,19 @@ TEST_CASE(ff_mersenne127, "FF<Mersenne127> identities + metadata", false) {
   REQUIRE((std::is_same_v<math::Fp<1>, F61>));
 }
 
+TEST_CASE(ff_secp256k1_scalar, "FF<Secp256k1Scalar> identities + metadata", false) {
+  using FS = math::FF<math::ff::Secp256k1Scalar>;
+  field_identities<FS>("s");
+  REQUIRE(std::string(FS::name()) == "secp256k1_order");
+  REQUIRE(FS::byteSize() == 32);
+  REQUIRE(FS(123).toString() == "7b");
+  REQUIRE(FS(-1).toString() == "fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364140");  // p - 1
+  REQUIRE(FS::fromString("fffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141") == FS(0));  // p = 0
+  REQUIRE(FS::fromString("7b") == FS(123));
+  REQUIRE(FS::fromString("abc") == FS(0xabc));  // odd length is padded, not rejected (ff_ops_gmp.h:383-386)
+  REQUIRE_THROWS_MSG(FS::fromString(std::string(66, 'f')), std::invalid_argument, "hex string too large to parse");
+}
+
 TEST_CASE(ff_plugins, "plug-in fields: Mont128, GF(2^128) identities", false) {
   field_identities<math::FF<math::ff::Mont128>>("c");
   using G = math::FF<math::ff::GF2_128>;
@@ -381,6 +394,16 @@ TEST_CASE(shamir_gpu, "ss::shamir*", true) {
     REQUIRE(shares[0] == F127::fromString("68cb89a3b5d99924eddf871da5480cd8"));
     REQUIRE(shares[3] == F127::fromString("7009444c16f85b3b6d51f54c483ec2f8"));
     REQUIRE(ss::shamirRecoverP(shares) == F127(123));
+  }
+  {
+    // the field Feldman / Pedersen share over; share values from the reference (tests/golden, secp256k1_order)
+    using FS = math::FF<math::ff::Secp256k1Scalar>;
+    auto prg = util::PRG::create("shamir passive");
+    const auto shares = ss::shamirSecretShare(FS(123), 3, 4, prg);
+    REQUIRE(shares[0].toString() == "42a24b13e7a4eb634759f5de02b04555926a1896a2bdf2792f2b3d8df56b2fa3");
+    REQUIRE(shares[3].toString() == "b0bfa8fdf1b92683c3bb5984a733091c6aa2df05a498f9eca488ea175c4bc281");
+    REQUIRE(ss::shamirRecoverP(shares) == FS(123));
+    REQUIRE(prg.counter() == 8);  // Vector::random(4) of 32-byte elements = 8 blocks
   }
   // :42-66 t=5, n=100, nodes 4..9 at x=0 and x=27
   {

@@ -17,8 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "golden_v1.json")) as fh:
     GOLD = json.load(fh)
 
-FIELDS = [(O.M61, "Mersenne61"), (O.M127, "Mersenne127")]
-ALL_FIELDS = [O.M61, O.M127, O.MONT128, O.GF2_128]
+FIELDS = [(O.M61, "Mersenne61"), (O.M127, "Mersenne127"), (O.SECP256K1_SCALAR, "secp256k1_order")]
+ALL_FIELDS = [O.M61, O.M127, O.MONT128, O.GF2_128, O.SECP256K1_SCALAR]
+SLOW_ORACLE = (O.MONT128, O.GF2_128, O.SECP256K1_SCALAR)  # bit-serial / Fermat inversions in the C oracle
 
 
 @pytest.fixture(scope="module")
@@ -82,7 +83,7 @@ def test_elementwise_vs_oracle(scl, port, f, n):
         for i in range(n):
             if np.array_equal(nzb[i], zero):
                 nzb[i] = port.from_int(f, 9)
-        if f in (O.MONT128, O.GF2_128) and n > 300:
+        if f in SLOW_ORACLE and n > 300:
             nz, nzb = nz[:300], nzb[:300]  # bit-serial oracle inversions are slow
         assert np.array_equal(host(scl, scl.ew(f, O.INV, dev(scl, nz))), port.ew(f, O.INV, nz))
         assert np.array_equal(host(scl, scl.ew(f, O.DIV, dev(scl, nz), dev(scl, nzb))), port.ew(f, O.DIV, nz, nzb))
@@ -113,6 +114,8 @@ def test_size_mismatch_message(scl, port):
 def test_elementwise_golden(scl, f, name):
     g, L = GOLD["fields"][name], O.LIMBS[f]
     for key in ("ew", "ew_edge_pairs"):
+        if key not in g:
+            continue
         e = g[key]
         a, b = dev(scl, O.from_ints(ints(e["a"]), L)), dev(scl, O.from_ints(ints(e["b"]), L))
         assert O.to_ints(host(scl, scl.ew(f, O.ADD, a, b))) == ints(e["add"])
@@ -136,7 +139,7 @@ def test_elementwise_golden(scl, f, name):
 @pytest.mark.parametrize("n", [0, 1, 63, 1000, 100003])
 def test_sum_dot_equals(scl, port, f, n):
     L = O.LIMBS[f]
-    if f in (O.MONT128, O.GF2_128) and n > 1000:
+    if f in SLOW_ORACLE and n > 1000:
         n = 5001
     a = rand_elems(port, f, n, b"sd-a") if n else np.zeros((0, L), np.uint64)
     b = rand_elems(port, f, n, b"sd-b") if n else np.zeros((0, L), np.uint64)
@@ -214,8 +217,10 @@ def test_shamir_golden(scl, f, name):
                                    (17, 16, 64), (1, 0, 5), (5, 4, 1)])
 def test_shamir_share_recover_vs_oracle(scl, port, f, n, t, N):
     L = O.LIMBS[f]
-    if f in (O.MONT128, O.GF2_128):
+    if f in SLOW_ORACLE:
         N = min(N, 40)  # bit-serial / Fermat oracle is slow
+    if n > 256 // L:
+        pytest.skip("more parties than the table kernels hold for this field")
     secrets = rand_elems(port, f, N, b"secrets")
     seed = b"share-seed"
     # PRG-driven: bit-identical to per-secret shamirSecretShare on one PRG
@@ -359,13 +364,13 @@ def test_worst_case_lazy_accumulation(scl, port):
 @pytest.mark.parametrize("f,name", FIELDS)
 def test_lagrange_golden_and_errors(scl, f, name):
     g, L = GOLD["fields"][name], O.LIMBS[f]
-    p = O.P[f]
+    port = O.Port()
     for c in g["lagrange"]:
-        nodes = O.from_ints([v % p for v in c["nodes"]], L)
-        x = O.from_ints([c["x"] % p], L)[0]
+        nodes = np.stack([port.from_int(f, v) for v in c["nodes"]])
+        x = port.from_int(f, c["x"])
         assert O.to_ints(scl.lagrange_basis(f, len(c["nodes"]), nodes, x)) == ints(c["out"])
     with pytest.raises(scl.SclError) as ei:
-        scl.lagrange_basis(f, 3, O.from_ints([1, 2, 2], L))
+        scl.lagrange_basis(f, 3, np.stack([port.from_int(f, v) for v in (1, 2, 2)]))
     assert ei.value.reference_message == g["lagrange_dup_error"]
     for c in g["recover_at"]:
         al = O.from_ints(ints(c["alphas"]), L)
@@ -464,7 +469,7 @@ def test_matrix_golden(scl, f, name):
 @pytest.mark.parametrize("M,K,N", [(1, 1, 1), (10, 4, 1000), (128, 43, 300), (3, 70, 65), (129, 5, 2)])
 def test_matmul_vs_oracle(scl, port, f, M, K, N):
     L = O.LIMBS[f]
-    if f in (O.MONT128, O.GF2_128):
+    if f in SLOW_ORACLE:
         M, N = min(M, 20), min(N, 30)
     A = rand_elems(port, f, M * K, b"A").reshape(M, K, L)
     B = rand_elems(port, f, K * N, b"B").reshape(K, N, L)
@@ -505,7 +510,7 @@ def test_vandermonde_matmul_is_sharing(scl, port):
 def test_wire_image(scl, port, f):
     """seri::Serializer<Vector<FF>>: u32 count || FF::write images; golden bytes from the reference"""
     L = O.LIMBS[f]
-    name = {O.M61: "Mersenne61", O.M127: "Mersenne127"}.get(f)
+    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order"}.get(f)
     if name:
         for c in GOLD["fields"][name]["wire"]:
             el = O.from_ints(ints(c["elems"]), L) if c["elems"] else np.zeros((0, L), np.uint64)
