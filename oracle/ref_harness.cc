@@ -469,7 +469,7 @@ int sclref_time_shamir(int field, std::size_t N, std::size_t t, std::size_t n,
       auto b = clk::now();
       for (std::size_t i = 0; i < cnt; ++i) {
         const F r = scl::ss::shamirRecoverP(held[i]);
-        std::uint64_t w[2] = {0, 0};
+        std::uint64_t w[4] = {0, 0, 0, 0};
         store<F>(w, r);
         acc += w[0];
         bad += !(r == F((int)((s0 + i) & 0x7fffffff)));
