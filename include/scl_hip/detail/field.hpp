@@ -59,6 +59,86 @@ SCL_HD u128 bswap128(u128 v) {
   return ((u128)__builtin_bswap64((u64)v) << 64) | __builtin_bswap64((u64)(v >> 64));
 }
 
+// ---- lazy product sums for the Montgomery fields -------------------------------------------------------
+// A sum of K products of L-limb operands (32-bit limbs) kept as 2L-1 column sums of 32x32 partial products:
+// column k = sum over i+j=k of a_i*b_j, held as a 64-bit low word plus a count of its carries.  That is one
+// v_mad_u64_u32 and one v_addc per partial product and no reduction until the end, half the multiplies of the
+// interleaved Montgomery product per term.  Good for K <= 2^24 products.
+template <int L>
+struct LazyCols {
+  u64 lo[2 * L - 1];
+  u32 hi[2 * L - 1];
+};
+
+SCL_HD void lazy_col_mad(u64& lo, u32& hi, u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc");
+#else
+  const u64 s = lo + (u64)a * b;
+  hi += s < lo ? 1u : 0u;
+  lo = s;
+#endif
+}
+
+template <int L>
+SCL_HD void lazy_zero(LazyCols<L>& c) {
+#pragma unroll
+  for (int k = 0; k < 2 * L - 1; ++k) {
+    c.lo[k] = 0;
+    c.hi[k] = 0;
+  }
+}
+
+template <int L>
+SCL_HD void lazy_mac(LazyCols<L>& c, const u32* a, const u32* b) {
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+#pragma unroll
+    for (int j = 0; j < L; ++j) lazy_col_mad(c.lo[i + j], c.hi[i + j], a[i], b[j]);
+  }
+}
+
+// column sums -> the NT 32-bit limbs of the integer they stand for (which must be < 2^(32 NT))
+template <int L, int NT>
+SCL_HD void lazy_limbs(const LazyCols<L>& c, u32* t) {
+  u64 cy = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * L - 1; ++k) {
+    const u64 s = c.lo[k] + cy;
+    const u32 wrap = s < cy ? 1u : 0u;
+    t[k] = (u32)s;
+    cy = (s >> 32) + ((u64)(c.hi[k] + wrap) << 32);
+  }
+#pragma unroll
+  for (int k = 2 * L - 1; k < NT; ++k) {
+    t[k] = (u32)cy;
+    cy >>= 32;
+  }
+}
+
+// NR rounds of word-32 Montgomery reduction of t[0..NT): afterwards t[NR..NT) = (T + Q p) / 2^(32 NR) with
+// Q < 2^(32 NR); p has L limbs, mc = -p^-1 mod 2^32
+template <int L, int NR, int NT, typename PF>
+SCL_HD void lazy_redc(u32* t, PF p, u32 mc) {
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const u32 q = t[i] * mc;
+    u64 cy = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      const u64 s = (u64)q * p(j) + t[i + j] + cy;
+      t[i + j] = (u32)s;
+      cy = s >> 32;
+    }
+#pragma unroll
+    for (int k = i + L; k < NT; ++k) {
+      const u64 s = (u64)t[k] + cy;
+      t[k] = (u32)s;
+      cy = s >> 32;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ Mersenne61
 struct M61 {
   typedef u64 E;
@@ -249,8 +329,9 @@ struct Mont128 {
   typedef u128 E;
   struct Ctx {
     u128 p, mc, one, r2;  // modulus, -p^-1 mod R, R mod p, R^2 mod p
+    u128 k32;             // 2^32 * R mod p (undoes the extra word of the lazy accumulator's reduction)
   };
-  enum { LIMBS = 2, ACC_TERMS = 1 << 30, TAG = 2 };
+  enum { LIMBS = 2, ACC_TERMS = 1 << 24, TAG = 2 };
 
   // parameters for an odd modulus p >= 3 (host side)
   static inline Ctx make_ctx(u128 p) {
@@ -267,6 +348,7 @@ struct Mont128 {
       if (i == 127) c.one = r;
     }
     c.r2 = r;
+    c.k32 = mul(c, (u128)1 << 32, c.r2);
     return c;
   }
 
@@ -308,14 +390,42 @@ struct Mont128 {
   static SCL_HD E from_u64(const Ctx& c, u64 v) { return to_mont(c, v); }
   // fromBytes of the gmp family is BIG-endian (ff_ops_gmp.h:279-290); raw is the LE load
   static SCL_HD E from_le_word(const Ctx& c, u128 raw) { return to_mont(c, bswap128(raw)); }
+  static SCL_HD E raw_from_le_word(u128 raw) { return bswap128(raw); }  // the integer, not a residue
 
+  // Lazy accumulator: products summed unreduced (LazyCols), plain elements summed modularly beside them.
+  // The fold reduces by FIVE 32-bit words instead of four, (T + Q p) / 2^160 < p (K p / 2^160 + 1) < 2p for any
+  // K <= 2^32 terms and ANY odd p, so one conditional subtraction lands in [0,p); the spare factor 2^-32 is
+  // taken back by one Montgomery product with k32 = 2^32 R.
   struct Acc {
-    u128 v;
+    LazyCols<4> c;
+    E e;
   };
-  static SCL_HD Acc acc_zero() { return Acc{0}; }
-  static SCL_HD void mac(const Ctx& c, Acc& acc, E a, E b) { acc.v = add(c, acc.v, mul(c, a, b)); }
-  static SCL_HD void acc_add(const Ctx& c, Acc& acc, E a) { acc.v = add(c, acc.v, a); }
-  static SCL_HD E acc_fold(const Ctx&, const Acc& acc) { return acc.v; }
+  static SCL_HD Acc acc_zero() {
+    Acc a;
+    lazy_zero(a.c);
+    a.e = 0;
+    return a;
+  }
+  static SCL_HD void mac(const Ctx&, Acc& acc, E a, E b) {
+    const u32 al[4] = {(u32)a, (u32)(a >> 32), (u32)(a >> 64), (u32)(a >> 96)};
+    const u32 bl[4] = {(u32)b, (u32)(b >> 32), (u32)(b >> 64), (u32)(b >> 96)};
+    lazy_mac<4>(acc.c, al, bl);
+  }
+  static SCL_HD void acc_add(const Ctx& c, Acc& acc, E a) { acc.e = add(c, acc.e, a); }
+  static SCL_HD E fold_wide(const Ctx& c, const Acc& acc) {
+    u32 t[10];
+    lazy_limbs<4, 10>(acc.c, t);
+    const u128 p = c.p;
+    lazy_redc<4, 5, 10>(t, [p](int j) { return (u32)(p >> (32 * j)); }, (u32)c.mc);
+    u128 r = (u128)t[5] | ((u128)t[6] << 32) | ((u128)t[7] << 64) | ((u128)t[8] << 96);
+    if (t[9] || r >= p) r -= p;
+    return r;  // = sum / 2^160
+  }
+  static SCL_HD E acc_fold(const Ctx& c, const Acc& acc) { return add(c, mul(c, fold_wide(c, acc), c.k32), acc.e); }
+  // Tables of constants can carry the factor 2^32 themselves: with every mac(acc, a, table_scale(b)) the
+  // fold needs no product at all.
+  static SCL_HD E table_scale(const Ctx& c, E b) { return mul(c, b, c.k32); }
+  static SCL_HD E acc_fold_scaled(const Ctx& c, const Acc& acc) { return add(c, fold_wide(c, acc), acc.e); }
 
   static SCL_HD E inv(const Ctx& c, E a) {  // a^(p-2), square-and-multiply MSB first
     const u128 e = c.p - 2;
@@ -420,7 +530,7 @@ struct U256 {
 struct Secp256k1Scalar {
   typedef U256 E;
   struct Ctx {};
-  enum { LIMBS = 4, ACC_TERMS = 1 << 30, TAG = 4, SMALL_BITS = 0 };
+  enum { LIMBS = 4, ACC_TERMS = 1 << 24, TAG = 4, SMALL_BITS = 0 };
 
   static SCL_HD u64 P(int i) {  // p = FFFFFFFF FFFFFFFF FFFFFFFF FFFFFFFE BAAEDCE6 AF48A03B BFD25E8C D0364141
     return i == 0 ? 0xBFD25E8CD0364141ull : i == 1 ? 0xBAAEDCE6AF48A03Bull : i == 2 ? 0xFFFFFFFFFFFFFFFEull : 0xFFFFFFFFFFFFFFFFull;
@@ -525,6 +635,10 @@ struct Secp256k1Scalar {
     return to_mont(c, make(__builtin_bswap64(raw.w[3]), __builtin_bswap64(raw.w[2]), __builtin_bswap64(raw.w[1]),
                            __builtin_bswap64(raw.w[0])));
   }
+  static SCL_HD E raw_from_le_word(const E& raw) {  // the integer the bytes spell, not a residue
+    return make(__builtin_bswap64(raw.w[3]), __builtin_bswap64(raw.w[2]), __builtin_bswap64(raw.w[1]),
+                __builtin_bswap64(raw.w[0]));
+  }
   // toBytes image (montyToBytes, ff_ops_gmp.h:298-314) as four little-endian words in memory order
   static SCL_HD E to_be_image(const Ctx& c, const E& a) {
     const E v = from_mont(c, a);
@@ -534,13 +648,61 @@ struct Secp256k1Scalar {
   static SCL_HD E muladd_small_lazy(const E& y, u32, const E&) { return y; }
   static SCL_HD E canon(const E& r) { return r; }
 
+  // Lazy accumulator: products summed unreduced (LazyCols), plain elements summed modularly beside them.
+  // Fold: eight word-32 Montgomery rounds leave T' = (T + Q p) / 2^256 < (K + 1) p in nine limbs; the top limb
+  // h comes back down as h * (2^256 - p) (p is 2^256 minus a 129-bit constant), twice at most, and one
+  // conditional subtraction lands in [0,p) -- the same residue the reference reaches one montyModMul and one
+  // montyModAdd at a time.
   struct Acc {
-    E v;
+    LazyCols<8> c;
+    E e;
   };
-  static SCL_HD Acc acc_zero() { return Acc{zero()}; }
-  static SCL_HD void mac(const Ctx& c, Acc& acc, const E& a, const E& b) { acc.v = add(c, acc.v, mul(c, a, b)); }
-  static SCL_HD void acc_add(const Ctx& c, Acc& acc, const E& a) { acc.v = add(c, acc.v, a); }
-  static SCL_HD E acc_fold(const Ctx&, const Acc& acc) { return acc.v; }
+  static SCL_HD Acc acc_zero() {
+    Acc a;
+    lazy_zero(a.c);
+    a.e = zero();
+    return a;
+  }
+  static SCL_HD void mac(const Ctx&, Acc& acc, const E& a, const E& b) {
+    u32 al[8], bl[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      al[2 * i] = (u32)a.w[i];
+      al[2 * i + 1] = (u32)(a.w[i] >> 32);
+      bl[2 * i] = (u32)b.w[i];
+      bl[2 * i + 1] = (u32)(b.w[i] >> 32);
+    }
+    lazy_mac<8>(acc.c, al, bl);
+  }
+  static SCL_HD void acc_add(const Ctx& c, Acc& acc, const E& a) { acc.e = add(c, acc.e, a); }
+  static SCL_HD u32 P32(int j) { return (u32)(P(j >> 1) >> (32 * (j & 1))); }
+  static SCL_HD u32 C32(int j) {  // 2^256 - p = 1 45512319 50B75FC4 402DA173 2FC9BEBF
+    return j == 0 ? 0x2FC9BEBFu : j == 1 ? 0x402DA173u : j == 2 ? 0x50B75FC4u : j == 3 ? 0x45512319u : j == 4 ? 1u : 0u;
+  }
+  static SCL_HD u32 fold_top(u32* r, u32 h) {  // r[0..8) += h * (2^256 - p); returns the carry out
+    u64 cy = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const u64 s = (u64)h * C32(j) + r[j] + cy;
+      r[j] = (u32)s;
+      cy = s >> 32;
+    }
+    return (u32)cy;
+  }
+  static SCL_HD E acc_fold(const Ctx& c, const Acc& acc) {
+    u32 t[17];
+    lazy_limbs<8, 17>(acc.c, t);
+    lazy_redc<8, 8, 17>(t, [](int j) { return P32(j); }, (u32)MC0);
+    u32* r = t + 8;
+    const u32 again = fold_top(r, r[8]);
+    fold_top(r, again);
+    E v = make((u64)r[0] | ((u64)r[1] << 32), (u64)r[2] | ((u64)r[3] << 32), (u64)r[4] | ((u64)r[5] << 32),
+               (u64)r[6] | ((u64)r[7] << 32));
+    if (geq_p(v)) sub_n(v, v, prime());
+    return add(c, v, acc.e);
+  }
+  static SCL_HD E table_scale(const Ctx&, const E& b) { return b; }
+  static SCL_HD E acc_fold_scaled(const Ctx& c, const Acc& acc) { return acc_fold(c, acc); }
 
   // montyModInv (ff_ops_gmp.h:225-260): a^(p-2) by square-and-multiply from the top bit; inv(0) = 0
   static SCL_HD E inv(const Ctx& c, const E& a) {

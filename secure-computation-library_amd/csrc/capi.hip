@@ -404,6 +404,60 @@ int share_mfma(const BigTable<M61>& al, u64* shares, size_t stride, const u64* s
   return fail(SCL_ERR_BAD_ARG, "share_mfma: unsupported shape");
 }
 
+// Device-resident Vandermonde power tables of the Montgomery-field share kernels (k_share_vdm): row i holds
+// table_scale(alpha_i^k), k = 1..t.  Cached per (device, field parameters, nodes, t) like the MFMA tables.
+struct VdmTable {
+  int device, tag, n, t;
+  std::vector<u64> key;  // raw_coeffs flag, field parameters (Mont128: the prime), then the nodes
+  void* dev;
+};
+std::mutex g_vdm_mu;
+std::vector<VdmTable> g_vdm_tables;  // immutable once built; never freed
+
+template <class F>
+bool vdm_eligible(size_t n, size_t t) {
+  return (F::TAG == 2 || F::TAG == 4) && t >= 1 && t <= 16 && n * t * F::LIMBS <= (size_t)VdmLds::WORDS;
+}
+
+template <class F>
+int vdm_table(const typename F::Ctx& ctx, const BigTable<F>& al, size_t n, size_t t, bool raw_coeffs, const u64** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::vector<u64> key{raw_coeffs ? 1u : 0u};
+  if constexpr (F::TAG == 2) {
+    key.push_back((u64)ctx.p);
+    key.push_back((u64)(ctx.p >> 64));
+  }
+  for (size_t i = 0; i < n; ++i) {
+    u64 w[F::LIMBS];
+    F::st(w, al.v[i]);
+    key.insert(key.end(), w, w + F::LIMBS);
+  }
+  std::lock_guard<std::mutex> lk(g_vdm_mu);
+  for (const VdmTable& e : g_vdm_tables) {
+    if (e.device == dev && e.tag == (int)F::TAG && e.n == (int)n && e.t == (int)t && e.key == key) {
+      *out = static_cast<const u64*>(e.dev);
+      return SCL_OK;
+    }
+  }
+  std::vector<u64> host(n * t * F::LIMBS);
+  for (size_t i = 0; i < n; ++i) {
+    typename F::E v = al.v[i];  // alpha_i^k, Matrix::vandermonde (matrix.h:444-460)
+    for (size_t k = 1; k <= t; ++k) {
+      // raw_coeffs: the kernel multiplies by plain integers x, not residues xR, so the row carries the R
+      const typename F::E entry = raw_coeffs ? F::to_mont(ctx, v) : v;
+      F::st(host.data() + (i * t + (k - 1)) * F::LIMBS, F::table_scale(ctx, entry));
+      v = F::mul(ctx, v, al.v[i]);
+    }
+  }
+  VdmTable e{dev, (int)F::TAG, (int)n, (int)t, key, nullptr};
+  HIP_TRY(hipMalloc(&e.dev, host.size() * sizeof(u64)));
+  HIP_TRY(hipMemcpy(e.dev, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
+  g_vdm_tables.push_back(e);
+  *out = static_cast<const u64*>(e.dev);
+  return SCL_OK;
+}
+
 // Runs body(VEC-tag, first_element, npacks) for the vectorisable head and the scalar tail of [0,N).
 template <class F, class Body>
 int split_vec(int vec, size_t N, Body&& body) {
@@ -874,6 +928,21 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
         });
       }
     }
+    if constexpr (F::TAG == 2 || F::TAG == 4) {
+      if (vdm_eligible<F>(n, t) && !g_force_table.load()) {
+        const u64* vdm = nullptr;
+        SCL_TRY((vdm_table<F>(ctx, al, n, t, false, &vdm)));
+        const dim3 g(grid_for(N)), blk(BLOCK);
+        if (t <= 4)
+          hipLaunchKernelGGL((k_share_vdm<F, 4>), g, blk, 0, S(stream), ctx, shares, share_stride, secrets, coeffs,
+                             coeff_stride, vdm, (int)t, (int)n, N);
+        else
+          hipLaunchKernelGGL((k_share_vdm<F, 16>), g, blk, 0, S(stream), ctx, shares, share_stride, secrets, coeffs,
+                             coeff_stride, vdm, (int)t, (int)n, N);
+        LAUNCH_CHECK();
+        return SCL_OK;
+      }
+    }
     return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;
       u64* sh = shares + first * F::LIMBS;
@@ -944,6 +1013,21 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
           LAUNCH_CHECK();
           return SCL_OK;
         });
+      }
+    }
+    if constexpr (F::TAG == 2 || F::TAG == 4) {
+      if (vdm_eligible<F>(n, t) && !g_force_table.load()) {
+        const u64* vdm = nullptr;
+        SCL_TRY((vdm_table<F>(ctx, al, n, t, true, &vdm)));
+        const dim3 g(grid_aes(N)), blk(BLOCK);
+        if (t <= 4)
+          hipLaunchKernelGGL((k_share_prg_vdm<F, 4>), g, blk, 0, S(stream), ctx, shares, share_stride, secrets, key,
+                             (u64)counter0, vdm, (int)t, (int)n, N);
+        else
+          hipLaunchKernelGGL((k_share_prg_vdm<F, 16>), g, blk, 0, S(stream), ctx, shares, share_stride, secrets, key,
+                             (u64)counter0, vdm, (int)t, (int)n, N);
+        LAUNCH_CHECK();
+        return SCL_OK;
       }
     }
     return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {

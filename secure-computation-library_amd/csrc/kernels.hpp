@@ -420,6 +420,50 @@ __global__ __launch_bounds__(BLOCK) void k_share(typename F::Ctx ctx, u64* share
   }
 }
 
+// Vandermonde-row formulation for the Montgomery fields, whose nodes are full-width residues: share_i =
+// c_0 + sum_{k=1..t} c_k * alpha_i^k with the powers alpha_i^k (host table in device memory, residues scaled
+// by F::table_scale) staged in LDS, the t products of a share summed unreduced in the field's lazy
+// accumulator and reduced once -- half the multiplier work of Horner's t Montgomery products.
+struct VdmLds {
+  enum { WORDS = 4096 };  // 32 KiB: n * t * LIMBS <= WORDS
+};
+
+template <class F, int TREG>
+__device__ __forceinline__ void vdm_rows(const typename F::Ctx& ctx, const Pack<F, 1> (&c)[TREG + 1], int t,
+                                         const u64* vdm_lds, int n, u64* shares, size_t stride, size_t off) {
+  for (int i = 0; i < n; ++i) {
+    typename F::Acc acc = F::acc_zero();
+    F::acc_add(ctx, acc, c[0].v[0]);
+    const u64* row = vdm_lds + (size_t)i * t * F::LIMBS;
+#pragma unroll
+    for (int k = 1; k <= TREG; ++k) {
+      if (k <= t) F::mac(ctx, acc, c[k].v[0], F::ld(row + (k - 1) * F::LIMBS));  // wave-uniform
+    }
+    Pack<F, 1> y;
+    y.v[0] = F::acc_fold_scaled(ctx, acc);
+    store_pack<F, 1, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
+  }
+}
+
+template <class F, int TREG>
+__global__ __launch_bounds__(BLOCK) void k_share_vdm(typename F::Ctx ctx, u64* shares, size_t stride,
+                                                     const u64* secrets, const u64* coeffs, size_t cstride,
+                                                     const u64* vdm, int t, int n, size_t N) {
+  __shared__ u64 V[VdmLds::WORDS];
+  for (int i = threadIdx.x; i < n * t * F::LIMBS; i += BLOCK) V[i] = vdm[i];
+  __syncthreads();
+  SCL_GRID_STRIDE(q, N) {
+    const size_t off = q * F::LIMBS;
+    Pack<F, 1> c[TREG + 1];
+    c[0] = load_pack<F, 1, true>(secrets + off);
+#pragma unroll
+    for (int k = 1; k <= TREG; ++k) {
+      if (k <= t) c[k] = load_pack<F, 1, true>(coeffs + (size_t)(k - 1) * cstride * F::LIMBS + off);
+    }
+    vdm_rows<F, TREG>(ctx, c, t, V, n, shares, stride, off);
+  }
+}
+
 // Vandermonde-row formulation for SMALL nodes (the default nodes 1..n): share_i = sum_k c_k * V[i][k]
 // with V[i][k] = alpha_i^k < 2^29 held as u32 in LDS.  A 61/127-bit coefficient times a 29-bit
 // constant is one v_mad_u64_u32 per 32-bit limb, accumulated lazily per limb (<= 7 terms cannot
@@ -615,17 +659,21 @@ __device__ __forceinline__ void aes_ctr_multi(const u32* tl, const AesKey& key, 
 }
 
 // FF::read over the AES stream: element bytes = F::LIMBS/2 consecutive blocks (128- and 256-bit fields)
-template <class F>
+// RAW: the integer the bytes spell, not yet a residue (for kernels whose constant tables absorb the conversion)
+template <class F, bool RAW = false>
 __device__ __forceinline__ typename F::E elem_from_blocks(const typename F::Ctx& ctx, const u64* lo, const u64* hi) {
   if constexpr (F::LIMBS == 2) {
-    return F::from_le_word(ctx, ((u128)hi[0] << 64) | lo[0]);
+    const u128 raw = ((u128)hi[0] << 64) | lo[0];
+    if constexpr (RAW) return F::raw_from_le_word(raw);
+    else return F::from_le_word(ctx, raw);
   } else {
     typename F::E raw;
     raw.w[0] = lo[0];
     raw.w[1] = hi[0];
     raw.w[2] = lo[1];
     raw.w[3] = hi[1];
-    return F::from_le_word(ctx, raw);
+    if constexpr (RAW) return F::raw_from_le_word(raw);
+    else return F::from_le_word(ctx, raw);
   }
 }
 
@@ -725,7 +773,7 @@ __global__ __launch_bounds__(BLOCK) void k_vector_random(typename F::Ctx ctx, u6
 // Coefficients of secret q*VEC + v of a batch whose first draw starts at block counter0, under the reference PRG discipline (SURVEY.md
 // section 8a note P): Vector::random(t+1) from counters [s*B, (s+1)*B), B = ceil((t+1)*byteSize/16);
 // c_0's draw is discarded and replaced by the secret (shamir.h:56-57).
-template <class F, int VEC, int TREG>
+template <class F, int VEC, int TREG, bool RAW = false>
 __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, VEC> (&c)[TREG + 1], const u32* te0,
                                            const AesKey& key, u64 counter0, size_t q, int t) {
   constexpr int BPE = F::LIMBS >= 2 ? F::LIMBS / 2 : 1;  // AES blocks per coefficient (wide fields)
@@ -752,7 +800,7 @@ __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, V
           u64 lo[BPE], hi[BPE];
 #pragma unroll
           for (int b = 0; b < BPE; ++b) aes_ctr_block(te0, key, ctr0 + (u64)k * BPE + b, lo[b], hi[b]);
-          c[k].v[v] = elem_from_blocks<F>(ctx, lo, hi);
+          c[k].v[v] = elem_from_blocks<F, RAW>(ctx, lo, hi);
         }
       }
     }
@@ -775,6 +823,27 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* s
     c[0] = load_pack<F, VEC, true>(secrets + off);
     prg_coeffs<F, VEC, TREG>(ctx, c, te0, key, counter0, q, t);
     horner_rows<F, VEC, TREG, SMALLX>(ctx, c, t, alpha, alpha32, n, shares, stride, off);
+  }
+}
+
+// Same for the Montgomery fields: Vandermonde rows in LDS, lazy products (see k_share_vdm).  The drawn
+// coefficients stay the plain integers their bytes spell (FF::read's montyIn would cost a Montgomery product
+// each); the table rows carry the extra factor R instead, so each share still comes out as the residue
+// c_0 + sum_k montyIn(x_k) * alpha_i^k.
+template <class F, int TREG>
+__global__ __launch_bounds__(BLOCK) void k_share_prg_vdm(typename F::Ctx ctx, u64* shares, size_t stride,
+                                                         const u64* secrets, AesKey key, u64 counter0,
+                                                         const u64* vdm, int t, int n, size_t N) {
+  SCL_AES_PROLOGUE(key)
+  __shared__ u64 V[VdmLds::WORDS];
+  for (int i = threadIdx.x; i < n * t * F::LIMBS; i += BLOCK) V[i] = vdm[i];
+  __syncthreads();
+  SCL_GRID_STRIDE(q, N) {
+    const size_t off = q * F::LIMBS;
+    Pack<F, 1> c[TREG + 1];
+    c[0] = load_pack<F, 1, true>(secrets + off);
+    prg_coeffs<F, 1, TREG, true>(ctx, c, te0, key, counter0, q, t);  // raw integers: the table holds alpha^k * R
+    vdm_rows<F, TREG>(ctx, c, t, V, n, shares, stride, off);
   }
 }
 

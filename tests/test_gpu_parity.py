@@ -345,10 +345,13 @@ def test_recover_fixed_and_table_kernels_agree(scl, port, f):
 
 
 def test_worst_case_lazy_accumulation(scl, port):
-    """all operands p-1: the lazy 128-bit accumulators must not wrap (M61: 64-term bound)"""
-    for f in (O.M61, O.M127):
+    """all operands p-1: the lazy 128-bit accumulators must not wrap (M61: 64-term bound); for the Montgomery
+    fields the unreduced column sums and their single reduction at the largest residue"""
+    for f in (O.M61, O.M127, O.MONT128, O.SECP256K1_SCALAR):
         L = O.LIMBS[f]
         for m in (16, 64, 65, 128, 200 if f == O.M61 else 128):
+            if m > 256 // L:
+                continue
             N = 130
             pm1 = port.from_int(f, -1)
             shares = np.tile(pm1, (m, N, 1))
@@ -359,6 +362,16 @@ def test_worst_case_lazy_accumulation(scl, port):
         a = np.tile(port.from_int(f, -1), (n, 1))
         assert np.array_equal(scl.dot(f, dev(scl, a), dev(scl, a)), port.dot(f, a, a))
         assert np.array_equal(scl.vsum(f, dev(scl, a)), port.sum(f, a))
+        # sharing with every coefficient and every node at p-1 (full-width nodes: Horner / Vandermonde-table kernels)
+        N, t, n = 70, 3, 6
+        pm1 = port.from_int(f, -1)
+        secrets = np.tile(pm1, (N, 1))
+        coeffs = np.tile(pm1, (N, t, 1))
+        nodes = np.stack([port.from_int(f, -1 - i) for i in range(n)])
+        want = soa(np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)]))
+        got = scl.shamir_share(f, dev(scl, secrets), dev(scl, np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2)))), n,
+                               alphas=nodes)
+        assert np.array_equal(host(scl, got), want), f
 
 
 @pytest.mark.parametrize("f,name", FIELDS)
