@@ -206,6 +206,17 @@ int scl_hip_wire_pack(int field, unsigned char* dst_dev, const uint64_t* src_dev
 int scl_hip_wire_unpack(int field, uint64_t* dst_dev, size_t capacity, const unsigned char* src_dev,
                         size_t nbytes, size_t* n_host, void* stream);
 
+/* seri::Serializer<Matrix<FF>> (include/scl/math/matrix.h:910-963): u32 rows, u32 cols, then the vector image
+ * (u32 count = rows*cols, elements row-major).  src/dst are row-major device matrices with a pitch of ld >= cols
+ * elements.  unpack reads the 12-byte header synchronously; an image whose count differs from rows*cols is
+ * refused (the reference does not check, matrix.h:420). */
+size_t scl_hip_wire_size_matrix(int field, size_t rows, size_t cols); /* 12 + rows * cols * byteSize */
+int scl_hip_wire_pack_matrix(int field, unsigned char* dst_dev, const uint64_t* src_dev, size_t ld, size_t rows,
+                             size_t cols, void* stream);
+int scl_hip_wire_unpack_matrix(int field, uint64_t* dst_dev, size_t ld, size_t capacity_rows,
+                               const unsigned char* src_dev, size_t nbytes, size_t* rows_host, size_t* cols_host,
+                               void* stream);
+
 /* ---- roofline probe -------------------------------------------------------- */
 /* plain device copy kernel (16 B per lane) used to measure achievable HBM bandwidth */
 int scl_hip_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream);

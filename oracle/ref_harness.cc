@@ -442,6 +442,30 @@ int sclref_unwire_vector(int field, const unsigned char* in, std::uint64_t* elem
   return 0;
 }
 
+// seri::Serializer<math::Matrix<F>> wire image (matrix.h:910-963)
+int sclref_wire_matrix(int field, const std::uint64_t* elems, std::size_t rows, std::size_t cols,
+                       unsigned char* out, std::size_t* outlen) {
+  DISPATCH(field, {
+    const auto m = (rows && cols) ? loadMat<F>(elems, rows, cols) : Matrix<F>();  // Matrix(0, m) throws; Matrix() is 0 x 0
+    using S = scl::seri::Serializer<Matrix<F>>;
+    *outlen = S::sizeOf(m);
+    if (out) S::write(m, out);
+  });
+  return 0;
+}
+
+int sclref_unwire_matrix(int field, const unsigned char* in, std::uint64_t* elems, std::size_t* rows,
+                         std::size_t* cols) {
+  DISPATCH(field, {
+    Matrix<F> m;
+    scl::seri::Serializer<Matrix<F>>::read(m, in);
+    *rows = m.rows();
+    *cols = m.cols();
+    if (elems && m.rows() && m.cols()) storeMat<F>(elems, m);
+  });
+  return 0;
+}
+
 // The reference CPU path, timed: per secret shamirSecretShare(...) followed by
 // shamirRecoverP(shares), exactly as a user of the library would call them
 // (one heap Vector per secret, basis recomputed per call).  Secrets are

@@ -918,6 +918,31 @@ int sclo_unwire_vector(int field, const unsigned char* in, size_t nbytes, uint64
   return sclo_from_bytes(field, in + 4, cnt, elems);
 }
 
+/* Serializer<Matrix> (matrix.h:910-963): u32 rows, u32 cols, then the vector image of the row-major values */
+size_t sclo_wire_matrix(int field, const uint64_t* elems, size_t rows, size_t cols, unsigned char* out) {
+  if (out) {
+    const uint32_t r = (uint32_t)rows, c = (uint32_t)cols;
+    memcpy(out, &r, 4);
+    memcpy(out + 4, &c, 4);
+  }
+  return 8 + sclo_wire_vector(field, elems, rows * cols, out ? out + 8 : NULL);
+}
+
+int sclo_unwire_matrix(int field, const unsigned char* in, size_t nbytes, uint64_t* elems, size_t capacity,
+                       size_t* rows, size_t* cols) {
+  uint32_t r, c;
+  size_t n = 0;
+  if (nbytes < 12) return SCLO_BAD_ARG;
+  memcpy(&r, in, 4);
+  memcpy(&c, in + 4, 4);
+  const int st = sclo_unwire_vector(field, in + 8, nbytes - 8, elems, capacity, &n);
+  if (st != SCLO_OK) return st;
+  if (n != (size_t)r * c) return SCLO_BAD_ARG; /* the reference trusts the sender here (matrix.h:420) */
+  *rows = r;
+  *cols = c;
+  return SCLO_OK;
+}
+
 int sclo_time_shamir(int field, size_t N, size_t t, size_t n, const unsigned char* seed,
                      size_t seed_len, double* share_s, double* recover_s, uint64_t* mismatches,
                      uint64_t* checksum) {

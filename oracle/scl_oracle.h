@@ -102,6 +102,11 @@ int sclo_matmul(int field, const uint64_t* A, const uint64_t* B, size_t n, size_
 size_t sclo_wire_vector(int field, const uint64_t* elems, size_t n, unsigned char* out);
 int sclo_unwire_vector(int field, const unsigned char* in, size_t nbytes, uint64_t* elems, size_t capacity,
                        size_t* n);
+/* wire image of a matrix: seri::Serializer<math::Matrix<T>> (matrix.h:910-963) = u32 rows, u32 cols, then the
+ * vector image of the rows*cols row-major values */
+size_t sclo_wire_matrix(int field, const uint64_t* elems, size_t rows, size_t cols, unsigned char* out);
+int sclo_unwire_matrix(int field, const unsigned char* in, size_t nbytes, uint64_t* elems, size_t capacity,
+                       size_t* rows, size_t* cols);
 
 /* MONT128 plugin field: choose the modulus (odd, 2^127 < p < 2^128 not required;
  * any odd p >= 3 below 2^128).  Default: p = 2^128 - 159.  Not thread safe. */

@@ -1276,8 +1276,64 @@ int scl_hip_wire_pack(int field, unsigned char* dst, const uint64_t* src, size_t
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({src}));
+    const WireGeom g{{(u32)n, 0, 0}, 1, n, n};
     hipLaunchKernelGGL((k_wire_pack<F>), dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, S(stream), ctx,
-                       reinterpret_cast<u32*>(dst), src, n);
+                       reinterpret_cast<u32*>(dst), src, n, g);
+    LAUNCH_CHECK();
+    return SCL_OK;
+  });
+}
+
+size_t scl_hip_wire_size_matrix(int field, size_t rows, size_t cols) {
+  const int L = scl_hip_limbs(field);
+  return L < 0 ? 0 : 12 + rows * cols * (size_t)L * 8;
+}
+
+int scl_hip_wire_pack_matrix(int field, unsigned char* dst, const uint64_t* src, size_t ld, size_t rows, size_t cols,
+                             void* stream) {
+  const size_t n = rows * cols;
+  if (!dst || (n && !src)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (reinterpret_cast<uintptr_t>(dst) & 3) return fail(SCL_ERR_BAD_ARG, "wire buffer not 4-byte aligned");
+  if (rows > 0xFFFFFFFFull || cols > 0xFFFFFFFFull || n > 0xFFFFFFFFull)
+    return fail(SCL_ERR_BAD_ARG, "matrix too large for the u32 dimensions of its wire image");  // matrix.h:913
+  if (n && ld < cols) return fail(SCL_ERR_SIZE_MISMATCH, "ld < cols");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({src}));
+    const WireGeom g{{(u32)rows, (u32)cols, (u32)n}, 3, cols ? cols : 1, n ? ld : 1};
+    hipLaunchKernelGGL((k_wire_pack<F>), dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, S(stream), ctx,
+                       reinterpret_cast<u32*>(dst), src, n, g);
+    LAUNCH_CHECK();
+    return SCL_OK;
+  });
+}
+
+int scl_hip_wire_unpack_matrix(int field, uint64_t* dst, size_t ld, size_t capacity_rows, const unsigned char* src,
+                               size_t nbytes, size_t* rows_host, size_t* cols_host, void* stream) {
+  if (!src || !rows_host || !cols_host) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (reinterpret_cast<uintptr_t>(src) & 3) return fail(SCL_ERR_BAD_ARG, "wire buffer not 4-byte aligned");
+  if (nbytes < 12) return fail(SCL_ERR_BAD_ARG, "wire image shorter than its header");
+  u32 hdr[3] = {0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(hdr, src, 12, hipMemcpyDeviceToHost, S(stream)));
+  HIP_TRY(hipStreamSynchronize(S(stream)));
+  const int L = scl_hip_limbs(field);
+  if (L < 0) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
+  const size_t rows = hdr[0], cols = hdr[1], cnt = hdr[2];
+  // the reference builds Matrix(rows, cols, values) without looking (matrix.h:420,956-960); an image whose
+  // count disagrees with its dimensions is refused here
+  if (cnt != rows * cols) return fail(SCL_ERR_BAD_ARG, "wire image: count != rows * cols");
+  if (12 + cnt * L * 8 > nbytes) return fail(SCL_ERR_BAD_ARG, "wire image truncated");
+  if (cnt && (rows > capacity_rows || cols > ld)) return fail(SCL_ERR_SIZE_MISMATCH, "destination too small for the wire image");
+  *rows_host = rows;
+  *cols_host = cols;
+  if (cnt == 0) return SCL_OK;
+  if (!dst) return fail(SCL_ERR_BAD_ARG, "dst is NULL");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    SCL_TRY(check_align<F>({dst}));
+    const WireGeom g{{0, 0, 0}, 3, cols, ld};
+    hipLaunchKernelGGL((k_wire_unpack<F>), dim3(grid_for(cnt)), dim3(BLOCK), 0, S(stream), ctx, dst,
+                       reinterpret_cast<const u32*>(src), cnt, g);
     LAUNCH_CHECK();
     return SCL_OK;
   });
@@ -1301,8 +1357,9 @@ int scl_hip_wire_unpack(int field, uint64_t* dst, size_t capacity, const unsigne
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({dst}));
+    const WireGeom g{{0, 0, 0}, 1, cnt, cnt};
     hipLaunchKernelGGL((k_wire_unpack<F>), dim3(grid_for(cnt)), dim3(BLOCK), 0, S(stream), ctx, dst,
-                       reinterpret_cast<const u32*>(src), (size_t)cnt);
+                       reinterpret_cast<const u32*>(src), (size_t)cnt, g);
     LAUNCH_CHECK();
     return SCL_OK;
   });

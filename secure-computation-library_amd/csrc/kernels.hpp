@@ -1125,24 +1125,37 @@ __global__ __launch_bounds__(BLOCK) void k_transpose(u64* dst, const u64* src, s
 // seri::Serializer<Vector<FF>> (include/scl/serialization/serializer.h:157-190, ff.h:355-391): u32 count
 // then count elements as FF::write emits them.  The payload starts 4 bytes into the buffer, so it is moved
 // as 32-bit words (buffers must be 4-byte aligned).
+// Serializer<Matrix> (matrix.h:910-963) puts u32 rows, u32 cols in front of the vector image of the row-major
+// values; WireGeom carries that header and the row pitch of the device matrix (ld >= cols elements).
+struct WireGeom {
+  u32 hdr[3];
+  int nhdr;         // 1: Vector (count)   3: Matrix (rows, cols, count)
+  size_t cols, ld;  // element e of the image lives at element (e / cols) * ld + e % cols of the device buffer
+  __device__ __forceinline__ size_t at(size_t e) const { return ld == cols ? e : (e / cols) * ld + e % cols; }
+};
+
 template <class F>
-__global__ __launch_bounds__(BLOCK) void k_wire_pack(typename F::Ctx ctx, u32* dst, const u64* src, size_t n) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) dst[0] = (u32)n;
+__global__ __launch_bounds__(BLOCK) void k_wire_pack(typename F::Ctx ctx, u32* dst, const u64* src, size_t n,
+                                                     WireGeom g) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int i = 0; i < g.nhdr; ++i) dst[i] = g.hdr[i];
+  }
   SCL_GRID_STRIDE(e, n) {
-    u32* o = dst + 1 + e * (2 * F::LIMBS);
+    u32* o = dst + g.nhdr + e * (2 * F::LIMBS);
+    const size_t se = g.at(e);
     if constexpr (F::LIMBS == 1) {
-      const u64 v = src[e];
+      const u64 v = src[se];
       o[0] = (u32)v;
       o[1] = (u32)(v >> 32);
     } else if constexpr (F::LIMBS == 2) {
-      u128 v = F::ld(src + 2 * e);
+      u128 v = F::ld(src + 2 * se);
       if constexpr (F::TAG == 2) v = bswap128(F::from_mont(ctx, v));  // Montgomery family: value, big-endian
       o[0] = (u32)v;
       o[1] = (u32)(v >> 32);
       o[2] = (u32)(v >> 64);
       o[3] = (u32)(v >> 96);
     } else {
-      const typename F::E img = F::to_be_image(ctx, F::ld(src + 4 * e));  // montyToBytes
+      const typename F::E img = F::to_be_image(ctx, F::ld(src + 4 * se));  // montyToBytes
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         o[2 * j] = (u32)img.w[j];
@@ -1153,19 +1166,21 @@ __global__ __launch_bounds__(BLOCK) void k_wire_pack(typename F::Ctx ctx, u32* d
 }
 
 template <class F>
-__global__ __launch_bounds__(BLOCK) void k_wire_unpack(typename F::Ctx ctx, u64* dst, const u32* src, size_t n) {
+__global__ __launch_bounds__(BLOCK) void k_wire_unpack(typename F::Ctx ctx, u64* dst, const u32* src, size_t n,
+                                                       WireGeom g) {
   SCL_GRID_STRIDE(e, n) {
-    const u32* in = src + 1 + e * (2 * F::LIMBS);
+    const u32* in = src + g.nhdr + e * (2 * F::LIMBS);
+    const size_t de = g.at(e);
     if constexpr (F::LIMBS == 1) {
-      dst[e] = F::from_le_word(ctx, (u64)in[0] | ((u64)in[1] << 32));
+      dst[de] = F::from_le_word(ctx, (u64)in[0] | ((u64)in[1] << 32));
     } else if constexpr (F::LIMBS == 2) {
       const u128 raw = (u128)in[0] | ((u128)in[1] << 32) | ((u128)in[2] << 64) | ((u128)in[3] << 96);
-      F::st(dst + 2 * e, F::from_le_word(ctx, raw));
+      F::st(dst + 2 * de, F::from_le_word(ctx, raw));
     } else {
       typename F::E raw;
 #pragma unroll
       for (int j = 0; j < 4; ++j) raw.w[j] = (u64)in[2 * j] | ((u64)in[2 * j + 1] << 32);
-      F::st(dst + 4 * e, F::from_le_word(ctx, raw));
+      F::st(dst + 4 * de, F::from_le_word(ctx, raw));
     }
   }
 }

@@ -340,6 +340,31 @@ def wire_unpack(field, raw: torch.Tensor, capacity: int | None = None) -> torch.
     return out[: n.value]
 
 
+def wire_pack_matrix(field, m: torch.Tensor) -> torch.Tensor:
+    """row-major matrix [rows][cols][L] -> uint8 device buffer: u32 rows || u32 cols || vector image (matrix.h:910-963)"""
+    rows, cols = (m.shape[0], m.shape[1]) if m.numel() else (0, 0)
+    lib.scl_hip_wire_size_matrix.restype = C.c_size_t
+    out = torch.empty(lib.scl_hip_wire_size_matrix(field, C.c_size_t(rows), C.c_size_t(cols)), dtype=torch.uint8,
+                      device=m.device)
+    _chk(lib.scl_hip_wire_pack_matrix(field, _dev(out), _dev(m) if m.numel() else None, C.c_size_t(cols), C.c_size_t(rows),
+                                      C.c_size_t(cols), _stream()))
+    return out
+
+
+def wire_unpack_matrix(field, raw: torch.Tensor, capacity=None) -> torch.Tensor:
+    """inverse of wire_pack_matrix; capacity = (rows, cols) of the destination (default: sized from the image)"""
+    L = limbs(field)
+    if capacity is None:
+        hdr = raw[:12].cpu().numpy().view("<u4")
+        capacity = (int(hdr[0]), int(hdr[1]))
+    cr, cc = capacity
+    out = empty(field, max(cr, 1), max(cc, 1), device=raw.device)
+    r, c = C.c_size_t(0), C.c_size_t(0)
+    _chk(lib.scl_hip_wire_unpack_matrix(field, _dev(out), C.c_size_t(max(cc, 1)), C.c_size_t(cr), _dev(raw),
+                                        C.c_size_t(raw.numel()), C.byref(r), C.byref(c), _stream()))
+    return out[: r.value, : c.value]
+
+
 def stream_copy(dst: torch.Tensor, src: torch.Tensor):
     _chk(lib.scl_hip_stream_copy(_dev(dst), _dev(src), C.c_size_t(src.numel() * src.element_size()), _stream()))
 

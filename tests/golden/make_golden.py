@@ -131,6 +131,8 @@ def gen_montgomery_field(ref, f):
     fd["vandermonde_eval"] = {"n": 10, "m": 4, "N": 5, "C": hx(Cm), "out": hx(ref.matmul(f, V, Cm))}
     fd["wire"] = [{"elems": hx(a[:12]), "bytes": ref.wire_vector(f, a[:12]).hex()},
                   {"elems": [], "bytes": ref.wire_vector(f, np.zeros((0, L), np.uint64)).hex()}]
+    fd["wire_matrix"] = [{"rows": 2, "cols": 10, "elems": hx(A), "bytes": ref.wire_matrix(f, A).hex()},
+                         {"rows": 0, "cols": 0, "elems": [], "bytes": ref.wire_matrix(f, np.zeros((0, 0, L), np.uint64)).hex()}]
     return fd
 
 
@@ -289,6 +291,11 @@ def main():
         fd["wire"] = [{"elems": hx(wv), "bytes": ref.wire_vector(f, wv).hex()},
                       {"elems": hx(a[:40]), "bytes": ref.wire_vector(f, a[:40]).hex()},
                       {"elems": [], "bytes": ref.wire_vector(f, np.zeros((0, L), np.uint64)).hex()}]
+        # Serializer<Matrix> (matrix.h:910-963; test/scl/serialization/test_serializer.cc matrix case)
+        fd["wire_matrix"] = [{"rows": 2, "cols": 10, "elems": hx(A), "bytes": ref.wire_matrix(f, A).hex()},
+                             {"rows": 2, "cols": 2, "elems": hx(A2), "bytes": ref.wire_matrix(f, A2).hex()},
+                             {"rows": 0, "cols": 0, "elems": [],
+                              "bytes": ref.wire_matrix(f, np.zeros((0, 0, L), np.uint64)).hex()}]
         doc["fields"][name] = fd
 
     doc["fields"]["secp256k1_order"] = gen_montgomery_field(ref, O.SECP256K1_SCALAR)

@@ -292,6 +292,34 @@ class _Base:
             self._call("unwire_vector", C.c_int(field), _b(src), C.c_size_t(len(raw)), _p(out), C.c_size_t(cap), C.byref(n))
         return out[: n.value]
 
+    def wire_matrix(self, field, mat) -> bytes:
+        L = LIMBS[field]
+        mat = np.ascontiguousarray(mat, dtype=np.uint64)
+        rows, cols = mat.shape[0], mat.shape[1]
+        out = np.zeros(12 + rows * cols * 8 * L, dtype=np.uint8)
+        if self.has_err:
+            ln = C.c_size_t(0)
+            self._call("wire_matrix", C.c_int(field), _p(mat), C.c_size_t(rows), C.c_size_t(cols), _b(out), C.byref(ln))
+            assert ln.value == out.size
+        else:
+            fn = self._f("wire_matrix")
+            fn.restype = C.c_size_t
+            assert fn(C.c_int(field), _p(mat), C.c_size_t(rows), C.c_size_t(cols), _b(out)) == out.size
+        return out.tobytes()
+
+    def unwire_matrix(self, field, raw: bytes):
+        L = LIMBS[field]
+        src = np.frombuffer(raw, dtype=np.uint8).copy()
+        cap = max(1, (len(raw) - 12) // (8 * L))
+        out = np.zeros((cap, L), dtype=np.uint64)
+        r, c = C.c_size_t(0), C.c_size_t(0)
+        if self.has_err:
+            self._call("unwire_matrix", C.c_int(field), _b(src), _p(out), C.byref(r), C.byref(c))
+        else:
+            self._call("unwire_matrix", C.c_int(field), _b(src), C.c_size_t(len(raw)), _p(out), C.c_size_t(cap),
+                       C.byref(r), C.byref(c))
+        return out[: r.value * c.value].reshape(r.value, c.value, L)
+
     def time_shamir(self, field, N, t, n, seed: bytes = b"scl-bench"):
         ss, rs = C.c_double(), C.c_double()
         bad, chk = C.c_uint64(), C.c_uint64()

@@ -544,6 +544,36 @@ def test_wire_image(scl, port, f):
         scl.wire_unpack(f, rt[: 4 + 8 * L * 10].clone())  # count says 50, only 10 present
 
 
+@pytest.mark.parametrize("f", ALL_FIELDS)
+def test_wire_matrix_image(scl, port, f):
+    """seri::Serializer<Matrix<FF>>: u32 rows || u32 cols || vector image; golden bytes from the reference"""
+    L = O.LIMBS[f]
+    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order"}.get(f)
+    if name:
+        for c in GOLD["fields"][name]["wire_matrix"]:
+            m = O.from_ints(ints(c["elems"]), L).reshape(c["rows"], c["cols"], L) if c["elems"] else None
+            got = scl.wire_pack_matrix(f, dev(scl, m) if m is not None else scl.empty(f, 0))
+            assert bytes(got.cpu().numpy()).hex() == c["bytes"]
+            back = scl.wire_unpack_matrix(f, got)
+            assert tuple(back.shape[:2]) == (c["rows"], c["cols"])
+            if m is not None:
+                assert np.array_equal(host(scl, back), m)
+    for rows, cols in ((1, 1), (3, 7), (43, 128), (128, 43)):
+        m = rand_elems(port, f, rows * cols, b"wm").reshape(rows, cols, L)
+        raw = scl.wire_pack_matrix(f, dev(scl, m))
+        assert bytes(raw.cpu().numpy()) == port.wire_matrix(f, m)
+        assert np.array_equal(host(scl, scl.wire_unpack_matrix(f, raw)), m)
+        # into a wider destination (pitch > cols) and out of it again
+        wide = scl.wire_unpack_matrix(f, raw, capacity=(rows + 2, cols + 5))
+        assert np.array_equal(host(scl, wide), m)
+    bad = bytearray(port.wire_matrix(f, rand_elems(port, f, 4, b"wm").reshape(2, 2, L)))
+    bad[0] = 3
+    with pytest.raises(scl.SclError):
+        scl.wire_unpack_matrix(f, torch.frombuffer(bad, dtype=torch.uint8).cuda(), capacity=(4, 4))
+    with pytest.raises(scl.SclError):
+        scl.wire_unpack_matrix(f, raw, capacity=(1, 1))
+
+
 # ---------------------------------------------------------------------------------------------- full size properties
 @pytest.mark.parametrize("f,n,t,N", [(O.M61, 10, 3, 10_000_000), (O.M127, 10, 3, 2_000_000)])
 def test_full_size_round_trip(scl, port, f, n, t, N):

@@ -183,6 +183,23 @@ def test_wire_image(port, f, name):
     assert len(port.wire_vector(f, np.stack([port.from_int(f, v) for v in (1, 2, 3)]))) == 4 + 3 * 8 * L
 
 
+@pytest.mark.parametrize("f,name", FIELDS)
+def test_wire_matrix_image(port, f, name):
+    """seri::Serializer<Matrix<FF>> (matrix.h:910-963): u32 rows, u32 cols, vector image"""
+    g, L = GOLD["fields"][name], O.LIMBS[f]
+    for c in g["wire_matrix"]:
+        m = arr(c["elems"], L).reshape(c["rows"], c["cols"], L) if c["elems"] else np.zeros((0, 0, L), np.uint64)
+        raw = port.wire_matrix(f, m)
+        assert raw.hex() == c["bytes"]
+        back = port.unwire_matrix(f, raw)
+        assert back.shape[:2] == (c["rows"], c["cols"]) and np.array_equal(back, m.reshape(c["rows"], c["cols"], L))
+    # count that disagrees with the dimensions is refused by the port (the reference does not look)
+    bad = bytearray(port.wire_matrix(f, np.stack([port.from_int(f, v) for v in (1, 2, 3, 4)]).reshape(2, 2, L)))
+    bad[0] = 3
+    with pytest.raises(O.OracleError):
+        port.unwire_matrix(f, bytes(bad))
+
+
 # ---- known answers held by the reference's own tests for this path ----
 def test_reference_test_suite_kats(port):
     f, L = O.M61, 1
