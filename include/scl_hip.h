@@ -45,6 +45,14 @@ extern "C" {
 #endif
 
 typedef enum { SCL_M61 = 0, SCL_M127 = 1, SCL_MONT128 = 2, SCL_GF2_128 = 3, SCL_SECP256K1_SCALAR = 4 } scl_field;
+/* Rings scl::math::Z2k<K> (include/scl/math/z2k.h:39-320, z2k/z2k_ops.h:32-150), 1 <= K <= 128: tag
+ * SCL_Z2K(K).  One limb for K <= 64, two above (Z2k::ValueType); values are taken modulo 2^K on entry and are
+ * returned masked.  Accepted by the entry points that make sense in a ring: scl_hip_ew (INV / DIV need odd
+ * operands, else SCL_ERR_NOT_INVERTIBLE_2K), scalar_mul, sum, dot, equals (compares modulo 2^K), from_bytes and
+ * vector_random (stride Z2k::byteSize() = (K-1)/8 + 1 bytes), additive_share(_prg), additive_recover, matmul,
+ * aos_to_soa / soa_to_aos.  The Shamir / Lagrange / Vandermonde entry points refuse ring tags, and so do the
+ * wire functions: the reference has no Serializer for Z2k. */
+#define SCL_Z2K(K) (0x100 + (K))
 
 typedef enum { SCL_OP_ADD = 0, SCL_OP_SUB = 1, SCL_OP_MUL = 2, SCL_OP_NEG = 3, SCL_OP_INV = 4,
                SCL_OP_DIV = 5 } scl_op;
@@ -60,7 +68,8 @@ typedef enum {
   SCL_ERR_NOT_ENOUGH_SHARES = 7, /* std::logic_error("not enough shares provided to detect errors") shamir.h:123 */
   SCL_ERR_MATMUL_DIMS = 8,    /* std::invalid_argument("matmul: this->cols() != that->rows()") matrix.h:480 */
   SCL_ERR_VANDERMONDE_XS = 9, /* std::invalid_argument("|xs| != number of rows")         matrix.h:449     */
-  SCL_ERR_INVALID_RANGE = 10  /* std::invalid_argument("invalid range")                  vector.h:493     */
+  SCL_ERR_INVALID_RANGE = 10, /* std::invalid_argument("invalid range")                  vector.h:493     */
+  SCL_ERR_NOT_INVERTIBLE_2K = 11 /* std::invalid_argument("value not invertible modulo 2^K") z2k/z2k_ops.h:82 */
 } scl_status;
 
 int scl_hip_abi_version(void);

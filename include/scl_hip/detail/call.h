@@ -30,6 +30,7 @@ namespace scl::hip::detail {
     case SCL_ERR_MATMUL_DIMS:
     case SCL_ERR_VANDERMONDE_XS:
     case SCL_ERR_INVALID_RANGE:
+    case SCL_ERR_NOT_INVERTIBLE_2K:
       throw std::invalid_argument(ref);
     default:
       throw std::runtime_error(ref + ": " + scl_hip_last_error());

@@ -716,4 +716,62 @@ struct Secp256k1Scalar {
   }
 };
 
+// ------------------------------------------------------------------------------- rings Z2k<K>
+// scl::math::Z2k<K> of the reference (include/scl/math/z2k.h:39-320, include/scl/math/z2k/z2k_ops.h:32-150):
+// arithmetic modulo 2^K on one 64-bit word (K <= 64) or one 128-bit word.  The reference wraps at the word and
+// masks only when a value is compared, written or printed; results here are masked as they are produced, the
+// same residue mod 2^K.  Not a field: only odd values have inverses (Newton iteration, z2k_ops.h:80-93).
+template <typename W, int LIMBS_, int TAG_>
+struct Z2kRing {
+  typedef W E;
+  struct Ctx {
+    W mask;  // 2^K - 1
+    int K;
+  };
+  enum { LIMBS = LIMBS_, ACC_TERMS = 1 << 30, TAG = TAG_, SMALL_BITS = 0 };
+
+  static inline Ctx make_ctx(int K) {
+    Ctx c;
+    c.K = K;
+    c.mask = K >= (int)(8 * sizeof(W)) ? ~(W)0 : (W)(((W)1 << K) - 1);
+    return c;
+  }
+  static SCL_HD E zero() { return 0; }
+  static SCL_HD E one(const Ctx& c) { return (E)1 & c.mask; }
+  static SCL_HD E from_u64(const Ctx& c, u64 v) { return (E)v & c.mask; }
+  static SCL_HD bool is_zero(E a) { return a == 0; }
+  static SCL_HD bool eq(E a, E b) { return a == b; }
+  static SCL_HD u32 low32(E v) { return (u32)v; }
+  static SCL_HD E ld(const u64* p) {
+    if constexpr (LIMBS_ == 1) return p[0];
+    else return ((E)p[1] << 64) | p[0];
+  }
+  static SCL_HD void st(u64* p, E v) {
+    p[0] = (u64)v;
+    if constexpr (LIMBS_ == 2) p[1] = (u64)(v >> 64);
+  }
+  static SCL_HD E add(const Ctx& c, E a, E b) { return (a + b) & c.mask; }
+  static SCL_HD E sub(const Ctx& c, E a, E b) { return (a - b) & c.mask; }
+  static SCL_HD E mul(const Ctx& c, E a, E b) { return (a * b) & c.mask; }
+  static SCL_HD E neg(const Ctx& c, E a) { return ((E)0 - a) & c.mask; }
+  static SCL_HD E canon(E r) { return r; }
+  static SCL_HD E from_le_word(const Ctx& c, E raw) { return raw & c.mask; }  // fromBytes, z2k_ops.h:107-112
+  // invert (z2k_ops.h:80-93): z = 3v xor 2 is right to 5 bits, each step doubles that; even v has no inverse
+  // (the caller raises "value not invertible modulo 2^K")
+  static SCL_HD E inv(const Ctx& c, E v) {
+    E z = (v * 3) ^ 2;
+    for (int bits = 5; bits <= c.K; bits *= 2) z *= (E)2 - v * z;
+    return z & c.mask;
+  }
+  struct Acc {
+    E v;
+  };
+  static SCL_HD Acc acc_zero() { return Acc{0}; }
+  static SCL_HD void mac(const Ctx&, Acc& acc, E a, E b) { acc.v += a * b; }
+  static SCL_HD void acc_add(const Ctx&, Acc& acc, E a) { acc.v += a; }
+  static SCL_HD E acc_fold(const Ctx& c, const Acc& acc) { return acc.v & c.mask; }
+};
+typedef Z2kRing<u64, 1, 5> Z2k64;
+typedef Z2kRing<u128, 2, 6> Z2k128;
+
 }  // namespace sclhip

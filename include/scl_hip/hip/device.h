@@ -55,15 +55,23 @@ class DeviceBuffer {
   std::size_t m_bytes = 0;
 };
 
-/// N field elements in HBM.  T is an scl::math::FF<FIELD>.
+/// 64-bit limbs of T's element image on the C ABI: byteSize() / 8 for the fields, T::kLimbs where the type says
+/// otherwise (Z2k<K>: one word for K <= 64, two above, whatever its byteSize())
+template <typename T>
+constexpr std::size_t limbsOf() {
+  if constexpr (requires { T::kLimbs; }) return T::kLimbs;
+  else return T::byteSize() / 8;
+}
+
+/// N elements in HBM.  T is an scl::math::FF<FIELD> or an scl::math::Z2k<K>.
 template <typename T>
 class DeviceVector {
  public:
   static constexpr int FIELD_TAG = T::Field::TAG;
-  static constexpr std::size_t LIMBS = T::byteSize() / 8;
+  static constexpr std::size_t LIMBS = limbsOf<T>();
 
   DeviceVector() = default;
-  explicit DeviceVector(std::size_t n) : m_buf(n * T::byteSize()), m_size(n) {}
+  explicit DeviceVector(std::size_t n) : m_buf(n * LIMBS * 8), m_size(n) {}
 
   /// upload (element image = the C ABI's little-endian limbs)
   explicit DeviceVector(const std::vector<T>& host) : DeviceVector(host.size()) {
@@ -99,11 +107,11 @@ class DeviceVector {
 template <typename T>
 class ShareMatrix {
  public:
-  static constexpr std::size_t LIMBS = T::byteSize() / 8;
+  static constexpr std::size_t LIMBS = limbsOf<T>();
 
   ShareMatrix() = default;
   ShareMatrix(std::size_t parties, std::size_t secrets)
-      : m_buf(parties * secrets * T::byteSize()), m_parties(parties), m_secrets(secrets) {}
+      : m_buf(parties * secrets * LIMBS * 8), m_parties(parties), m_secrets(secrets) {}
 
   std::size_t parties() const { return m_parties; }
   std::size_t secrets() const { return m_secrets; }

@@ -12,7 +12,7 @@ namespace scl::math {
 
 template <typename T>
 Vector<T> computeLagrangeBasis(const Vector<T>& nodes, const T& x) {
-  constexpr std::size_t L = T::byteSize() / 8;
+  constexpr std::size_t L = hip::limbsOf<T>();
   const std::size_t n = nodes.size();
   std::vector<std::uint64_t> nd(n * L + 1), out(n * L + 1);
   std::uint64_t xl[L];

@@ -21,7 +21,7 @@ namespace scl::math {
 
 template <typename ELEMENT>
 class Matrix {
-  static constexpr std::size_t L = ELEMENT::byteSize() / 8;
+  static constexpr std::size_t L = hip::limbsOf<ELEMENT>();
   static constexpr int TAG = ELEMENT::Field::TAG;
 
  public:

@@ -53,7 +53,7 @@ T innerProd(IT0 xb, IT0 xe, IT1 yb) {
   std::vector<T> y(yb, yb + static_cast<std::ptrdiff_t>(x.size()));
   if (x.empty()) return T{};
   hip::DeviceVector<T> dx(x), dy(y);
-  std::uint64_t limbs[T::byteSize() / 8];
+  std::uint64_t limbs[hip::limbsOf<T>()];
   hip::check(scl_hip_dot(vec_detail::tag<T>(), limbs, dx.data(), dy.data(), x.size(), nullptr));
   return T::fromLimbs(limbs);
 }
@@ -118,7 +118,7 @@ class Vector final {
   ELEMENT sum() const {
     if (empty()) return ELEMENT{};
     hip::DeviceVector<ELEMENT> d(m_values);
-    std::uint64_t limbs[ELEMENT::byteSize() / 8];
+    std::uint64_t limbs[hip::limbsOf<ELEMENT>()];
     hip::check(scl_hip_sum(vec_detail::tag<ELEMENT>(), limbs, d.data(), m_values.size(), nullptr));
     return ELEMENT::fromLimbs(limbs);
   }
@@ -126,7 +126,7 @@ class Vector final {
   Vector scalarMultiply(const ELEMENT& scalar) const {
     if (empty()) return Vector{};
     hip::DeviceVector<ELEMENT> d(m_values), out(m_values.size());
-    std::uint64_t limbs[ELEMENT::byteSize() / 8];
+    std::uint64_t limbs[hip::limbsOf<ELEMENT>()];
     scalar.toLimbs(limbs);
     hip::check(scl_hip_scalar_mul(vec_detail::tag<ELEMENT>(), out.data(), d.data(), limbs, m_values.size(), nullptr));
     return Vector(out.toHost());

@@ -8,6 +8,7 @@
 #include "math/matrix.h"
 #include "math/poly.h"
 #include "math/vector.h"
+#include "math/z2k.h"
 #include "ss/additive.h"
 #include "ss/shamir.h"
 #include "util/prg.h"

@@ -20,7 +20,7 @@ hip::ShareMatrix<T> additiveShare(const hip::DeviceVector<T>& secrets, std::size
   const auto seed = prg.Seed();
   hip::check(scl_hip_additive_share_prg(T::Field::TAG, shares.data(), shares.stride(), secrets.data(), secrets.size(),
                                         n, seed.data(), seed.size(), prg.counter(), nullptr));
-  prg.advance(secrets.size() * (n - 1));  // one whole block per FF::random (ff.h:72-76)
+  prg.advance(secrets.size() * (n - 1) * ((T::byteSize() + 15) / 16));  // whole blocks per T::random (ff.h:72-76)
   return shares;
 }
 

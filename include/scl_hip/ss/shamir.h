@@ -20,7 +20,7 @@ namespace scl::ss {
 namespace shamir_detail {
 template <typename T>
 constexpr std::size_t limbs() {
-  return T::byteSize() / 8;
+  return hip::limbsOf<T>();
 }
 /// AES blocks one shamirSecretShare call draws: Vector::random(t+1) = ceil((t+1)*byteSize/16)
 template <typename T>

@@ -20,6 +20,7 @@
 #include <scl/math/matrix.h>
 #include <scl/math/poly.h>
 #include <scl/math/vector.h>
+#include <scl/math/z2k.h>
 #include <scl/serialization/serializer.h>
 #include <scl/ss/additive.h>
 #include <scl/ss/shamir.h>
@@ -41,24 +42,45 @@ using scl::math::Matrix;
 using scl::math::Vector;
 using scl::util::PRG;
 
+// Rings Z2k<K> cross this face under tag 0x100 + K: one limb for K <= 64, two above.  Z2k keeps its word
+// private and unnormalised (z2k_ops.h:32-62), so elements go in through the value constructor and come out
+// through Z2k::write (the masked byteSize() bytes, z2k_ops.h:117-124) into zeroed limbs.
+template <typename T>
+struct IsZ2k : std::false_type {};
+template <std::size_t K>
+struct IsZ2k<scl::math::Z2k<K>> : std::true_type {};
+
 template <typename F>
 constexpr std::size_t limbs() {
-  return F::byteSize() / 8;
+  if constexpr (IsZ2k<F>::value) return sizeof(typename F::ValueType) / 8;
+  else return F::byteSize() / 8;
 }
 
 // Elements cross this face as the raw FF::m_value image (what std::vector<FF>::data() holds):
 // the canonical integer for the Mersenne fields, the Montgomery residue limbs for secp256k1_order.
 template <typename F>
 F load(const std::uint64_t* p) {
-  F e;
-  std::memcpy(&e.value(), p, sizeof(e.value()));
-  return e;
+  if constexpr (IsZ2k<F>::value) {
+    typename F::ValueType w;
+    std::memcpy(&w, p, sizeof(w));
+    return F(w);
+  } else {
+    F e;
+    std::memcpy(&e.value(), p, sizeof(e.value()));
+    return e;
+  }
 }
 
 template <typename F>
 void store(std::uint64_t* p, const F& v) {
-  const auto raw = v.value();
-  std::memcpy(p, &raw, sizeof(raw));
+  if constexpr (IsZ2k<F>::value) {
+    unsigned char buf[sizeof(typename F::ValueType)] = {0};
+    v.write(buf);
+    std::memcpy(p, buf, sizeof(buf));
+  } else {
+    const auto raw = v.value();
+    std::memcpy(p, &raw, sizeof(raw));
+  }
 }
 
 template <typename F>
@@ -206,9 +228,25 @@ void storeMat(std::uint64_t* p, const Matrix<F>& m) {
     }                              \
   } while (0)
 
+// fields and the rings Z2k<K> instantiated here (K is a template parameter in the reference)
+#define RING_CASE(K, ...)                 \
+  if ((field) == 0x100 + (K)) {           \
+    using F = scl::math::Z2k<K>;          \
+    __VA_ARGS__;                          \
+  } else
+#define DISPATCH_R(field, ...)                                                                          \
+  do {                                                                                                  \
+    RING_CASE(1, __VA_ARGS__) RING_CASE(32, __VA_ARGS__) RING_CASE(62, __VA_ARGS__)                     \
+    RING_CASE(64, __VA_ARGS__) RING_CASE(65, __VA_ARGS__) RING_CASE(123, __VA_ARGS__)                   \
+    RING_CASE(128, __VA_ARGS__) DISPATCH(field, __VA_ARGS__);                                           \
+  } while (0)
+
 extern "C" {
 
-int sclref_limbs(int field) { return field == 0 ? 1 : field == 1 ? 2 : field == 4 ? 4 : -1; }
+int sclref_limbs(int field) {
+  if (field > 0x100 && field <= 0x100 + 128) return field - 0x100 <= 64 ? 1 : 2;
+  return field == 0 ? 1 : field == 1 ? 2 : field == 4 ? 4 : -1;
+}
 
 const char* sclref_field_name(int field) {
   return field == 0 ? F61::name() : field == 1 ? F127::name() : field == 4 ? F256::name() : "";
@@ -219,7 +257,7 @@ int sclref_ew(int field, int op, std::uint64_t* dst, const std::uint64_t* a,
               const std::uint64_t* b, std::size_t n, char* err, std::size_t errlen) {
   try {
     int r = 0;
-    DISPATCH(field, r = ewOp<F>(op, dst, a, b, n));
+    DISPATCH_R(field, r = ewOp<F>(op, dst, a, b, n));
     return r;
   } catch (const std::exception& e) {
     if (err && errlen) {
@@ -231,13 +269,13 @@ int sclref_ew(int field, int op, std::uint64_t* dst, const std::uint64_t* a,
 }
 
 int sclref_from_int(int field, int v, std::uint64_t* dst) {
-  DISPATCH(field, store<F>(dst, F(v)));
+  DISPATCH_R(field, store<F>(dst, F(v)));
   return 0;
 }
 
 int sclref_from_bytes(int field, const unsigned char* src, std::size_t n,
                       std::uint64_t* dst) {
-  DISPATCH(field, {
+  DISPATCH_R(field, {
     for (std::size_t i = 0; i < n; ++i)
       store<F>(dst + i * limbs<F>(), F::read(src + i * F::byteSize()));
   });
@@ -245,7 +283,7 @@ int sclref_from_bytes(int field, const unsigned char* src, std::size_t n,
 }
 
 int sclref_to_bytes(int field, const std::uint64_t* src, std::size_t n, unsigned char* dst) {
-  DISPATCH(field, {
+  DISPATCH_R(field, {
     for (std::size_t i = 0; i < n; ++i) load<F>(src + i * limbs<F>()).write(dst + i * F::byteSize());
   });
   return 0;
@@ -254,7 +292,7 @@ int sclref_to_bytes(int field, const std::uint64_t* src, std::size_t n, unsigned
 int sclref_from_hex(int field, const char* hex, std::uint64_t* dst, char* err,
                     std::size_t errlen) {
   try {
-    DISPATCH(field, store<F>(dst, F::fromString(hex)));
+    DISPATCH_R(field, store<F>(dst, F::fromString(hex)));
     return 0;
   } catch (const std::exception& e) {
     if (err && errlen) {
@@ -267,7 +305,7 @@ int sclref_from_hex(int field, const char* hex, std::uint64_t* dst, char* err,
 
 int sclref_to_hex(int field, const std::uint64_t* a, char* out, std::size_t outlen) {
   std::string s;
-  DISPATCH(field, s = load<F>(a).toString());
+  DISPATCH_R(field, s = load<F>(a).toString());
   if (s.size() + 1 > outlen) return -1;
   std::memcpy(out, s.c_str(), s.size() + 1);
   return 0;
@@ -293,7 +331,7 @@ int sclref_prg(const unsigned char* seed, std::size_t seed_len,
 int sclref_vector_random(int field, const unsigned char* seed, std::size_t seed_len,
                          std::size_t n, std::uint64_t* out) {
   auto prg = makePrg(seed, seed_len);
-  DISPATCH(field, storeVec<F>(out, Vector<F>::random(n, prg)));
+  DISPATCH_R(field, storeVec<F>(out, Vector<F>::random(n, prg)));
   return 0;
 }
 
@@ -352,30 +390,30 @@ int sclref_lagrange_basis(int field, const std::uint64_t* nodes, std::size_t m,
 int sclref_additive_share(int field, const unsigned char* seed, std::size_t seed_len,
                           const std::uint64_t* secrets, std::size_t N, std::size_t n,
                           std::uint64_t* shares) {
-  DISPATCH(field, additiveShare<F>(seed, seed_len, secrets, N, n, shares));
+  DISPATCH_R(field, additiveShare<F>(seed, seed_len, secrets, N, n, shares));
   return 0;
 }
 
 int sclref_additive_recover(int field, const std::uint64_t* shares, std::size_t n,
                             std::size_t N, std::uint64_t* out) {
-  DISPATCH(field, additiveRecover<F>(shares, n, N, out));
+  DISPATCH_R(field, additiveRecover<F>(shares, n, N, out));
   return 0;
 }
 
 int sclref_dot(int field, const std::uint64_t* a, const std::uint64_t* b,
                std::size_t n, std::uint64_t* out) {
-  DISPATCH(field, store<F>(out, loadVec<F>(a, n).dot(loadVec<F>(b, n))));
+  DISPATCH_R(field, store<F>(out, loadVec<F>(a, n).dot(loadVec<F>(b, n))));
   return 0;
 }
 
 int sclref_sum(int field, const std::uint64_t* a, std::size_t n, std::uint64_t* out) {
-  DISPATCH(field, store<F>(out, loadVec<F>(a, n).sum()));
+  DISPATCH_R(field, store<F>(out, loadVec<F>(a, n).sum()));
   return 0;
 }
 
 int sclref_scalar_mul(int field, const std::uint64_t* a, const std::uint64_t* scalar,
                       std::size_t n, std::uint64_t* out) {
-  DISPATCH(field, storeVec<F>(out, loadVec<F>(a, n).scalarMultiply(load<F>(scalar))));
+  DISPATCH_R(field, storeVec<F>(out, loadVec<F>(a, n).scalarMultiply(load<F>(scalar))));
   return 0;
 }
 
@@ -408,7 +446,7 @@ int sclref_hyper_invertible(int field, std::size_t n, std::size_t m, std::uint64
 // C[n x m] = A[n x k] * B[k x m], row-major
 int sclref_matmul(int field, const std::uint64_t* A, const std::uint64_t* B,
                   std::size_t n, std::size_t k, std::size_t m, std::uint64_t* C) {
-  DISPATCH(field, storeMat<F>(C, loadMat<F>(A, n, k).multiply(loadMat<F>(B, k, m))));
+  DISPATCH_R(field, storeMat<F>(C, loadMat<F>(A, n, k).multiply(loadMat<F>(B, k, m))));
   return 0;
 }
 

@@ -604,7 +604,136 @@ static void secpq_ensure(void) {
 #undef LIMBS
 
 /* ================================================================ dispatch */
-int sclo_limbs(int field) { return field == SCLO_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : field == SCLO_SECP256K1_SCALAR ? 4 : -1; }
+/* ------------------------------------------------------------------------------------------------
+ * Rings Z2k<K>, tag SCLO_Z2K(K) = 0x100 + K, 1 <= K <= 128 (include/scl/math/z2k.h:39-320,
+ * include/scl/math/z2k/z2k_ops.h:32-150).  One limb for K <= 64, two above, like Z2k::ValueType
+ * (z2k.h:44-45).  The reference computes on the whole word and masks only when a value is compared,
+ * written or printed (z2k_ops.h:97-141); every result here is stored masked, which is the same residue
+ * mod 2^K.  byteSize = (K-1)/8 + 1 (z2k.h:50-52) is the stride of read / Vector::random.
+ * The reference has no Serializer for Z2k, so the wire functions refuse ring tags. */
+#define SCLO_IS_RING(field) ((field) > 0x100 && (field) <= 0x100 + 128)
+#define RING_K(field) ((field)-0x100)
+
+static u128 ring_mask(int K) { return K >= 128 ? ~(u128)0 : (((u128)1 << K) - 1); }
+static size_t ring_limbs(int K) { return K <= 64 ? 1 : 2; }
+static size_t ring_bytes(int K) { return (size_t)(K - 1) / 8 + 1; }
+static u128 ring_ld(const uint64_t* p, int K) { return K <= 64 ? (u128)p[0] : (((u128)p[1] << 64) | p[0]); }
+static void ring_st(uint64_t* p, int K, u128 v) {
+  v &= ring_mask(K);
+  p[0] = (uint64_t)v;
+  if (K > 64) p[1] = (uint64_t)(v >> 64);
+}
+/* fromBytes: load the word, mask (z2k_ops.h:107-112); only the first byteSize bytes can matter */
+static u128 ring_from_bytes(const unsigned char* src, int K) {
+  u128 v = 0;
+  for (size_t b = 0; b < ring_bytes(K); ++b) v |= (u128)src[b] << (8 * b);
+  return v & ring_mask(K);
+}
+/* invert (z2k_ops.h:80-93): odd values only; Newton steps doubling the correct bits from 5 */
+static int ring_inv(u128* out, u128 v, int K) {
+  if (!(v & 1)) return SCLO_NOT_INVERTIBLE_2K;
+  const int wide = K > 64;
+  u128 z = (v * 3) ^ 2;
+  for (size_t bits = 5; bits <= (size_t)K; bits *= 2) {
+    z *= 2 - v * z;
+    if (!wide) z = (uint64_t)z; /* the reference's word is 64 bits here */
+  }
+  *out = z;
+  return SCLO_OK;
+}
+
+static int ring_ew(int K, int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n) {
+  const size_t L = ring_limbs(K);
+  for (size_t i = 0; i < n; ++i) {
+    u128 x = ring_ld(a + i * L, K), y = b ? ring_ld(b + i * L, K) : 0, t;
+    int st = SCLO_OK;
+    switch (op) {
+      case SCLO_ADD: x += y; break;
+      case SCLO_SUB: x -= y; break;
+      case SCLO_MUL: x *= y; break;
+      case SCLO_NEG: x = (u128)0 - x; break;
+      case SCLO_INV: st = ring_inv(&x, x, K); break;
+      case SCLO_DIV: st = ring_inv(&t, y, K); x *= t; break; /* operator/= (z2k.h:183-186) */
+      default: return SCLO_BAD_ARG;
+    }
+    if (st) return st;
+    ring_st(dst + i * L, K, x);
+  }
+  return SCLO_OK;
+}
+
+static int ring_from_bytes_n(int K, const unsigned char* src, size_t n, uint64_t* dst) {
+  for (size_t i = 0; i < n; ++i) ring_st(dst + i * ring_limbs(K), K, ring_from_bytes(src + i * ring_bytes(K), K));
+  return SCLO_OK;
+}
+
+/* Vector::random (vector.h:507-519): ONE prg.next(n * byteSize), then read at stride byteSize */
+static int ring_vector_random(int K, const unsigned char* seed, size_t seed_len, size_t n, uint64_t* out) {
+  sclo_prg_t g;
+  prg_init(&g, seed, seed_len);
+  unsigned char* buf = (unsigned char*)malloc(n * ring_bytes(K) + 16);
+  if (!buf) return SCLO_BAD_ARG;
+  prg_next(&g, buf, n * ring_bytes(K));
+  ring_from_bytes_n(K, buf, n, out);
+  free(buf);
+  return SCLO_OK;
+}
+
+/* additiveShare (additive.h:41-53) per secret on one PRG: n-1 draws of T::random (one prg.next(byteSize)
+ * each, i.e. one AES block), last = secret - sum */
+static int ring_additive_share(int K, const unsigned char* seed, size_t seed_len, const uint64_t* secrets,
+                               size_t N, size_t n, uint64_t* shares) {
+  const size_t L = ring_limbs(K);
+  if (n == 0) return SCLO_BAD_ARG;
+  sclo_prg_t g;
+  prg_init(&g, seed, seed_len);
+  for (size_t s = 0; s < N; ++s) {
+    u128 sum = 0;
+    for (size_t i = 0; i + 1 < n; ++i) {
+      unsigned char buf[16];
+      prg_next(&g, buf, ring_bytes(K));
+      const u128 r = ring_from_bytes(buf, K);
+      ring_st(shares + (s * n + i) * L, K, r);
+      sum += r;
+    }
+    ring_st(shares + (s * n + n - 1) * L, K, ring_ld(secrets + s * L, K) - sum);
+  }
+  return SCLO_OK;
+}
+
+static int ring_additive_recover(int K, const uint64_t* shares, size_t n, size_t N, uint64_t* out) {
+  const size_t L = ring_limbs(K);
+  for (size_t s = 0; s < N; ++s) {
+    u128 sum = 0;
+    for (size_t i = 0; i < n; ++i) sum += ring_ld(shares + (s * n + i) * L, K);
+    ring_st(out + s * L, K, sum);
+  }
+  return SCLO_OK;
+}
+
+static int ring_dot(int K, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  const size_t L = ring_limbs(K);
+  u128 acc = 0;
+  for (size_t i = 0; i < n; ++i) acc += ring_ld(a + i * L, K) * (b ? ring_ld(b + i * L, K) : 1);
+  ring_st(out, K, acc);
+  return SCLO_OK;
+}
+
+static int ring_matmul(int K, const uint64_t* A, const uint64_t* B, size_t n, size_t k, size_t m, uint64_t* C) {
+  const size_t L = ring_limbs(K);
+  for (size_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < m; ++j) {
+      u128 acc = 0;
+      for (size_t l = 0; l < k; ++l) acc += ring_ld(A + (i * k + l) * L, K) * ring_ld(B + (l * m + j) * L, K);
+      ring_st(C + (i * m + j) * L, K, acc);
+    }
+  return SCLO_OK;
+}
+
+int sclo_limbs(int field) {
+  if (SCLO_IS_RING(field)) return (int)ring_limbs(RING_K(field));
+  return field == SCLO_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : field == SCLO_SECP256K1_SCALAR ? 4 : -1;
+}
 
 const char* sclo_field_name(int field) {
   switch (field) {
@@ -624,6 +753,7 @@ const char* sclo_status_message(int status) {
     case SCLO_BAD_HEX_LEN: return "odd-length hex string";          /* str.h:52 */
     case SCLO_BAD_HEX_CHAR: return "encountered invalid hex character"; /* str.h:38 */
     case SCLO_ERROR_DETECTED: return "error detected during recovery";  /* shamir.h:135 */
+    case SCLO_NOT_INVERTIBLE_2K: return "value not invertible modulo 2^K"; /* z2k_ops.h:82 */
     default: return "bad argument";
   }
 }
@@ -643,18 +773,24 @@ const char* sclo_status_message(int status) {
   return SCLO_BAD_ARG;
 
 int sclo_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n) {
+  if (SCLO_IS_RING(field)) return ring_ew(RING_K(field), op, dst, a, b, n);
 #define BODY(P) return CAT(P, ew)(op, dst, a, b, n);
   FIELD_SWITCH(field, BODY)
 #undef BODY
 }
 
 int sclo_from_int(int field, int v, uint64_t* dst) {
+  if (SCLO_IS_RING(field)) { /* Z2k(ValueType) from a sign-extended int */
+    ring_st(dst, RING_K(field), (u128)(__int128)v);
+    return SCLO_OK;
+  }
 #define BODY(P) CAT(P, st)(dst, CAT(P, from_int)(v)); return SCLO_OK;
   FIELD_SWITCH(field, BODY)
 #undef BODY
 }
 
 int sclo_from_bytes(int field, const unsigned char* src, size_t n, uint64_t* dst) {
+  if (SCLO_IS_RING(field)) return ring_from_bytes_n(RING_K(field), src, n, dst);
   const size_t L = (size_t)sclo_limbs(field);
 #define BODY(P) for (size_t i = 0; i < n; ++i) CAT(P, st)(dst + i * L, CAT(P, from_bytes)(src + i * L * 8)); return SCLO_OK;
   FIELD_SWITCH(field, BODY)
@@ -773,6 +909,7 @@ int sclo_exp(int field, const uint64_t* base, size_t e, uint64_t* dst) {
 
 int sclo_vector_random(int field, const unsigned char* seed, size_t seed_len, size_t n,
                        uint64_t* out) {
+  if (SCLO_IS_RING(field)) return ring_vector_random(RING_K(field), seed, seed_len, n, out);
   const size_t L = (size_t)sclo_limbs(field);
   sclo_prg_t g;
   prg_init(&g, seed, seed_len);
@@ -834,24 +971,28 @@ int sclo_lagrange_basis(int field, const uint64_t* nodes, size_t m, const uint64
 
 int sclo_additive_share(int field, const unsigned char* seed, size_t seed_len,
                         const uint64_t* secrets, size_t N, size_t n, uint64_t* shares) {
+  if (SCLO_IS_RING(field)) return ring_additive_share(RING_K(field), seed, seed_len, secrets, N, n, shares);
 #define BODY(P) return CAT(P, additive_share)(seed, seed_len, secrets, N, n, shares);
   FIELD_SWITCH(field, BODY)
 #undef BODY
 }
 
 int sclo_additive_recover(int field, const uint64_t* shares, size_t n, size_t N, uint64_t* out) {
+  if (SCLO_IS_RING(field)) return ring_additive_recover(RING_K(field), shares, n, N, out);
 #define BODY(P) return CAT(P, additive_recover)(shares, n, N, out);
   FIELD_SWITCH(field, BODY)
 #undef BODY
 }
 
 int sclo_dot(int field, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  if (SCLO_IS_RING(field)) return ring_dot(RING_K(field), a, b, n, out);
 #define BODY(P) CAT(P, st)(out, CAT(P, vdot)(a, b, n)); return SCLO_OK;
   FIELD_SWITCH(field, BODY)
 #undef BODY
 }
 
 int sclo_sum(int field, const uint64_t* a, size_t n, uint64_t* out) {
+  if (SCLO_IS_RING(field)) return ring_dot(RING_K(field), a, NULL, n, out);
 #define BODY(P) CAT(P, st)(out, CAT(P, vsum)(a, n)); return SCLO_OK;
   FIELD_SWITCH(field, BODY)
 #undef BODY
@@ -859,6 +1000,12 @@ int sclo_sum(int field, const uint64_t* a, size_t n, uint64_t* out) {
 
 /* Vector::scalarMultiply: r_i = scalar * v_i (vector.h:274-285) */
 int sclo_scalar_mul(int field, const uint64_t* a, const uint64_t* scalar, size_t n, uint64_t* out) {
+  if (SCLO_IS_RING(field)) {
+    const size_t L_ = ring_limbs(RING_K(field));
+    for (size_t i = 0; i < n; ++i)
+      ring_st(out + i * L_, RING_K(field), ring_ld(scalar, RING_K(field)) * ring_ld(a + i * L_, RING_K(field)));
+    return SCLO_OK;
+  }
   const size_t L = (size_t)sclo_limbs(field);
 #define BODY(P) for (size_t i = 0; i < n; ++i) CAT(P, st)(out + i * L, CAT(P, mul)(CAT(P, ld)(scalar), CAT(P, ld)(a + i * L))); return SCLO_OK;
   FIELD_SWITCH(field, BODY)
@@ -880,6 +1027,7 @@ int sclo_vandermonde(int field, size_t n, size_t m, const uint64_t* xs, uint64_t
 
 int sclo_matmul(int field, const uint64_t* A, const uint64_t* B, size_t n, size_t k, size_t m,
                 uint64_t* C) {
+  if (SCLO_IS_RING(field)) return ring_matmul(RING_K(field), A, B, n, k, m, C);
 #define BODY(P) CAT(P, matmul)(A, B, n, k, m, C); return SCLO_OK;
   FIELD_SWITCH(field, BODY)
 #undef BODY

@@ -34,10 +34,13 @@ extern "C" {
 #endif
 
 enum { SCLO_M61 = 0, SCLO_M127 = 1, SCLO_MONT128 = 2, SCLO_GF2_128 = 3, SCLO_SECP256K1_SCALAR = 4 };
+/* rings Z2k<K> (include/scl/math/z2k.h): element-wise ops, from_bytes, vector_random, additive sharing, sum, dot,
+ * scalar_mul and matmul take these tags; one limb for K <= 64, two above */
+#define SCLO_Z2K(K) (0x100 + (K))
 enum { SCLO_ADD = 0, SCLO_SUB = 1, SCLO_MUL = 2, SCLO_NEG = 3, SCLO_INV = 4, SCLO_DIV = 5 };
 /* status codes */
 enum { SCLO_OK = 0, SCLO_ZERO_INVERSE = 1, SCLO_BAD_ARG = 2, SCLO_BAD_HEX_LEN = 3,
-       SCLO_BAD_HEX_CHAR = 4, SCLO_ERROR_DETECTED = 5 };
+       SCLO_BAD_HEX_CHAR = 4, SCLO_ERROR_DETECTED = 5, SCLO_NOT_INVERTIBLE_2K = 6 };
 
 int sclo_limbs(int field);
 const char* sclo_field_name(int field);

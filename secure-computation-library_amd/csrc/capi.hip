@@ -110,6 +110,21 @@ int with_field(int field, Fn&& fn) {
   }
 }
 
+// Rings Z2k<K> travel under the tag SCL_Z2K(K) = 0x100 + K.  Only the entry points that make sense in a ring
+// dispatch through here (element-wise, reductions, randomness, additive sharing, matmul); the Shamir and
+// Lagrange entry points stay on with_field and refuse ring tags, as division by node differences would.
+inline bool is_ring(int field) { return field > 0x100 && field <= 0x100 + 128; }
+
+template <class Fn>
+int with_ring_or_field(int field, Fn&& fn) {
+  if (is_ring(field)) {
+    const int K = field - 0x100;
+    if (K <= 64) return fn(Z2k64{}, Z2k64::make_ctx(K));
+    return fn(Z2k128{}, Z2k128::make_ctx(K));
+  }
+  return with_field(field, fn);
+}
+
 // ---- per-thread device scratch (only used by calls that synchronise before returning) -------------
 struct Scratch {
   int device = -1;
@@ -514,13 +529,18 @@ const char* scl_hip_status_message(int status) {
     case SCL_ERR_MATMUL_DIMS: return "matmul: this->cols() != that->rows()";
     case SCL_ERR_VANDERMONDE_XS: return "|xs| != number of rows";
     case SCL_ERR_INVALID_RANGE: return "invalid range";
+    case SCL_ERR_NOT_INVERTIBLE_2K: return "value not invertible modulo 2^K";
     default: return "unknown status";
   }
 }
 
-int scl_hip_limbs(int field) { return field == SCL_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : field == SCL_SECP256K1_SCALAR ? 4 : -1; }
+int scl_hip_limbs(int field) {
+  if (is_ring(field)) return field - 0x100 <= 64 ? 1 : 2;
+  return field == SCL_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : field == SCL_SECP256K1_SCALAR ? 4 : -1;
+}
 
 const char* scl_hip_field_name(int field) {
+  if (is_ring(field)) return "Z2k";  // z2k.h:64-66
   switch (field) {
     case SCL_M61: return "Mersenne61";
     case SCL_M127: return "Mersenne127";
@@ -646,7 +666,7 @@ int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64
   const bool binary = (op == SCL_OP_ADD || op == SCL_OP_SUB || op == SCL_OP_MUL || op == SCL_OP_DIV);
   if (n == 0) return SCL_OK;
   if (!dst || !a || (binary && !b)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
-  return with_field(field, [&](auto f, auto ctx) -> int {
+  return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({dst, a, binary ? b : nullptr}));
     unsigned* flag = nullptr;
@@ -682,7 +702,10 @@ int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64
       unsigned h = 0;
       HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, S(stream)));
       HIP_TRY(hipStreamSynchronize(S(stream)));
-      if (h) return fail(SCL_ERR_ZERO_INVERSE, scl_hip_status_message(SCL_ERR_ZERO_INVERSE));
+      if (h) {
+        const int code = F::TAG >= 5 ? SCL_ERR_NOT_INVERTIBLE_2K : SCL_ERR_ZERO_INVERSE;
+        return fail(code, scl_hip_status_message(code));
+      }
     }
     return SCL_OK;
   });
@@ -692,7 +715,7 @@ int scl_hip_scalar_mul(int field, uint64_t* dst, const uint64_t* a, const uint64
                        void* stream) {
   if (n == 0) return SCL_OK;
   if (!dst || !a || !scalar_host) return fail(SCL_ERR_BAD_ARG, "NULL operand");
-  return with_field(field, [&](auto f, auto ctx) -> int {
+  return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({dst, a}));
     Table<F> sc;
@@ -711,7 +734,7 @@ int scl_hip_scalar_mul(int field, uint64_t* dst, const uint64_t* a, const uint64
 static int reduce_impl(int field, uint64_t* out_host, const uint64_t* a, const uint64_t* b, size_t n, void* stream,
                        bool is_dot) {
   if (!out_host) return fail(SCL_ERR_BAD_ARG, "out is NULL");
-  return with_field(field, [&](auto f, auto ctx) -> int {
+  return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     if (n == 0) {
       F::st(out_host, F::zero());
@@ -770,7 +793,13 @@ int scl_hip_equals(int field, int* equal_host, const uint64_t* a, const uint64_t
   unsigned long long* cnt = static_cast<unsigned long long*>(sc);
   HIP_TRY(hipMemsetAsync(cnt, 0, 8, S(stream)));
   const size_t words = n * (size_t)L;
-  hipLaunchKernelGGL(k_count_diff, dim3(grid_for(words)), dim3(BLOCK), 0, S(stream), cnt, a, b, words);
+  if (is_ring(field)) {
+    const int K = field - 0x100;
+    const u64 lo = K >= 64 ? ~0ull : ((1ull << K) - 1), hi = K >= 128 ? ~0ull : K > 64 ? ((1ull << (K - 64)) - 1) : 0;
+    hipLaunchKernelGGL(k_count_diff_masked, dim3(grid_for(words)), dim3(BLOCK), 0, S(stream), cnt, a, b, words, lo, hi, L);
+  } else {
+    hipLaunchKernelGGL(k_count_diff, dim3(grid_for(words)), dim3(BLOCK), 0, S(stream), cnt, a, b, words);
+  }
   LAUNCH_CHECK();
   unsigned long long h = 0;
   HIP_TRY(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, S(stream)));
@@ -793,9 +822,26 @@ int scl_hip_prg_blocks(unsigned char* dst, size_t nblocks, const unsigned char* 
   return SCL_OK;
 }
 
+// Z2k::read per element at a stride of byteSize (z2k.h:50-52,71-75)
+static int ring_from_bytes(int field, uint64_t* dst, const unsigned char* src, size_t n, hipStream_t st) {
+  const int bs = (field - 0x100 - 1) / 8 + 1;
+  return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    if constexpr (F::TAG >= 5) {
+      SCL_TRY(check_align<F>({dst}));
+      hipLaunchKernelGGL((k_ring_from_bytes<F>), dim3(grid_for(n)), dim3(BLOCK), 0, st, ctx, dst, src, n, bs);
+      LAUNCH_CHECK();
+      return SCL_OK;
+    } else {
+      return fail(SCL_ERR_BAD_ARG, "not a ring tag");
+    }
+  });
+}
+
 int scl_hip_from_bytes(int field, uint64_t* dst, const unsigned char* src, size_t n, void* stream) {
   if (n == 0) return SCL_OK;
   if (!dst || !src) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (is_ring(field)) return ring_from_bytes(field, dst, src, n, S(stream));
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({dst}));
@@ -809,6 +855,17 @@ int scl_hip_vector_random(int field, uint64_t* dst, size_t n, const unsigned cha
                           uint64_t counter0, void* stream) {
   if (n == 0) return SCL_OK;
   if (!dst) return fail(SCL_ERR_BAD_ARG, "dst is NULL");
+  if (is_ring(field)) {
+    // Vector<Z2k>::random (vector.h:507-519): one prg.next(n * byteSize) = ceil(n * byteSize / 16) blocks into a
+    // stream-ordered temporary, then Z2k::read at a stride of byteSize
+    const size_t bs = (size_t)(field - 0x100 - 1) / 8 + 1, nblocks = (n * bs + 15) / 16;
+    void* tmp = nullptr;
+    HIP_TRY(hipMallocAsync(&tmp, nblocks * 16, S(stream)));
+    int rc = scl_hip_prg_blocks(static_cast<unsigned char*>(tmp), nblocks, seed, seed_len, counter0, stream);
+    if (rc == SCL_OK) rc = ring_from_bytes(field, dst, static_cast<const unsigned char*>(tmp), n, S(stream));
+    (void)hipFreeAsync(tmp, S(stream));
+    return rc;
+  }
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({dst}));
@@ -1106,7 +1163,7 @@ int scl_hip_additive_share(int field, uint64_t* shares, size_t share_stride, con
   if (N == 0) return SCL_OK;
   if (!shares || !secrets || (n > 1 && !rnd)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (share_stride < N || (n > 1 && rnd_stride < N)) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
-  return with_field(field, [&](auto f, auto ctx) -> int {
+  return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({shares, secrets, rnd}));
     const int vec = vec_width<F>({shares, secrets, rnd}, {share_stride, n > 1 ? rnd_stride : 0});
@@ -1128,7 +1185,7 @@ int scl_hip_additive_share_prg(int field, uint64_t* shares, size_t share_stride,
   if (N == 0) return SCL_OK;
   if (!shares || !secrets) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (share_stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
-  return with_field(field, [&](auto f, auto ctx) -> int {
+  return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({shares, secrets}));
     AesKey key;
@@ -1150,7 +1207,7 @@ int scl_hip_additive_recover(int field, uint64_t* out, const uint64_t* shares, s
   if (N == 0) return SCL_OK;
   if (!out || !shares) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "share_stride < N");
-  return with_field(field, [&](auto f, auto ctx) -> int {
+  return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({out, shares}));
     const int vec = vec_width<F>({out, shares}, {stride});
@@ -1200,7 +1257,7 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
   if (!C || (K && (!A || !B))) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (ldc < N || (K && (lda < K || ldb < N))) return fail(SCL_ERR_MATMUL_DIMS, scl_hip_status_message(SCL_ERR_MATMUL_DIMS));
   if (M > (1u << 20) || K > (1u << 20)) return fail(SCL_ERR_BAD_ARG, "matmul: M or K too large");
-  return with_field(field, [&](auto f, auto ctx) -> int {
+  return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({C, A, B}));
     if constexpr (F::TAG == 0) {

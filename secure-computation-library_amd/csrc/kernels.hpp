@@ -110,6 +110,13 @@ struct BigTable {
   for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < (npacks); q += (size_t)gridDim.x * BLOCK)
 
 // ---- element-wise --------------------------------------------------------------------------
+// what FF::invert / Z2k::invert refuse: zero in a field (small_ff.h:61-70), even values in a ring (z2k_ops.h:81-83)
+template <class F>
+__device__ __forceinline__ bool not_invertible(const typename F::E& a) {
+  if constexpr (F::TAG >= 5) return (F::low32(a) & 1u) == 0;
+  else return F::is_zero(a);
+}
+
 // Vector::add/subtract/multiplyEntryWise, FF::negate/invert/operator/ (vector.h:199-245, ff.h:203-246)
 template <class F, int OP, int VEC, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_ew(typename F::Ctx ctx, u64* dst, const u64* a, const u64* b,
@@ -125,11 +132,11 @@ __global__ __launch_bounds__(BLOCK) void k_ew(typename F::Ctx ctx, u64* dst, con
       if constexpr (OP == 2) r.v[v] = F::mul(ctx, x.v[v], y.v[v]);
       if constexpr (OP == 3) r.v[v] = F::neg(ctx, x.v[v]);
       if constexpr (OP == 4) {
-        if (F::is_zero(x.v[v])) atomicOr(zero_flag, 1u);
+        if (not_invertible<F>(x.v[v])) atomicOr(zero_flag, 1u);
         r.v[v] = F::inv(ctx, x.v[v]);
       }
       if constexpr (OP == 5) {
-        if (F::is_zero(y.v[v])) atomicOr(zero_flag, 1u);
+        if (not_invertible<F>(y.v[v])) atomicOr(zero_flag, 1u);
         r.v[v] = F::mul(ctx, x.v[v], F::inv(ctx, y.v[v]));
       }
     }
@@ -215,6 +222,17 @@ __global__ __launch_bounds__(BLOCK) void k_count_diff(unsigned long long* count,
                                                       size_t nwords) {
   unsigned long long local = 0;
   SCL_GRID_STRIDE(q, nwords) local += (a[q] != b[q]);
+  if (local) atomicAdd(count, local);
+}
+
+// Z2k equality compares modulo 2^K (z2k_ops.h:97-103): mask = 2^K - 1 as (lo, hi) words, L limbs per element
+__global__ __launch_bounds__(BLOCK) void k_count_diff_masked(unsigned long long* count, const u64* a, const u64* b,
+                                                             size_t nwords, u64 mask_lo, u64 mask_hi, int L) {
+  unsigned long long local = 0;
+  SCL_GRID_STRIDE(q, nwords) {
+    const u64 m = (L == 2 && (q & 1)) ? mask_hi : mask_lo;
+    local += ((a[q] ^ b[q]) & m) != 0;
+  }
   if (local) atomicAdd(count, local);
 }
 
@@ -723,6 +741,19 @@ __global__ __launch_bounds__(BLOCK) void k_from_bytes(typename F::Ctx ctx, u64* 
       __builtin_memcpy(raw.w, src + 32 * q, 32);
       F::st(dst + 4 * q, F::from_le_word(ctx, raw));
     }
+  }
+}
+
+// Z2k::read at a stride of byteSize = (K-1)/8 + 1 bytes (z2k.h:50-52,71-75, z2k_ops.h:107-112): the bytes
+// are gathered one at a time (the stride is odd in general), the mask drops what lies above bit K
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_ring_from_bytes(typename F::Ctx ctx, u64* dst, const unsigned char* src,
+                                                           size_t n, int bs) {
+  SCL_GRID_STRIDE(q, n) {
+    const unsigned char* p = src + q * (size_t)bs;
+    typename F::E v = 0;
+    for (int b = 0; b < bs; ++b) v |= (typename F::E)p[b] << (8 * b);
+    F::st(dst + q * F::LIMBS, F::from_le_word(ctx, v));
   }
 }
 

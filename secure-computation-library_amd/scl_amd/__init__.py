@@ -26,6 +26,19 @@ if not os.path.exists(_SO):
 lib = C.CDLL(_SO)
 
 M61, M127, MONT128, GF2_128, SECP256K1_SCALAR = 0, 1, 2, 3, 4
+
+
+def Z2K(bits: int) -> int:
+    """tag of the ring scl::math::Z2k<bits> (include/scl/math/z2k.h), 1 <= bits <= 128; see SCL_Z2K in scl_hip.h"""
+    if not 1 <= bits <= 128:
+        raise ValueError("Z2k bit size must be in 1..128")
+    return 0x100 + bits
+
+
+def byte_size(field) -> int:
+    """T::byteSize(): the stride of read / Vector::random -- (K-1)/8 + 1 for Z2k<K>, 8 * limbs for the fields"""
+    return (field - 0x100 - 1) // 8 + 1 if 0x100 < field <= 0x100 + 128 else 8 * limbs(field)
+
 ADD, SUB, MUL, NEG, INV, DIV = range(6)
 OK, ERR_SIZE_MISMATCH, ERR_ZERO_INVERSE, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_ERROR_DETECTED, \
     ERR_NOT_ENOUGH_SHARES, ERR_MATMUL_DIMS, ERR_VANDERMONDE_XS, ERR_INVALID_RANGE = range(11)
@@ -158,8 +171,7 @@ def prg_blocks(nblocks: int, seed: bytes, counter0: int = 0, device="cuda") -> t
 
 
 def from_bytes(field, raw: torch.Tensor) -> torch.Tensor:
-    L = limbs(field)
-    n = raw.numel() // (8 * L)
+    n = raw.numel() // byte_size(field)
     out = empty(field, n, device=raw.device)
     _chk(lib.scl_hip_from_bytes(field, _dev(out), _dev(raw), C.c_size_t(n), _stream()))
     return out

@@ -497,6 +497,90 @@ TEST_CASE(additive_gpu, "ss::additiveShare", true) {
   REQUIRE(math::Vector<F61>(m.sharesOf(7)) == ss::additiveShare(secrets[7], 3, prg4));
 }
 
+// ---------------------------------------------------------------------------- rings Z2k<K>
+template <typename Z>
+static void ring_identities() {
+  // test/scl/math/test_z2k.cc:34-166 restated
+  REQUIRE(std::string(Z::name()) == "Z2k");
+  const Z a = Z::fromString("9e3779b97f4a7c15f39cc0605cedc834"), b = Z::fromString("1082276bf3a27251f86c6a11d0c18e95");
+  const Z zero = Z::zero(), one = Z::one();
+  REQUIRE(a + b == b + a);
+  REQUIRE(a + zero == a);
+  REQUIRE(a - a == zero);
+  REQUIRE(a + (-a) == zero);
+  REQUIRE(a * one == a);
+  REQUIRE(a * b == b * a);
+  REQUIRE((a + b) * a == a * a + b * a);
+  Z big = Z::zero() - Z::one();  // 2^K - 1
+  REQUIRE(big + one == zero);
+  REQUIRE(big * big == one);
+  Z odd = a;
+  if (!odd.lsb()) odd += one;
+  REQUIRE(odd * odd.inverse() == one);
+  REQUIRE((b / odd) * odd == b);
+  REQUIRE_THROWS_MSG(Z(2).inverse(), std::invalid_argument, "value not invertible modulo 2^K");
+  unsigned char buf[17] = {0};
+  a.write(buf);
+  REQUIRE(Z::read(buf) == a);
+  REQUIRE(Z::fromString(a.toString().size() % 2 ? "0" + a.toString() : a.toString()) == a || Z::bitSize() > 64);
+}
+
+TEST_CASE(z2k_host, "Z2k<62> / Z2k<123> / Z2k<32> identities (host scalars)", false) {
+  ring_identities<math::Z2k<62>>();
+  ring_identities<math::Z2k<123>>();
+  ring_identities<math::Z2k<32>>();
+  ring_identities<math::Z2k<64>>();
+  ring_identities<math::Z2k<128>>();
+  using Z = math::Z2k<32>;
+  REQUIRE(Z::byteSize() == 4 && math::Z2k<62>::byteSize() == 8 && math::Z2k<123>::byteSize() == 16);
+  REQUIRE(Z(0xFFFFFFFFull) + Z(1) == Z(0));
+  REQUIRE(Z(3).inverse() == Z(0xAAAAAAABull));  // 3 * 0xAAAAAAAB = 2^33 + 1
+  REQUIRE(Z(0x1234567890ull).toString() == "34567890");
+}
+
+TEST_CASE(z2k_gpu, "Vector<Z2k>, additive sharing over a ring", true) {
+  using Z = math::Z2k<62>;
+  using Zb = math::Z2k<123>;
+  {
+    auto p0 = util::PRG::create("shamir passive");
+    REQUIRE(Zb::random(p0).toString() == "6ce7720f22f666734dc2c3c3df35e96");  // reference golden, first element
+    REQUIRE(p0.counter() == 1);
+  }
+  auto prg = util::PRG::create("shamir passive");
+  const auto v = math::Vector<Zb>::random(4, prg);
+  REQUIRE(prg.counter() == 4);
+  REQUIRE(v[0].toString() == "6ce7720f22f666734dc2c3c3df35e96");  // reference golden
+  REQUIRE(v[1].toString() == "2c7ae6bf3761e8becf7c069a3d98c04");
+  auto prg2 = util::PRG::create("ring");
+  const auto x = math::Vector<Z>::random(100, prg2), y = math::Vector<Z>::random(100, prg2);
+  REQUIRE(prg2.counter() == 100);
+  const auto s = x.add(y), p = x.multiplyEntryWise(y);
+  bool ok = true;
+  Z dot = Z::zero(), sum = Z::zero();
+  for (std::size_t i = 0; i < 100; ++i) {
+    ok = ok && s[i] == x[i] + y[i] && p[i] == x[i] * y[i];
+    dot += x[i] * y[i];
+    sum += x[i];
+  }
+  REQUIRE(ok);
+  REQUIRE(x.dot(y) == dot);
+  REQUIRE(x.sum() == sum);
+  // additive sharing over the ring: shares sum to the secret modulo 2^K
+  auto prg3 = util::PRG::create();
+  const auto shares = ss::additiveShare(Z(12345), 3, prg3);
+  REQUIRE(shares.size() == 3 && prg3.counter() == 2);
+  REQUIRE(shares.sum() == Z(12345));
+  std::vector<Zb> secrets;
+  for (int i = 0; i < 257; ++i) secrets.emplace_back(Zb((__uint128_t)i * 0x9E3779B97F4A7C15ull));
+  auto prg4 = util::PRG::create("ring-batch");
+  const auto m = ss::additiveShare(hip::DeviceVector<Zb>(secrets), 5, prg4);
+  REQUIRE(prg4.counter() == 257 * 4);
+  REQUIRE(math::Vector<Zb>(ss::additiveRecover(m).toHost()) == math::Vector<Zb>(secrets));
+  auto prg5 = util::PRG::create("ring-batch");
+  prg5.advance(9 * 4);
+  REQUIRE(math::Vector<Zb>(m.sharesOf(9)) == ss::additiveShare(secrets[9], 5, prg5));
+}
+
 int main(int argc, char** argv) {
   const bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
   int ran = 0;

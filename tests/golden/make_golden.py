@@ -136,6 +136,49 @@ def gen_montgomery_field(ref, f):
     return fd
 
 
+def gen_ring(ref, K):
+    """Z2k<K> (include/scl/math/z2k.h:39-320; cases of test/scl/math/test_z2k.cc restated): values cross as the
+    masked little-endian word Z2k::write emits, zero-extended to 1 (K <= 64) or 2 limbs"""
+    f, L = O.Z2K(K), O.LIMBS[O.Z2K(K)]
+    rng = np.random.default_rng(1000 + K)
+    I = lambda v: ref.from_int(f, v)
+    fd = {"bits": K, "limbs": L, "byte_size": O.byte_size(f)}
+    raw = rng.bytes(O.byte_size(f) * 40)
+    a = ref.from_bytes(f, raw)
+    b = ref.from_bytes(f, rng.bytes(O.byte_size(f) * 40))
+    a[:6] = np.stack([I(0), I(1), I(-1), I(2), I(-2), I(3)])
+    b[:6] = np.stack([I(-1), I(-1), I(-1), I(5), I(7), I(0)])
+    fd["from_bytes"] = {"bytes": raw.hex(), "out": hx(ref.from_bytes(f, raw))}
+    ew = {"a": hx(a), "b": hx(b)}
+    for name, op in (("add", O.ADD), ("sub", O.SUB), ("mul", O.MUL)):
+        ew[name] = hx(ref.ew(f, op, a, b))
+    ew["neg"] = hx(ref.ew(f, O.NEG, a))
+    fd["ew"] = ew
+    odd = a.copy()
+    odd[:, 0] |= np.uint64(1)
+    fd["inverse"] = {"in": hx(odd), "out": hx(ref.ew(f, O.INV, odd)), "div_b_by_in": hx(ref.ew(f, O.DIV, b, odd))}
+    try:
+        ref.ew(f, O.INV, I(2).reshape(1, L))
+        fd["inverse_even_error"] = None
+    except O.OracleError as e:
+        fd["inverse_even_error"] = e.message
+    fd["vector_random"] = [{"seed": s.hex(), "n": n, "out": hx(ref.vector_random(f, s, n))}
+                           for s, n in ((b"shamir passive", 4), (b"", 1), (b"vec", 33))]
+    ad = []
+    for (n, N, seed) in ((3, 8, b""), (10, 3, b"additive"), (1, 2, b"one")):
+        secrets = np.concatenate([I(12345).reshape(1, L), ref.from_bytes(f, rng.bytes(O.byte_size(f) * (N - 1)))])
+        shares = ref.additive_share(f, seed, secrets, n)
+        ad.append({"n": n, "seed": seed.hex(), "secrets": hx(secrets), "shares": hx(shares),
+                   "sum": hx(ref.additive_recover(f, shares))})
+    fd["additive"] = ad
+    fd["dot"] = {"a": hx(a), "b": hx(b), "out": hx(ref.dot(f, a, b).reshape(1, L))[0]}
+    fd["sum"] = {"a": hx(a), "out": hx(ref.sum(f, a).reshape(1, L))[0]}
+    fd["scalar_mul"] = {"a": hx(a), "scalar": hx(b[7].reshape(1, L))[0], "out": hx(ref.scalar_mul(f, a, b[7]))}
+    A, B = a[:20].reshape(2, 10, L), b[:30].reshape(10, 3, L)
+    fd["matmul"] = [{"n": 2, "k": 10, "m": 3, "A": hx(A), "B": hx(B), "C": hx(ref.matmul(f, A, B))}]
+    return fd
+
+
 def main():
     ref = O.Ref()
     rng = np.random.default_rng(20261003)
@@ -299,6 +342,8 @@ def main():
         doc["fields"][name] = fd
 
     doc["fields"]["secp256k1_order"] = gen_montgomery_field(ref, O.SECP256K1_SCALAR)
+
+    doc["rings"] = {f"Z2k<{K}>": gen_ring(ref, K) for K in O.REF_RING_BITS}
 
     path = os.path.join(HERE, "golden_v1.json")
     with open(path, "w") as fh_:

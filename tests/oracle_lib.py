@@ -23,7 +23,36 @@ REF_SO = os.path.join(ORACLE_DIR, "_ref", "libscl_ref.so")
 
 M61, M127, MONT128, GF2_128, SECP256K1_SCALAR = 0, 1, 2, 3, 4
 ADD, SUB, MUL, NEG, INV, DIV = range(6)
-LIMBS = {M61: 1, M127: 2, MONT128: 2, GF2_128: 2, SECP256K1_SCALAR: 4}
+
+
+def Z2K(bits: int) -> int:
+    """tag of the ring Z2k<bits> (include/scl/math/z2k.h); the reference harness instantiates REF_RING_BITS"""
+    assert 1 <= bits <= 128
+    return 0x100 + bits
+
+
+REF_RING_BITS = (1, 32, 62, 64, 65, 123, 128)
+
+
+def is_ring(field: int) -> bool:
+    return 0x100 < field <= 0x100 + 128
+
+
+class _Limbs(dict):
+    def __missing__(self, field):
+        if is_ring(field):
+            return 1 if field - 0x100 <= 64 else 2
+        raise KeyError(field)
+
+
+LIMBS = _Limbs({M61: 1, M127: 2, MONT128: 2, GF2_128: 2, SECP256K1_SCALAR: 4})
+
+
+def byte_size(field: int) -> int:
+    """T::byteSize(): what read / write / Vector::random step by"""
+    return (field - 0x100 - 1) // 8 + 1 if is_ring(field) else 8 * LIMBS[field]
+
+
 P = {M61: (1 << 61) - 1, M127: (1 << 127) - 1}
 
 u64p = C.POINTER(C.c_uint64)
@@ -124,8 +153,8 @@ class _Base:
 
     def from_bytes(self, field, raw: bytes):
         L = LIMBS[field]
-        n = len(raw) // (8 * L)
-        src = np.frombuffer(raw, dtype=np.uint8).copy()
+        n = len(raw) // byte_size(field)
+        src = np.frombuffer(raw + bytes(16), dtype=np.uint8).copy()  # Z2k::read loads a whole word (z2k_ops.h:109)
         dst = np.zeros((n, L), dtype=np.uint64)
         self._call("from_bytes", C.c_int(field), _b(src), C.c_size_t(n), _p(dst))
         return dst

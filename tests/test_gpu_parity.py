@@ -574,6 +574,91 @@ def test_wire_matrix_image(scl, port, f):
         scl.wire_unpack_matrix(f, raw, capacity=(1, 1))
 
 
+# ------------------------------------------------------------------------------------------------------- rings Z2k<K>
+RING_BITS_REF = sorted(GOLD["rings"], key=lambda k: GOLD["rings"][k]["bits"])
+
+
+@pytest.mark.parametrize("name", RING_BITS_REF)
+def test_ring_against_reference_golden(scl, name):
+    """Z2k<K> on the GPU against vectors emitted by the reference (include/scl/math/z2k.h, test_z2k.cc)"""
+    g = GOLD["rings"][name]
+    f, L = scl.Z2K(g["bits"]), g["limbs"]
+    assert scl.limbs(f) == L and scl.byte_size(f) == g["byte_size"]
+    A = lambda hexes: O.from_ints(ints(hexes), L)
+    eq = lambda t, hexes: O.to_ints(host(scl, t)) == ints(hexes)
+    raw = torch.frombuffer(bytearray(bytes.fromhex(g["from_bytes"]["bytes"])), dtype=torch.uint8).cuda()
+    assert eq(scl.from_bytes(f, raw), g["from_bytes"]["out"])
+    a, b = dev(scl, A(g["ew"]["a"])), dev(scl, A(g["ew"]["b"]))
+    for nm, op in (("add", O.ADD), ("sub", O.SUB), ("mul", O.MUL)):
+        assert eq(scl.ew(f, op, a, b), g["ew"][nm]), nm
+    assert eq(scl.ew(f, O.NEG, a), g["ew"]["neg"])
+    odd = dev(scl, A(g["inverse"]["in"]))
+    assert eq(scl.ew(f, O.INV, odd), g["inverse"]["out"])
+    assert eq(scl.ew(f, O.DIV, b, odd), g["inverse"]["div_b_by_in"])
+    with pytest.raises(scl.SclError) as ei:
+        scl.ew(f, O.INV, dev(scl, O.from_ints([2], L)))
+    assert ei.value.reference_message == g["inverse_even_error"] == "value not invertible modulo 2^K"
+    for c in g["vector_random"]:
+        assert eq(scl.vector_random(f, c["n"], bytes.fromhex(c["seed"])), c["out"])
+    for c in g["additive"]:
+        n = c["n"]
+        sec = A(c["secrets"])
+        sh = scl.additive_share_prg(f, dev(scl, sec), n, bytes.fromhex(c["seed"]))
+        want = soa(A(c["shares"]).reshape(len(sec), n, L))
+        assert np.array_equal(host(scl, sh), want)
+        assert eq(scl.additive_recover(f, sh), c["sum"])
+    assert O.to_ints(scl.dot(f, a, b)) == ints([g["dot"]["out"]])
+    assert O.to_ints(scl.vsum(f, a)) == ints([g["sum"]["out"]])
+    assert eq(scl.scalar_mul(f, a, A([g["scalar_mul"]["scalar"]])[0]), g["scalar_mul"]["out"])
+    for c in g["matmul"]:
+        Cm = scl.matmul(f, dev(scl, A(c["A"]).reshape(c["n"], c["k"], L)), dev(scl, A(c["B"]).reshape(c["k"], c["m"], L)))
+        assert eq(Cm, c["C"])
+
+
+@pytest.mark.parametrize("K", [1, 2, 7, 8, 9, 31, 32, 33, 62, 63, 64, 65, 66, 96, 123, 127, 128])
+def test_ring_vs_oracle(scl, port, K):
+    """every ring width against the CPU restatement at sizes that exercise the vector paths and ragged tails"""
+    f = scl.Z2K(K)
+    L, bs = O.LIMBS[f], O.byte_size(f)
+    for n in (1, 2, 255, 4097):
+        raw = port.prg(b"ring-%d" % K, [2 * n * bs])
+        a, b = port.from_bytes(f, raw[: n * bs]), port.from_bytes(f, raw[n * bs:])
+        rt = torch.frombuffer(bytearray(raw[: n * bs]), dtype=torch.uint8).cuda()
+        assert np.array_equal(host(scl, scl.from_bytes(f, rt)), a)
+        da, db = dev(scl, a), dev(scl, b)
+        for op in (O.ADD, O.SUB, O.MUL):
+            assert np.array_equal(host(scl, scl.ew(f, op, da, db)), port.ew(f, op, a, b)), (K, n, op)
+        assert np.array_equal(host(scl, scl.ew(f, O.NEG, da)), port.ew(f, O.NEG, a))
+        odd = a.copy()
+        odd[:, 0] |= np.uint64(1)
+        assert np.array_equal(host(scl, scl.ew(f, O.INV, dev(scl, odd))), port.ew(f, O.INV, odd))
+        assert np.array_equal(host(scl, scl.ew(f, O.DIV, db, dev(scl, odd))), port.ew(f, O.DIV, b, odd))
+        assert np.array_equal(scl.dot(f, da, db), port.dot(f, a, b))
+        assert np.array_equal(scl.vsum(f, da), port.sum(f, a))
+        assert np.array_equal(host(scl, scl.vector_random(f, n, b"vr", counter0=3)),
+                              port.from_bytes(f, port.prg_blocks(b"vr", 3, (n * bs + 15) // 16)[: n * bs]))
+        assert scl.equals(f, da, da) and (n < 2 or K < 8 or not scl.equals(f, da, db))
+        # equality is modulo 2^K: garbage above bit K does not matter (z2k_ops.h:97-103)
+        if K not in (64, 128):
+            noisy = a.copy()
+            noisy[:, K // 64] |= np.uint64(1) << np.uint64(K % 64)   # bit K: outside the ring
+            assert scl.equals(f, da, dev(scl, noisy))
+            assert np.array_equal(host(scl, scl.ew(f, O.ADD, dev(scl, noisy), db)), port.ew(f, O.ADD, a, b))
+    for n, N in ((1, 5), (3, 1000), (10, 333)):
+        sec = port.from_bytes(f, port.prg(b"rsec", [N * bs]))
+        want = port.additive_share(f, b"radd", sec, n)
+        got = scl.additive_share_prg(f, dev(scl, sec), n, b"radd")
+        assert np.array_equal(host(scl, got), soa(want)), (K, n, N)
+        assert np.array_equal(host(scl, scl.additive_recover(f, got)), sec)
+    A_, B_ = port.from_bytes(f, port.prg(b"rA", [5 * 9 * bs])).reshape(5, 9, L), port.from_bytes(f, port.prg(b"rB", [9 * 70 * bs])).reshape(9, 70, L)
+    assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A_), dev(scl, B_))), port.matmul(f, A_, B_))
+    # the field-only entry points refuse ring tags
+    with pytest.raises(scl.SclError):
+        scl.lagrange_basis(f, 3)
+    with pytest.raises(scl.SclError):
+        scl.wire_pack(f, da)
+
+
 # ---------------------------------------------------------------------------------------------- full size properties
 @pytest.mark.parametrize("f,n,t,N", [(O.M61, 10, 3, 10_000_000), (O.M127, 10, 3, 2_000_000)])
 def test_full_size_round_trip(scl, port, f, n, t, N):

@@ -200,6 +200,67 @@ def test_wire_matrix_image(port, f, name):
         port.unwire_matrix(f, bytes(bad))
 
 
+# ---- rings Z2k<K> (include/scl/math/z2k.h; cases of test/scl/math/test_z2k.cc) ----
+RINGS = sorted(GOLD["rings"])
+
+
+@pytest.mark.parametrize("name", RINGS)
+def test_ring_against_reference_golden(port, name):
+    g = GOLD["rings"][name]
+    f, L = O.Z2K(g["bits"]), g["limbs"]
+    assert O.LIMBS[f] == L and O.byte_size(f) == g["byte_size"]
+    eq(port.from_bytes(f, bytes.fromhex(g["from_bytes"]["bytes"])), g["from_bytes"]["out"])
+    a, b = arr(g["ew"]["a"], L), arr(g["ew"]["b"], L)
+    for nm, op in (("add", O.ADD), ("sub", O.SUB), ("mul", O.MUL)):
+        eq(port.ew(f, op, a, b), g["ew"][nm])
+    eq(port.ew(f, O.NEG, a), g["ew"]["neg"])
+    odd = arr(g["inverse"]["in"], L)
+    eq(port.ew(f, O.INV, odd), g["inverse"]["out"])
+    eq(port.ew(f, O.DIV, b, odd), g["inverse"]["div_b_by_in"])
+    eq(port.ew(f, O.MUL, odd, port.ew(f, O.INV, odd)), ["1"] * len(odd))
+    with pytest.raises(O.OracleError) as ei:
+        port.ew(f, O.INV, port.from_int(f, 2).reshape(1, L))
+    assert ei.value.message == g["inverse_even_error"] == "value not invertible modulo 2^K"  # z2k_ops.h:82
+    for c in g["vector_random"]:
+        eq(port.vector_random(f, bytes.fromhex(c["seed"]), c["n"]), c["out"])
+    for c in g["additive"]:
+        sec = arr(c["secrets"], L)
+        sh = port.additive_share(f, bytes.fromhex(c["seed"]), sec, c["n"])
+        eq(sh, c["shares"])
+        eq(port.additive_recover(f, sh), c["sum"])
+        assert c["sum"] == c["secrets"]
+    eq(port.dot(f, a, b), [g["dot"]["out"]])
+    eq(port.sum(f, a), [g["sum"]["out"]])
+    eq(port.scalar_mul(f, a, arr([g["scalar_mul"]["scalar"]], L)[0]), g["scalar_mul"]["out"])
+    for c in g["matmul"]:
+        eq(port.matmul(f, arr(c["A"], L).reshape(c["n"], c["k"], L), arr(c["B"], L).reshape(c["k"], c["m"], L)), c["C"])
+
+
+def test_ring_known_answers(port):
+    """test/scl/math/test_z2k.cc restated: wrap-around arithmetic of Z2k<62> / Z2k<123>, inverse, bytes"""
+    for K in (62, 123, 32):
+        f, L = O.Z2K(K), O.LIMBS[O.Z2K(K)]
+        I = lambda v: port.from_int(f, v)
+        mod = 1 << K
+        assert O.to_ints(port.ew(f, O.ADD, I(-1).reshape(1, L), I(1).reshape(1, L))) == [0]          # (2^K - 1) + 1 wraps
+        assert O.to_ints(I(-1).reshape(1, L)) == [mod - 1]
+        assert O.to_ints(port.ew(f, O.MUL, I(-1).reshape(1, L), I(-1).reshape(1, L))) == [1]
+        assert O.to_ints(port.ew(f, O.NEG, I(5).reshape(1, L))) == [mod - 5]
+        for v in (1, 3, 12345, -1, 2 ** 31 - 1):
+            inv = O.to_ints(port.ew(f, O.INV, I(v).reshape(1, L)))[0]
+            assert (inv * (v % mod)) % mod == 1
+    # all ring widths, not only the ones the reference harness instantiates
+    rng = np.random.default_rng(5)
+    for K in (2, 7, 8, 9, 31, 33, 63, 66, 96, 127):
+        f, L = O.Z2K(K), O.LIMBS[O.Z2K(K)]
+        x = [int.from_bytes(rng.bytes(16), "little") % (1 << K) | 1 for _ in range(20)]
+        inv = O.to_ints(port.ew(f, O.INV, O.from_ints(x, L)))
+        assert all((a * b) % (1 << K) == 1 for a, b in zip(x, inv)), K
+        raw = rng.bytes(O.byte_size(f) * 9)
+        want = [int.from_bytes(raw[i * O.byte_size(f):(i + 1) * O.byte_size(f)], "little") % (1 << K) for i in range(9)]
+        assert O.to_ints(port.from_bytes(f, raw)) == want
+
+
 # ---- known answers held by the reference's own tests for this path ----
 def test_reference_test_suite_kats(port):
     f, L = O.M61, 1
