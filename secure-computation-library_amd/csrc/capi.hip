@@ -293,6 +293,38 @@ bool small_vandermonde(const BigTable<F>& al, size_t n, size_t t, SmallVdm& sv) 
   return true;
 }
 
+// Blocked small-node form (k_share_blocked): the largest group size G in {8, 6, 4} with every alpha_i^(G-1) < 2^29
+// and every alpha_i^G < 2^32 as integers; 0 if none fits.
+template <class F>
+int blocked_vandermonde(const BigTable<F>& al, size_t n, BlockVdm& bv) {
+  if (g_force_table.load()) return 0;
+  for (int G : {8, 6, 4}) {
+    if (n * (size_t)(G + 1) > (size_t)BlockVdm::CAP) continue;
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; ++i) {
+      const u128 a = al.v[i];
+      if (a >> 29) {
+        ok = false;
+        break;
+      }
+      u128 pw = 1;  // a < 2^29 and pw < 2^32 before each product: no overflow
+      for (int r = 0; r <= G; ++r) {
+        if (r < G) {
+          if (pw >> 29) ok = false;
+          else bv.v[i * G + r] = (u32)pw;
+        } else {
+          if (pw >> 32) ok = false;
+          else bv.v[n * G + i] = (u32)pw;
+        }
+        if (!ok) break;
+        pw *= a;
+      }
+    }
+    if (ok) return G;
+  }
+  return 0;
+}
+
 // every node below 2^SMALL_BITS as an integer / bit pattern -> the Horner kernels' small-constant form
 template <class F>
 bool small_nodes(const BigTable<F>& al, size_t n) {
@@ -965,9 +997,14 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
       const long mode = g_mfma.load();
       SmallVdm probe;
       const bool eligible = n <= 128 && t >= 1 && t <= 63;
-      // measured on MI355X (profiles/r1_probe_mfma.txt): the matrix-core path wins from about
-      // n*(t+1) >= 512 multiply-adds per secret ((40,13): 1.0x, (64,21): 3.5x, (128,42): 3.6x over Horner)
-      if (eligible && (mode > 0 || (mode == 0 && n * (t + 1) >= 512 && !small_vandermonde<F>(al, n, t, probe) &&
+      // measured on MI355X (profiles/r1_probe_mfma.txt, r1_probe_share_paths.txt): against Horner the matrix-core
+      // path wins from about n*(t+1) >= 512 multiply-adds per secret ((64,21): 3.5x, (128,42): 3.6x); where the
+      // blocked small-node kernel applies (t <= 16, small nodes) that one is ahead up to about 1024
+      // ((40,13): 2.5 vs 4.0 ms, (64,16): 2.4 vs 2.0 ms)
+      BlockVdm bprobe;
+      const bool blocked = t <= (size_t)BlockVdm::TMAX && blocked_vandermonde<F>(al, n, bprobe) != 0;
+      const size_t work_min = blocked ? 1024 : 512;
+      if (eligible && (mode > 0 || (mode == 0 && n * (t + 1) >= work_min && !small_vandermonde<F>(al, n, t, probe) &&
                                     !g_force_table.load())))
         return share_mfma(al, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, S(stream));
     }
@@ -980,6 +1017,27 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
           hipLaunchKernelGGL((k_share_small<F, VEC>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream),
                              shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS,
                              coeffs + first * F::LIMBS, coeff_stride, sv, (int)t, (int)n, npacks);
+          LAUNCH_CHECK();
+          return SCL_OK;
+        });
+      }
+    }
+    if constexpr (F::TAG == 0) {  // Mersenne127 gains nothing here (its lazy Horner step is already 4 multiplies + a fold)
+      BlockVdm bv;
+      const int G = (t >= 1 && t <= (size_t)BlockVdm::TMAX) ? blocked_vandermonde<F>(al, n, bv) : 0;
+      if (G) {
+        return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+          constexpr int VEC = decltype(V)::value;
+          u64* sh = shares + first * F::LIMBS;
+          const u64* se = secrets + first * F::LIMBS;
+          const u64* co = coeffs + first * F::LIMBS;
+          const dim3 g(grid_for(npacks)), blk(BLOCK);
+#define BLK_LAUNCH(GG) \
+  hipLaunchKernelGGL((k_share_blocked<F, VEC, GG>), g, blk, 0, S(stream), sh, share_stride, se, co, coeff_stride, bv, (int)t, (int)n, npacks)
+          if (G == 8) BLK_LAUNCH(8);
+          else if (G == 6) BLK_LAUNCH(6);
+          else BLK_LAUNCH(4);
+#undef BLK_LAUNCH
           LAUNCH_CHECK();
           return SCL_OK;
         });

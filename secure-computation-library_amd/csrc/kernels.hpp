@@ -418,6 +418,40 @@ __device__ __forceinline__ void stage_nodes(const BigTable<F>& tab, int n, typen
   __syncthreads();
 }
 
+// One pack with the threshold T known at compile time: the party loop carries no per-term control flow (the
+// wave-uniform "k <= t" tests of horner_rows cost about as much as the arithmetic at t ~ 10).
+template <class F, int VEC, int T, bool SMALLX>
+__device__ __forceinline__ void horner_pack_exact(const typename F::Ctx& ctx, u64* shares, size_t stride,
+                                                  const u64* secrets, const u64* coeffs, size_t cstride,
+                                                  const typename F::E* alpha_lds, const u32* alpha32_lds, int n,
+                                                  size_t off) {
+  Pack<F, VEC> c[T + 1];
+  c[0] = load_pack<F, VEC, true>(secrets + off);
+#pragma unroll
+  for (int k = 1; k <= T; ++k) c[k] = load_pack<F, VEC, true>(coeffs + (size_t)(k - 1) * cstride * F::LIMBS + off);
+  for (int i = 0; i < n; ++i) {
+    Pack<F, VEC> y = c[T];
+    if constexpr (SMALLX) {
+      const u32 x = alpha32_lds[i];
+#pragma unroll
+      for (int k = T - 1; k >= 0; --k) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) y.v[v] = F::muladd_small_lazy(y.v[v], x, c[k].v[v]);
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) y.v[v] = F::canon(y.v[v]);
+    } else {
+      const typename F::E x = alpha_lds[i];
+#pragma unroll
+      for (int k = T - 1; k >= 0; --k) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) y.v[v] = F::add(ctx, F::mul(ctx, y.v[v], x), c[k].v[v]);
+      }
+    }
+    store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
+  }
+}
+
 // shamirSecretShare with explicit coefficients (shamir.h:51-68): c_0 = secret, c_k = coeffs[k-1]
 template <class F, int VEC, int TREG, bool SMALLX>
 __global__ __launch_bounds__(BLOCK) void k_share(typename F::Ctx ctx, u64* shares, size_t stride,
@@ -426,6 +460,20 @@ __global__ __launch_bounds__(BLOCK) void k_share(typename F::Ctx ctx, u64* share
   __shared__ typename F::E alpha[SMALLX ? 1 : BigTable<F>::CAP];
   __shared__ u32 alpha32[SMALLX ? BigTable<F>::CAP : 1];
   stage_nodes<F, SMALLX>(tab, n, alpha, alpha32);
+  if constexpr (TREG == 16 && F::LIMBS <= 2) {  // 5 <= t <= 16: one specialised body per threshold
+    SCL_GRID_STRIDE(q, npacks) {
+      const size_t off = q * VEC * F::LIMBS;
+#define SCL_HX_CASE(T) \
+  case T: horner_pack_exact<F, VEC, T, SMALLX>(ctx, shares, stride, secrets, coeffs, cstride, alpha, alpha32, n, off); break;
+      switch (t) {  // wave-uniform
+        SCL_HX_CASE(5) SCL_HX_CASE(6) SCL_HX_CASE(7) SCL_HX_CASE(8) SCL_HX_CASE(9) SCL_HX_CASE(10) SCL_HX_CASE(11)
+        SCL_HX_CASE(12) SCL_HX_CASE(13) SCL_HX_CASE(14) SCL_HX_CASE(15) SCL_HX_CASE(16)
+        default: break;
+      }
+#undef SCL_HX_CASE
+    }
+    return;
+  }
   SCL_GRID_STRIDE(q, npacks) {
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> c[TREG + 1];
@@ -522,16 +570,22 @@ struct SmallAcc<M127> {
     a[2] += (u64)(u32)(c >> 64) * v;
     a[3] += (u64)(u32)(c >> 96) * v;
   }
-  // c0 + sum_j a_j 2^(32j) mod p: assemble a 192-bit value, then hi*2^128 = 2*hi (mod p)
+  // c0 + sum_j a_j 2^(32j) mod p: the four accumulators overlap by 32 bits, so sum them limb-wise (each limb
+  // sum < 2^34), ripple the carries once, then 2^128 = 2 (mod p)
   __device__ __forceinline__ u128 fold(u128 c0) const {
-    M127::Acc acc = M127::acc_zero();
-    M127::acc_add_raw(acc, c0);
-    M127::acc_add_raw(acc, (u128)a[0]);
-    M127::acc_add_raw(acc, (u128)a[1] << 32);
-    M127::acc_add_raw(acc, (u128)a[2] << 64);
-    M127::acc_add_raw(acc, (u128)a[3] << 96);  // low 32 bits of a3 land in bits 96..127
-    acc.hi += (u64)(a[3] >> 32);                // the rest of a3 is a multiple of 2^128
-    return M127::acc_fold(M127::Ctx{}, acc);
+    u64 l0 = (u64)(u32)a[0] + (u32)c0;
+    u64 l1 = (a[0] >> 32) + (u64)(u32)a[1] + (u32)(c0 >> 32);
+    u64 l2 = (a[1] >> 32) + (u64)(u32)a[2] + (u32)(c0 >> 64);
+    u64 l3 = (a[2] >> 32) + (u64)(u32)a[3] + (u32)(c0 >> 96);
+    u64 l4 = (a[3] >> 32);
+    l1 += l0 >> 32;
+    l2 += l1 >> 32;
+    l3 += l2 >> 32;
+    l4 += l3 >> 32;  // < 2^33
+    const u128 x = (u128)((u64)(u32)l0 | (l1 << 32)) | ((u128)((u64)(u32)l2 | (l3 << 32)) << 64);
+    const u128 v = (x & M127::P()) + (x >> 127) + ((u128)l4 << 1);  // < 2^127 + 2^35
+    const u128 r = (v & M127::P()) + (v >> 127);
+    return r >= M127::P() ? r - M127::P() : r;
   }
 };
 
@@ -574,6 +628,78 @@ __global__ __launch_bounds__(BLOCK) void k_share_small(u64* shares, size_t strid
       if (k <= t) c[k] = load_pack<F, VEC, true>(coeffs + (size_t)(k - 1) * cstride * F::LIMBS + off);
     }
     small_rows<F, VEC>(c, V, t, n, shares, stride, off);
+  }
+}
+
+// Blocked form of the small-node evaluation for larger t: the polynomial is cut into groups of G coefficients,
+//   f(x) = sum_j x^(G j) * g_j(x),   g_j(x) = sum_{r<G} c_{Gj+r} x^r,
+// each g_j(x_i) summed lazily against the small powers x_i^r < 2^29 (one v_mad_u64_u32 per 32-bit limb and
+// term, as in k_share_small) and folded once, the groups then combined by Horner in x_i^G < 2^32 with the
+// field's small-constant step.  Per term that is the bare multiply-accumulate plus 1/G of a fold and a Horner
+// step, against a full lazy Horner step per term in k_share<SMALLX>.
+struct BlockVdm {
+  enum { CAP = 768, TMAX = 16 };
+  u32 v[CAP];  // [n][G] powers x_i^0 .. x_i^(G-1), then x_i^G at v[n*G + i]
+};
+
+// One pack, exact threshold T known at compile time: no per-term control flow in the party loop.
+template <class F, int VEC, int G, int T>
+__device__ __forceinline__ void blocked_pack(u64* shares, size_t stride, const u64* secrets, const u64* coeffs,
+                                             size_t cstride, const u32* V, int n, size_t off) {
+  Pack<F, VEC> c[T + 1];
+  c[0] = load_pack<F, VEC, true>(secrets + off);
+#pragma unroll
+  for (int k = 1; k <= T; ++k) c[k] = load_pack<F, VEC, true>(coeffs + (size_t)(k - 1) * cstride * F::LIMBS + off);
+  for (int i = 0; i < n; ++i) {
+    const u32* row = V + i * G;
+    u32 w[G];
+#pragma unroll
+    for (int r = 1; r < G; ++r) w[r] = row[r];
+    const u32 xg = V[n * G + i];
+    SmallAcc<F> acc[VEC];
+    Pack<F, VEC> y;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v].init();
+#pragma unroll
+    for (int k = T; k >= 0; --k) {
+      if (k % G != 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v].mac(c[k].v[v], w[k % G]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const typename F::E gv = acc[v].fold(c[k].v[v]);  // g_j(x_i), canonical
+          acc[v].init();
+          if (k / G == T / G) y.v[v] = gv;
+          else y.v[v] = F::muladd_small_lazy(y.v[v], xg, gv);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) y.v[v] = F::canon(y.v[v]);
+    store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
+  }
+}
+
+template <class F, int VEC, int G>
+__global__ __launch_bounds__(BLOCK) void k_share_blocked(u64* shares, size_t stride, const u64* secrets,
+                                                         const u64* coeffs, size_t cstride, BlockVdm tab, int t, int n,
+                                                         size_t npacks) {
+  static_assert(G >= 2 && G <= 8, "at most 7 lazy terms per group (SmallAcc bound)");
+  __shared__ u32 V[BlockVdm::CAP];
+  for (int i = threadIdx.x; i < n * (G + 1); i += BLOCK) V[i] = tab.v[i];
+  __syncthreads();
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+#define SCL_BLK_CASE(T) \
+  case T: blocked_pack<F, VEC, G, T>(shares, stride, secrets, coeffs, cstride, V, n, off); break;
+    switch (t) {  // wave-uniform; BlockVdm::TMAX cases
+      SCL_BLK_CASE(1) SCL_BLK_CASE(2) SCL_BLK_CASE(3) SCL_BLK_CASE(4) SCL_BLK_CASE(5) SCL_BLK_CASE(6) SCL_BLK_CASE(7)
+      SCL_BLK_CASE(8) SCL_BLK_CASE(9) SCL_BLK_CASE(10) SCL_BLK_CASE(11) SCL_BLK_CASE(12) SCL_BLK_CASE(13)
+      SCL_BLK_CASE(14) SCL_BLK_CASE(15) SCL_BLK_CASE(16)
+      default: break;
+    }
+#undef SCL_BLK_CASE
   }
 }
 

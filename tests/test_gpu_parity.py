@@ -292,6 +292,41 @@ def test_share_with_explicit_nodes(scl, port, f):
             assert np.array_equal(host(scl, scl.shamir_recover(f, got, lam)), secrets)
 
 
+@pytest.mark.parametrize("f", [O.M61, O.M127, O.GF2_128])
+@pytest.mark.parametrize("n", [5, 10, 40, 128])
+def test_share_every_threshold_up_to_16(scl, port, f, n):
+    """k_share_blocked (Mersenne61, group size 8 / 8 / 6 / 4 for these n) and the per-threshold Horner bodies:
+    every t in 1..16, odd N (vector head + scalar tail), p-1 everywhere in one secret, against the oracle"""
+    L, N = O.LIMBS[f], 131
+    secrets = rand_elems(port, f, N, b"bl-s")
+    allc = rand_elems(port, f, 16 * N, b"bl-c").reshape(N, 16, L)
+    secrets[0] = port.from_int(f, -1)
+    allc[0] = port.from_int(f, -1)
+    allc[N - 1] = port.from_int(f, 0)
+    nodes_big = O.from_ints([811 + 7 * i for i in range(n)], L)   # small nodes whose 4th powers pass 2^29
+    for t in range(1, 17):
+        coeffs = np.ascontiguousarray(allc[:, :t])
+        dco = dev(scl, np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2))))
+        if f == O.GF2_128:   # default nodes are the bit patterns of 1..n (the x++ walk of shamir.h:62-65 cycles 1,0,1,.. here)
+            nodes = O.from_ints(list(range(1, n + 1)), L)
+            want = soa(np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)]))
+        else:
+            want = soa(port.shamir_share_coeffs(f, secrets, coeffs, n))
+        for mode in ((-1, 0), (-1, 1)):      # blocked / small-node kernels, then plain Horner
+            scl.set_tuning("mfma", mode[0])
+            scl.set_tuning("force_table", mode[1])
+            try:
+                got = scl.shamir_share(f, dev(scl, secrets), dco, n)
+            finally:
+                scl.set_tuning("mfma", 0)
+                scl.set_tuning("force_table", 0)
+            assert np.array_equal(host(scl, got), want), (t, mode)
+        if t in (5, 9, 16) and n <= 40:
+            want2 = soa(np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes_big) for s in range(N)]))
+            got2 = scl.shamir_share(f, dev(scl, secrets), dco, n, alphas=nodes_big)
+            assert np.array_equal(host(scl, got2), want2), t
+
+
 @pytest.mark.parametrize("n,t,N", [(128, 42, 300), (40, 13, 257), (10, 3, 1000), (33, 8, 31), (64, 31, 65), (65, 32, 96),
                                    (5, 1, 7), (128, 48, 129), (1, 1, 40), (32, 31, 64)])
 def test_share_on_matrix_cores_vs_oracle(scl, port, n, t, N):
