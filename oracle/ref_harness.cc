@@ -371,6 +371,32 @@ int sclref_shamir_recover_d(int field, const std::uint64_t* shares, std::size_t 
   return 0;
 }
 
+// ss::shamirRecoverC (Berlekamp-Welch) per secret; same output convention as sclo_shamir_recover_c
+int sclref_shamir_recover_c(int field, const std::uint64_t* shares, const std::uint64_t* alphas,
+                            std::size_t count, std::size_t N, std::uint64_t* f_out, std::uint64_t* e_out,
+                            unsigned char* status, unsigned* nerr) {
+  DISPATCH(field, {
+    constexpr auto L = limbs<F>();
+    const std::size_t t = (count - 1) / 3, n = 3 * t + 1;
+    for (std::size_t s = 0; s < N; ++s) {
+      const auto sh = loadVec<F>(shares + s * count * L, count);
+      for (std::size_t j = 0; j < n; ++j) store<F>(f_out + (s * n + j) * L, F{});
+      for (std::size_t j = 0; j <= t; ++j) store<F>(e_out + (s * (t + 1) + j) * L, F{});
+      try {
+        const auto r = alphas ? scl::ss::shamirRecoverC(sh, loadVec<F>(alphas, count)) : scl::ss::shamirRecoverC(sh);
+        for (std::size_t j = 0; j <= r.f.degree() && j < n; ++j) store<F>(f_out + (s * n + j) * L, r.f[j]);
+        for (std::size_t j = 0; j <= r.err.degree() && j <= t; ++j) store<F>(e_out + (s * (t + 1) + j) * L, r.err[j]);
+        nerr[s] = static_cast<unsigned>(r.err.degree());
+        status[s] = 0;
+      } catch (const std::logic_error&) {
+        nerr[s] = 0;
+        status[s] = 1;
+      }
+    }
+  });
+  return 0;
+}
+
 int sclref_lagrange_basis(int field, const std::uint64_t* nodes, std::size_t m,
                           const std::uint64_t* x, std::uint64_t* out, char* err,
                           std::size_t errlen) {

@@ -962,6 +962,13 @@ int sclo_shamir_recover_d(int field, const uint64_t* shares, size_t n, size_t t,
 #undef BODY
 }
 
+int sclo_shamir_recover_c(int field, const uint64_t* shares, const uint64_t* alphas, size_t count, size_t N,
+                          uint64_t* f_out, uint64_t* e_out, unsigned char* status, unsigned* nerr) {
+#define BODY(P) return CAT(P, shamir_recover_c)(shares, alphas, count, N, f_out, e_out, status, nerr);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
 int sclo_lagrange_basis(int field, const uint64_t* nodes, size_t m, const uint64_t* x,
                         uint64_t* out) {
 #define BODY(P) return CAT(P, lagrange_api)(nodes, m, x, out);

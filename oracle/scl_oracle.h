@@ -83,6 +83,12 @@ int sclo_shamir_recover_at(int field, const uint64_t* shares, const uint64_t* al
 /* short overload shamirRecoverD(shares, t): status[s]=1 where the reference throws */
 int sclo_shamir_recover_d(int field, const uint64_t* shares, size_t n, size_t t, size_t N,
                           uint64_t* out, unsigned char* status);
+/* shamirRecoverC (Berlekamp-Welch, shamir.h:202-259) per secret: t = (count-1)/3, the first n = 3t+1 shares are
+ * used.  f_out [N][n] = coefficients of the corrected polynomial (zero padded), e_out [N][t+1] = the monic error
+ * locator (zero padded), nerr[N] its degree; status[s] = 1 where the reference throws "could not correct shares"
+ * (outputs zeroed). */
+int sclo_shamir_recover_c(int field, const uint64_t* shares, const uint64_t* alphas, size_t count, size_t N,
+                          uint64_t* f_out, uint64_t* e_out, unsigned char* status, unsigned* nerr);
 int sclo_lagrange_basis(int field, const uint64_t* nodes, size_t m, const uint64_t* x,
                         uint64_t* out);
 

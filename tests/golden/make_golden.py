@@ -136,6 +136,35 @@ def gen_montgomery_field(ref, f):
     return fd
 
 
+def gen_recover_c(ref, f, rng):
+    """shamirRecoverC (Berlekamp-Welch, shamir.h:202-259; test/scl/ss/test_shamir.cc:111-160 restated at more
+    shapes): shares with 0 .. t+2 corrupted positions, so both the correcting and the failing regime are held"""
+    L = O.LIMBS[f]
+    out = []
+    for (n, t) in ((4, 1), (7, 2), (10, 3), (13, 4), (12, 3)):
+        N = 2 * (t + 3)
+        secrets = ref.from_bytes(f, rng.bytes(8 * L * N))
+        shares = ref.shamir_share(f, b"recover-c", secrets, t, n)
+        for s in range(N):
+            for i in rng.choice(n, size=min(s % (t + 3), n), replace=False):
+                shares[s, i] = ref.from_bytes(f, rng.bytes(8 * L))[0]
+        shares[N - 1] = 0
+        fo, eo, st, ne = ref.shamir_recover_c(f, shares)
+        out.append({"n": n, "t": t, "secrets": hx(secrets), "shares": hx(shares), "f": hx(fo), "err": hx(eo),
+                    "status": st.tolist(), "nerr": ne.tolist()})
+    al = np.stack([ref.from_int(f, v) for v in (42, 43, 44, 45, 46, 47, 48)])
+    sec = ref.from_bytes(f, rng.bytes(8 * L * 5))
+    co = ref.from_bytes(f, rng.bytes(8 * L * 10)).reshape(5, 2, L)
+    sh = np.stack([ref.poly_eval(f, np.concatenate([sec[s:s + 1], co[s]]), al) for s in range(5)])
+    sh[1, 2] = ref.from_int(f, 7)
+    sh[2, 0] = ref.from_int(f, 9)
+    sh[2, 6] = ref.from_int(f, 9)
+    fo, eo, st, ne = ref.shamir_recover_c(f, sh, al)
+    out.append({"n": 7, "t": 2, "alphas": hx(al), "secrets": hx(sec), "shares": hx(sh), "f": hx(fo), "err": hx(eo),
+                "status": st.tolist(), "nerr": ne.tolist()})
+    return out
+
+
 def gen_ring(ref, K):
     """Z2k<K> (include/scl/math/z2k.h:39-320; cases of test/scl/math/test_z2k.cc restated): values cross as the
     masked little-endian word Z2k::write emits, zero-extended to 1 (K <= 64) or 2 limbs"""
@@ -343,6 +372,8 @@ def main():
 
     doc["fields"]["secp256k1_order"] = gen_montgomery_field(ref, O.SECP256K1_SCALAR)
 
+    for name, f in (("Mersenne61", O.M61), ("Mersenne127", O.M127), ("secp256k1_order", O.SECP256K1_SCALAR)):
+        doc["fields"][name]["recover_c"] = gen_recover_c(ref, f, np.random.default_rng(77 + f))
     doc["rings"] = {f"Z2k<{K}>": gen_ring(ref, K) for K in O.REF_RING_BITS}
 
     path = os.path.join(HERE, "golden_v1.json")

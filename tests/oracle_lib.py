@@ -223,6 +223,22 @@ class _Base:
                    _p(out), _b(status))
         return out, status
 
+    def shamir_recover_c(self, field, shares, alphas=None):
+        """shamirRecoverC per secret: shares [N][count][L] -> (f [N][3t+1][L], err [N][t+1][L], status [N], nerr [N])"""
+        L = LIMBS[field]
+        shares = np.ascontiguousarray(shares, dtype=np.uint64)
+        N, count = shares.shape[0], shares.shape[1]
+        t = (count - 1) // 3
+        n = 3 * t + 1
+        f = np.zeros((N, n, L), dtype=np.uint64)
+        e = np.zeros((N, t + 1, L), dtype=np.uint64)
+        status = np.zeros(N, dtype=np.uint8)
+        nerr = np.zeros(N, dtype=np.uint32)
+        al = _arr(alphas, L) if alphas is not None else None
+        self._call("shamir_recover_c", C.c_int(field), _p(shares), _p(al) if al is not None else None, C.c_size_t(count),
+                   C.c_size_t(N), _p(f), _p(e), status.ctypes.data_as(u8p), nerr.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return f, e, status, nerr
+
     def lagrange_basis(self, field, nodes, x):
         L = LIMBS[field]
         nodes, x = _arr(nodes, L), _arr(x, L)

@@ -200,6 +200,26 @@ def test_wire_matrix_image(port, f, name):
         port.unwire_matrix(f, bytes(bad))
 
 
+@pytest.mark.parametrize("f,name", FIELDS)
+def test_recover_c_berlekamp_welch(port, f, name):
+    """shamirRecoverC against the reference's outputs, correcting and failing regimes alike"""
+    L = O.LIMBS[f]
+    for c in GOLD["fields"][name]["recover_c"]:
+        n, t = c["n"], c["t"]
+        N = len(c["status"])
+        shares = arr(c["shares"], L).reshape(N, n, L)
+        al = arr(c["alphas"], L) if "alphas" in c else None
+        fo, eo, st, ne = port.shamir_recover_c(f, shares, al)
+        eq(fo, c["f"])
+        eq(eo, c["err"])
+        assert st.tolist() == c["status"] and ne.tolist() == c["nerr"]
+        # up to t corrupted shares: the secret comes back and the locator has one root per corrupted share
+        secrets = arr(c["secrets"], L)
+        for s in range(N - 1):
+            if "alphas" not in c and n == 3 * t + 1 and s % (t + 3) <= t:
+                assert st[s] == 0 and ne[s] == s % (t + 3) and np.array_equal(fo[s, 0], secrets[s])
+
+
 # ---- rings Z2k<K> (include/scl/math/z2k.h; cases of test/scl/math/test_z2k.cc) ----
 RINGS = sorted(GOLD["rings"])
 
