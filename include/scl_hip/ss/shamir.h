@@ -175,6 +175,69 @@ T shamirRecoverD(const math::Vector<T>& shares, std::size_t t) {
   return shamirRecoverD(shares, math::Vector<T>::range(1, n + 1), t, t, T{});
 }
 
+// ------------------------------------------------------------------------------- error correction
+/// what shamirRecoverC returns per secret (shamir.h:160-180): the corrected polynomial (the secret is
+/// f.evaluate(0)) and the monic error locator, whose roots are the nodes of the corrupted shares
+template <typename T>
+struct ErrorCorrectedSecret {
+  math::Polynomial<T> f;
+  math::Polynomial<T> err;
+};
+
+/// batch shamirRecoverC (Berlekamp-Welch, shamir.h:202-259) over device-resident shares: t = (parties-1)/3, the
+/// first 3t+1 share vectors are used.  Row k of `f` / `err` holds coefficient k for every secret (zero padded).
+template <typename T>
+struct ErrorCorrectedBatch {
+  hip::ShareMatrix<T> f;      ///< [3t+1][N]; row 0 = the secrets
+  hip::ShareMatrix<T> err;    ///< [t+1][N]
+  std::vector<unsigned char> status;  ///< 1 where the reference throws "could not correct shares"
+  std::vector<unsigned> errors;       ///< degree of the locator = number of shares corrected
+  std::size_t solved = 0;     ///< secrets that needed the linear systems (the others were already consistent)
+  std::size_t failed = 0;
+
+  ErrorCorrectedSecret<T> at(std::size_t s) const {
+    if (status[s]) throw std::logic_error("could not correct shares");
+    return {math::Polynomial<T>::create(math::Vector<T>(f.sharesOf(s))),
+            math::Polynomial<T>::create(math::Vector<T>(err.sharesOf(s)))};
+  }
+};
+
+template <typename T>
+ErrorCorrectedBatch<T> shamirRecoverC(const hip::ShareMatrix<T>& shares, const math::Vector<T>* alphas = nullptr) {
+  const std::size_t m = shares.parties(), N = shares.secrets();
+  if (m == 0) throw std::invalid_argument("no shares");
+  const std::size_t t = (m - 1) / 3, n = 3 * t + 1;
+  ErrorCorrectedBatch<T> out{hip::ShareMatrix<T>(n, N), hip::ShareMatrix<T>(t + 1, N), {}, {}, 0, 0};
+  hip::DeviceBuffer status(N ? N : 1), nerr((N ? N : 1) * sizeof(unsigned));
+  std::vector<std::uint64_t> al;
+  if (alphas) al = shamir_detail::toLimbs(alphas->subVector(n));
+  hip::check(scl_hip_shamir_recover_correct(T::Field::TAG, out.f.data(), out.f.stride(), out.err.data(), out.err.stride(),
+                                            static_cast<unsigned char*>(status.get()),
+                                            static_cast<unsigned*>(nerr.get()), shares.data(), shares.stride(), m, N,
+                                            alphas ? al.data() : nullptr, &out.solved, &out.failed, nullptr));
+  out.status.resize(N);
+  out.errors.resize(N);
+  if (N) {
+    hip::check(scl_hip_memcpy_d2h(out.status.data(), status.get(), N, nullptr));
+    hip::check(scl_hip_memcpy_d2h(out.errors.data(), nerr.get(), N * sizeof(unsigned), nullptr));
+  }
+  return out;
+}
+
+/// shamirRecoverC(shares, alphas) (shamir.h:202-250)
+template <typename T>
+ErrorCorrectedSecret<T> shamirRecoverC(const math::Vector<T>& shares, const math::Vector<T>& alphas) {
+  const auto sm = shamir_detail::upload(shares, shares.size());
+  return shamirRecoverC(sm, &alphas).at(0);
+}
+
+/// shamirRecoverC(shares) (shamir.h:255-259): nodes 1..size
+template <typename T>
+ErrorCorrectedSecret<T> shamirRecoverC(const math::Vector<T>& shares) {
+  const auto sm = shamir_detail::upload(shares, shares.size());
+  return shamirRecoverC<T>(sm, nullptr).at(0);
+}
+
 }  // namespace scl::ss
 
 #endif

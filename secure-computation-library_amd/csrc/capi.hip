@@ -1214,6 +1214,110 @@ int scl_hip_shamir_recover_detect(int field, uint64_t* out, unsigned char* statu
   });
 }
 
+// Batched shamirRecoverC (Berlekamp-Welch, shamir.h:202-259).
+int scl_hip_shamir_recover_correct(int field, uint64_t* f_out, size_t f_stride, uint64_t* e_out, size_t e_stride,
+                                   unsigned char* status, unsigned* nerr, const uint64_t* shares, size_t stride,
+                                   size_t m, size_t N, const uint64_t* alphas_host, size_t* num_queued_host,
+                                   size_t* num_failed_host, void* stream) {
+  if (num_queued_host) *num_queued_host = 0;
+  if (num_failed_host) *num_failed_host = 0;
+  if (m == 0) return fail(SCL_ERR_BAD_ARG, "recover_correct: need at least one share");
+  if (N == 0) return SCL_OK;
+  if (!f_out || !e_out || !status || !nerr || !shares) return fail(SCL_ERR_BAD_ARG, "NULL operand");
+  if (stride < N || f_stride < N || e_stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
+  if (N > 0xFFFFFFFFull) return fail(SCL_ERR_BAD_ARG, "recover_correct: at most 2^32 - 1 secrets per call");
+  const size_t t = (m - 1) / 3, n = 3 * t + 1, d1 = t + 1, nchk = n - d1;  // shamir.h:205-206: the first 3t+1 shares
+  if (n > (size_t)BW_WAVE) return fail(SCL_ERR_BAD_ARG, "recover_correct: at most 64 shares (t <= 21)");
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    typedef typename F::E E;
+    SCL_TRY(check_align<F>({f_out, e_out, shares}));
+    if (n > (size_t)BigTable<F>::CAP) return fail(SCL_ERR_BAD_ARG, "recover_correct: too many shares for this field's node table");
+    std::vector<E> alphas;
+    if (alphas_host) load_host<F>(alphas_host, n, alphas);
+    else default_nodes<F>(ctx, n, alphas);
+    alphas.resize(n);
+    // L = [ nchk rows: share d1+r from the first d1 | d1 rows: coefficient k of the interpolant ]
+    std::vector<E> ns(alphas.begin(), alphas.begin() + d1), L((nchk + d1) * d1);
+    for (size_t r = 0; r < nchk; ++r) SCL_TRY(lagrange<F>(ctx, ns, alphas[d1 + r], L.data() + r * d1));
+    {
+      // coefficients of l_i(x) = prod_{j != i} (x - a_j) / (a_i - a_j): master polynomial P = prod (x - a_j), then
+      // P / (x - a_i) by synthetic division, scaled by 1 / P'(a_i)
+      std::vector<E> P(d1 + 1, F::zero()), q(d1);
+      P[0] = F::one(ctx);
+      for (size_t j = 0; j < d1; ++j) {  // multiply by (x - a_j)
+        for (size_t k = j + 1; k > 0; --k) P[k] = F::sub(ctx, P[k - 1], F::mul(ctx, P[k], ns[j]));
+        P[0] = F::neg(ctx, F::mul(ctx, P[0], ns[j]));
+      }
+      for (size_t i = 0; i < d1; ++i) {
+        E den = F::one(ctx);
+        for (size_t j = 0; j < d1; ++j) {
+          if (j == i) continue;
+          const E d = F::sub(ctx, ns[i], ns[j]);
+          if (F::is_zero(d)) return fail(SCL_ERR_ZERO_INVERSE, scl_hip_status_message(SCL_ERR_ZERO_INVERSE));
+          den = F::mul(ctx, den, d);
+        }
+        const E dinv = F::inv(ctx, den);
+        E carry = P[d1];  // = 1
+        for (size_t k = d1; k > 0; --k) {
+          q[k - 1] = carry;
+          carry = F::add(ctx, P[k - 1], F::mul(ctx, carry, ns[i]));
+        }
+        for (size_t k = 0; k < d1; ++k) L[(nchk + k) * d1 + i] = F::mul(ctx, q[k], dinv);
+      }
+    }
+    // duplicates anywhere among the n nodes would make every system singular
+    for (size_t i = 0; i < n; ++i)
+      for (size_t j = i + 1; j < n; ++j)
+        if (F::eq(alphas[i], alphas[j])) return fail(SCL_ERR_ZERO_INVERSE, scl_hip_status_message(SCL_ERR_ZERO_INVERSE));
+    std::vector<u64> Ll(L.size() * F::LIMBS);
+    for (size_t i = 0; i < L.size(); ++i) F::st(Ll.data() + i * F::LIMBS, L[i]);
+    const size_t lbytes = Ll.size() * 8;
+    const size_t solve_bytes = bw_lds_elems(n) * sizeof(E);
+    if (lbytes > 150 * 1024 || solve_bytes > 150 * 1024)
+      return fail(SCL_ERR_BAD_ARG, "recover_correct: the systems for this many shares exceed LDS");
+    void* sc;
+    SCL_TRY(scratch(lbytes + 64, &sc));
+    unsigned* counters = static_cast<unsigned*>(sc);  // [0] queued, [1] failed
+    u64* L_dev = reinterpret_cast<u64*>(static_cast<unsigned char*>(sc) + 64);
+    void* queue = nullptr;
+    HIP_TRY(hipMallocAsync(&queue, N * sizeof(unsigned), S(stream)));
+    auto body = [&]() -> int {
+      HIP_TRY(hipMemsetAsync(counters, 0, 8, S(stream)));
+      HIP_TRY(hipMemcpyAsync(L_dev, Ll.data(), lbytes, hipMemcpyHostToDevice, S(stream)));
+      if (lbytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bw_consistent<F>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbytes));
+      hipLaunchKernelGGL((k_bw_consistent<F>), dim3(grid_for(N)), dim3(BLOCK), lbytes, S(stream), ctx, f_out, f_stride,
+                         e_out, e_stride, status, nerr, shares, stride, L_dev, (int)d1, (int)nchk, N,
+                         static_cast<unsigned*>(queue), counters);
+      LAUNCH_CHECK();
+      unsigned h[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, S(stream)));
+      HIP_TRY(hipStreamSynchronize(S(stream)));
+      if (num_queued_host) *num_queued_host = h[0];
+      if (h[0] == 0) return SCL_OK;
+      BigTable<F> nodes;
+      for (size_t i = 0; i < n; ++i) nodes.v[i] = alphas[i];
+      if (solve_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bw_solve<F>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_bytes));
+      const unsigned grid = h[0] < 8192u ? h[0] : 8192u;
+      hipLaunchKernelGGL((k_bw_solve<F>), dim3(grid), dim3(BW_WAVE), solve_bytes, S(stream), ctx, f_out, f_stride, e_out,
+                         e_stride, status, nerr, shares, stride, nodes, (int)n, static_cast<const unsigned*>(queue), h[0],
+                         counters + 1);
+      LAUNCH_CHECK();
+      HIP_TRY(hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, S(stream)));
+      HIP_TRY(hipStreamSynchronize(S(stream)));
+      if (num_failed_host) *num_failed_host = h[1];
+      return SCL_OK;
+    };
+    const int rc = body();
+    (void)hipFreeAsync(queue, S(stream));
+    return rc;
+  });
+}
+
 // ---- additive ------------------------------------------------------------------------------------------------------
 int scl_hip_additive_share(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets,
                            const uint64_t* rnd, size_t rnd_stride, size_t N, size_t n, void* stream) {

@@ -1193,6 +1193,160 @@ __global__ __launch_bounds__(BLOCK) void k_recover_detect(typename F::Ctx ctx, u
   if (local_bad) atomicAdd(bad_count, local_bad);
 }
 
+// ---- error-correcting recovery: shamirRecoverC (Berlekamp-Welch, shamir.h:202-259) ----------------------------
+// What the reference computes per secret is fixed by algebra, not by its elimination order: for e = t, t-1, .. 0
+// it builds the n x n system  s_i E(a_i) = Q(a_i)  (E monic of degree e, deg Q <= n-1-e, n = 3t+1) and takes the
+// first e whose matrix is NONSINGULAR (solveLinearSystem accepts unique solutions only, matrix.h:811-828); then
+// f = Q / E, and a non-zero remainder is "could not correct shares".  e = 0 is plain interpolation and always
+// succeeds.  Two kernels:
+//   k_bw_consistent  one thread per secret: if the n shares lie on one polynomial of degree <= t (the common
+//                    case; then every e > 0 system is singular and e = 0 returns that polynomial) write its
+//                    coefficients and E = 1, else queue the secret;
+//   k_bw_solve       one wavefront per queued secret: the systems, in LDS, by Gauss-Jordan with lanes over rows.
+// L is [(nchk + d1)][d1] row-major: nchk rows that re-derive share d1+r from the first d1 = t+1 shares, then d1
+// rows that give coefficient k of the interpolant.
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_bw_consistent(typename F::Ctx ctx, u64* f_out, size_t f_stride, u64* e_out,
+                                                         size_t e_stride, unsigned char* status, unsigned* nerr,
+                                                         const u64* shares, size_t stride, const u64* L_dev, int d1,
+                                                         int nchk, size_t N, unsigned* queue, unsigned* queued) {
+  extern __shared__ unsigned char smem_raw[];
+  typename F::E* L = reinterpret_cast<typename F::E*>(smem_raw);
+  for (int i = threadIdx.x; i < (nchk + d1) * d1; i += BLOCK) L[i] = F::ld(L_dev + (size_t)i * F::LIMBS);
+  __syncthreads();
+  const int n = d1 + nchk;
+  SCL_GRID_STRIDE(s, N) {
+    bool bad = false;
+    for (int r = 0; r < nchk + d1; ++r) {
+      if (r == nchk && bad) break;  // inconsistent: the coefficient rows are not needed
+      typename F::Acc acc = F::acc_zero();
+      for (int k = 0; k < d1; ++k) F::mac(ctx, acc, L[r * d1 + k], F::ld(shares + ((size_t)k * stride + s) * F::LIMBS));
+      const typename F::E y = F::acc_fold(ctx, acc);
+      if (r < nchk) bad |= !F::eq(y, F::ld(shares + ((size_t)(d1 + r) * stride + s) * F::LIMBS));
+      else F::st(f_out + ((size_t)(r - nchk) * f_stride + s) * F::LIMBS, y);
+    }
+    if (bad) {
+      queue[atomicAdd(queued, 1u)] = (unsigned)s;
+    } else {
+      for (int k = d1; k < n; ++k) F::st(f_out + ((size_t)k * f_stride + s) * F::LIMBS, F::zero());
+      F::st(e_out + s * F::LIMBS, F::one(ctx));
+      for (int k = 1; k < d1; ++k) F::st(e_out + ((size_t)k * e_stride + s) * F::LIMBS, F::zero());
+      status[s] = 0;
+      nerr[s] = 0;
+    }
+  }
+}
+
+constexpr int BW_WAVE = 64;
+
+// LDS elements k_bw_solve needs for n shares (t = (n-1)/3): the augmented matrix, the nodes, the shares, the
+// quotient and the locator
+inline size_t bw_lds_elems(size_t n) { return n * (n + 1) + 3 * n + (n - 1) / 3 + 1; }
+
+template <class F>
+__global__ __launch_bounds__(BW_WAVE) void k_bw_solve(typename F::Ctx ctx, u64* f_out, size_t f_stride, u64* e_out,
+                                                      size_t e_stride, unsigned char* status, unsigned* nerr,
+                                                      const u64* shares, size_t stride, BigTable<F> nodes, int n,
+                                                      const unsigned* queue, unsigned nqueued, unsigned* failed) {
+  typedef typename F::E E;
+  extern __shared__ unsigned char smem_raw[];
+  const int t = (n - 1) / 3, m = n + 1, lane = threadIdx.x;
+  E* M = reinterpret_cast<E*>(smem_raw);  // [n][m]
+  E* al = M + (size_t)n * m;              // [n]
+  E* sh = al + n;                         // [n]
+  E* fq = sh + n;                         // [n] quotient
+  E* ec = fq + n;                         // [t+1] locator
+  if (lane < n) al[lane] = nodes.v[lane];
+  for (unsigned item = blockIdx.x; item < nqueued; item += gridDim.x) {
+    const size_t s = queue[item];
+    __syncthreads();
+    if (lane < n) sh[lane] = F::ld(shares + ((size_t)lane * stride + s) * F::LIMBS);
+    __syncthreads();
+    int e = t;
+    for (; e >= 0; --e) {
+      // row i of [A | b] (shamir.h:217-231): s a^j for j < e, -1 at e, -a^(j-e) above, b = -s a^e
+      if (lane < n) {
+        E* row = M + (size_t)lane * m;
+        const E a = al[lane], si = sh[lane];
+        E v = si;
+        for (int j = 0; j < e; ++j) {
+          row[j] = v;
+          v = F::mul(ctx, v, a);
+        }
+        row[n] = F::neg(ctx, v);
+        v = F::neg(ctx, F::one(ctx));
+        for (int j = e; j < n; ++j) {
+          row[j] = v;
+          v = F::mul(ctx, v, a);
+        }
+      }
+      __syncthreads();
+      bool singular = false;
+      for (int c = 0; c < n; ++c) {
+        const bool nz = lane >= c && lane < n && !F::is_zero(M[(size_t)lane * m + c]);
+        const unsigned long long cand = __ballot(nz);
+        if (cand == 0) {  // wave-uniform: no pivot in this column, the matrix is singular
+          singular = true;
+          break;
+        }
+        const int p = __ffsll((long long)cand) - 1;
+        if (p != c) {
+          for (int j = lane; j < m; j += BW_WAVE) {
+            const E tmp = M[(size_t)p * m + j];
+            M[(size_t)p * m + j] = M[(size_t)c * m + j];
+            M[(size_t)c * m + j] = tmp;
+          }
+          __syncthreads();
+        }
+        const E pv = F::inv(ctx, M[(size_t)c * m + c]);
+        __syncthreads();
+        for (int j = lane; j < m; j += BW_WAVE) M[(size_t)c * m + j] = F::mul(ctx, M[(size_t)c * m + j], pv);
+        __syncthreads();
+        if (lane < n && lane != c) {
+          E* row = M + (size_t)lane * m;
+          const E tk = row[c];
+          if (!F::is_zero(tk)) {
+            const E nt = F::neg(ctx, tk);
+            for (int j = c; j < m; ++j) row[j] = F::add(ctx, row[j], F::mul(ctx, M[(size_t)c * m + j], nt));
+          }
+        }
+        __syncthreads();
+      }
+      if (!singular) break;
+      __syncthreads();
+    }
+    // the e = 0 system is a Vandermonde system, nonsingular for distinct nodes (the host checks them)
+    const bool solved = e >= 0;
+    if (!solved) e = 0;
+    // x_j = M[j][n]; E = x[0..e) then 1, Q = x[e..n)
+    bool ok = solved;
+    if (lane == 0 && solved) {
+      for (int j = 0; j <= t; ++j) ec[j] = j < e ? M[(size_t)j * m + n] : (j == e ? F::one(ctx) : F::zero());
+      const int qn = n - e;  // Q has qn coefficients; reuse column n of M as the running remainder
+      for (int j = 0; j < n; ++j) fq[j] = F::zero();
+      for (int d = qn - 1 - e; d >= 0; --d) {  // synthetic division by the monic E
+        const E lead = M[(size_t)(e + d + e) * m + n];
+        fq[d] = lead;
+        for (int j = 0; j < e; ++j) {
+          E& r = M[(size_t)(e + d + j) * m + n];
+          r = F::sub(ctx, r, F::mul(ctx, lead, ec[j]));
+        }
+      }
+      const int rem = qn - 1 - e >= 0 ? e : qn;  // remainder coefficients left in Q[0..rem)
+      for (int j = 0; j < rem; ++j) ok = ok && F::is_zero(M[(size_t)(e + j) * m + n]);
+    }
+    ok = __shfl((int)ok, 0) != 0;
+    __syncthreads();
+    for (int k = lane; k < n; k += BW_WAVE) F::st(f_out + ((size_t)k * f_stride + s) * F::LIMBS, ok ? fq[k] : F::zero());
+    for (int k = lane; k <= t; k += BW_WAVE) F::st(e_out + ((size_t)k * e_stride + s) * F::LIMBS, ok ? ec[k] : F::zero());
+    if (lane == 0) {
+      status[s] = ok ? 0 : 1;
+      nerr[s] = ok ? (unsigned)e : 0u;
+      if (!ok) atomicAdd(failed, 1u);
+    }
+  }
+}
+
 // ---- matrices ---------------------------------------------------------------------------------------
 // Matrix::multiply (matrix.h:477-495): C[M x N] = A[M x K] * B[K x N].  One thread per column j,
 // RM rows of A at a time (A tile in LDS, wave-uniform reads), B streamed coalesced.

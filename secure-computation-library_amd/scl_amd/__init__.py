@@ -263,6 +263,26 @@ def shamir_recover_detect(field, shares, t: int, d: int | None = None, alphas=No
     return out, status[:N], bad.value
 
 
+def shamir_recover_correct(field, shares, alphas=None):
+    """Batched shamirRecoverC (Berlekamp-Welch).  shares [m][N][L] -> dict(f [3t+1][N][L], err [t+1][N][L],
+    status uint8 [N], nerr int32 [N], queued, failed); the secrets are f[0]."""
+    L = limbs(field)
+    m, N = shares.shape[0], shares.shape[1]
+    t = (m - 1) // 3
+    n = 3 * t + 1
+    f = empty(field, n, N, device=shares.device)
+    e = empty(field, t + 1, N, device=shares.device)
+    status = torch.empty(max(N, 1), dtype=torch.uint8, device=shares.device)
+    nerr = torch.empty(max(N, 1), dtype=torch.int32, device=shares.device)
+    al = _host(alphas).reshape(-1, L) if alphas is not None else None
+    queued, failed = C.c_size_t(0), C.c_size_t(0)
+    _chk(lib.scl_hip_shamir_recover_correct(field, _dev(f), C.c_size_t(N), _dev(e), C.c_size_t(N), _dev(status), _dev(nerr),
+                                            _dev(shares), C.c_size_t(N), C.c_size_t(m), C.c_size_t(N),
+                                            _hp(al) if al is not None else None, C.byref(queued), C.byref(failed),
+                                            _stream()))
+    return {"f": f, "err": e, "status": status[:N], "nerr": nerr[:N], "queued": queued.value, "failed": failed.value}
+
+
 # ---- additive ----------------------------------------------------------------------------------------------------
 def additive_share(field, secrets, rnd, n: int, out=None):
     N = secrets.shape[0]

@@ -470,6 +470,80 @@ TEST_CASE(shamir_gpu, "ss::shamir*", true) {
   }
 }
 
+TEST_CASE(recover_c_gpu, "ss::shamirRecoverC (Berlekamp-Welch)", true) {
+  // test/scl/ss/test_shamir.cc:111-126
+  {
+    auto prg = util::PRG::create("shamir correct");
+    auto shares = ss::shamirSecretShare(F61(123), 2, 7, prg);
+    REQUIRE(ss::shamirRecoverC(shares).f.evaluate(F61{0}) == F61(123));
+    shares[0] = F61(22);
+    shares[1] = F61(23);
+    const auto r = ss::shamirRecoverC(shares);
+    REQUIRE(r.f.evaluate(F61{0}) == F61(123));
+    REQUIRE(r.err.degree() == 2);
+    REQUIRE(r.err.evaluate(F61(1)) == F61(0));
+    REQUIRE(r.err.evaluate(F61(2)) == F61(0));
+    shares[2] = F61(24);
+    REQUIRE_THROWS_MSG(ss::shamirRecoverC(shares), std::logic_error, "could not correct shares");
+  }
+  // test_shamir.cc:128-142: nodes 42..49 (one more node than shares, as there)
+  {
+    auto prg = util::PRG::create("shamir correct2");
+    const auto alphas = math::Vector<F61>::range(42, 50);
+    const auto coeffs = math::Vector<F61>::random(3, prg);
+    std::vector<F61> c = {F61(123), coeffs[1], coeffs[2]};
+    const auto p = math::Polynomial<F61>::create(math::Vector<F61>(c));
+    std::vector<F61> sv;
+    for (int i = 0; i < 7; ++i) sv.push_back(p.evaluate(alphas[i]));
+    math::Vector<F61> shares(sv);
+    REQUIRE(ss::shamirRecoverC(shares, alphas).f.constantTerm() == F61(123));
+    shares[4] = F61(5555);
+    const auto r = ss::shamirRecoverC(shares, alphas);
+    REQUIRE(r.f.constantTerm() == F61(123));
+    REQUIRE(r.err.evaluate(alphas[4]) == F61(0));
+  }
+  // batch: 500 secrets, every third one with up to t corrupted shares
+  {
+    std::vector<F61> secrets;
+    for (int s = 0; s < 500; ++s) secrets.emplace_back(s * 7 + 1);
+    auto prg = util::PRG::create("bw-batch");
+    const std::size_t t = 3, n = 10;
+    const auto m = ss::shamirSecretShare(hip::DeviceVector<F61>(secrets), t, n, prg);
+    // pull to the host, corrupt, push back
+    std::vector<std::vector<F61>> rows;
+    for (std::size_t i = 0; i < n; ++i) {
+      std::vector<std::uint64_t> l(500);
+      hip::check(scl_hip_memcpy_d2h(l.data(), m.row(i), 500 * 8, nullptr));
+      hip::check(scl_hip_stream_sync(nullptr));
+      std::vector<F61> r;
+      for (auto v : l) r.push_back(F61::fromLimbs(&v));
+      rows.push_back(r);
+    }
+    for (int s = 0; s < 500; s += 3)
+      for (int k = 0; k < (s / 3) % 4; ++k) rows[(s + 3 * k) % n][s] = F61(99 + k);
+    hip::ShareMatrix<F61> bad(n, 500);
+    for (std::size_t i = 0; i < n; ++i) {
+      std::vector<std::uint64_t> l(500);
+      for (int s = 0; s < 500; ++s) rows[i][s].toLimbs(&l[s]);
+      hip::check(scl_hip_memcpy_h2d(bad.data() + i * 500, l.data(), 500 * 8, nullptr));
+      hip::check(scl_hip_stream_sync(nullptr));  // l dies with this iteration
+    }
+    const auto r = ss::shamirRecoverC(bad);
+    REQUIRE(r.failed == 0);
+    REQUIRE(r.solved > 0 && r.solved <= 167);
+    REQUIRE(math::Vector<F61>(r.f.sharesOf(0)).size() == 10);
+    bool all = true;
+    for (int s = 0; s < 500; ++s) all = all && r.at(s).f.evaluate(F61{0}) == secrets[s];
+    if (!all) {
+      for (int s = 0; s < 13; ++s)
+        std::printf("    s=%d status=%d errors=%u f0=%s want=%s\n", s, (int)r.status[s], r.errors[s],
+                    r.status[s] ? "-" : r.at(s).f.evaluate(F61{0}).toString().c_str(), secrets[s].toString().c_str());
+    }
+    REQUIRE(all);
+    REQUIRE(r.errors[3] == 1 && r.errors[6] == 2 && r.errors[9] == 3 && r.errors[1] == 0);
+  }
+}
+
 TEST_CASE(additive_gpu, "ss::additiveShare", true) {
   // test/scl/ss/test_additive.cc:26-41
   auto prg = util::PRG::create();

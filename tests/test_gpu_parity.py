@@ -609,6 +609,106 @@ def test_wire_matrix_image(scl, port, f):
         scl.wire_unpack_matrix(f, raw, capacity=(1, 1))
 
 
+# ------------------------------------------------------------------------------------ Berlekamp-Welch (shamirRecoverC)
+def _check_recover_c(scl, port, f, shares_aos, alphas=None):
+    """GPU against the oracle, output for output"""
+    L = O.LIMBS[f]
+    fo, eo, st, ne = port.shamir_recover_c(f, shares_aos, alphas)
+    r = scl.shamir_recover_correct(f, dev(scl, soa(shares_aos)), alphas)
+    assert np.array_equal(host(scl, r["f"]), soa(fo))
+    assert np.array_equal(host(scl, r["err"]), soa(eo))
+    assert r["status"].cpu().numpy().tolist() == st.tolist()
+    assert r["nerr"].cpu().numpy().tolist() == ne.tolist()
+    assert r["failed"] == int(st.sum())
+    return r, (fo, eo, st, ne)
+
+
+@pytest.mark.parametrize("f,name", FIELDS)
+def test_recover_correct_golden(scl, port, f, name):
+    """shamirRecoverC: the reference's own outputs (correcting and failing regimes) through the GPU path"""
+    L = O.LIMBS[f]
+    for c in GOLD["fields"][name]["recover_c"]:
+        n, N = c["n"], len(c["status"])
+        shares = O.from_ints(ints(c["shares"]), L).reshape(N, n, L)
+        al = O.from_ints(ints(c["alphas"]), L) if "alphas" in c else None
+        r = scl.shamir_recover_correct(f, dev(scl, soa(shares)), al)
+        t = c["t"]
+        assert O.to_ints(host(scl, r["f"]).transpose(1, 0, 2)) == ints(c["f"])
+        assert O.to_ints(host(scl, r["err"]).transpose(1, 0, 2)) == ints(c["err"])
+        assert r["status"].cpu().numpy().tolist() == c["status"]
+        assert r["nerr"].cpu().numpy().tolist() == c["nerr"]
+
+
+@pytest.mark.parametrize("f", ALL_FIELDS)
+@pytest.mark.parametrize("n,t,N", [(4, 1, 300), (10, 3, 1000), (13, 4, 200), (12, 3, 77), (1, 0, 5), (3, 0, 9), (40, 13, 40), (64, 21, 6)])
+def test_recover_correct_vs_oracle(scl, port, f, n, t, N):
+    if f in SLOW_ORACLE and n >= 40:
+        N = min(N, 6 if n == 40 else 2)
+    if f == O.SECP256K1_SCALAR and n > 40:
+        pytest.skip("node table of the 256-bit field holds 64 entries but the oracle takes minutes here")
+    L = O.LIMBS[f]
+    rng = np.random.default_rng(n * 100 + t)
+    secrets = rand_elems(port, f, N, b"bw-s")
+    coeffs = rand_elems(port, f, max(t, 1) * N, b"bw-c").reshape(N, max(t, 1), L)[:, :t]
+    nodes = O.from_ints(list(range(1, n + 1)), L) if f == O.GF2_128 else np.stack([port.from_int(f, i + 1) for i in range(n)])
+    shares = np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)])
+    junk = rand_elems(port, f, N * n, b"bw-j").reshape(N, n, L)
+    nbad = np.zeros(N, dtype=int)
+    for s in range(N):
+        k = 0 if s % 3 == 0 else int(rng.integers(0, t + 3))     # a third clean, the rest 0 .. t+2 corrupted shares
+        nbad[s] = k
+        for i in rng.choice(n, size=min(k, n), replace=False):
+            shares[s, i] = junk[s, i]
+    r, (fo, eo, st, ne) = _check_recover_c(scl, port, f, shares, nodes if f == O.GF2_128 else None)
+    used = 3 * t + 1
+    for s in range(N):
+        if nbad[s] <= t and n == used:      # within the correction radius: the secret and the number of errors come back
+            assert st[s] == 0 and ne[s] == nbad[s] and np.array_equal(fo[s, 0], secrets[s])
+    assert r["queued"] <= int((nbad > 0).sum())
+
+
+def test_recover_correct_wikipedia_gf7(scl, port):
+    """test/scl/ss/test_shamir.cc:144-160: the Berlekamp-Welch example over GF(7), here through the plug-in
+    Montgomery field with p = 7"""
+    f, L = O.MONT128, 2
+    scl.set_mont128_prime(7)
+    port.mont128_set_prime(7)
+    try:
+        I = lambda v: port.from_int(f, v)
+        bs = np.stack([I(v) for v in (1, 5, 3, 6, 3, 2, 2)]).reshape(1, 7, L)
+        corrected = [1, 6, 3, 6, 1, 2, 2]
+        r, (fo, eo, st, ne) = _check_recover_c(scl, port, f, bs)
+        assert st[0] == 0 and ne[0] == 2
+        for root in (2, 5):
+            assert O.to_ints(port.poly_eval(f, eo[0], I(root).reshape(1, L))) == [0]
+        got = port.poly_eval(f, fo[0], np.stack([I(i + 1) for i in range(7)]))
+        assert np.array_equal(got, np.stack([I(v) for v in corrected]))
+    finally:
+        scl.set_mont128_prime(2 ** 128 - 159)
+        port.mont128_set_prime(2 ** 128 - 159)
+
+
+def test_recover_correct_edges(scl, port):
+    f, L = O.M61, 1
+    # explicit nodes 42..48 (test_shamir.cc:81-109 nodes), all-zero shares, every share of one secret corrupted
+    al = np.stack([port.from_int(f, v) for v in range(42, 49)])
+    sec = rand_elems(port, f, 50, b"bwe")
+    co = rand_elems(port, f, 100, b"bwc").reshape(50, 2, L)
+    sh = np.stack([port.poly_eval(f, np.concatenate([sec[s:s + 1], co[s]]), al) for s in range(50)])
+    sh[1, 2] = port.from_int(f, 7)
+    sh[2, 0] = sh[2, 6] = port.from_int(f, 9)
+    sh[3] = 0
+    sh[4] = rand_elems(port, f, 7, b"bwx")
+    _check_recover_c(scl, port, f, sh, al)
+    with pytest.raises(scl.SclError):      # duplicate nodes: "0 not invertible modulo prime" like computeLagrangeBasis
+        scl.shamir_recover_correct(f, dev(scl, soa(sh)), np.stack([al[0]] * 7))
+    with pytest.raises(scl.SclError):      # rings have no Berlekamp-Welch
+        scl.shamir_recover_correct(scl.Z2K(62), dev(scl, soa(sh)))
+    big = rand_elems(port, f, 67 * 3, b"bwb").reshape(3, 67, L)
+    with pytest.raises(scl.SclError):      # 3t+1 = 67 > 64 shares
+        scl.shamir_recover_correct(f, dev(scl, soa(big)))
+
+
 # ------------------------------------------------------------------------------------------------------- rings Z2k<K>
 RING_BITS_REF = sorted(GOLD["rings"], key=lambda k: GOLD["rings"][k]["bits"])
 
