@@ -242,6 +242,18 @@ int scl_hip_wire_unpack_matrix(int field, uint64_t* dst_dev, size_t ld, size_t c
                                const unsigned char* src_dev, size_t nbytes, size_t* rows_host, size_t* cols_host,
                                void* stream);
 
+/* What TcpChannel::send writes for a Packet holding one Vector / Matrix (include/scl/net/tcp_channel.h:125-160,
+ * include/scl/net/packet.h:65-313): u32 packet size, then the packet bytes = the wire image above.
+ * scl_hip_frame_size(image_bytes) = 4 + image_bytes.  frame_unpack reads a Vector frame the way TcpChannel::recv +
+ * `packet.read<Vector>()` would: it looks at exactly packet-size bytes.  (A Matrix frame is its 4-byte size in
+ * front of scl_hip_wire_unpack_matrix's input.) */
+size_t scl_hip_frame_size(size_t image_bytes);
+int scl_hip_frame_pack(int field, unsigned char* dst_dev, const uint64_t* src_dev, size_t n, void* stream);
+int scl_hip_frame_pack_matrix(int field, unsigned char* dst_dev, const uint64_t* src_dev, size_t ld, size_t rows,
+                              size_t cols, void* stream);
+int scl_hip_frame_unpack(int field, uint64_t* dst_dev, size_t capacity, const unsigned char* src_dev, size_t nbytes,
+                         size_t* n_host, void* stream);
+
 /* ---- roofline probe -------------------------------------------------------- */
 /* plain device copy kernel (16 B per lane) used to measure achievable HBM bandwidth */
 int scl_hip_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream);

@@ -21,6 +21,7 @@
 #include <scl/math/poly.h>
 #include <scl/math/vector.h>
 #include <scl/math/z2k.h>
+#include <scl/net/packet.h>
 #include <scl/serialization/serializer.h>
 #include <scl/ss/additive.h>
 #include <scl/ss/shamir.h>
@@ -526,6 +527,24 @@ int sclref_unwire_matrix(int field, const unsigned char* in, std::uint64_t* elem
     *rows = m.rows();
     *cols = m.cols();
     if (elems && m.rows() && m.cols()) storeMat<F>(elems, m);
+  });
+  return 0;
+}
+
+// What TcpChannel::send puts on the socket for a Packet holding one Vector (rows == 0) or one Matrix
+// (include/scl/net/tcp_channel.h:125-160, packet.h:65-313): u32 packet size, then the packet bytes.
+int sclref_frame(int field, const std::uint64_t* elems, std::size_t rows, std::size_t cols, int as_matrix,
+                 unsigned char* out, std::size_t* outlen) {
+  DISPATCH(field, {
+    scl::net::Packet pkt;
+    if (as_matrix) pkt << ((rows && cols) ? loadMat<F>(elems, rows, cols) : Matrix<F>());
+    else pkt << loadVec<F>(elems, cols);
+    const scl::net::Packet::SizeType size = pkt.size();
+    *outlen = sizeof(size) + size;
+    if (out) {
+      std::memcpy(out, &size, sizeof(size));
+      std::memcpy(out + sizeof(size), pkt.get(), size);
+    }
   });
   return 0;
 }

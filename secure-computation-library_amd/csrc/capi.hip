@@ -1488,14 +1488,25 @@ size_t scl_hip_wire_size(int field, size_t n) {
   return L < 0 ? 0 : 4 + n * (size_t)L * 8;
 }
 
+static int wire_pack_impl(int field, unsigned char* dst, const uint64_t* src, size_t n, bool framed, void* stream);
 int scl_hip_wire_pack(int field, unsigned char* dst, const uint64_t* src, size_t n, void* stream) {
+  return wire_pack_impl(field, dst, src, n, false, stream);
+}
+size_t scl_hip_frame_size(size_t image_bytes) { return 4 + image_bytes; }
+int scl_hip_frame_pack(int field, unsigned char* dst, const uint64_t* src, size_t n, void* stream) {
+  return wire_pack_impl(field, dst, src, n, true, stream);
+}
+static int wire_pack_impl(int field, unsigned char* dst, const uint64_t* src, size_t n, bool framed, void* stream) {
   if (!dst || (n && !src)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (reinterpret_cast<uintptr_t>(dst) & 3) return fail(SCL_ERR_BAD_ARG, "wire buffer not 4-byte aligned");
   if (n > 0xFFFFFFFFull) return fail(SCL_ERR_BAD_ARG, "vector too long for the u32 count");  // Vector::SizeType, vector.h:73
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({src}));
-    const WireGeom g{{(u32)n, 0, 0}, 1, n, n};
+    // framed: TcpChannel::send's u32 packet size in front (tcp_channel.h:127-137)
+    const u32 image = (u32)(4 + n * F::LIMBS * 8);
+    const WireGeom g = framed ? WireGeom{{image, (u32)n, 0, 0}, 2, n, n} : WireGeom{{(u32)n, 0, 0, 0}, 1, n, n};
+    if (framed && 4 + n * F::LIMBS * 8 > 0xFFFFFFFFull) return fail(SCL_ERR_BAD_ARG, "frame larger than the u32 packet size");
     hipLaunchKernelGGL((k_wire_pack<F>), dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, S(stream), ctx,
                        reinterpret_cast<u32*>(dst), src, n, g);
     LAUNCH_CHECK();
@@ -1508,8 +1519,18 @@ size_t scl_hip_wire_size_matrix(int field, size_t rows, size_t cols) {
   return L < 0 ? 0 : 12 + rows * cols * (size_t)L * 8;
 }
 
+static int wire_pack_matrix_impl(int field, unsigned char* dst, const uint64_t* src, size_t ld, size_t rows, size_t cols,
+                                 bool framed, void* stream);
 int scl_hip_wire_pack_matrix(int field, unsigned char* dst, const uint64_t* src, size_t ld, size_t rows, size_t cols,
                              void* stream) {
+  return wire_pack_matrix_impl(field, dst, src, ld, rows, cols, false, stream);
+}
+int scl_hip_frame_pack_matrix(int field, unsigned char* dst, const uint64_t* src, size_t ld, size_t rows, size_t cols,
+                              void* stream) {
+  return wire_pack_matrix_impl(field, dst, src, ld, rows, cols, true, stream);
+}
+static int wire_pack_matrix_impl(int field, unsigned char* dst, const uint64_t* src, size_t ld, size_t rows, size_t cols,
+                                 bool framed, void* stream) {
   const size_t n = rows * cols;
   if (!dst || (n && !src)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (reinterpret_cast<uintptr_t>(dst) & 3) return fail(SCL_ERR_BAD_ARG, "wire buffer not 4-byte aligned");
@@ -1519,7 +1540,10 @@ int scl_hip_wire_pack_matrix(int field, unsigned char* dst, const uint64_t* src,
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({src}));
-    const WireGeom g{{(u32)rows, (u32)cols, (u32)n}, 3, cols ? cols : 1, n ? ld : 1};
+    const u32 image = (u32)(12 + n * F::LIMBS * 8);
+    if (framed && 12 + n * F::LIMBS * 8 > 0xFFFFFFFFull) return fail(SCL_ERR_BAD_ARG, "frame larger than the u32 packet size");
+    const WireGeom g = framed ? WireGeom{{image, (u32)rows, (u32)cols, (u32)n}, 4, cols ? cols : 1, n ? ld : 1}
+                              : WireGeom{{(u32)rows, (u32)cols, (u32)n, 0}, 3, cols ? cols : 1, n ? ld : 1};
     hipLaunchKernelGGL((k_wire_pack<F>), dim3(grid_for(n ? n : 1)), dim3(BLOCK), 0, S(stream), ctx,
                        reinterpret_cast<u32*>(dst), src, n, g);
     LAUNCH_CHECK();
@@ -1550,7 +1574,7 @@ int scl_hip_wire_unpack_matrix(int field, uint64_t* dst, size_t ld, size_t capac
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({dst}));
-    const WireGeom g{{0, 0, 0}, 3, cols, ld};
+    const WireGeom g{{0, 0, 0, 0}, 3, cols, ld};
     hipLaunchKernelGGL((k_wire_unpack<F>), dim3(grid_for(cnt)), dim3(BLOCK), 0, S(stream), ctx, dst,
                        reinterpret_cast<const u32*>(src), cnt, g);
     LAUNCH_CHECK();
@@ -1558,14 +1582,31 @@ int scl_hip_wire_unpack_matrix(int field, uint64_t* dst, size_t ld, size_t capac
   });
 }
 
+static int wire_unpack_impl(int field, uint64_t* dst, size_t capacity, const unsigned char* src, size_t nbytes,
+                            size_t* n_host, bool framed, void* stream);
 int scl_hip_wire_unpack(int field, uint64_t* dst, size_t capacity, const unsigned char* src, size_t nbytes,
                         size_t* n_host, void* stream) {
+  return wire_unpack_impl(field, dst, capacity, src, nbytes, n_host, false, stream);
+}
+int scl_hip_frame_unpack(int field, uint64_t* dst, size_t capacity, const unsigned char* src, size_t nbytes,
+                         size_t* n_host, void* stream) {
+  return wire_unpack_impl(field, dst, capacity, src, nbytes, n_host, true, stream);
+}
+static int wire_unpack_impl(int field, uint64_t* dst, size_t capacity, const unsigned char* src, size_t nbytes,
+                            size_t* n_host, bool framed, void* stream) {
   if (!src || !n_host) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (reinterpret_cast<uintptr_t>(src) & 3) return fail(SCL_ERR_BAD_ARG, "wire buffer not 4-byte aligned");
-  if (nbytes < 4) return fail(SCL_ERR_BAD_ARG, "wire image shorter than its count");
-  u32 cnt = 0;
-  HIP_TRY(hipMemcpyAsync(&cnt, src, 4, hipMemcpyDeviceToHost, S(stream)));
+  const size_t hdr_bytes = framed ? 8 : 4;
+  if (nbytes < hdr_bytes) return fail(SCL_ERR_BAD_ARG, "wire image shorter than its count");
+  u32 head[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(head, src, hdr_bytes, hipMemcpyDeviceToHost, S(stream)));
   HIP_TRY(hipStreamSynchronize(S(stream)));
+  const u32 cnt = framed ? head[1] : head[0];
+  if (framed) {  // TcpChannel::recv reads exactly packet-size bytes (tcp_channel.h:190-206)
+    if ((size_t)head[0] + 4 > nbytes) return fail(SCL_ERR_BAD_ARG, "frame truncated");
+    nbytes = (size_t)head[0];
+    src += 4;
+  }
   const int L = scl_hip_limbs(field);
   if (L < 0) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
   if (4 + (size_t)cnt * L * 8 > nbytes) return fail(SCL_ERR_BAD_ARG, "wire image truncated");
@@ -1576,7 +1617,7 @@ int scl_hip_wire_unpack(int field, uint64_t* dst, size_t capacity, const unsigne
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({dst}));
-    const WireGeom g{{0, 0, 0}, 1, cnt, cnt};
+    const WireGeom g{{0, 0, 0, 0}, 1, cnt, cnt};
     hipLaunchKernelGGL((k_wire_unpack<F>), dim3(grid_for(cnt)), dim3(BLOCK), 0, S(stream), ctx, dst,
                        reinterpret_cast<const u32*>(src), (size_t)cnt, g);
     LAUNCH_CHECK();

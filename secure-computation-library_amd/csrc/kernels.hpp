@@ -1439,8 +1439,8 @@ __global__ __launch_bounds__(BLOCK) void k_transpose(u64* dst, const u64* src, s
 // Serializer<Matrix> (matrix.h:910-963) puts u32 rows, u32 cols in front of the vector image of the row-major
 // values; WireGeom carries that header and the row pitch of the device matrix (ld >= cols elements).
 struct WireGeom {
-  u32 hdr[3];
-  int nhdr;         // 1: Vector (count)   3: Matrix (rows, cols, count)
+  u32 hdr[4];
+  int nhdr;         // 1: Vector (count)   3: Matrix (rows, cols, count)   +1 in front for a frame (packet size)
   size_t cols, ld;  // element e of the image lives at element (e / cols) * ld + e % cols of the device buffer
   __device__ __forceinline__ size_t at(size_t e) const { return ld == cols ? e : (e / cols) * ld + e % cols; }
 };

@@ -397,6 +397,34 @@ def wire_unpack_matrix(field, raw: torch.Tensor, capacity=None) -> torch.Tensor:
     return out[: r.value, : c.value]
 
 
+def frame_pack(field, a: torch.Tensor, as_matrix: bool = False) -> torch.Tensor:
+    """TcpChannel frame (u32 packet size || packet) of a Packet holding this Vector [n][L] / Matrix [rows][cols][L]"""
+    L = limbs(field)
+    lib.scl_hip_wire_size.restype = lib.scl_hip_wire_size_matrix.restype = lib.scl_hip_frame_size.restype = C.c_size_t
+    if as_matrix:
+        rows, cols = (a.shape[0], a.shape[1]) if a.numel() else (0, 0)
+        image = lib.scl_hip_wire_size_matrix(field, C.c_size_t(rows), C.c_size_t(cols))
+        out = torch.empty(lib.scl_hip_frame_size(C.c_size_t(image)), dtype=torch.uint8, device=a.device)
+        _chk(lib.scl_hip_frame_pack_matrix(field, _dev(out), _dev(a) if a.numel() else None, C.c_size_t(cols),
+                                           C.c_size_t(rows), C.c_size_t(cols), _stream()))
+        return out
+    n = a.numel() // L
+    image = lib.scl_hip_wire_size(field, C.c_size_t(n))
+    out = torch.empty(lib.scl_hip_frame_size(C.c_size_t(image)), dtype=torch.uint8, device=a.device)
+    _chk(lib.scl_hip_frame_pack(field, _dev(out), _dev(a) if n else None, C.c_size_t(n), _stream()))
+    return out
+
+
+def frame_unpack(field, raw: torch.Tensor) -> torch.Tensor:
+    L = limbs(field)
+    cap = max(0, (raw.numel() - 8) // (8 * L))
+    out = empty(field, max(cap, 1), device=raw.device)
+    n = C.c_size_t(0)
+    _chk(lib.scl_hip_frame_unpack(field, _dev(out), C.c_size_t(cap), _dev(raw), C.c_size_t(raw.numel()), C.byref(n),
+                                  _stream()))
+    return out[: n.value]
+
+
 def stream_copy(dst: torch.Tensor, src: torch.Tensor):
     _chk(lib.scl_hip_stream_copy(_dev(dst), _dev(src), C.c_size_t(src.numel() * src.element_size()), _stream()))
 

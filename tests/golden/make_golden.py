@@ -133,6 +133,7 @@ def gen_montgomery_field(ref, f):
                   {"elems": [], "bytes": ref.wire_vector(f, np.zeros((0, L), np.uint64)).hex()}]
     fd["wire_matrix"] = [{"rows": 2, "cols": 10, "elems": hx(A), "bytes": ref.wire_matrix(f, A).hex()},
                          {"rows": 0, "cols": 0, "elems": [], "bytes": ref.wire_matrix(f, np.zeros((0, 0, L), np.uint64)).hex()}]
+    fd["frame"] = gen_frames(ref, f, a[:12], A)
     return fd
 
 
@@ -163,6 +164,15 @@ def gen_recover_c(ref, f, rng):
     out.append({"n": 7, "t": 2, "alphas": hx(al), "secrets": hx(sec), "shares": hx(sh), "f": hx(fo), "err": hx(eo),
                 "status": st.tolist(), "nerr": ne.tolist()})
     return out
+
+
+def gen_frames(ref, f, vec, mat):
+    """TcpChannel frames (tcp_channel.h:125-160): u32 packet size || Packet bytes, for a Packet with one Vector / Matrix"""
+    L = O.LIMBS[f]
+    return [{"kind": "vector", "elems": hx(vec), "bytes": ref.frame(f, vec).hex()},
+            {"kind": "vector", "elems": [], "bytes": ref.frame(f, np.zeros((0, L), np.uint64)).hex()},
+            {"kind": "matrix", "rows": int(mat.shape[0]), "cols": int(mat.shape[1]), "elems": hx(mat),
+             "bytes": ref.frame(f, mat, as_matrix=True).hex()}]
 
 
 def gen_ring(ref, K):
@@ -368,6 +378,7 @@ def main():
                              {"rows": 2, "cols": 2, "elems": hx(A2), "bytes": ref.wire_matrix(f, A2).hex()},
                              {"rows": 0, "cols": 0, "elems": [],
                               "bytes": ref.wire_matrix(f, np.zeros((0, 0, L), np.uint64)).hex()}]
+        fd["frame"] = gen_frames(ref, f, a[:40], A)
         doc["fields"][name] = fd
 
     doc["fields"]["secp256k1_order"] = gen_montgomery_field(ref, O.SECP256K1_SCALAR)

@@ -365,6 +365,21 @@ class _Base:
                        C.byref(r), C.byref(c))
         return out[: r.value * c.value].reshape(r.value, c.value, L)
 
+    def frame(self, field, elems, as_matrix=False) -> bytes:
+        """TcpChannel frame (u32 packet size || packet) of a Packet holding one Vector / Matrix"""
+        L = LIMBS[field]
+        a = np.ascontiguousarray(elems, dtype=np.uint64)
+        rows, cols = (a.shape[0], a.shape[1]) if as_matrix else (0, a.reshape(-1, L).shape[0])
+        inner = self.wire_matrix(field, a) if as_matrix else self.wire_vector(field, a)
+        if not self.has_err:   # the port: the frame is the length prefix on the image (tcp_channel.h:127-137)
+            return len(inner).to_bytes(4, "little") + inner
+        out = np.zeros(4 + len(inner), dtype=np.uint8)
+        ln = C.c_size_t(0)
+        self._call("frame", C.c_int(field), _p(a), C.c_size_t(rows), C.c_size_t(cols), C.c_int(1 if as_matrix else 0),
+                   _b(out), C.byref(ln))
+        assert ln.value == out.size
+        return out.tobytes()
+
     def time_shamir(self, field, N, t, n, seed: bytes = b"scl-bench"):
         ss, rs = C.c_double(), C.c_double()
         bad, chk = C.c_uint64(), C.c_uint64()

@@ -609,6 +609,35 @@ def test_wire_matrix_image(scl, port, f):
         scl.wire_unpack_matrix(f, raw, capacity=(1, 1))
 
 
+@pytest.mark.parametrize("f", ALL_FIELDS)
+def test_tcp_frames(scl, port, f):
+    """TcpChannel frame = u32 packet size || Packet bytes (tcp_channel.h:125-160); golden frames from the reference"""
+    L = O.LIMBS[f]
+    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order"}.get(f)
+    if name:
+        for c in GOLD["fields"][name]["frame"]:
+            if c["kind"] == "vector":
+                el = O.from_ints(ints(c["elems"]), L) if c["elems"] else None
+                got = scl.frame_pack(f, dev(scl, el) if el is not None else scl.empty(f, 0))
+                assert bytes(got.cpu().numpy()).hex() == c["bytes"]
+                back = scl.frame_unpack(f, got)
+                assert np.array_equal(host(scl, back), el if el is not None else np.zeros((0, L), np.uint64))
+            else:
+                m = O.from_ints(ints(c["elems"]), L).reshape(c["rows"], c["cols"], L)
+                got = scl.frame_pack(f, dev(scl, m), as_matrix=True)
+                assert bytes(got.cpu().numpy()).hex() == c["bytes"]
+                assert np.array_equal(host(scl, scl.wire_unpack_matrix(f, got[4:].clone())), m)
+    for n in (1, 1000):
+        el = rand_elems(port, f, n, b"frame")
+        raw = scl.frame_pack(f, dev(scl, el))
+        assert bytes(raw.cpu().numpy()) == port.frame(f, el)
+        # a receive buffer with trailing bytes of the next frame: only packet-size bytes are looked at
+        longer = torch.cat([raw, raw[:12]])
+        assert np.array_equal(host(scl, scl.frame_unpack(f, longer)), el)
+    with pytest.raises(scl.SclError):
+        scl.frame_unpack(f, raw[: raw.numel() - 8].clone())     # frame says more bytes than present
+
+
 # ------------------------------------------------------------------------------------ Berlekamp-Welch (shamirRecoverC)
 def _check_recover_c(scl, port, f, shares_aos, alphas=None):
     """GPU against the oracle, output for output"""

@@ -201,6 +201,18 @@ def test_wire_matrix_image(port, f, name):
 
 
 @pytest.mark.parametrize("f,name", FIELDS)
+def test_tcp_frames(port, f, name):
+    """the frame is the u32 packet size in front of the wire image (tcp_channel.h:125-160)"""
+    L = O.LIMBS[f]
+    for c in GOLD["fields"][name]["frame"]:
+        if c["kind"] == "vector":
+            el = arr(c["elems"], L) if c["elems"] else np.zeros((0, L), np.uint64)
+            assert port.frame(f, el).hex() == c["bytes"]
+        else:
+            assert port.frame(f, arr(c["elems"], L).reshape(c["rows"], c["cols"], L), as_matrix=True).hex() == c["bytes"]
+
+
+@pytest.mark.parametrize("f,name", FIELDS)
 def test_recover_c_berlekamp_welch(port, f, name):
     """shamirRecoverC against the reference's outputs, correcting and failing regimes alike"""
     L = O.LIMBS[f]
