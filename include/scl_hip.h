@@ -157,6 +157,15 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares_dev, size_t share_strid
                              const uint64_t* secrets_dev, size_t N, size_t t, size_t n,
                              const unsigned char* seed_host, size_t seed_len,
                              uint64_t counter0, void* stream);
+/* shamirSecretShare over math::Array<FF, W> (include/scl/math/array.h:69-415) -- what pedersenSecretShare runs with
+ * W = 2: {secret, blinding} (include/scl/ss/pedersen.h:127-140).  Vector<Array>::random(t+1) is one draw of
+ * (t+1)*W elements and component j of coefficient k is element k*W + j; arithmetic is component-wise, nodes 1..n.
+ * secrets_dev: component j at secrets_dev + j * secret_stride elements; shares_dev: component j, party i at
+ * shares_dev + (j * n + i) * share_stride elements.  Secret s starts at block counter0 + s * ceil((t+1)*W*byteSize/16).
+ * The EC commitments of Feldman / Pedersen stay with the caller. */
+int scl_hip_shamir_share_prg_packed(int field, uint64_t* shares_dev, size_t share_stride, const uint64_t* secrets_dev,
+                                    size_t secret_stride, size_t N, size_t t, size_t n, size_t width,
+                                    const unsigned char* seed_host, size_t seed_len, uint64_t counter0, void* stream);
 /* Batched shamirRecoverP (shamir.h:81-104) with the basis hoisted out of the per-secret
  * call: out[s] = sum_{i<m} lambda[i] * shares[i][s]. */
 int scl_hip_shamir_recover(int field, uint64_t* out_dev, const uint64_t* shares_dev,

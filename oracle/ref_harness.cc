@@ -20,6 +20,7 @@
 #include <scl/math/matrix.h>
 #include <scl/math/poly.h>
 #include <scl/math/vector.h>
+#include <scl/math/array.h>
 #include <scl/math/z2k.h>
 #include <scl/net/packet.h>
 #include <scl/serialization/serializer.h>
@@ -229,6 +230,22 @@ void storeMat(std::uint64_t* p, const Matrix<F>& m) {
     }                              \
   } while (0)
 
+// ss::shamirSecretShare over math::Array<F, W> for W = 2 (pedersen.h:138) and W = 3; secrets [N][W], shares [N][n][W]
+template <typename F, std::size_t W>
+void shamirSharePacked(const unsigned char* seed, std::size_t seed_len, const std::uint64_t* secrets, std::size_t N,
+                       std::size_t t, std::size_t n, std::uint64_t* shares) {
+  constexpr auto L = limbs<F>();
+  using A = scl::math::Array<F, W>;
+  auto prg = makePrg(seed, seed_len);
+  for (std::size_t s = 0; s < N; ++s) {
+    A secret;
+    for (std::size_t j = 0; j < W; ++j) secret[j] = load<F>(secrets + (s * W + j) * L);
+    const auto sh = scl::ss::shamirSecretShare(secret, t, n, prg);
+    for (std::size_t i = 0; i < n; ++i)
+      for (std::size_t j = 0; j < W; ++j) store<F>(shares + ((s * n + i) * W + j) * L, sh[i][j]);
+  }
+}
+
 // fields and the rings Z2k<K> instantiated here (K is a template parameter in the reference)
 #define RING_CASE(K, ...)                 \
   if ((field) == 0x100 + (K)) {           \
@@ -340,6 +357,18 @@ int sclref_shamir_share(int field, const unsigned char* seed, std::size_t seed_l
                         const std::uint64_t* secrets, std::size_t N, std::size_t t,
                         std::size_t n, std::uint64_t* shares) {
   DISPATCH(field, shamirShare<F>(seed, seed_len, secrets, N, t, n, shares));
+  return 0;
+}
+
+int sclref_shamir_share_packed(int field, const unsigned char* seed, std::size_t seed_len, const std::uint64_t* secrets,
+                               std::size_t N, std::size_t t, std::size_t n, std::size_t W, std::uint64_t* shares) {
+  if (W == 2) {
+    DISPATCH(field, (shamirSharePacked<F, 2>(seed, seed_len, secrets, N, t, n, shares)));
+  } else if (W == 3) {
+    DISPATCH(field, (shamirSharePacked<F, 3>(seed, seed_len, secrets, N, t, n, shares)));
+  } else {
+    return -2;
+  }
   return 0;
 }
 

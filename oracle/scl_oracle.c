@@ -928,6 +928,14 @@ int sclo_shamir_share(int field, const unsigned char* seed, size_t seed_len,
 #undef BODY
 }
 
+int sclo_shamir_share_packed(int field, const unsigned char* seed, size_t seed_len, const uint64_t* secrets, size_t N,
+                             size_t t, size_t n, size_t W, uint64_t* shares) {
+  if (W == 0) return SCLO_BAD_ARG;
+#define BODY(P) return CAT(P, shamir_share_packed)(seed, seed_len, secrets, N, t, n, W, shares);
+  FIELD_SWITCH(field, BODY)
+#undef BODY
+}
+
 int sclo_shamir_share_coeffs(int field, const uint64_t* secrets, const uint64_t* coeffs, size_t N,
                              size_t t, size_t n, uint64_t* shares) {
 #define BODY(P) return CAT(P, shamir_share_coeffs)(secrets, coeffs, N, t, n, shares);

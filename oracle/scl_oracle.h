@@ -71,6 +71,9 @@ int sclo_vector_random(int field, const unsigned char* seed, size_t seed_len, si
 int sclo_shamir_share(int field, const unsigned char* seed, size_t seed_len,
                       const uint64_t* secrets, size_t N, size_t t, size_t n, uint64_t* shares);
 /* same polynomial evaluation but with explicit coefficients coeffs[N][t] (c_1..c_t) */
+/* shamirSecretShare over math::Array<FF, W> (pedersen.h:138 uses W = 2): secrets [N][W], shares [N][n][W] */
+int sclo_shamir_share_packed(int field, const unsigned char* seed, size_t seed_len, const uint64_t* secrets, size_t N,
+                             size_t t, size_t n, size_t W, uint64_t* shares);
 int sclo_shamir_share_coeffs(int field, const uint64_t* secrets, const uint64_t* coeffs, size_t N,
                              size_t t, size_t n, uint64_t* shares);
 /* faithful: recompute the basis for alphas 1..n at x=0 on every secret */

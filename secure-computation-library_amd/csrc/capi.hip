@@ -1083,9 +1083,35 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
   });
 }
 
+static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N, size_t t,
+                          size_t n, const unsigned char* seed, size_t seed_len, uint64_t counter0, ArrayLane lane,
+                          void* stream);
+
 int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N,
                              size_t t, size_t n, const unsigned char* seed, size_t seed_len, uint64_t counter0,
                              void* stream) {
+  return share_prg_impl(field, shares, share_stride, secrets, N, t, n, seed, seed_len, counter0, ArrayLane{1, 0}, stream);
+}
+
+// shamirSecretShare over math::Array<FF, W> (pedersen.h:138): W interleaved sharings on one PRG draw
+int scl_hip_shamir_share_prg_packed(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets,
+                                    size_t secret_stride, size_t N, size_t t, size_t n, size_t width,
+                                    const unsigned char* seed, size_t seed_len, uint64_t counter0, void* stream) {
+  if (width == 0 || width > 16) return fail(SCL_ERR_BAD_ARG, "share_prg_packed: width must be in 1..16");
+  if (N == 0 || n == 0) return SCL_OK;
+  if (secret_stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
+  const int L = scl_hip_limbs(field);
+  if (L < 0) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
+  for (size_t j = 0; j < width; ++j)
+    SCL_TRY(share_prg_impl(field, shares + j * n * share_stride * (size_t)L, share_stride,
+                           secrets + j * secret_stride * (size_t)L, N, t, n, seed, seed_len, counter0,
+                           ArrayLane{(int)width, (int)j}, stream));
+  return SCL_OK;
+}
+
+static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N, size_t t,
+                          size_t n, const unsigned char* seed, size_t seed_len, uint64_t counter0, ArrayLane lane,
+                          void* stream) {
   if (N == 0 || n == 0) return SCL_OK;
   if (!shares || !secrets) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (t > 48) return fail(SCL_ERR_BAD_ARG, "share: t > 48 not supported");
@@ -1099,10 +1125,10 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
     AesKey key;
     make_aes_key(seed, seed_len, key);
     const int vec = vec_width<F>({shares, secrets}, {share_stride});
-    const u64 blocks_per_secret = ((u64)(t + 1) * F::LIMBS * 8 + 15) / 16;  // ceil((t+1)*byteSize/16)
+    const u64 blocks_per_secret = ((u64)(t + 1) * lane.W * F::LIMBS * 8 + 15) / 16;  // ceil((t+1)*W*byteSize/16)
     if constexpr (F::TAG <= 1) {
       SmallVdm sv;
-      if (t >= 1 && small_vandermonde<F>(al, n, t, sv)) {
+      if (lane.W == 1 && t >= 1 && small_vandermonde<F>(al, n, t, sv)) {
         return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
           constexpr int VEC = decltype(V)::value;
           const int nblk = F::LIMBS == 1 ? (int)(t / 2 + 1) : (int)t;
@@ -1137,10 +1163,10 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
         const dim3 g(grid_aes(N)), blk(BLOCK);
         if (t <= 4)
           hipLaunchKernelGGL((k_share_prg_vdm<F, 4>), g, blk, 0, S(stream), ctx, shares, share_stride, secrets, key,
-                             (u64)counter0, vdm, (int)t, (int)n, N);
+                             (u64)counter0, vdm, (int)t, (int)n, N, lane);
         else
           hipLaunchKernelGGL((k_share_prg_vdm<F, 16>), g, blk, 0, S(stream), ctx, shares, share_stride, secrets, key,
-                             (u64)counter0, vdm, (int)t, (int)n, N);
+                             (u64)counter0, vdm, (int)t, (int)n, N, lane);
         LAUNCH_CHECK();
         return SCL_OK;
       }
@@ -1154,10 +1180,10 @@ int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, c
   do {                                                                                                           \
     if (smallx)                                                                                                  \
       hipLaunchKernelGGL((k_share_prg<F, VEC, TREG, true>), g, blk, 0, S(stream), ctx, sh, share_stride, se,     \
-                         key, (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks);          \
+                         key, (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks, lane);    \
     else                                                                                                         \
       hipLaunchKernelGGL((k_share_prg<F, VEC, TREG, false>), g, blk, 0, S(stream), ctx, sh, share_stride, se,    \
-                         key, (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks);          \
+                         key, (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks, lane);    \
   } while (0)
       if (t <= 4) SHAREP_LAUNCH(4);
       else if (t <= 16) SHAREP_LAUNCH(16);

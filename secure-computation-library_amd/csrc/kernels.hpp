@@ -930,15 +930,35 @@ __global__ __launch_bounds__(BLOCK) void k_vector_random(typename F::Ctx ctx, u6
 // Coefficients of secret q*VEC + v of a batch whose first draw starts at block counter0, under the reference PRG discipline (SURVEY.md
 // section 8a note P): Vector::random(t+1) from counters [s*B, (s+1)*B), B = ceil((t+1)*byteSize/16);
 // c_0's draw is discarded and replaced by the secret (shamir.h:56-57).
+//
+// Sharing over math::Array<FF, W> (array.h:69-415; pedersenSecretShare uses W = 2, pedersen.h:138): the draw is
+// Vector<Array>::random(t+1) = (t+1)*W consecutive elements and component `lane` of coefficient k is element
+// k*W + lane.  W = 1, lane = 0 is the plain case.
+struct ArrayLane {
+  int W, lane;
+};
+
 template <class F, int VEC, int TREG, bool RAW = false>
 __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, VEC> (&c)[TREG + 1], const u32* te0,
-                                           const AesKey& key, u64 counter0, size_t q, int t) {
+                                           const AesKey& key, u64 counter0, size_t q, int t, ArrayLane al = {1, 0}) {
   constexpr int BPE = F::LIMBS >= 2 ? F::LIMBS / 2 : 1;  // AES blocks per coefficient (wide fields)
-  const u64 B = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1) * BPE;
+  const u64 B = F::LIMBS == 1 ? ((u64)(t + 1) * al.W + 1) / 2 : (u64)(t + 1) * BPE * al.W;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     const u64 ctr0 = counter0 + (q * VEC + v) * B;
     if constexpr (F::LIMBS == 1) {
+      if (al.W != 1) {  // wave-uniform: element e = k*W + lane is half (e & 1) of block e >> 1
+#pragma unroll
+        for (int k = 1; k <= TREG; ++k) {
+          if (k <= t) {
+            const u64 e = (u64)k * al.W + al.lane;
+            u64 lo, hi;
+            aes_ctr_block(te0, key, ctr0 + (e >> 1), lo, hi);
+            c[k].v[v] = F::from_le_word(ctx, (e & 1) ? hi : lo);
+          }
+        }
+        continue;
+      }
       // block j holds coefficients 2j (low 8 bytes) and 2j+1 (high 8 bytes)
 #pragma unroll
       for (int j = 0; j <= TREG / 2; ++j) {
@@ -956,7 +976,8 @@ __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, V
         if (k <= t) {
           u64 lo[BPE], hi[BPE];
 #pragma unroll
-          for (int b = 0; b < BPE; ++b) aes_ctr_block(te0, key, ctr0 + (u64)k * BPE + b, lo[b], hi[b]);
+          for (int b = 0; b < BPE; ++b)
+            aes_ctr_block(te0, key, ctr0 + ((u64)k * al.W + al.lane) * BPE + b, lo[b], hi[b]);
           c[k].v[v] = elem_from_blocks<F, RAW>(ctx, lo, hi);
         }
       }
@@ -969,7 +990,7 @@ __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, V
 template <class F, int VEC, int TREG, bool SMALLX>
 __global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* shares, size_t stride,
                                                      const u64* secrets, AesKey key, u64 counter0,
-                                                     BigTable<F> tab, int t, int n, size_t npacks) {
+                                                     BigTable<F> tab, int t, int n, size_t npacks, ArrayLane al) {
   SCL_AES_PROLOGUE(key)
   __shared__ typename F::E alpha[SMALLX ? 1 : BigTable<F>::CAP];
   __shared__ u32 alpha32[SMALLX ? BigTable<F>::CAP : 1];
@@ -978,7 +999,7 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* s
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> c[TREG + 1];
     c[0] = load_pack<F, VEC, true>(secrets + off);
-    prg_coeffs<F, VEC, TREG>(ctx, c, te0, key, counter0, q, t);
+    prg_coeffs<F, VEC, TREG>(ctx, c, te0, key, counter0, q, t, al);
     horner_rows<F, VEC, TREG, SMALLX>(ctx, c, t, alpha, alpha32, n, shares, stride, off);
   }
 }
@@ -990,7 +1011,7 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* s
 template <class F, int TREG>
 __global__ __launch_bounds__(BLOCK) void k_share_prg_vdm(typename F::Ctx ctx, u64* shares, size_t stride,
                                                          const u64* secrets, AesKey key, u64 counter0,
-                                                         const u64* vdm, int t, int n, size_t N) {
+                                                         const u64* vdm, int t, int n, size_t N, ArrayLane al) {
   SCL_AES_PROLOGUE(key)
   __shared__ u64 V[VdmLds::WORDS];
   for (int i = threadIdx.x; i < n * t * F::LIMBS; i += BLOCK) V[i] = vdm[i];
@@ -999,7 +1020,7 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg_vdm(typename F::Ctx ctx, u6
     const size_t off = q * F::LIMBS;
     Pack<F, 1> c[TREG + 1];
     c[0] = load_pack<F, 1, true>(secrets + off);
-    prg_coeffs<F, 1, TREG, true>(ctx, c, te0, key, counter0, q, t);  // raw integers: the table holds alpha^k * R
+    prg_coeffs<F, 1, TREG, true>(ctx, c, te0, key, counter0, q, t, al);  // raw integers: the table holds alpha^k * R
     vdm_rows<F, TREG>(ctx, c, t, V, n, shares, stride, off);
   }
 }

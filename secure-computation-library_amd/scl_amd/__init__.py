@@ -263,6 +263,16 @@ def shamir_recover_detect(field, shares, t: int, d: int | None = None, alphas=No
     return out, status[:N], bad.value
 
 
+def shamir_share_prg_packed(field, secrets, t: int, n: int, seed: bytes, counter0: int = 0):
+    """shamirSecretShare over Array<FF, W>: secrets [W][N][L] -> shares [W][n][N][L] (component-major SoA)"""
+    W, N = secrets.shape[0], secrets.shape[1]
+    out = empty(field, W, n, N, device=secrets.device)
+    _chk(lib.scl_hip_shamir_share_prg_packed(field, _dev(out), C.c_size_t(N), _dev(secrets), C.c_size_t(N), C.c_size_t(N),
+                                             C.c_size_t(t), C.c_size_t(n), C.c_size_t(W), seed, C.c_size_t(len(seed)),
+                                             C.c_uint64(counter0), _stream()))
+    return out
+
+
 def shamir_recover_correct(field, shares, alphas=None):
     """Batched shamirRecoverC (Berlekamp-Welch).  shares [m][N][L] -> dict(f [3t+1][N][L], err [t+1][N][L],
     status uint8 [N], nerr int32 [N], queued, failed); the secrets are f[0]."""

@@ -385,6 +385,15 @@ def main():
 
     for name, f in (("Mersenne61", O.M61), ("Mersenne127", O.M127), ("secp256k1_order", O.SECP256K1_SCALAR)):
         doc["fields"][name]["recover_c"] = gen_recover_c(ref, f, np.random.default_rng(77 + f))
+        # shamirSecretShare over math::Array<FF, W> (pedersen.h:138: W = 2): secrets [N][W], shares [N][n][W]
+        L = O.LIMBS[f]
+        rng = np.random.default_rng(99 + f)
+        pk = []
+        for (W, n, t, N, seed) in ((2, 4, 3, 5, b"pedersen"), (2, 10, 3, 4, b"pedersen-2"), (3, 5, 2, 3, b"array3")):
+            sec = ref.from_bytes(f, rng.bytes(8 * L * W * N)).reshape(N, W, L)
+            pk.append({"W": W, "n": n, "t": t, "seed": seed.hex(), "secrets": hx(sec.reshape(-1, L)),
+                       "shares": hx(ref.shamir_share_packed(f, seed, sec, t, n).reshape(-1, L))})
+        doc["fields"][name]["shamir_packed"] = pk
     doc["rings"] = {f"Z2k<{K}>": gen_ring(ref, K) for K in O.REF_RING_BITS}
 
     path = os.path.join(HERE, "golden_v1.json")

@@ -196,6 +196,16 @@ class _Base:
                    C.c_size_t(t), C.c_size_t(n), _p(out))
         return out
 
+    def shamir_share_packed(self, field, seed: bytes, secrets, t, n):
+        """shamirSecretShare over Array<FF, W>: secrets [N][W][L] -> shares [N][n][W][L]"""
+        L = LIMBS[field]
+        secrets = np.ascontiguousarray(secrets, dtype=np.uint64)
+        N, W = secrets.shape[0], secrets.shape[1]
+        out = np.zeros((N, n, W, L), dtype=np.uint64)
+        self._call("shamir_share_packed", C.c_int(field), seed, C.c_size_t(len(seed)), _p(secrets), C.c_size_t(N),
+                   C.c_size_t(t), C.c_size_t(n), C.c_size_t(W), _p(out))
+        return out
+
     def shamir_recover(self, field, shares):
         L = LIMBS[field]
         shares = _arr(shares, L)

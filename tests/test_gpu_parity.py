@@ -610,6 +610,30 @@ def test_wire_matrix_image(scl, port, f):
 
 
 @pytest.mark.parametrize("f", ALL_FIELDS)
+def test_shamir_over_arrays(scl, port, f):
+    """shamirSecretShare<Array<FF, W>> (pedersen.h:138): golden shares from the reference, then the oracle at more
+    shapes; every component reconstructs on its own"""
+    L = O.LIMBS[f]
+    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order"}.get(f)
+    cases = []
+    if name:
+        for c in GOLD["fields"][name]["shamir_packed"]:
+            sec = O.from_ints(ints(c["secrets"]), L).reshape(-1, c["W"], L)
+            want = O.from_ints(ints(c["shares"]), L).reshape(sec.shape[0], c["n"], c["W"], L)
+            cases.append((sec, c["t"], c["n"], bytes.fromhex(c["seed"]), want))
+    if f != O.GF2_128:     # (the oracle's GF(2^128) nodes follow the x++ walk, see test_share_every_threshold_up_to_16)
+        for W, n, t, N in ((2, 10, 3, 777), (2, 40, 13, 65), (3, 7, 0, 20), (5, 4, 3, 33), (2, 10, 9, 50)):
+            sec = rand_elems(port, f, N * W, b"pk-s").reshape(N, W, L)
+            cases.append((sec, t, n, b"pk-seed", port.shamir_share_packed(f, b"pk-seed", sec, t, n)))
+    for sec, t, n, seed, want in cases:
+        got = scl.shamir_share_prg_packed(f, dev(scl, np.ascontiguousarray(sec.transpose(1, 0, 2))), t, n, seed)
+        assert np.array_equal(host(scl, got), want.transpose(2, 1, 0, 3)), (t, n)     # [W][n][N][L]
+        lam = scl.lagrange_basis(f, n)
+        for j in range(sec.shape[1]):
+            assert np.array_equal(host(scl, scl.shamir_recover(f, got[j], lam)), sec[:, j])
+
+
+@pytest.mark.parametrize("f", ALL_FIELDS)
 def test_tcp_frames(scl, port, f):
     """TcpChannel frame = u32 packet size || Packet bytes (tcp_channel.h:125-160); golden frames from the reference"""
     L = O.LIMBS[f]

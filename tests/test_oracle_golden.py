@@ -201,6 +201,19 @@ def test_wire_matrix_image(port, f, name):
 
 
 @pytest.mark.parametrize("f,name", FIELDS)
+def test_shamir_over_arrays(port, f, name):
+    """shamirSecretShare<Array<FF, W>> (what pedersenSecretShare runs, pedersen.h:138): interleaved PRG draws"""
+    L = O.LIMBS[f]
+    for c in GOLD["fields"][name]["shamir_packed"]:
+        W, n, t = c["W"], c["n"], c["t"]
+        sec = arr(c["secrets"], L).reshape(-1, W, L)
+        got = port.shamir_share_packed(f, bytes.fromhex(c["seed"]), sec, t, n)
+        eq(got.reshape(-1, L), c["shares"])
+        for j in range(W):
+            assert np.array_equal(port.shamir_recover(f, np.ascontiguousarray(got[:, :, j])), sec[:, j])
+
+
+@pytest.mark.parametrize("f,name", FIELDS)
 def test_tcp_frames(port, f, name):
     """the frame is the u32 packet size in front of the wire image (tcp_channel.h:125-160)"""
     L = O.LIMBS[f]
