@@ -150,6 +150,47 @@ int scratch(size_t bytes, void** out) {
   return SCL_OK;
 }
 
+// ---- per-thread device temporary for asynchronous calls ---------------------------------------------------
+// A kernel-written temporary that outlives the call (the call returns before its kernels ran).  One buffer per
+// host thread, kept and grown; an event recorded after the last use makes the next user -- possibly on another
+// stream -- wait for it.  (hipMallocAsync / hipFreeAsync on the null stream proved unreliable under the ROCm 7.2
+// runtime: a queue allocated that way lost writes between two kernels of one call.)
+struct TempArena {
+  int device = -1;
+  void* dev = nullptr;
+  size_t bytes = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+thread_local TempArena g_temp;
+
+int temp_acquire(size_t bytes, hipStream_t st, void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  TempArena& a = g_temp;
+  if (a.dev && (a.device != dev || a.bytes < bytes)) {
+    if (a.pending) HIP_TRY(hipEventSynchronize(a.done));
+    (void)hipFree(a.dev);
+    (void)hipEventDestroy(a.done);
+    a = TempArena{};
+  }
+  if (!a.dev) {
+    HIP_TRY(hipMalloc(&a.dev, bytes < (1u << 20) ? (1u << 20) : bytes));
+    HIP_TRY(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+    a.device = dev;
+    a.bytes = bytes < (1u << 20) ? (1u << 20) : bytes;
+  }
+  if (a.pending) HIP_TRY(hipStreamWaitEvent(st, a.done, 0));
+  *out = a.dev;
+  return SCL_OK;
+}
+
+int temp_release(hipStream_t st) {
+  HIP_TRY(hipEventRecord(g_temp.done, st));
+  g_temp.pending = true;
+  return SCL_OK;
+}
+
 // ---- host tables ---------------------------------------------------------------------------------
 template <class F>
 void default_nodes(const typename F::Ctx& ctx, size_t n, std::vector<typename F::E>& out) {
@@ -415,7 +456,7 @@ int matmul_mfma_impl(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B,
                      size_t N, hipStream_t st) {
   void* tab = nullptr;
   const size_t bytes = mf_a_bytes(KS, MT);
-  HIP_TRY(hipMallocAsync(&tab, bytes, st));
+  SCL_TRY(temp_acquire(bytes, st, &tab));
   HIP_TRY(hipMemsetAsync(tab, 0, bytes, st));
   hipLaunchKernelGGL((k_mfma_planes_from_matrix<KS, MT>), dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, st,
                      static_cast<unsigned char*>(tab), A, lda, (int)M, (int)K);
@@ -423,7 +464,7 @@ int matmul_mfma_impl(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B,
   if (rc == SCL_OK)
     rc = launch_share_mfma<KS, MT>(C, ldc, B, B + ldb, ldb, static_cast<const unsigned char*>(tab), (int)K - 1, (int)M, N,
                                    st);
-  (void)hipFreeAsync(tab, st);
+  (void)temp_release(st);
   return rc;
 }
 
@@ -889,13 +930,13 @@ int scl_hip_vector_random(int field, uint64_t* dst, size_t n, const unsigned cha
   if (!dst) return fail(SCL_ERR_BAD_ARG, "dst is NULL");
   if (is_ring(field)) {
     // Vector<Z2k>::random (vector.h:507-519): one prg.next(n * byteSize) = ceil(n * byteSize / 16) blocks into a
-    // stream-ordered temporary, then Z2k::read at a stride of byteSize
+    // per-thread temporary, then Z2k::read at a stride of byteSize
     const size_t bs = (size_t)(field - 0x100 - 1) / 8 + 1, nblocks = (n * bs + 15) / 16;
     void* tmp = nullptr;
-    HIP_TRY(hipMallocAsync(&tmp, nblocks * 16, S(stream)));
+    SCL_TRY(temp_acquire(nblocks * 16, S(stream), &tmp));
     int rc = scl_hip_prg_blocks(static_cast<unsigned char*>(tmp), nblocks, seed, seed_len, counter0, stream);
     if (rc == SCL_OK) rc = ring_from_bytes(field, dst, static_cast<const unsigned char*>(tmp), n, S(stream));
-    (void)hipFreeAsync(tmp, S(stream));
+    (void)temp_release(S(stream));
     return rc;
   }
   return with_field(field, [&](auto f, auto ctx) -> int {
@@ -1307,7 +1348,7 @@ int scl_hip_shamir_recover_correct(int field, uint64_t* f_out, size_t f_stride, 
     unsigned* counters = static_cast<unsigned*>(sc);  // [0] queued, [1] failed
     u64* L_dev = reinterpret_cast<u64*>(static_cast<unsigned char*>(sc) + 64);
     void* queue = nullptr;
-    HIP_TRY(hipMallocAsync(&queue, N * sizeof(unsigned), S(stream)));
+    HIP_TRY(hipMalloc(&queue, N * sizeof(unsigned)));
     auto body = [&]() -> int {
       HIP_TRY(hipMemsetAsync(counters, 0, 8, S(stream)));
       HIP_TRY(hipMemcpyAsync(L_dev, Ll.data(), lbytes, hipMemcpyHostToDevice, S(stream)));
@@ -1339,7 +1380,7 @@ int scl_hip_shamir_recover_correct(int field, uint64_t* f_out, size_t f_stride, 
       return SCL_OK;
     };
     const int rc = body();
-    (void)hipFreeAsync(queue, S(stream));
+    (void)hipFree(queue);
     return rc;
   });
 }

@@ -1223,7 +1223,8 @@ __global__ __launch_bounds__(BLOCK) void k_recover_detect(typename F::Ctx ctx, u
 //   k_bw_consistent  one thread per secret: if the n shares lie on one polynomial of degree <= t (the common
 //                    case; then every e > 0 system is singular and e = 0 returns that polynomial) write its
 //                    coefficients and E = 1, else queue the secret;
-//   k_bw_solve       one wavefront per queued secret: the systems, in LDS, by Gauss-Jordan with lanes over rows.
+//   k_bw_solve       one wavefront per queued secret: the systems, in LDS, by division-free Gauss-Jordan with lanes
+//                    over rows; the only inversions are the n diagonal ones of the accepted system, done in parallel.
 // L is [(nchk + d1)][d1] row-major: nchk rows that re-derive share d1+r from the first d1 = t+1 shares, then d1
 // rows that give coefficient k of the interpolant.
 template <class F>
@@ -1302,6 +1303,8 @@ __global__ __launch_bounds__(BW_WAVE) void k_bw_solve(typename F::Ctx ctx, u64* 
         }
       }
       __syncthreads();
+      // Division-free Gauss-Jordan: rows k != c become row_k * pivot - row_c * M[k][c], which keeps the solution
+      // set (the pivot is non-zero) and needs no inversion to decide the rank; the matrix ends up diagonal.
       bool singular = false;
       for (int c = 0; c < n; ++c) {
         const bool nz = lane >= c && lane < n && !F::is_zero(M[(size_t)lane * m + c]);
@@ -1319,17 +1322,15 @@ __global__ __launch_bounds__(BW_WAVE) void k_bw_solve(typename F::Ctx ctx, u64* 
           }
           __syncthreads();
         }
-        const E pv = F::inv(ctx, M[(size_t)c * m + c]);
-        __syncthreads();
-        for (int j = lane; j < m; j += BW_WAVE) M[(size_t)c * m + j] = F::mul(ctx, M[(size_t)c * m + j], pv);
-        __syncthreads();
+        const E pv = M[(size_t)c * m + c];
         if (lane < n && lane != c) {
           E* row = M + (size_t)lane * m;
-          const E tk = row[c];
-          if (!F::is_zero(tk)) {
-            const E nt = F::neg(ctx, tk);
-            for (int j = c; j < m; ++j) row[j] = F::add(ctx, row[j], F::mul(ctx, M[(size_t)c * m + j], nt));
-          }
+          const E nt = F::neg(ctx, row[c]);
+          row[c] = F::zero();
+          // columns left of c: zero in row c, so only the scaling by the pivot remains (rows above c carry their
+          // own diagonal entry there)
+          if (lane < c) row[lane] = F::mul(ctx, row[lane], pv);
+          for (int j = c + 1; j < m; ++j) row[j] = F::add(ctx, F::mul(ctx, row[j], pv), F::mul(ctx, M[(size_t)c * m + j], nt));
         }
         __syncthreads();
       }
@@ -1339,7 +1340,10 @@ __global__ __launch_bounds__(BW_WAVE) void k_bw_solve(typename F::Ctx ctx, u64* 
     // the e = 0 system is a Vandermonde system, nonsingular for distinct nodes (the host checks them)
     const bool solved = e >= 0;
     if (!solved) e = 0;
-    // x_j = M[j][n]; E = x[0..e) then 1, Q = x[e..n)
+    // the system is diagonal now: x_j = M[j][n] / M[j][j], every lane inverting its own diagonal entry at once
+    if (solved && lane < n) M[(size_t)lane * m + n] = F::mul(ctx, M[(size_t)lane * m + n], F::inv(ctx, M[(size_t)lane * m + lane]));
+    __syncthreads();
+    // E = x[0..e) then 1, Q = x[e..n)
     bool ok = solved;
     if (lane == 0 && solved) {
       for (int j = 0; j <= t; ++j) ec[j] = j < e ? M[(size_t)j * m + n] : (j == e ? F::one(ctx) : F::zero());

@@ -535,6 +535,10 @@ TEST_CASE(recover_c_gpu, "ss::shamirRecoverC (Berlekamp-Welch)", true) {
     bool all = true;
     for (int s = 0; s < 500; ++s) all = all && r.at(s).f.evaluate(F61{0}) == secrets[s];
     if (!all) {
+      const auto dbg = bad.sharesOf(6);
+      std::printf("    shares of s=6:");
+      for (const auto& v : dbg) std::printf(" %s", v.toString().c_str());
+      std::printf("\n    solved=%zu failed=%zu\n", r.solved, r.failed);
       for (int s = 0; s < 13; ++s)
         std::printf("    s=%d status=%d errors=%u f0=%s want=%s\n", s, (int)r.status[s], r.errors[s],
                     r.status[s] ? "-" : r.at(s).f.evaluate(F61{0}).toString().c_str(), secrets[s].toString().c_str());
