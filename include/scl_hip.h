@@ -95,7 +95,11 @@ int scl_hip_timer_destroy(void* timer);
 int scl_hip_timer_start(void* timer, void* stream);
 int scl_hip_timer_stop(void* timer, void* stream);
 int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the stop event */
-/* launch geometry knobs for tuning (0 = built-in default) */
+/* knobs for tuning and for the tests that pin a kernel path (0 = built-in default unless noted):
+ *   max_blocks, aes_blocks   grid caps;  nontemporal (default 1);  force_scalar (no 16-byte packs)
+ *   force_table  1: no small-node / blocked / Vandermonde-table share kernels, 2: also no small-node Horner
+ *   mfma         1: force the matrix-core share / matmul path, -1: never use it
+ *   mfma_areg    (default 1) matrix-core kernel keeps V's digit fragments in registers for 97..128 parties */
 int scl_hip_set_tuning(const char* key, long value);
 
 /* ---- element-wise: scl::math::Vector<FF> members ------------------------- */

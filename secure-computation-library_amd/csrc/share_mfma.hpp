@@ -100,9 +100,69 @@ __device__ __forceinline__ void mf_word(const unsigned char* arow, const unsigne
   }
 }
 
+// Register-resident variant.  V's digit fragments of this wave's row tile never change, so they are loaded once
+// per kernel (KS * 8 fragments, 4 VGPRs each) and the LDS only feeds the coefficient digits: one ds_read_b128 per
+// (digit plane m, k-step), reused by the up to four diagonals of the word that pair it with a V digit -- 16 LDS
+// fragment loads per word instead of the 48 of mf_word.  The four MFMAs that share a B fragment go to four
+// different accumulator tiles, so consecutive matrix instructions are independent.
+template <int A, int KS, int MT, int COLS>
+__device__ __forceinline__ void mf_word_r(const v4i (&afrag)[MF_LIMBS][KS], const unsigned char* brow, u64 (&S)[16]) {
+  constexpr int ROWB = mf_rowb(KS);
+  constexpr int L = MF_LIMBS;
+  constexpr int DMAX = 2 * (L - 1);
+  // digit planes of C this word touches: m = d - l over its diagonals d = 4A .. min(4A+3, DMAX), 0 <= l < L
+  constexpr int M_LO = 4 * A - (L - 1) > 0 ? 4 * A - (L - 1) : 0;
+  constexpr int M_HI = (4 * A + 3 < L - 1 ? 4 * A + 3 : L - 1);
+  v16i acc[4];
+  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // software pipeline: the fragments of plane m+1 are requested before the matrix instructions of plane m are
+  // issued (sched_barrier pins that order), so the LDS latency hides under up to 4*KS MFMAs
+  v4i bcur[KS], bnxt[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) bcur[ks] = *reinterpret_cast<const v4i*>(brow + (size_t)M_LO * COLS * ROWB + ks * 32);
+#pragma unroll
+  for (int m = M_LO; m <= M_HI; ++m) {
+    if (m < M_HI) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        bnxt[ks] = *reinterpret_cast<const v4i*>(brow + (size_t)(m + 1) * COLS * ROWB + ks * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int d = 4 * A + j, l = d - m;
+        if (d <= DMAX && l >= 0 && l < L) {
+          const int m_first = d > L - 1 ? d - (L - 1) : 0;  // the chain's first MFMA takes the inline-constant 0 as C
+          acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[l][ks], bcur[ks], (m == m_first && ks == 0) ? zero : acc[j], 0,
+                                                         0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnxt[ks];
+  }
+  int m8 = 256, m16 = 65536, m24 = 16777216, m0 = 1;
+  asm volatile("" : "+s"(m8), "+s"(m16), "+s"(m24), "+s"(m0));
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    long long T = (long long)acc[0][e] * m0 + (long long)MF_WORD_BIAS;
+    T = (long long)acc[1][e] * m8 + T;
+    T = (long long)acc[2][e] * m16 + T;
+    if (4 * A + 3 <= DMAX) T = (long long)acc[3][e] * m24 + T;
+    const u64 w = (u64)T;  // 0 < w < 2^51
+    if constexpr (A == 3) S[e] = rotl61(w, 35);   // 2^96
+    if constexpr (A == 2) S[e] += w << 3;         // 2^64
+    if constexpr (A == 1) S[e] += rotl61(w, 32);  // 2^32
+    if constexpr (A == 0) S[e] += w;
+  }
+}
+
 // A table layout (host-built, see mfma_table in capi.hip): [digit l][m-tile][row 0..31][mf_rowb] bytes,
 // byte k of a row = signed digit l of V[mtile*32 + row][k] (0 for k > t or row >= n).
-template <int KS, int MT>
+template <int KS, int MT, bool AREG = false>
 __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stride, const u64* secrets,
                                                         const u64* coeffs, size_t cstride,
                                                         const unsigned char* Atab, int t, int n, size_t N) {
@@ -188,6 +248,14 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
   size_t blk = blockIdx.x;
   if (blk < nblocks) fetch(blk);
   __syncthreads();  // As is in place
+  v4i afrag[MF_LIMBS][KS];
+  if constexpr (AREG) {
+#pragma unroll
+    for (int l = 0; l < MF_LIMBS; ++l)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        afrag[l][ks] = *reinterpret_cast<const v4i*>(arow + (size_t)l * MT * 32 * ROWB + ks * 32);
+  }
   if (blk < nblocks) recode();
   __syncthreads();
   if (blk + gridDim.x < nblocks) fetch(blk + gridDim.x);
@@ -204,11 +272,20 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
     asm volatile("" : "+s"(a));
 #pragma unroll 1
     for (; a >= 0; --a) {
-      switch (a) {
-        case 3: mf_word<3, KS, MT, COLS>(arow, brow, S); break;
-        case 2: mf_word<2, KS, MT, COLS>(arow, brow, S); break;
-        case 1: mf_word<1, KS, MT, COLS>(arow, brow, S); break;
-        default: mf_word<0, KS, MT, COLS>(arow, brow, S); break;
+      if constexpr (AREG) {
+        switch (a) {
+          case 3: mf_word_r<3, KS, MT, COLS>(afrag, brow, S); break;
+          case 2: mf_word_r<2, KS, MT, COLS>(afrag, brow, S); break;
+          case 1: mf_word_r<1, KS, MT, COLS>(afrag, brow, S); break;
+          default: mf_word_r<0, KS, MT, COLS>(afrag, brow, S); break;
+        }
+      } else {
+        switch (a) {
+          case 3: mf_word<3, KS, MT, COLS>(arow, brow, S); break;
+          case 2: mf_word<2, KS, MT, COLS>(arow, brow, S); break;
+          case 1: mf_word<1, KS, MT, COLS>(arow, brow, S); break;
+          default: mf_word<0, KS, MT, COLS>(arow, brow, S); break;
+        }
       }
     }
     __syncthreads();  // every wave is done reading this block's digits
