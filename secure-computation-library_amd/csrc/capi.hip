@@ -51,6 +51,7 @@ std::atomic<long> g_max_blocks{0};
 std::atomic<long> g_nontemporal{1};
 std::atomic<long> g_force_scalar{0};
 std::atomic<long> g_force_table{0};
+std::atomic<long> g_mfma_tpb{0};
 std::atomic<long> g_mfma_areg{1};  // register-resident V fragments for the 4-row-tile shapes ("mfma_areg" tuning key)
 std::atomic<long> g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
 
@@ -437,9 +438,23 @@ int mfma_table(const BigTable<M61>& al, size_t n, size_t t, int KS, int MT, cons
 template <int KS, int MT>
 int launch_share_mfma(u64* shares, size_t stride, const u64* secrets, const u64* coeffs, size_t cstride,
                       const unsigned char* tab, int t, int n, size_t N, hipStream_t st) {
-  const size_t shmem = mf_a_bytes(KS, MT) + mf_b_bytes(KS, MT);
-  // per device and cheap: set on every call so that multi-device processes are covered
   const bool areg = g_mfma_areg.load() != 0 && MT == 4;
+  const long tpb_mode = g_mfma_tpb.load();
+  if (areg && tpb_mode == 256) {
+    constexpr int TPB = 256;
+    const size_t shmem = mf_b_bytes(KS, MT, 1);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_mfma_m61<KS, MT, (MT == 4), TPB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    const size_t cols = (size_t)(4 / MT) * 32;
+    const size_t nblocks = (N + cols - 1) / cols;
+    const unsigned grid = (unsigned)(nblocks < 512 ? nblocks : 512);  // two 4-wave workgroups per CU
+    hipLaunchKernelGGL((k_share_mfma_m61<KS, MT, (MT == 4), TPB>), dim3(grid), dim3(TPB), shmem, st, shares, stride,
+                       secrets, coeffs, cstride, tab, t, n, N);
+    HIP_TRY(hipGetLastError());
+    return SCL_OK;
+  }
+  const size_t shmem = (areg ? 0 : mf_a_bytes(KS, MT)) + mf_b_bytes(KS, MT);
+  // per device and cheap: set on every call so that multi-device processes are covered
   if (areg)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_mfma_m61<KS, MT, (MT == 4)>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -730,6 +745,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "force_scalar") g_force_scalar = value;
   else if (k == "force_table") g_force_table = value;
   else if (k == "mfma_areg") g_mfma_areg = value;
+  else if (k == "mfma_tpb") g_mfma_tpb = value;
   else if (k == "aes_blocks") g_aes_blocks = value;
   else if (k == "mfma") g_mfma = value;
   else return fail(SCL_ERR_BAD_ARG, "unknown tuning key " + k);

@@ -42,7 +42,9 @@ constexpr u64 MF_RECODE = 0x8080808080808080ull;
 
 __host__ __device__ constexpr int mf_rowb(int KS) { return KS * 32 + MF_PAD; }
 __host__ __device__ constexpr size_t mf_a_bytes(int KS, int MT) { return (size_t)MF_LIMBS * MT * 32 * mf_rowb(KS); }
-__host__ __device__ constexpr size_t mf_b_bytes(int KS, int MT) { return (size_t)MF_LIMBS * 2 * (4 / MT) * 32 * mf_rowb(KS); }
+__host__ __device__ constexpr size_t mf_b_bytes(int KS, int MT, int groups = 2) {
+  return (size_t)MF_LIMBS * groups * (4 / MT) * 32 * mf_rowb(KS);
+}
 
 // signed digits of x (x < 2^61) as the 8 bytes of the result (two's complement i8 each)
 __host__ __device__ inline u64 mf_recode(u64 x) { return (x + MF_RECODE) ^ MF_RECODE; }
@@ -162,22 +164,27 @@ __device__ __forceinline__ void mf_word_r(const v4i (&afrag)[MF_LIMBS][KS], cons
 
 // A table layout (host-built, see mfma_table in capi.hip): [digit l][m-tile][row 0..31][mf_rowb] bytes,
 // byte k of a row = signed digit l of V[mtile*32 + row][k] (0 for k > t or row >= n).
-template <int KS, int MT, bool AREG = false>
-__global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stride, const u64* secrets,
+// TPB = 512: one workgroup of two 4-wave groups per CU.  TPB = 256: one 4-wave group per workgroup, two workgroups
+// per CU -- their barriers are independent, so one workgroup's matrix phase runs under the other's VALU / store
+// phase instead of all eight waves of the CU moving in step.
+template <int KS, int MT, bool AREG = false, int TPB = 512>
+__global__ __launch_bounds__(TPB, 512 / TPB) void k_share_mfma_m61(u64* shares, size_t stride, const u64* secrets,
                                                         const u64* coeffs, size_t cstride,
                                                         const unsigned char* Atab, int t, int n, size_t N) {
   constexpr int ROWB = mf_rowb(KS);
   constexpr int NBLK = 4 / MT;         // N-tiles per 4-wave group
-  constexpr int COLS = 2 * NBLK * 32;  // secrets per workgroup iteration (two groups)
+  constexpr int GROUPS = TPB / 256;
+  constexpr int COLS = GROUPS * NBLK * 32;  // secrets per workgroup iteration
   constexpr int KG = KS * 8;           // groups of four k-slots
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // AREG: V's digit planes go from the table in global memory straight into registers and take no LDS
   unsigned char* As = smem;
-  unsigned char* Bs = smem + mf_a_bytes(KS, MT);  // [digit][2*NBLK n-tiles * 32 cols][ROWB]
+  unsigned char* Bs = smem + (AREG ? 0 : mf_a_bytes(KS, MT));  // [digit][GROUPS*NBLK n-tiles * 32 cols][ROWB]
 
-  {
+  if constexpr (!AREG) {
     const uint4* src = reinterpret_cast<const uint4*>(Atab);
     uint4* dst = reinterpret_cast<uint4*>(As);
-    for (int i = threadIdx.x; i < (int)(mf_a_bytes(KS, MT) / 16); i += 512) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (int)(mf_a_bytes(KS, MT) / 16); i += TPB) dst[i] = src[i];
   }
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int nt = (w >> 2) * NBLK + (w & 3) / MT, mt = (w & 3) % MT;
@@ -185,13 +192,13 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
   const u64 P = M61::P;
 
   // coefficient words of the NEXT block travel in registers while the current block is on the matrix cores
-  constexpr int ITEMS = (COLS * KG + 511) / 512;  // (column, k-group) items per thread
+  constexpr int ITEMS = (COLS * KG + TPB - 1) / TPB;  // (column, k-group) items per thread
   u64 creg[ITEMS][4];
   auto fetch = [&](size_t blk) {
     const size_t s_base = blk * COLS;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-      const int e = threadIdx.x + it * 512;
+      const int e = threadIdx.x + it * TPB;
       const int col = e % COLS, kg = e / COLS;
       const size_t s = s_base + col;
 #pragma unroll
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
   auto recode = [&]() {
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-      const int e = threadIdx.x + it * 512;
+      const int e = threadIdx.x + it * TPB;
       if (e < COLS * KG) {
         const int col = e % COLS, kg = e / COLS;
         unsigned char* dst = Bs + (size_t)col * ROWB + 4 * kg;
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(512) void k_share_mfma_m61(u64* shares, size_t stri
   };
 
   const unsigned char* brow = Bs + ((size_t)nt * 32 + r) * ROWB + 16 * h;
-  const unsigned char* arow = As + ((size_t)mt * 32 + r) * ROWB + 16 * h;
+  const unsigned char* arow = (AREG ? Atab : As) + ((size_t)mt * 32 + r) * ROWB + 16 * h;
 
   // Software pipeline over blocks (b0 = this workgroup's first block, step = gridDim.x):
   //   prologue: fetch(b0); recode -> Bs; fetch(b0 + step)

@@ -28,12 +28,14 @@ for n, t, N in ((128, 42, 10_000_000), (100, 33, 10_000_000), (128, 20, 10_000_0
     shares = scl.empty(f, n, N)
     ref = None
     scl.set_tuning("mfma", 1)
-    for areg in (0, 1):
+    for areg, tpb in ((0, 0), (1, 0), (1, 256)):
         scl.set_tuning("mfma_areg", areg)
+        scl.set_tuning("mfma_tpb", tpb)
         ms = timeit(lambda: scl.shamir_share(f, secrets, coeffs, n, out=shares))
         chk = int(shares.view(-1)[:: max(1, shares.numel() // 1000003)].sum().item())
         ref = chk if ref is None else ref
-        print(f"n={n} t={t} N={N} areg={areg}: {ms:8.3f} ms  {((1 + t) + n) * 8 * N / ms / 1e6:6.0f} GB/s  {N / ms / 1e6:6.2f} Gsec/s  "
+        print(f"n={n} t={t} N={N} areg={areg} tpb={tpb or 512}: {ms:8.3f} ms  {((1 + t) + n) * 8 * N / ms / 1e6:6.0f} GB/s  {N / ms / 1e6:6.2f} Gsec/s  "
               f"{'same' if chk == ref else 'DIFFERENT'}", flush=True)
     scl.set_tuning("mfma_areg", 1)
+    scl.set_tuning("mfma_tpb", 0)
     scl.set_tuning("mfma", 0)
