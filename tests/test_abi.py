@@ -89,3 +89,14 @@ def test_batch_calls_fail_loudly_without_a_gpu(scl):
     a = torch.zeros(4, 1, dtype=torch.int64)
     with pytest.raises(scl.SclError):
         scl.ew(O.M61, O.ADD, a, a)
+
+
+def test_bench_cpu_baseline_leg():
+    """bench.py's cpu_baseline object (the reference where oracle/_ref is built, else the port) on a tiny sample"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cb = bench.cpu_baseline("m61", 10, 3, 2000)
+    assert cb["unit"] == "reconstructions/s" and cb["cores"] == 1 and cb["kind"] in ("reference", "port")
+    assert cb["value"] > 1e4 and "2000 secrets" in cb["sample"]
