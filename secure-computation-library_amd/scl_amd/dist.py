@@ -82,3 +82,33 @@ def open_and_reconstruct(field: int, local: torch.Tensor, n: int, lam, chunk: in
         pwork.wait()
         recover(field, pbuf[:n], lam, out[ps0:ps0 + pc])
     return out
+
+
+def open_by_partial_sums(local: torch.Tensor, lam_local, group=None, partial=None, fold=None) -> torch.Tensor:
+    """Mersenne61 only (the alternative to the all-gather): every rank reduces ITS parties
+    to the canonical partial sum sum_j lambda_j * share_j (< p = 2^61 - 1), one reduce-scatter(SUM) over <= 8
+    ranks adds the partials as plain 64-bit integers -- 8 (2^61 - 2) < 2^64 cannot wrap -- and each rank folds its
+    1/G slice of the secrets modulo p once.  Moves 1/n of the all-gather's volume.  Returns this rank's slice
+    [N / world][1]; N must divide by the world size.
+
+    local: [parties of this rank][N][1]; lam_local: their Lagrange coefficients.  `partial(field, shares, lam)` and
+    `fold(field, words)` default to the HIP kernels (shamir_recover, from_bytes = FF::read's "% p"); the gloo tests
+    inject CPU checkers."""
+    from . import M61
+    world = dist.get_world_size(group)
+    if world > 8:
+        raise ValueError("the unreduced 64-bit sum is only safe for at most 8 ranks")
+    N = local.shape[1]
+    if N % world:
+        raise ValueError("N must be a multiple of the world size")
+    if partial is None:
+        from . import shamir_recover as partial
+    if fold is None:
+        from . import from_bytes
+
+        def fold(field, words):
+            return from_bytes(field, words.view(torch.uint8).reshape(-1))
+    part = partial(M61, local, lam_local).reshape(N)              # canonical, < 2^61
+    mine = torch.empty(N // world, dtype=part.dtype, device=part.device)
+    dist.reduce_scatter_tensor(mine, part.contiguous(), op=dist.ReduceOp.SUM, group=group)
+    return fold(M61, mine).reshape(N // world, 1)

@@ -106,3 +106,38 @@ def test_shard_bounds_cover_everything():
                 assert a + c == b
     assert [sd.party_slab(40, r, 8) for r in range(8)] == [(5 * r, 5) for r in range(8)]
     assert [sd.party_slab(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 3), (9, 1)]
+
+
+def _partial_sum_worker(rank, world, n, t, N):
+    """open_by_partial_sums over gloo: the oracle computes each rank's partial sums and the final fold, the
+    collective is the real reduce-scatter; every rank's slice must equal the secrets"""
+    from scl_amd import dist as sd
+    port = O.Port()
+    f = O.M61
+    secrets = port.vector_random(f, b"ps-secrets", N)
+    secrets[0] = port.from_int(f, -1)                       # p - 1: the partial sums at their largest
+    full = _soa(port.shamir_share(f, b"ps-seed", secrets, t, n))
+    nodes = np.stack([port.from_int(f, i + 1) for i in range(n)])
+    lam = port.lagrange_basis(f, nodes, port.from_int(f, 0))
+    first, cnt = sd.party_slab(n, rank, world)
+    local = torch.from_numpy(np.ascontiguousarray(full[first:first + cnt]).view(np.int64))
+
+    def partial(field, shares, lam_):
+        sh = shares.numpy().view(np.uint64)
+        if sh.shape[0] == 0:
+            return torch.zeros((sh.shape[1], 1), dtype=torch.int64)
+        rec = port.shamir_recover_lambda(field, np.ascontiguousarray(np.transpose(sh, (1, 0, 2))), lam_)
+        assert int(rec.max()) < (1 << 61) - 1                # canonical, so that 8 of them cannot wrap 64 bits
+        return torch.from_numpy(rec.view(np.int64))
+
+    def fold(field, words):
+        return torch.from_numpy(port.from_bytes(field, words.numpy().tobytes()).view(np.int64))
+
+    mine = sd.open_by_partial_sums(local, lam[first:first + cnt], partial=partial, fold=fold)
+    lo = rank * (N // world)
+    assert np.array_equal(mine.numpy().view(np.uint64), secrets[lo:lo + N // world])
+
+
+@pytest.mark.parametrize("world,n,t,N", [(2, 10, 3, 64), (3, 7, 2, 33), (2, 3, 1, 8)])
+def test_open_by_partial_sums(world, n, t, N):
+    _run(_partial_sum_worker, world, n, t, N)

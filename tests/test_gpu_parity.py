@@ -847,6 +847,33 @@ def test_ring_vs_oracle(scl, port, K):
         scl.wire_pack(f, da)
 
 
+def test_open_step_on_one_rank_rccl(scl, port):
+    """scl_amd.dist with the HIP kernels and a one-rank RCCL group: the all-gather open and the Mersenne61
+    partial-sum open (reduce-scatter + one fold) both give back the secrets"""
+    import socket
+    import torch.distributed as dist
+    from scl_amd import dist as sd
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        prt = sck.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(prt), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        f, n, t, N = O.M61, 10, 3, 4096
+        secrets = rand_elems(port, f, N, b"open1")
+        secrets[0] = port.from_int(f, -1)
+        shares = scl.shamir_share_prg(f, dev(scl, secrets), t, n, b"open1-seed")
+        lam = scl.lagrange_basis(f, n)
+        out = sd.open_and_reconstruct(f, shares, n, lam, chunk=1000)
+        assert np.array_equal(host(scl, out), secrets)
+        mine = sd.open_by_partial_sums(shares, lam)
+        assert np.array_equal(host(scl, mine), secrets)
+    finally:
+        dist.destroy_process_group()
+
+
 # ---------------------------------------------------------------------------------------------- full size properties
 @pytest.mark.parametrize("f,n,t,N", [(O.M61, 10, 3, 10_000_000), (O.M127, 10, 3, 2_000_000)])
 def test_full_size_round_trip(scl, port, f, n, t, N):
