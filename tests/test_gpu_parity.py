@@ -874,6 +874,69 @@ def test_open_step_on_one_rank_rccl(scl, port):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("t,mode", [(3, {}), (9, {}), (9, {"force_table": 1}), (20, {"mfma": 1}), (3, {"force_scalar": 1})])
+def test_odd_strides_and_8_byte_alignment_through_the_raw_abi(scl, port, t, mode):
+    """Mersenne61 rows that are only 8-byte aligned and row strides that are odd (so the 16-byte packs cannot be
+    used, or only for every other row): the C ABI called directly with offset pointers, against the oracle"""
+    import ctypes as C
+    f, n, N = O.M61, 10, 1001
+    stride, cstride = N + 3, N + 5
+    secrets = rand_elems(port, f, N, b"st-s")
+    coeffs = rand_elems(port, f, t * N, b"st-c").reshape(N, t, 1)
+    want = soa(port.shamir_share_coeffs(f, secrets, coeffs, n))            # [n][N][1]
+    lib = scl.lib
+    sec_buf = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
+    sec_buf[1:] = torch.from_numpy(secrets.view(np.int64).reshape(N)).cuda()       # starts 8 bytes into the buffer
+    co_buf = torch.zeros(t * cstride + 1, dtype=torch.int64, device="cuda")
+    co_view = co_buf[1:].view(-1)[: t * cstride].view(t, cstride)
+    co_view[:, :N] = torch.from_numpy(np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2))).view(np.int64).reshape(t, N)).cuda()
+    sh_buf = torch.full((n * stride + 1,), -1, dtype=torch.int64, device="cuda")
+    p = lambda tns, off=0: C.c_void_p(tns.data_ptr() + 8 * off)
+    for k, v in mode.items():
+        scl.set_tuning(k, v)
+    try:
+        st = lib.scl_hip_shamir_share(f, p(sh_buf, 1), C.c_size_t(stride), p(sec_buf, 1), p(co_buf, 1), C.c_size_t(cstride),
+                                      C.c_size_t(N), C.c_size_t(t), C.c_size_t(n), None, None)
+        assert st == 0, scl.lib.scl_hip_last_error()
+        got = sh_buf[1:].view(n, stride).cpu().numpy().view(np.uint64)
+        assert np.array_equal(got[:, :N], want[:, :, 0])
+        assert (got[:, N:] == np.uint64(2 ** 64 - 1)).all()                 # the padding between rows is untouched
+        # reconstruct from the strided, 8-byte aligned matrix into an 8-byte aligned output
+        lam = scl.lagrange_basis(f, n)
+        out_buf = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
+        st = lib.scl_hip_shamir_recover(f, p(out_buf, 1), p(sh_buf, 1), C.c_size_t(stride),
+                                        lam.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.c_size_t(N), None)
+        assert st == 0
+        if t < n:    # (with t >= n the n shares do not determine the polynomial)
+            assert np.array_equal(out_buf[1:].cpu().numpy().view(np.uint64), secrets[:, 0])
+        else:
+            assert np.array_equal(out_buf[1:].cpu().numpy().view(np.uint64),
+                                  port.shamir_recover_lambda(f, np.ascontiguousarray(np.transpose(want, (1, 0, 2))), lam)[:, 0])
+        # element-wise on the misaligned rows
+        dst = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
+        st = lib.scl_hip_ew(f, O.MUL, p(dst, 1), p(sh_buf, 1), p(sh_buf, 1 + stride), C.c_size_t(N), None)
+        assert st == 0
+        assert np.array_equal(dst[1:].cpu().numpy().view(np.uint64),
+                              port.ew(f, O.MUL, want[0], want[1])[:, 0])
+        # error correction straight from the same buffer
+        if t == 3:
+            fo = torch.zeros(n * stride, dtype=torch.int64, device="cuda")
+            eo = torch.zeros((t + 1) * stride, dtype=torch.int64, device="cuda")
+            status = torch.zeros(N, dtype=torch.uint8, device="cuda")
+            nerr = torch.zeros(N, dtype=torch.int32, device="cuda")
+            sh_buf[1 + 2 * stride + 5] = 12345                              # corrupt party 2's share of secret 5
+            q, fl = C.c_size_t(0), C.c_size_t(0)
+            st = lib.scl_hip_shamir_recover_correct(f, p(fo), C.c_size_t(stride), p(eo), C.c_size_t(stride), p(status), p(nerr),
+                                                    p(sh_buf, 1), C.c_size_t(stride), C.c_size_t(n), C.c_size_t(N), None,
+                                                    C.byref(q), C.byref(fl), None)
+            assert st == 0 and q.value == 1 and fl.value == 0
+            assert np.array_equal(fo.view(n, stride)[0, :N].cpu().numpy().view(np.uint64), secrets[:, 0])
+            assert nerr.cpu().numpy().tolist() == [1 if s == 5 else 0 for s in range(N)]
+    finally:
+        for k in mode:
+            scl.set_tuning(k, 0)
+
+
 # ---------------------------------------------------------------------------------------------- full size properties
 @pytest.mark.parametrize("f,n,t,N", [(O.M61, 10, 3, 10_000_000), (O.M127, 10, 3, 2_000_000)])
 def test_full_size_round_trip(scl, port, f, n, t, N):
