@@ -937,6 +937,33 @@ def test_odd_strides_and_8_byte_alignment_through_the_raw_abi(scl, port, t, mode
             scl.set_tuning(k, 0)
 
 
+@pytest.mark.parametrize("f", ALL_FIELDS)
+def test_random_shapes_share_and_recover(scl, port, f):
+    """a seeded sweep over (n, t, N): PRG-mode and coefficient-mode sharing against the oracle, reconstruction of
+    every shape that has more than t shares -- whatever kernel the dispatch picks for the shape"""
+    L = O.LIMBS[f]
+    rng = np.random.default_rng(1234 + f)
+    budget = 30_000 if f in SLOW_ORACLE else 400_000          # oracle multiply-adds per case
+    for case in range(24):
+        n = int(rng.integers(1, 65 if L == 4 else 129))
+        t = int(rng.integers(0, min(48, 2 * n) + 1))
+        N = int(max(1, min(700, budget // (n * (t + 1)))))
+        N = int(rng.integers(1, N + 1))
+        secrets = rand_elems(port, f, N, b"rs-%d" % case)
+        if f == O.GF2_128:      # (default nodes differ between the x++ walk and the bit patterns: explicit coefficients only)
+            nodes = O.from_ints(list(range(1, n + 1)), L)
+            coeffs = rand_elems(port, f, max(t, 1) * N, b"rc-%d" % case).reshape(N, max(t, 1), L)[:, :t]
+            want = soa(np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)]))
+            got = scl.shamir_share(f, dev(scl, secrets), dev(scl, np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2)))) if t else None, n)
+        else:
+            want = soa(port.shamir_share(f, b"rs-seed", secrets, t, n))
+            got = scl.shamir_share_prg(f, dev(scl, secrets), t, n, b"rs-seed")
+        assert np.array_equal(host(scl, got), want), (n, t, N)
+        if n > t:
+            lam = scl.lagrange_basis(f, n)
+            assert np.array_equal(host(scl, scl.shamir_recover(f, got, lam)), secrets), (n, t, N)
+
+
 # ---------------------------------------------------------------------------------------------- full size properties
 @pytest.mark.parametrize("f,n,t,N", [(O.M61, 10, 3, 10_000_000), (O.M127, 10, 3, 2_000_000)])
 def test_full_size_round_trip(scl, port, f, n, t, N):
