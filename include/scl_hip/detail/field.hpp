@@ -22,6 +22,11 @@
 //   F::one(ctx), F::from_u64(ctx,v) (v small, < p), F::from_le_word(ctx, raw) (FF::read: "% p")
 //   F::Acc                lazy dot-product accumulator: acc_zero, mac(acc,a,b), acc_add(acc,a),
 //                         acc_fold(ctx,acc) -> canonical; good for >= F::ACC_TERMS terms
+//   F::KC / F::KAcc       multiply-accumulate against a PREPARED constant (a table entry that is the same for
+//                         every lane: Lagrange rows, Vandermonde entries): kc_make(ctx,c) once per entry,
+//                         kmac(ctx,acc,k,x) per term, kacc_fold(ctx,acc) -> canonical; good for F::K_TERMS terms.
+//                         The Mersenne fields split the constant so that the term is a handful of independent
+//                         32x32 multiply-adds into 64-bit columns with no carries; the others alias Acc / mac.
 #pragma once
 
 #include <stddef.h>
@@ -77,6 +82,18 @@ SCL_HD void lazy_col_mad(u64& lo, u32& hi, u32 a, u32 b) {
   const u64 s = lo + (u64)a * b;
   hi += s < lo ? 1u : 0u;
   lo = s;
+#endif
+}
+
+// acc += a * b, one 32 x 32 -> 64 multiply-add.  Written out so that the product is never widened or split
+// from its accumulation (the compiler turns "acc += (u64)a * b" on loop-carried limbs into a 64 x 32 product
+// or into a multiply by zero followed by a 64-bit add).
+SCL_HD void mad32(u64& acc, u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 carry_unused;  // an SGPR pair of the compiler's choosing (naming vcc costs a hazard nop per instruction)
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry_unused) : "v"(a), "v"(b));
+#else
+  acc += (u64)a * b;
 #endif
 }
 
@@ -138,6 +155,16 @@ SCL_HD void lazy_redc(u32* t, PF p, u32 mc) {
     }
   }
 }
+
+// KC interface of the fields that have no cheaper prepared-constant form: it is their Acc / mac
+#define SCL_KC_IS_ACC()                                                                              \
+  typedef E KC;                                                                                      \
+  typedef Acc KAcc;                                                                                  \
+  enum { K_TERMS = ACC_TERMS };                                                                      \
+  static SCL_HD KC kc_make(const Ctx&, const E& c) { return c; }                                     \
+  static SCL_HD KAcc kacc_zero() { return acc_zero(); }                                              \
+  static SCL_HD void kmac(const Ctx& ctx, KAcc& a, const KC& k, const E& x) { mac(ctx, a, k, x); }   \
+  static SCL_HD E kacc_fold(const Ctx& ctx, const KAcc& a) { return acc_fold(ctx, a); }
 
 // ------------------------------------------------------------------ Mersenne61
 struct M61 {
@@ -202,6 +229,41 @@ struct M61 {
     return r >= P ? r - P : r;
   }
   static SCL_HD E acc_fold(const Ctx&, const Acc& acc) { return fold128(acc.v); }
+
+  // Prepared constant c: 21-bit limbs of c (w[0..2]) and of c*2^32 mod p (w[3..5]).  With x = x0 + x1*2^32,
+  //   c*x = sum_j 2^(21j) * (x0*w[j] + x1*w[3+j])   (mod p):
+  // six independent 32x32 multiply-adds into three 64-bit columns, each product < 2^53, so 1024 terms fit
+  // without a carry; x may be any 64-bit value.
+  struct KC {
+    u32 w[6];
+  };
+  struct KAcc {
+    u64 c[3];
+  };
+  enum { K_TERMS = 1024 };
+  static SCL_HD KC kc_make(const Ctx& ctx, E c) {
+    const E h = mul(ctx, c, (E)1 << 32);
+    KC k;
+    k.w[0] = (u32)(c & 0x1FFFFF);
+    k.w[1] = (u32)((c >> 21) & 0x1FFFFF);
+    k.w[2] = (u32)(c >> 42);
+    k.w[3] = (u32)(h & 0x1FFFFF);
+    k.w[4] = (u32)((h >> 21) & 0x1FFFFF);
+    k.w[5] = (u32)(h >> 42);
+    return k;
+  }
+  static SCL_HD KAcc kacc_zero() { return KAcc{{0, 0, 0}}; }
+  static SCL_HD void kmac(const Ctx&, KAcc& a, const KC& k, E x) {
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      mad32(a.c[j], x0, k.w[j]);
+      mad32(a.c[j], x1, k.w[3 + j]);
+    }
+  }
+  static SCL_HD E kacc_fold(const Ctx&, const KAcc& a) {
+    return fold128((u128)a.c[0] + ((u128)a.c[1] << 21) + ((u128)a.c[2] << 42));
+  }
 
   // x^(2^k) * y
   static SCL_HD E sqn_mul(const Ctx& c, E x, int k, E y) {
@@ -299,6 +361,46 @@ struct M127 {
     const u128 v = (acc.lo & P()) + (acc.lo >> 127) + ((u128)acc.hi << 1);
     const u128 r = (v & P()) + (v >> 127);
     return r >= P() ? r - P() : r;
+  }
+
+  // Prepared constant c: for each 32-bit limb position i of x, the 22-bit limbs w[6i..6i+5] of c*2^(32i) mod p:
+  //   c*x = sum_j 2^(22j) * sum_i x_i*w[6i+j]   (mod p):
+  // 24 independent 32x32 multiply-adds into six 64-bit columns, each product < 2^54, so 256 terms fit without a
+  // carry (the general product costs 16 multiplies and as many carry chains again); x may be any 128-bit value.
+  struct KC {
+    u32 w[24];
+  };
+  struct KAcc {
+    u64 c[6];
+  };
+  enum { K_TERMS = 256 };
+  static SCL_HD KC kc_make(const Ctx& ctx, E c) {
+    KC k;
+    E v = c;
+    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 6; ++j) k.w[6 * i + j] = (u32)(v >> (22 * j)) & 0x3FFFFFu;
+      v = mul(ctx, v, (E)1 << 32);
+    }
+    return k;
+  }
+  static SCL_HD KAcc kacc_zero() { return KAcc{{0, 0, 0, 0, 0, 0}}; }
+  static SCL_HD void kmac(const Ctx&, KAcc& a, const KC& k, E x) {
+    const u64 xl = (u64)x, xh = (u64)(x >> 64);
+    const u32 xi[4] = {(u32)xl, (u32)(xl >> 32), (u32)xh, (u32)(xh >> 32)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) mad32(a.c[j], xi[i], k.w[6 * i + j]);
+  }
+  static SCL_HD E kacc_fold(const Ctx& ctx, const KAcc& a) {
+    Acc t = acc_zero();
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int sh = 22 * j;  // column weight 2^sh; the part at or above 2^128 goes to t.hi
+      acc_add_raw(t, (u128)a.c[j] << sh);
+      if (sh > 64) t.hi += a.c[j] >> (128 - sh);
+    }
+    return acc_fold(ctx, t);
   }
 
   static SCL_HD E sqn_mul(const Ctx& c, E x, int k, E y) {
@@ -426,6 +528,7 @@ struct Mont128 {
   // fold needs no product at all.
   static SCL_HD E table_scale(const Ctx& c, E b) { return mul(c, b, c.k32); }
   static SCL_HD E acc_fold_scaled(const Ctx& c, const Acc& acc) { return add(c, fold_wide(c, acc), acc.e); }
+  SCL_KC_IS_ACC()
 
   static SCL_HD E inv(const Ctx& c, E a) {  // a^(p-2), square-and-multiply MSB first
     const u128 e = c.p - 2;
@@ -507,6 +610,7 @@ struct Gf128 {
   static SCL_HD void mac(const Ctx& c, Acc& acc, E a, E b) { acc.v ^= mul(c, a, b); }
   static SCL_HD void acc_add(const Ctx&, Acc& acc, E a) { acc.v ^= a; }
   static SCL_HD E acc_fold(const Ctx&, const Acc& acc) { return acc.v; }
+  SCL_KC_IS_ACC()
 
   static SCL_HD E inv(const Ctx& c, E a) {  // a^(2^128-2) = prod_{i=1..127} a^(2^i)
     E r = 1, sq = a;
@@ -703,6 +807,7 @@ struct Secp256k1Scalar {
   }
   static SCL_HD E table_scale(const Ctx&, const E& b) { return b; }
   static SCL_HD E acc_fold_scaled(const Ctx& c, const Acc& acc) { return acc_fold(c, acc); }
+  SCL_KC_IS_ACC()
 
   // montyModInv (ff_ops_gmp.h:225-260): a^(p-2) by square-and-multiply from the top bit; inv(0) = 0
   static SCL_HD E inv(const Ctx& c, const E& a) {
@@ -770,6 +875,7 @@ struct Z2kRing {
   static SCL_HD void mac(const Ctx&, Acc& acc, E a, E b) { acc.v += a * b; }
   static SCL_HD void acc_add(const Ctx&, Acc& acc, E a) { acc.v += a; }
   static SCL_HD E acc_fold(const Ctx& c, const Acc& acc) { return acc.v & c.mask; }
+  SCL_KC_IS_ACC()
 };
 typedef Z2kRing<u64, 1, 5> Z2k64;
 typedef Z2kRing<u128, 2, 6> Z2k128;

@@ -1283,22 +1283,48 @@ int scl_hip_shamir_recover_detect(int field, uint64_t* out, unsigned char* statu
     std::vector<typename F::E> ns(alphas.begin(), alphas.begin() + d1), L((nchk + 1) * d1);
     for (size_t r = 0; r < nchk; ++r) SCL_TRY(lagrange<F>(ctx, ns, alphas[d1 + r], L.data() + r * d1));
     SCL_TRY(lagrange<F>(ctx, ns, x_host ? F::ld(x_host) : F::zero(), L.data() + nchk * d1));
-    std::vector<u64> Ll(L.size() * F::LIMBS);
-    for (size_t i = 0; i < L.size(); ++i) F::st(Ll.data() + i * F::LIMBS, L[i]);
-    const size_t lbytes = Ll.size() * 8;
-    if (lbytes > 150 * 1024) return fail(SCL_ERR_BAD_ARG, "recover_detect: (t)(d+1) table exceeds LDS");
+    // device image of L as prepared constants: [row block][k][RB], zero rows pad the last block (k_recover_detect)
+    typedef typename F::KC KC;
+    const size_t rows = nchk + 1;
+    // rows per pass: the 256-bit field's accumulators are 24 registers each (two rows), the others take four or eight
+    // (sixteen rows per pass with one secret per lane was measured for Mersenne61: no faster -- the kernel is
+    // bound by multiply issue, not by the re-reads)
+    const int RBsel = F::LIMBS >= 4 ? 2 : rows <= 4 ? 4 : 8;
+    const size_t nblk = (rows + RBsel - 1) / RBsel;
+    std::vector<KC> Lk(nblk * d1 * RBsel, F::kc_make(ctx, F::zero()));
+    for (size_t r = 0; r < rows; ++r)
+      for (size_t k = 0; k < d1; ++k) Lk[((r / RBsel) * d1 + k) * RBsel + r % RBsel] = F::kc_make(ctx, L[r * d1 + k]);
+    const size_t tbytes = Lk.size() * sizeof(KC), lbytes = d1 * RBsel * sizeof(KC);
+    if (lbytes > 150 * 1024) return fail(SCL_ERR_BAD_ARG, "recover_detect: one row block of the (t)(d+1) table exceeds LDS");
     void* sc;
-    SCL_TRY(scratch(lbytes + 64, &sc));
+    SCL_TRY(scratch(tbytes + 64, &sc));
     unsigned long long* cnt = static_cast<unsigned long long*>(sc);
-    u64* L_dev = reinterpret_cast<u64*>(static_cast<unsigned char*>(sc) + 64);
+    KC* L_dev = reinterpret_cast<KC*>(static_cast<unsigned char*>(sc) + 64);
     HIP_TRY(hipMemsetAsync(cnt, 0, 8, S(stream)));
-    HIP_TRY(hipMemcpyAsync(L_dev, Ll.data(), lbytes, hipMemcpyHostToDevice, S(stream)));
-    if (lbytes > 48 * 1024)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_recover_detect<F>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbytes));
-    hipLaunchKernelGGL((k_recover_detect<F>), dim3(grid_for(N)), dim3(BLOCK), lbytes, S(stream), ctx, out, status,
-                       shares, stride, L_dev, (int)d1, (int)nchk, N, cnt);
-    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(L_dev, Lk.data(), tbytes, hipMemcpyHostToDevice, S(stream)));
+    const int vec = vec_width<F>({out, shares}, {stride});
+    SCL_TRY((split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+      constexpr int VEC = decltype(V)::value;
+      auto launch = [&](auto RBc) -> int {
+        constexpr int RB = decltype(RBc)::value;
+        auto kern = &k_recover_detect<F, VEC, RB>;
+        if (lbytes > 48 * 1024)
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lbytes));
+        const size_t blocks = (npacks + BLOCK - 1) / BLOCK;  // one pack per thread (the kernel has barriers)
+        if (blocks > 0x7fffffffull) return fail(SCL_ERR_BAD_ARG, "recover_detect: batch too large for one launch");
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lbytes, S(stream), ctx, out + first * F::LIMBS,
+                           status + first, shares + first * F::LIMBS, stride, L_dev, (int)d1, (int)nchk, npacks, cnt);
+        LAUNCH_CHECK();
+        return SCL_OK;
+      };
+      if constexpr (F::LIMBS >= 4) {
+        return launch(std::integral_constant<int, 2>{});
+      } else {
+        if (RBsel == 4) return launch(std::integral_constant<int, 4>{});
+        return launch(std::integral_constant<int, 8>{});
+      }
+    })));
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
@@ -1364,26 +1390,33 @@ int scl_hip_shamir_recover_correct(int field, uint64_t* f_out, size_t f_stride, 
     for (size_t i = 0; i < n; ++i)
       for (size_t j = i + 1; j < n; ++j)
         if (F::eq(alphas[i], alphas[j])) return fail(SCL_ERR_ZERO_INVERSE, scl_hip_status_message(SCL_ERR_ZERO_INVERSE));
-    std::vector<u64> Ll(L.size() * F::LIMBS);
-    for (size_t i = 0; i < L.size(); ++i) F::st(Ll.data() + i * F::LIMBS, L[i]);
-    const size_t lbytes = Ll.size() * 8;
+    // device image of L as prepared constants, [row block][k][RB], zero rows padding the last block
+    typedef typename F::KC KC;
+    constexpr int RB = F::LIMBS >= 4 ? 2 : 8;
+    const size_t rows = nchk + d1, nblk = (rows + RB - 1) / RB;
+    std::vector<KC> Lk(nblk * d1 * RB, F::kc_make(ctx, F::zero()));
+    for (size_t r = 0; r < rows; ++r)
+      for (size_t k = 0; k < d1; ++k) Lk[((r / RB) * d1 + k) * RB + r % RB] = F::kc_make(ctx, L[r * d1 + k]);
+    const size_t tbytes = Lk.size() * sizeof(KC), lbytes = d1 * RB * sizeof(KC);
     const size_t solve_bytes = bw_lds_elems(n) * sizeof(E);
     if (lbytes > 150 * 1024 || solve_bytes > 150 * 1024)
       return fail(SCL_ERR_BAD_ARG, "recover_correct: the systems for this many shares exceed LDS");
     void* sc;
-    SCL_TRY(scratch(lbytes + 64, &sc));
+    SCL_TRY(scratch(tbytes + 64, &sc));
     unsigned* counters = static_cast<unsigned*>(sc);  // [0] queued, [1] failed
-    u64* L_dev = reinterpret_cast<u64*>(static_cast<unsigned char*>(sc) + 64);
+    KC* L_dev = reinterpret_cast<KC*>(static_cast<unsigned char*>(sc) + 64);
     void* queue = nullptr;
     HIP_TRY(hipMalloc(&queue, N * sizeof(unsigned)));
     auto body = [&]() -> int {
       HIP_TRY(hipMemsetAsync(counters, 0, 8, S(stream)));
-      HIP_TRY(hipMemcpyAsync(L_dev, Ll.data(), lbytes, hipMemcpyHostToDevice, S(stream)));
+      HIP_TRY(hipMemcpyAsync(L_dev, Lk.data(), tbytes, hipMemcpyHostToDevice, S(stream)));
+      auto kern = &k_bw_consistent<F, RB>;
       if (lbytes > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bw_consistent<F>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbytes));
-      hipLaunchKernelGGL((k_bw_consistent<F>), dim3(grid_for(N)), dim3(BLOCK), lbytes, S(stream), ctx, f_out, f_stride,
-                         e_out, e_stride, status, nerr, shares, stride, L_dev, (int)d1, (int)nchk, N,
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lbytes));
+      // one secret per thread (the kernel has barriers); N < 2^32 was checked above
+      hipLaunchKernelGGL(kern, dim3((unsigned)((N + BLOCK - 1) / BLOCK)), dim3(BLOCK), lbytes, S(stream), ctx, f_out,
+                         f_stride, e_out, e_stride, status, nerr, shares, stride, L_dev, (int)d1, (int)nchk, N,
                          static_cast<unsigned*>(queue), counters);
       LAUNCH_CHECK();
       unsigned h[2] = {0, 0};

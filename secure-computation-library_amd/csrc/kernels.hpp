@@ -1171,47 +1171,120 @@ __global__ __launch_bounds__(BLOCK) void k_additive_recover(typename F::Ctx ctx,
   }
 }
 
+// ---- a block of table rows times the share columns of one pack ---------------------------------------
+// y[j] = sum_k L[k][j] * shares[k][pack], j < RB: each share is loaded once and feeds RB lazy accumulators through
+// F::kmac (prepared constants: six carry-free 32-bit multiply-adds per term for Mersenne61, 24 for Mersenne127).
+// L is one row block of a table laid out [row block][k][RB] (zero rows pad the last block), already in LDS and
+// read wave-uniformly; the next row's constant is on its way from LDS while this row's multiplies issue.
+template <class F, int VEC, int RB>
+__device__ __forceinline__ void rows_times_shares(const typename F::Ctx& ctx, const typename F::KC* L, const u64* shares,
+                                                  size_t stride, size_t off, int d1, Pack<F, VEC> (&y)[RB]) {
+  typedef typename F::KC KC;
+  typename F::KAcc acc[RB][VEC];
+  typename F::E run[RB][VEC];
+#pragma unroll
+  for (int j = 0; j < RB; ++j)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc[j][v] = F::kacc_zero();
+      run[j][v] = F::zero();
+    }
+  int terms = 0;
+  Pack<F, VEC> xn = load_pack<F, VEC, false>(shares + off);
+  for (int k = 0; k < d1; ++k) {
+    const Pack<F, VEC> x = xn;
+    if (k + 1 < d1) xn = load_pack<F, VEC, false>(shares + (size_t)(k + 1) * stride * F::LIMBS + off);
+    if (terms + 1 > F::K_TERMS) {
+#pragma unroll
+      for (int j = 0; j < RB; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          run[j][v] = F::add(ctx, run[j][v], F::kacc_fold(ctx, acc[j][v]));
+          acc[j][v] = F::kacc_zero();
+        }
+      terms = 0;
+    }
+    KC l = L[k * RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      KC ln = l;
+      if (j + 1 < RB) ln = L[k * RB + j + 1];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) F::kmac(ctx, acc[j][v], l, x.v[v]);
+      l = ln;
+    }
+    ++terms;
+  }
+#pragma unroll
+  for (int j = 0; j < RB; ++j)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) y[j].v[v] = F::add(ctx, run[j][v], F::kacc_fold(ctx, acc[j][v]));
+}
+
+// the workgroup copies row block b of the table (RB * d1 prepared constants) into LDS; barriers on both sides
+template <class KC, int RB>
+__device__ __forceinline__ void stage_row_block(unsigned char* smem, const KC* Lk, int b, int d1) {
+  static_assert((sizeof(KC) * RB) % 16 == 0, "row block image is copied 16 bytes at a time");
+  if (b) __syncthreads();
+  const uint4* src = reinterpret_cast<const uint4*>(Lk + (size_t)b * d1 * RB);
+  uint4* dst = reinterpret_cast<uint4*>(smem);
+  const int n16 = (int)((size_t)d1 * RB * sizeof(KC) / 16);
+  for (int i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
+  __syncthreads();
+}
+
 // ---- error-detecting recovery ---------------------------------------------------------------------
 // shamirRecoverD (shamir.h:116-139): rows 0..nchk-1 of L re-derive share d+1+r from the first d+1
-// shares, row nchk evaluates at x.  L is [(nchk+1)][d+1] row-major.
-template <class F>
+// shares, row nchk evaluates at x.  The nchk+1 inner products of one secret are taken RB rows at a time
+// (rows_times_shares): the shares are read once per row block (once in all when nchk < RB; the later passes
+// hit L2), so the kernel streams at HBM rate for small t and is bound by multiply issue for large t.
+// One pack per thread: the host launches ceil(npacks / BLOCK) workgroups (every thread reaches the barriers).
+template <class F, int VEC, int RB>
 __global__ __launch_bounds__(BLOCK) void k_recover_detect(typename F::Ctx ctx, u64* out, unsigned char* status,
-                                                          const u64* shares, size_t stride, const u64* L_dev, int d1,
-                                                          int nchk, size_t N, unsigned long long* bad_count) {
-  extern __shared__ unsigned char smem_raw[];
-  typename F::E* L = reinterpret_cast<typename F::E*>(smem_raw);
-  for (int i = threadIdx.x; i < (nchk + 1) * d1; i += BLOCK) L[i] = F::ld(L_dev + (size_t)i * F::LIMBS);
-  __syncthreads();
-  unsigned long long local_bad = 0;
-  SCL_GRID_STRIDE(s, N) {
-    bool bad = false;
-    typename F::E result = F::zero();
-    for (int r = 0; r <= nchk; ++r) {
-      typename F::E run = F::zero();
-      typename F::Acc acc = F::acc_zero();
-      int terms = 0;
-      for (int k = 0; k < d1; ++k) {
-        if (terms + 1 > F::ACC_TERMS) {
-          run = F::add(ctx, run, F::acc_fold(ctx, acc));
-          acc = F::acc_zero();
-          terms = 0;
-        }
-        F::mac(ctx, acc, L[r * d1 + k], F::ld(shares + ((size_t)k * stride + s) * F::LIMBS));
-        ++terms;
-      }
-      const typename F::E y = F::add(ctx, run, F::acc_fold(ctx, acc));
+                                                          const u64* shares, size_t stride,
+                                                          const typename F::KC* Lk, int d1, int nchk, size_t npacks,
+                                                          unsigned long long* bad_count) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  typedef typename F::KC KC;
+  const int nblk = (nchk + RB) / RB;  // ceil((nchk + 1) / RB)
+  const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const bool live = q < npacks;
+  const size_t off = q * VEC * F::LIMBS;
+  bool bad[VEC];
+  Pack<F, VEC> result;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    bad[v] = false;
+    result.v[v] = F::zero();
+  }
+  for (int b = 0; b < nblk; ++b) {
+    stage_row_block<KC, RB>(smem_raw, Lk, b, d1);
+    if (!live) continue;
+    Pack<F, VEC> y[RB];
+    rows_times_shares<F, VEC, RB>(ctx, reinterpret_cast<const KC*>(smem_raw), shares, stride, off, d1, y);
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int r = b * RB + j;
       if (r < nchk) {
-        const typename F::E got = F::ld(shares + ((size_t)(d1 + r) * stride + s) * F::LIMBS);
-        bad |= !F::eq(y, got);
-      } else {
-        result = y;
+        const Pack<F, VEC> got = load_pack<F, VEC, false>(shares + (size_t)(d1 + r) * stride * F::LIMBS + off);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) bad[v] |= !F::eq(y[j].v[v], got.v[v]);
+      } else if (r == nchk) {
+        result = y[j];
       }
     }
-    status[s] = bad ? 1 : 0;
-    F::st(out + s * F::LIMBS, bad ? F::zero() : result);
-    local_bad += bad;
   }
-  if (local_bad) atomicAdd(bad_count, local_bad);
+  if (live) {
+    unsigned nbad = 0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      status[q * VEC + v] = bad[v] ? 1 : 0;
+      if (bad[v]) result.v[v] = F::zero();
+      nbad += bad[v];
+    }
+    store_pack<F, VEC, false>(out + off, result);
+    if (nbad) atomicAdd(bad_count, (unsigned long long)nbad);
+  }
 }
 
 // ---- error-correcting recovery: shamirRecoverC (Berlekamp-Welch, shamir.h:202-259) ----------------------------
@@ -1225,37 +1298,43 @@ __global__ __launch_bounds__(BLOCK) void k_recover_detect(typename F::Ctx ctx, u
 //                    coefficients and E = 1, else queue the secret;
 //   k_bw_solve       one wavefront per queued secret: the systems, in LDS, by division-free Gauss-Jordan with lanes
 //                    over rows; the only inversions are the n diagonal ones of the accepted system, done in parallel.
-// L is [(nchk + d1)][d1] row-major: nchk rows that re-derive share d1+r from the first d1 = t+1 shares, then d1
-// rows that give coefficient k of the interpolant.
-template <class F>
+// Lk is [row block][k][RB] prepared constants over nchk + d1 rows: nchk rows that re-derive share d1+r from the
+// first d1 = t+1 shares, then d1 rows that give coefficient k of the interpolant (rows_times_shares, as in
+// k_recover_detect; one secret per thread, the host launches ceil(N / BLOCK) workgroups).
+template <class F, int RB>
 __global__ __launch_bounds__(BLOCK) void k_bw_consistent(typename F::Ctx ctx, u64* f_out, size_t f_stride, u64* e_out,
                                                          size_t e_stride, unsigned char* status, unsigned* nerr,
-                                                         const u64* shares, size_t stride, const u64* L_dev, int d1,
-                                                         int nchk, size_t N, unsigned* queue, unsigned* queued) {
-  extern __shared__ unsigned char smem_raw[];
-  typename F::E* L = reinterpret_cast<typename F::E*>(smem_raw);
-  for (int i = threadIdx.x; i < (nchk + d1) * d1; i += BLOCK) L[i] = F::ld(L_dev + (size_t)i * F::LIMBS);
-  __syncthreads();
+                                                         const u64* shares, size_t stride, const typename F::KC* Lk,
+                                                         int d1, int nchk, size_t N, unsigned* queue, unsigned* queued) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  typedef typename F::KC KC;
   const int n = d1 + nchk;
-  SCL_GRID_STRIDE(s, N) {
-    bool bad = false;
-    for (int r = 0; r < nchk + d1; ++r) {
-      if (r == nchk && bad) break;  // inconsistent: the coefficient rows are not needed
-      typename F::Acc acc = F::acc_zero();
-      for (int k = 0; k < d1; ++k) F::mac(ctx, acc, L[r * d1 + k], F::ld(shares + ((size_t)k * stride + s) * F::LIMBS));
-      const typename F::E y = F::acc_fold(ctx, acc);
-      if (r < nchk) bad |= !F::eq(y, F::ld(shares + ((size_t)(d1 + r) * stride + s) * F::LIMBS));
-      else F::st(f_out + ((size_t)(r - nchk) * f_stride + s) * F::LIMBS, y);
+  const int nblk = (n + RB - 1) / RB;
+  const size_t s = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const bool live = s < N;
+  const size_t off = s * F::LIMBS;
+  bool bad = false;
+  for (int b = 0; b < nblk; ++b) {
+    stage_row_block<KC, RB>(smem_raw, Lk, b, d1);
+    if (!live || (bad && b * RB >= nchk)) continue;  // inconsistent: the coefficient rows are not needed
+    Pack<F, 1> y[RB];
+    rows_times_shares<F, 1, RB>(ctx, reinterpret_cast<const KC*>(smem_raw), shares, stride, off, d1, y);
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int r = b * RB + j;
+      if (r < nchk) bad |= !F::eq(y[j].v[0], F::ld(shares + (size_t)(d1 + r) * stride * F::LIMBS + off));
+      else if (r < n && !bad) F::st(f_out + (size_t)(r - nchk) * f_stride * F::LIMBS + off, y[j].v[0]);
     }
-    if (bad) {
-      queue[atomicAdd(queued, 1u)] = (unsigned)s;
-    } else {
-      for (int k = d1; k < n; ++k) F::st(f_out + ((size_t)k * f_stride + s) * F::LIMBS, F::zero());
-      F::st(e_out + s * F::LIMBS, F::one(ctx));
-      for (int k = 1; k < d1; ++k) F::st(e_out + ((size_t)k * e_stride + s) * F::LIMBS, F::zero());
-      status[s] = 0;
-      nerr[s] = 0;
-    }
+  }
+  if (!live) return;
+  if (bad) {
+    queue[atomicAdd(queued, 1u)] = (unsigned)s;
+  } else {
+    for (int k = d1; k < n; ++k) F::st(f_out + (size_t)k * f_stride * F::LIMBS + off, F::zero());
+    F::st(e_out + off, F::one(ctx));
+    for (int k = 1; k < d1; ++k) F::st(e_out + (size_t)k * e_stride * F::LIMBS + off, F::zero());
+    status[s] = 0;
+    nerr[s] = 0;
   }
 }
 

@@ -228,6 +228,62 @@ TEST_CASE(small_forms, "detail/field.hpp: small-constant and lazy forms == gener
   }
 }
 
+TEST_CASE(prepared_constants, "detail/field.hpp: kc_make / kmac / kacc_fold == mul/add, K_TERMS worst case", false) {
+  // the table-driven kernels' multiply-accumulate against a prepared constant, on the host
+  std::uint64_t st = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() {
+    st ^= st << 13;
+    st ^= st >> 7;
+    st ^= st << 17;
+    return st;
+  };
+  using namespace sclhip;
+  {
+    const M61::Ctx c{};
+    for (int rep = 0; rep < 300; ++rep) {
+      M61::KAcc acc = M61::kacc_zero();
+      u64 want = 0;
+      const int terms = rep < 4 ? (int)M61::K_TERMS : 1 + (int)(rnd() % 64);
+      for (int i = 0; i < terms; ++i) {
+        // rep 0: every term the largest canonical product; rep 1: largest limbs (x need not be canonical)
+        const u64 k = rep == 0 ? M61::P - 1 : rep == 1 ? 0x1FFFFFFFFFFFFFull : rnd() % M61::P;
+        const u64 x = rep == 0 ? M61::P - 1 : rep == 1 ? ~0ull : rep == 2 ? rnd() : rnd() % M61::P;
+        M61::kmac(c, acc, M61::kc_make(c, k), x);
+        want = M61::add(c, want, M61::mul(c, k, M61::from_le_word(c, x)));
+      }
+      REQUIRE(M61::kacc_fold(c, acc) == want);
+    }
+  }
+  {
+    const M127::Ctx c{};
+    const u128 P = M127::P();
+    for (int rep = 0; rep < 300; ++rep) {
+      M127::KAcc acc = M127::kacc_zero();
+      u128 want = 0;
+      const int terms = rep < 4 ? (int)M127::K_TERMS : 1 + (int)(rnd() % 48);
+      for (int i = 0; i < terms; ++i) {
+        const u128 r1 = ((u128)rnd() << 64) | rnd(), r2 = ((u128)rnd() << 64) | rnd();
+        const u128 k = rep == 0 ? P - 1 : r1 % P;
+        const u128 x = rep == 0 ? P - 1 : rep == 1 ? ~(u128)0 : rep == 2 ? r2 : r2 % P;
+        M127::kmac(c, acc, M127::kc_make(c, k), x);
+        want = M127::add(c, want, M127::mul(c, k, M127::from_le_word(c, x)));
+      }
+      REQUIRE(M127::kacc_fold(c, acc) == want);
+    }
+    // all limbs of the prepared constant at their maximum, all limbs of x at theirs, K_TERMS times
+    M127::KC full;
+    for (int i = 0; i < 24; ++i) full.w[i] = 0x3FFFFFu;
+    M127::KAcc acc = M127::kacc_zero();
+    for (int i = 0; i < (int)M127::K_TERMS; ++i) M127::kmac(c, acc, full, ~(u128)0);
+    for (int j = 0; j < 6; ++j) REQUIRE(acc.c[j] == (u64)M127::K_TERMS * 4 * 0x3FFFFFull * 0xFFFFFFFFull);
+    M61::KC full61;
+    for (int i = 0; i < 6; ++i) full61.w[i] = 0x1FFFFFu;
+    M61::KAcc a61 = M61::kacc_zero();
+    for (int i = 0; i < (int)M61::K_TERMS; ++i) M61::kmac(M61::Ctx{}, a61, full61, ~0ull);
+    for (int j = 0; j < 3; ++j) REQUIRE(a61.c[j] == (u64)M61::K_TERMS * 2 * 0x1FFFFFull * 0xFFFFFFFFull);
+  }
+}
+
 TEST_CASE(poly_host, "Polynomial: create / evaluate / arithmetic", false) {
   using P = math::Polynomial<F61>;
   // test/scl/math/test_poly.cc:64-71: 4 + 5x + x^2 at 5 = 54
