@@ -52,6 +52,7 @@ std::atomic<long> g_nontemporal{1};
 std::atomic<long> g_force_scalar{0};
 std::atomic<long> g_force_table{0};
 std::atomic<long> g_mfma_tpb{0};
+std::atomic<long> g_mfma_pipe{1};  // software-pipelined one-wave-per-SIMD kernel for the 4-row-tile shapes ("mfma_pipe")
 std::atomic<long> g_mfma_areg{1};  // register-resident V fragments for the 4-row-tile shapes ("mfma_areg" tuning key)
 std::atomic<long> g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
 
@@ -440,6 +441,20 @@ int launch_share_mfma(u64* shares, size_t stride, const u64* secrets, const u64*
                       const unsigned char* tab, int t, int n, size_t N, hipStream_t st) {
   const bool areg = g_mfma_areg.load() != 0 && MT == 4;
   const long tpb_mode = g_mfma_tpb.load();
+  if constexpr (MT == 4) {
+    if (g_mfma_pipe.load() != 0) {
+      // k_share_mfma_m61_pipe: one 4-wave workgroup per CU, 32 secrets per trip
+      const size_t shmem = mf_b_bytes(KS, MT, 1);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_mfma_m61_pipe<KS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      const size_t nblocks = (N + 31) / 32;
+      const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
+      hipLaunchKernelGGL((k_share_mfma_m61_pipe<KS>), dim3(grid), dim3(256), shmem, st, shares, stride, secrets, coeffs,
+                         cstride, tab, t, n, N);
+      HIP_TRY(hipGetLastError());
+      return SCL_OK;
+    }
+  }
   if (areg && tpb_mode == 256) {
     constexpr int TPB = 256;
     const size_t shmem = mf_b_bytes(KS, MT, 1);
@@ -745,6 +760,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "force_scalar") g_force_scalar = value;
   else if (k == "force_table") g_force_table = value;
   else if (k == "mfma_areg") g_mfma_areg = value;
+  else if (k == "mfma_pipe") g_mfma_pipe = value;
   else if (k == "mfma_tpb") g_mfma_tpb = value;
   else if (k == "aes_blocks") g_aes_blocks = value;
   else if (k == "mfma") g_mfma = value;

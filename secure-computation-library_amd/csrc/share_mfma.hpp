@@ -28,6 +28,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "../../include/scl_hip/detail/field.hpp"
 
 namespace sclhip {
@@ -336,6 +338,297 @@ __global__ __launch_bounds__(TPB, 512 / TPB) void k_share_mfma_m61(u64* shares, 
       }
     }
     if (blk + 2 * (size_t)gridDim.x < nblocks) fetch(blk + 2 * (size_t)gridDim.x);
+  }
+}
+
+// ---- software-pipelined variant (n > 96: four row tiles) -----------------------------------------------------
+// Measured on MI355X (tools/coexec_bench.hip): one wave that issues {1 matrix instruction, ~7 integer VALU
+// instructions} in turn keeps both pipes busy -- 33 ns per group against 16 ns for the matrix instruction and
+// 31 ns for the VALU group alone -- and so do two waves of one SIMD.  The kernel above does not reach that: each
+// wave runs a word's 12-52 matrix instructions as one burst and then that word's ~150 VALU instructions, and the
+// two waves of a SIMD do so in step (matrix pipe 39 % busy).  Here ONE wave per SIMD (a 4-wave workgroup per CU,
+// up to 512 registers) carries two accumulator sets and issues, in source order pinned by sched_barrier, the
+// matrix instructions of word a-1 with the recombination of word a spread between them.  Both operands' digit
+// fragments sit in registers for the whole block (V's for the whole kernel), so the LDS is only the transposing
+// buffer for the recoded coefficients: the next block is recoded into it while this block is on the matrix cores.
+struct MfOp {
+  int l, m, ks, j;
+};
+// the i-th matrix instruction of word A: digit planes (l of V, m of C), k-step ks, diagonal j of the word.  The four
+// diagonals' chains alternate, so that consecutive matrix instructions never depend on each other.
+template <int A, int KS>
+__host__ __device__ constexpr MfOp mf_word_op(int i) {
+  int c = 0;
+  for (int m = 0; m < MF_LIMBS; ++m)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int j = 0; j < 4; ++j) {
+        const int d = 4 * A + j, l = d - m;
+        if (d <= 2 * (MF_LIMBS - 1) && l >= 0 && l < MF_LIMBS) {
+          if (c == i) return MfOp{l, m, ks, j};
+          ++c;
+        }
+      }
+  return MfOp{-1, -1, -1, c};  // j = the number of instructions of the word
+}
+template <int A, int KS>
+__host__ __device__ constexpr int mf_word_nops() { return mf_word_op<A, KS>(1 << 20).j; }
+template <int A, int KS>
+__host__ __device__ constexpr bool mf_word_first(int i) {  // no earlier instruction of the word feeds the same tile
+  for (int k = 0; k < i; ++k)
+    if (mf_word_op<A, KS>(k).j == mf_word_op<A, KS>(i).j) return false;
+  return true;
+}
+
+struct MfMul {  // the recombination multipliers, kept in scalar registers and opaque (see mf_word)
+  int m0, m8, m16, m24;
+};
+
+// Recombination of word A as 80 unit operations, ordered so that eight independent elements are in flight (a
+// dependent v_mad_i64_i32 issues ~20 cycles after its producer, measured in tools/coexec_bench.hip, and there is no
+// second wave on the SIMD to fill that gap): for each half h of the 16 elements, stage k = 0..3 adds diagonal
+// 4A+k of the eight elements into T (T = sum_j E_{4A+j}[e] 2^(8j) + bias), stage 4 rotates the finished words into S.
+constexpr int MF_UNITS = 80;
+template <int A, int U>
+__device__ __forceinline__ void mf_recombine_unit(const v16i (&acc)[4], const MfMul& mm, u64 (&T)[8], u64 (&S)[16]) {
+  constexpr int h = U / 40, k = (U % 40) / 8, i = U % 8, e = 8 * h + i;
+  if constexpr (k == 0) T[i] = (u64)((long long)acc[0][e] * mm.m0 + (long long)MF_WORD_BIAS);
+  if constexpr (k == 1) T[i] = (u64)((long long)acc[1][e] * mm.m8 + (long long)T[i]);
+  if constexpr (k == 2) T[i] = (u64)((long long)acc[2][e] * mm.m16 + (long long)T[i]);
+  if constexpr (k == 3 && 4 * A + 3 <= 2 * (MF_LIMBS - 1)) T[i] = (u64)((long long)acc[3][e] * mm.m24 + (long long)T[i]);
+  if constexpr (k == 4) {
+    const u64 w = T[i];  // 0 < w < 2^51
+    if constexpr (A == 3) S[e] = rotl61(w, 35);   // 2^96
+    if constexpr (A == 2) S[e] += w << 3;         // 2^64
+    if constexpr (A == 1) S[e] += rotl61(w, 32);  // 2^32
+    if constexpr (A == 0) S[e] += w;
+    asm volatile("" : "+v"(S[e]));
+  }
+  // pin the work here: without a use the optimiser sinks it below the last matrix instruction of the block,
+  // which keeps every accumulator tile alive
+  asm volatile("" : "+v"(T[i]));
+}
+template <int A, int U0, int U1>
+__device__ __forceinline__ void mf_recombine_units(const v16i (&acc)[4], const MfMul& mm, u64 (&T)[8], u64 (&S)[16]) {
+  if constexpr (U0 < U1) {
+    mf_recombine_unit<A, U0>(acc, mm, T, S);
+    mf_recombine_units<A, U0 + 1, U1>(acc, mm, T, S);
+  }
+}
+
+// instruction I of word A into accN; after it, the share of word A+1's recombination (accP) that spreads the
+// VALU work evenly between the word's matrix instructions
+template <int A, int KS, int I, int NM, bool PREV, int ABL, class Side>
+__device__ __forceinline__ void mf_pipe_op(const v4i (&afrag)[MF_LIMBS][KS], const v4i (&bfrag)[MF_LIMBS][KS],
+                                           v16i (&accN)[4], const v16i (&accP)[4], const MfMul& mm, u64 (&T)[8],
+                                           u64 (&S)[16], Side& side) {
+  constexpr MfOp op = mf_word_op<A, KS>(I);
+  constexpr bool first = mf_word_first<A, KS>(I);
+  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (!(ABL & 1))
+    accN[op.j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[op.l][op.ks], bfrag[op.m][op.ks], first ? zero : accN[op.j], 0, 0, 0);
+  else if (first) {
+    accN[op.j] = zero;
+    asm volatile("" : "+v"(accN[op.j]));  // opaque: the recombination is not folded away
+  }
+  if constexpr (PREV && !(ABL & 2)) mf_recombine_units<A + 1, MF_UNITS * I / NM, MF_UNITS * (I + 1) / NM>(accP, mm, T, S);
+  side(std::integral_constant<int, A>{}, std::integral_constant<int, I>{}, std::integral_constant<int, NM>{});
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int A, int KS, bool PREV, int ABL, class Side, int... Is>
+__device__ __forceinline__ void mf_pipe_word(const v4i (&afrag)[MF_LIMBS][KS], const v4i (&bfrag)[MF_LIMBS][KS],
+                                             v16i (&accN)[4], const v16i (&accP)[4], const MfMul& mm, u64 (&T)[8],
+                                             u64 (&S)[16], Side& side, std::integer_sequence<int, Is...>) {
+  (mf_pipe_op<A, KS, Is, (int)sizeof...(Is), PREV, ABL>(afrag, bfrag, accN, accP, mm, T, S, side), ...);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for the result
+// stores just issued and for the coefficient loads of the block after next -- with one wave per SIMD that wait is
+// fully exposed.  Nothing here communicates through global memory inside the kernel.
+__device__ __forceinline__ void mf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ABL: ablation switches of tools/mfma_bench.hip (1 no matrix instructions, 2 no recombination, 4 no stores,
+// 8 no recode / fetch); the library instantiates ABL = 0 only
+template <int KS, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void k_share_mfma_m61_pipe(u64* shares, size_t stride, const u64* secrets,
+                                                                const u64* coeffs, size_t cstride,
+                                                                const unsigned char* Atab, int t, int n, size_t N) {
+  constexpr int MT = 4, TPB = 256, COLS = 32;
+  constexpr int ROWB = mf_rowb(KS);
+  constexpr int KG = KS * 8;  // groups of four k-slots
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Bs = smem;  // [digit][32 cols][ROWB]
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int mt = w;
+  const size_t nblocks = (N + COLS - 1) / COLS;
+  const u64 P = M61::P;
+
+  constexpr int ITEMS = (COLS * KG + TPB - 1) / TPB;  // (column, k-group) items per thread
+  static_assert(COLS * KG == ITEMS * TPB, "every thread owns ITEMS whole items");
+  u64 creg[ITEMS][4];
+  // Item `it` of a thread is column lane & 31 of k-group kg = 2 wave + (lane >> 5) + 8 it: the two halves of a wave
+  // hold neighbouring k-groups, so whether a coefficient row exists (k <= t) is decided per wave with scalar
+  // branches -- with one wave per SIMD every divergent region's exec-mask bookkeeping is exposed latency.
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  auto fetch = [&](size_t blk) {
+    const size_t s_base = blk * COLS;
+    const size_t s = s_base + r;
+    const bool full = s_base + COLS <= N;  // block-uniform
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int kgw = 2 * wu + 8 * it;  // wave-uniform: the k-group of lanes 0..31, lanes 32..63 hold kgw + 1
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k_lo = 4 * kgw + j, k_hi = k_lo + 4;
+        const u64* p_lo = k_lo == 0 ? secrets : coeffs + (size_t)(k_lo - 1) * cstride;
+        const u64* p_hi = coeffs + (size_t)(k_hi - 1) * cstride;
+        const u64* p = (h ? p_hi : p_lo) + s;
+        creg[it][j] = 0;
+        if (full && k_hi <= t) {
+          creg[it][j] = __builtin_nontemporal_load(p);
+        } else if (k_lo <= t) {  // the last rows of the polynomial, or the ragged last block
+          if ((h ? k_hi : k_lo) <= t && s < N) creg[it][j] = __builtin_nontemporal_load(p);
+        }
+      }
+    }
+  };
+  auto recode_item = [&](int it) {
+    {
+      {
+        const int col = r, kg = 2 * w + h + 8 * it;
+        unsigned char* dst = Bs + (size_t)col * ROWB + 4 * kg;
+        u32 lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u64 u = mf_recode(creg[it][j]);
+          lo[j] = (u32)u;
+          hi[j] = (u32)(u >> 32);
+        }
+#pragma unroll
+        for (int m = 0; m < MF_LIMBS; ++m) {
+          const u32* src = m < 4 ? lo : hi;
+          const u32 b = m & 3;
+          const u32 sel = 0x0c0c0000u | ((4 + b) << 8) | b;
+          const u32 p01 = __builtin_amdgcn_perm(src[1], src[0], sel);
+          const u32 p23 = __builtin_amdgcn_perm(src[3], src[2], sel);
+          *reinterpret_cast<u32*>(dst + (size_t)m * COLS * ROWB) = p01 | (p23 << 16);
+        }
+      }
+    }
+  };
+  auto recode = [&]() {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) recode_item(it);
+  };
+
+  const unsigned char* brow = Bs + (size_t)r * ROWB + 16 * h;
+  const unsigned char* arow = Atab + ((size_t)mt * 32 + r) * ROWB + 16 * h;
+  v4i afrag[MF_LIMBS][KS], bfrag[MF_LIMBS][KS];
+#pragma unroll
+  for (int l = 0; l < MF_LIMBS; ++l)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      afrag[l][ks] = *reinterpret_cast<const v4i*>(arow + (size_t)l * MT * 32 * ROWB + ks * 32);
+      // operand fragments live in the accumulation registers (the matrix instructions read them there directly), which
+      // leaves the architectural registers to the accumulator tiles the VALU recombines
+      asm volatile("" : "=a"(afrag[l][ks]) : "0"(afrag[l][ks]));
+    }
+  MfMul mm{1, 256, 65536, 16777216};
+  asm volatile("" : "+s"(mm.m0), "+s"(mm.m8), "+s"(mm.m16), "+s"(mm.m24));
+  const bool rows_full = __builtin_amdgcn_readfirstlane(mt * 32 + 32 <= n);
+  const bool aligned_rows = (reinterpret_cast<uintptr_t>(shares) & 15) == 0 && (stride & 1) == 0;
+
+  size_t blk = blockIdx.x;
+  if (blk < nblocks) {
+    fetch(blk);
+    recode();
+  }
+  mf_lds_barrier();
+  if (blk + gridDim.x < nblocks) fetch(blk + gridDim.x);
+
+  for (; blk < nblocks; blk += gridDim.x) {
+    const size_t s_base = blk * COLS;
+    // this block's coefficient digits: LDS -> registers, then the LDS is free for the next block's
+#pragma unroll
+    for (int m = 0; m < MF_LIMBS; ++m)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bfrag[m][ks] = *reinterpret_cast<const v4i*>(brow + (size_t)m * COLS * ROWB + ks * 32);
+        asm volatile("" : "=a"(bfrag[m][ks]) : "0"(bfrag[m][ks]));
+      }
+    mf_lds_barrier();
+    // The next block's recode (its coefficients arrived during the previous block) and the fetch of the block after it
+    // ride under the matrix instructions of words 2 and 1, whose own recombination work leaves VALU slots free.
+    const bool have_next = blk + gridDim.x < nblocks, have_next2 = blk + 2 * (size_t)gridDim.x < nblocks;
+    auto side = [&](auto Ac, auto Ic, auto NMc) {
+      constexpr int A_ = decltype(Ac)::value, I_ = decltype(Ic)::value, NM_ = decltype(NMc)::value;
+      if constexpr (!(ABL & 8)) {
+        if constexpr (A_ == 2) {
+#pragma unroll
+          for (int it = 0; it < ITEMS; ++it)
+            if (I_ == (2 * it + 1) * NM_ / (2 * ITEMS)) {
+              if (have_next) recode_item(it);
+            }
+        }
+        if constexpr (A_ == 1 && I_ == NM_ / 4) {
+          if (have_next2) fetch(blk + 2 * (size_t)gridDim.x);
+        }
+      }
+    };
+
+    u64 S[16], T[8];
+    v16i accX[4], accY[4];
+    mf_pipe_word<3, KS, false, ABL>(afrag, bfrag, accX, accY, mm, T, S, side, std::make_integer_sequence<int, mf_word_nops<3, KS>()>{});
+    mf_pipe_word<2, KS, true, ABL>(afrag, bfrag, accY, accX, mm, T, S, side, std::make_integer_sequence<int, mf_word_nops<2, KS>()>{});
+    mf_pipe_word<1, KS, true, ABL>(afrag, bfrag, accX, accY, mm, T, S, side, std::make_integer_sequence<int, mf_word_nops<1, KS>()>{});
+    mf_pipe_word<0, KS, true, ABL>(afrag, bfrag, accY, accX, mm, T, S, side, std::make_integer_sequence<int, mf_word_nops<0, KS>()>{});
+    if constexpr (!(ABL & 2)) mf_recombine_units<0, 0, MF_UNITS>(accY, mm, T, S);
+    else
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S[e] = (u64)(accY[0][e] ^ accX[1][e] ^ accY[2][e] ^ accX[3][e]);
+
+    // ---- fold and store (as in k_share_mfma_m61: neighbouring lanes trade values for 16-byte stores).  Whole tiles
+    // of 16-byte aligned rows -- everything but the ragged edges -- store unconditionally from a running row pointer.
+    const size_t s_even = s_base + (size_t)(r & ~1);
+    const bool odd = lane & 1;
+    const bool fast = rows_full && aligned_rows && s_base + COLS <= N;  // wave-uniform
+    u64* rowp = shares + (size_t)(mt * 32 + 4 * h + (odd ? 1 : 0)) * stride + s_even;  // row of element pair 0
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+      u64 v[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u64 sum = S[e + j] + (P - MF_TOTAL_BIAS);  // < 2^63
+        const u64 f = (sum & P) + (sum >> 61);
+        v[j] = f >= P ? f - P : f;
+      }
+      const u64 give = odd ? v[0] : v[1];
+      const u32 glo = (u32)give, ghi = (u32)(give >> 32);
+      const u32 tlo = (u32)__builtin_amdgcn_update_dpp(0, (int)glo, 0xB1, 0xF, 0xF, false);
+      const u32 thi = (u32)__builtin_amdgcn_update_dpp(0, (int)ghi, 0xB1, 0xF, 0xF, false);
+      const u64 take = ((u64)thi << 32) | tlo;
+      const u64 keep = odd ? v[1] : v[0];
+      u64x2 out;
+      out.x = odd ? take : keep;
+      out.y = odd ? keep : take;
+      // element pair e covers rows (e & 3) + 8 (e >> 2) + {0, 1} of the tile half: +0, +2, +8, +10, +16, ...
+      u64* dst = rowp + (size_t)((e & 3) + 8 * (e >> 2)) * stride;
+      if (ABL & 4) {
+        if (out.x == 0x123456789ull) __builtin_nontemporal_store(out, reinterpret_cast<u64x2*>(dst));
+      } else if (fast) {
+        __builtin_nontemporal_store(out, reinterpret_cast<u64x2*>(dst));
+      } else {
+        const int i = mt * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * h;
+        if (i < n) {
+          if (s_even + 1 < N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+            __builtin_nontemporal_store(out, reinterpret_cast<u64x2*>(dst));
+          } else {  // ragged tail or an 8-byte-aligned row: two scalar stores
+            if (s_even < N) dst[0] = out.x;
+            if (s_even + 1 < N) dst[1] = out.y;
+          }
+        }
+      }
+    }
+    mf_lds_barrier();  // the next block's digits are complete in LDS
   }
 }
 

@@ -1,0 +1,122 @@
+// tools/mfma_bench.hip -- the Mersenne61 matrix-core share kernels side by side, outside the library:
+// k_share_mfma_m61 (two waves per SIMD, word bursts) against k_share_mfma_m61_pipe (one wave per SIMD, matrix
+// and VALU instructions interleaved).  Checks that the two agree bit for bit and a sample against a host Horner.
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/_build/mfma_bench tools/mfma_bench.hip
+// usage: mfma_bench [n=128] [t=42] [N=10000000]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../secure-computation-library_amd/csrc/share_mfma.hpp"
+using namespace sclhip;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1);} } while (0)
+
+static u64 rng_state = 0x9E3779B97F4A7C15ull;
+static u64 rnd() {
+  rng_state ^= rng_state << 13;
+  rng_state ^= rng_state >> 7;
+  rng_state ^= rng_state << 17;
+  return rng_state;
+}
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 128, t = argc > 2 ? atoi(argv[2]) : 42;
+  const size_t N = argc > 3 ? strtoull(argv[3], 0, 10) : 10000000;
+  constexpr int KS = 2, MT = 4;
+  if (t + 1 > 64 || n > 128 || n <= 96) { std::printf("needs 96 < n <= 128, t <= 63\n"); return 1; }
+  const M61::Ctx ctx{};
+  // table (as mfma_table in capi.hip)
+  const int ROWB = mf_rowb(KS);
+  std::vector<unsigned char> host(mf_a_bytes(KS, MT), 0);
+  for (int i = 0; i < n; ++i) {
+    u64 v = 1;
+    for (int k = 0; k <= t; ++k) {
+      if (k) v = M61::mul(ctx, v, (u64)(i + 1));
+      const u64 digits = mf_recode(v);
+      for (int l = 0; l < MF_LIMBS; ++l) host[((size_t)(l * MT + i / 32) * 32 + (i % 32)) * ROWB + k] = (unsigned char)(digits >> (8 * l));
+    }
+  }
+  unsigned char* tab;
+  CK(hipMalloc(&tab, host.size()));
+  CK(hipMemcpy(tab, host.data(), host.size(), hipMemcpyHostToDevice));
+  std::vector<u64> hc((size_t)(t + 1) * N);
+  for (auto& x : hc) x = rnd() % M61::P;
+  for (int k = 0; k <= t && N > 2; ++k) { hc[(size_t)k * N] = M61::P - 1; hc[(size_t)k * N + 1] = 0; }
+  u64 *c, *out0, *out1;
+  CK(hipMalloc(&c, hc.size() * 8));
+  CK(hipMemcpy(c, hc.data(), hc.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&out0, (size_t)n * N * 8));
+  CK(hipMalloc(&out1, (size_t)n * N * 8));
+  CK(hipMemset(out0, 0xAA, (size_t)n * N * 8));
+  CK(hipMemset(out1, 0x55, (size_t)n * N * 8));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  auto time_it = [&](auto launch, const char* name) {
+    launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 5;
+    std::printf("%-28s %8.3f ms  %6.2f G secrets/s  %6.0f GB/s\n", name, ms, N / ms / 1e6, (double)(t + 1 + n) * 8 * N / ms / 1e6);
+  };
+  {
+    const size_t shmem = mf_b_bytes(KS, MT);
+    auto kern = &k_share_mfma_m61<KS, MT, true, 512>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    const size_t nblocks = (N + 63) / 64;
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, 0, out0, N, c, c + N, N, tab, t, n, N); }, "k_share_mfma_m61 (bursts)");
+  }
+  {
+    const size_t shmem = mf_b_bytes(KS, MT, 1);
+    auto kern = &k_share_mfma_m61_pipe<KS>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    const size_t nblocks = (N + 31) / 32;
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, 0, out1, N, c, c + N, N, tab, t, n, N); }, "k_share_mfma_m61_pipe");
+  }
+  if (argc > 4) {  // ablations of the pipelined kernel (results are wrong by construction)
+    const size_t shmem = mf_b_bytes(KS, MT, 1);
+    const size_t nblocks = (N + 31) / 32;
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
+#define ABL_RUN(ABL, name)                                                                                             \
+  {                                                                                                                    \
+    auto kern = &k_share_mfma_m61_pipe<KS, ABL>;                                                                       \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, 0, out0, N, c, c + N, N, tab, t, n, N); }, name); \
+  }
+    ABL_RUN(1, "pipe: no matrix instrs")
+    ABL_RUN(2, "pipe: no recombination")
+    ABL_RUN(4, "pipe: no stores")
+    ABL_RUN(8, "pipe: no recode/fetch")
+    ABL_RUN(3, "pipe: no MFMA, no recomb")
+    ABL_RUN(7, "pipe: only recode/fetch")
+    ABL_RUN(12, "pipe: no stores, no recode")
+    ABL_RUN(14, "pipe: MFMA + epilogue VALU")
+    ABL_RUN(6, "pipe: MFMA + recode only")
+    ABL_RUN(15, "pipe: nothing")
+    return 0;
+  }
+  CK(hipGetLastError());
+  std::vector<u64> h0((size_t)n * N), h1((size_t)n * N);
+  CK(hipMemcpy(h0.data(), out0, h0.size() * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(h1.data(), out1, h1.size() * 8, hipMemcpyDeviceToHost));
+  size_t diff = 0;
+  for (size_t i = 0; i < h0.size(); ++i) diff += h0[i] != h1[i];
+  size_t bad = 0;
+  for (size_t s = 0; s < N; s += (s < 64 ? 1 : N / 97 + 1))
+    for (int i = 0; i < n; ++i) {
+      u64 y = 0;
+      for (int k = t; k >= 0; --k) y = M61::add(ctx, M61::mul(ctx, y, (u64)(i + 1)), hc[(size_t)k * N + s]);
+      bad += y != h1[(size_t)i * N + s];
+    }
+  std::printf("pipe vs bursts: %zu differing values; pipe vs host Horner sample: %zu wrong\n", diff, bad);
+  return diff || bad;
+}
