@@ -46,12 +46,38 @@ def cpu_baseline(field_key, n, t, sample):
     if r["mismatches"]:
         raise RuntimeError("CPU baseline failed its own round trip")
     total = r["share_s"] + r["recover_s"]
-    return {
+    out = {
         "value": sample / total, "unit": "reconstructions/s", "cores": 1, "kind": kind,
         "sample": f"{sample} secrets, per-secret shamirSecretShare + shamirRecoverP (n={n}, t={t}), "
                   f"share {r['share_s']:.2f}s + recover {r['recover_s']:.2f}s",
         "recover_only_per_s": sample / r["recover_s"], "share_only_per_s": sample / r["share_s"],
     }
+    # SURVEY.md section 8d asks for two more figures beside the faithful single-thread run (SCL itself is single-threaded;
+    # the threads below are this harness's, one PRG and one slab of secrets each):
+    #   all_cores  the same per-secret path on every host core this process may use
+    #   hoisted    one thread, Lagrange basis computed once instead of per secret (reference library only)
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        cores = len(os.sched_getaffinity(0))
+        per = max(1, sample // 4)          # a quarter of the sample per thread keeps the leg to a few seconds
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL for the duration of each call
+            rs = list(ex.map(lambda i: lib.time_shamir(f, per, t, n, b"scl-bench-%d" % i), range(cores)))
+        wall = time.perf_counter() - t0
+        if not any(x["mismatches"] for x in rs):
+            out["all_cores"] = {"value": per * cores / wall, "cores": cores,
+                                "sample": f"{per} secrets on each of {cores} threads, wall {wall:.2f}s"}
+    except Exception as e:  # the extra legs never fail the bench line
+        out["all_cores"] = {"error": str(e)}
+    if kind == "reference":
+        try:
+            hr = lib.time_shamir_hoisted(f, sample, t, n)
+            if not hr["mismatches"]:
+                out["hoisted_basis"] = {"value": sample / (hr["share_s"] + hr["recover_s"]), "cores": 1,
+                                        "recover_only_per_s": sample / hr["recover_s"]}
+        except Exception as e:
+            out["hoisted_basis"] = {"error": str(e)}
+    return out
 
 
 def main():

@@ -397,6 +397,14 @@ class _Base:
                    C.c_size_t(len(seed)), C.byref(ss), C.byref(rs), C.byref(bad), C.byref(chk))
         return {"share_s": ss.value, "recover_s": rs.value, "mismatches": bad.value, "checksum": chk.value}
 
+    def time_shamir_hoisted(self, field, N, t, n, seed: bytes = b"scl-bench"):
+        """as time_shamir with the Lagrange basis computed once (reference library only)"""
+        ss, rs = C.c_double(), C.c_double()
+        bad, chk = C.c_uint64(), C.c_uint64()
+        self._call("time_shamir_hoisted", C.c_int(field), C.c_size_t(N), C.c_size_t(t), C.c_size_t(n), seed,
+                   C.c_size_t(len(seed)), C.byref(ss), C.byref(rs), C.byref(bad), C.byref(chk))
+        return {"share_s": ss.value, "recover_s": rs.value, "mismatches": bad.value, "checksum": chk.value}
+
 
 class Port(_Base):
     prefix = "sclo_"
