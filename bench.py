@@ -54,11 +54,11 @@ def cpu_baseline(field_key, n, t, sample):
     }
     # SURVEY.md section 8d asks for two more figures beside the faithful single-thread run (SCL itself is single-threaded;
     # the threads below are this harness's, one PRG and one slab of secrets each):
-    #   all_cores  the same per-secret path on every host core this process may use
+    #   all_cores  the same per-secret path on the host cores that go with one GPU (at most 16 threads)
     #   hoisted    one thread, Lagrange basis computed once instead of per secret (reference library only)
     try:
         from concurrent.futures import ThreadPoolExecutor
-        cores = len(os.sched_getaffinity(0))
+        cores = min(len(os.sched_getaffinity(0)), 16)   # the CPU share that goes with one GPU on the bench boxes
         per = max(1, sample // 4)          # a quarter of the sample per thread keeps the leg to a few seconds
         t0 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL for the duration of each call
