@@ -454,6 +454,52 @@ def test_recover_detect(scl, port, f, name):
     assert ei.value.reference_message == "not enough shares provided to detect errors"
 
 
+@pytest.mark.parametrize("f", ALL_FIELDS)
+@pytest.mark.parametrize("t,N", [(1, 7), (2, 300), (4, 513), (5, 1001), (8, 257), (9, 600), (13, 333), (17, 64), (20, 129)])
+def test_recover_detect_row_blocks(scl, port, f, t, N):
+    """shamirRecoverD over one, two and three row blocks of the check table (t rows: RB = 4 up to t = 4, 8 above; two
+    rows per pass for the 256-bit field), odd batch sizes (the scalar tail of the 2-secrets-per-lane launch), errors in
+    every share position -- the last share (index 2t) is never checked by the reference's short overload."""
+    slow = f in SLOW_ORACLE
+    if slow and t > 5:
+        N = min(N, 40)
+    L = O.LIMBS[f]
+    n = 2 * t + 1
+    secrets = rand_elems(port, f, N, b"detb")
+    if f == O.GF2_128:   # the oracle's shamirSecretShare walks x++ like the reference (meaningless in characteristic 2)
+        nodes = O.from_ints(list(range(1, n + 1)), L)
+        coeffs = rand_elems(port, f, t * N, b"detb-c").reshape(N, t, L)
+        aos = np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)])
+    else:
+        aos = port.shamir_share(f, b"detb-seed-%d" % t, secrets, t, n)
+    clean = aos.copy()
+    rng = np.random.default_rng(100 * t + N)
+    junk = rand_elems(port, f, N, b"detb-junk")
+    hit = rng.choice(N, max(1, N // 5), replace=False)
+    for k, s in enumerate(hit):
+        aos[s, k % n] = junk[s]                      # walks over every party index, check rows of every block included
+    out, status, bad = scl.shamir_recover_detect(f, dev(scl, soa(aos)), t)
+    if not (slow and t > 5):                          # the C oracle's per-call bases take minutes for these
+        want_out, want_st = port.shamir_recover_d(f, aos, t)
+        assert np.array_equal(status.cpu().numpy(), want_st)
+        assert np.array_equal(host(scl, out), want_out)
+        assert bad == int(want_st.sum())
+    # what the algebra fixes without any oracle: a junk value at index 0..2t-1 is caught unless it equals the share,
+    # index 2t is never looked at, flagged secrets come back as zero, the others as the shared secret
+    st = status.cpu().numpy()
+    got = host(scl, out)
+    for k, s in enumerate(hit):
+        i = k % n
+        changed = not np.array_equal(aos[s, i], clean[s, i])
+        if i < 2 * t and changed and not (t == 1):    # t = 1 has no check row at all (shamir.h:129: i in [d+1, d+t))
+            assert st[s] == 1 and not got[s].any()
+        if i == 2 * t:
+            assert st[s] == 0 and np.array_equal(got[s], secrets[s])
+    untouched = np.setdiff1d(np.arange(N), hit)
+    assert not st[untouched].any() and np.array_equal(got[untouched], secrets[untouched])
+    assert bad == int(st.sum())
+
+
 # ---------------------------------------------------------------------------------------------- additive
 @pytest.mark.parametrize("f,name", FIELDS)
 def test_additive_golden(scl, f, name):
