@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--t", type=int, default=3)
     ap.add_argument("--secrets", type=int, default=100_000_000, help="secrets per GPU")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="secrets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--placement-probes", type=int, default=8,
+                    help="arrangements of the operands inside one HBM arena to time before the warm-up (0 = plain allocations)")
     ap.add_argument("--share-mode", default="coeffs", choices=["coeffs", "prg"],
                     help="coeffs: polynomial coefficients resident in HBM; prg: AES-CTR PRG inside the share kernel")
     args = ap.parse_args()
@@ -117,24 +119,87 @@ def main():
 
     # ---- synthetic inputs, generated on the device (uniform field elements from the AES-CTR PRG) ----
     seed = f"scl-bench-{args.field}-{rank}".encode()
-    secrets = scl.vector_random(f, N, seed + b"-secrets")
-    coeffs = None
-    if args.share_mode == "coeffs" and t:
-        coeffs = scl.empty(f, t, N)
-        for k in range(t):
-            blocks_per_row = (N * E + 15) // 16
-            coeffs[k].copy_(scl.vector_random(f, N, seed + b"-coeffs", counter0=k * blocks_per_row))
-    shares = scl.empty(f, n, N)
-    out = scl.empty(f, N)
     lam = scl.lagrange_basis(f, n)
+    tc = t if args.share_mode == "coeffs" else 0
+    rowN = N * L                                   # int64 words per row of N elements
+    blocks_per_row = (N * E + 15) // 16
+
+    def fill_inputs(secrets, coeffs):
+        secrets.copy_(scl.vector_random(f, N, seed + b"-secrets"))
+        for k in range(tc):
+            coeffs[k].copy_(scl.vector_random(f, N, seed + b"-coeffs", counter0=k * blocks_per_row))
+
+    def run_share(secrets, coeffs, dst):
+        if args.share_mode == "coeffs":
+            scl.shamir_share(f, secrets, coeffs if tc else None, n, out=dst)
+        else:
+            scl.shamir_share_prg(f, secrets, t, n, seed, out=dst)
+
+    # ---- where the operands land in HBM.  The same two kernels run up to 10 % apart depending on which physical
+    # region the share matrix, the inputs and the reconstruct output occupy (tools/probe_placement*.py: it follows
+    # the region, not the row stride or small offsets; read-heavy and write-heavy kernels prefer different
+    # arrangements).  So the operands are carved out of one arena at a few spread-out arrangements, each is timed for
+    # two passes, and the fastest is kept -- all before the warm-up; --placement-probes 0 allocates plainly.
+    placement = None
+    GiB = 1 << 30
+    up = lambda x: (x + 4095) // 4096 * 4096       # operands start on 4 KiB boundaries and never overlap
+    m_bytes, i_bytes, o_bytes = up(n * rowN * 8), up((1 + tc) * rowN * 8), up(rowN * 8)
+    need = m_bytes + i_bytes + o_bytes
+    arena = None
+    if args.placement_probes > 0:
+        free_b, _total = torch.cuda.mem_get_info()
+        arena_bytes = min(int(free_b * 0.6), max(4 * need, 44 * GiB)) // 4096 * 4096
+        if arena_bytes >= 2 * need + 3 * GiB:
+            arena = torch.empty(arena_bytes // 8, dtype=torch.int64, device="cuda")
+
+    def carve(off_bytes, rows):
+        assert off_bytes % 4096 == 0
+        off = off_bytes // 8
+        return arena[off: off + rows * rowN].view(rows, N, L)
+
+    if arena is not None:
+        top = arena.numel() * 8
+        lay = [  # (matrix, inputs, output) byte offsets: packed low, output / matrix / inputs moved to the far end, ...
+            (i_bytes + o_bytes, 0, i_bytes),
+            (i_bytes, 0, top - o_bytes),
+            (top - m_bytes, 0, i_bytes),
+            (0, top - i_bytes - o_bytes, top - o_bytes),
+            (top - m_bytes, top - m_bytes - i_bytes - o_bytes, top - m_bytes - o_bytes),
+            (up(top // 2), 0, top - o_bytes),
+            (0, up(top // 2), up(top // 2) + i_bytes),
+            (up(top // 3), top - i_bytes, 0),
+        ][: max(2, args.placement_probes)]
+        tm = scl.Timer()
+        times = []
+        for (mo, io, oo) in lay:
+            inp = carve(io, 1 + tc)
+            fill_inputs(inp[0], inp[1:])
+            M, O_ = carve(mo, n), carve(oo, 1)[0]
+            for rep in range(3):
+                if rep == 1:
+                    tm.start()
+                run_share(inp[0], inp[1:], M)
+                scl.shamir_recover(f, M, lam, out=O_)
+            tm.stop()
+            times.append(tm.elapsed_ms() / 2)
+        best = min(range(len(lay)), key=times.__getitem__)
+        mo, io, oo = lay[best]
+        inp = carve(io, 1 + tc)
+        fill_inputs(inp[0], inp[1:])
+        secrets, coeffs, shares, out = inp[0], (inp[1:] if tc else None), carve(mo, n), carve(oo, 1)[0]
+        placement = {"arena_GiB": round(top / GiB, 1), "layouts_GiB": [[round(x / GiB, 1) for x in l] for l in lay],
+                     "step_ms": [round(x, 4) for x in times], "chosen": best}
+    else:
+        secrets = scl.empty(f, N)
+        coeffs = scl.empty(f, tc, N) if tc else None
+        fill_inputs(secrets, coeffs)
+        shares = scl.empty(f, n, N)
+        out = scl.empty(f, N)
 
     def step(timers=None):
         if timers:
             timers[0].start()
-        if args.share_mode == "coeffs":
-            scl.shamir_share(f, secrets, coeffs, n, out=shares)
-        else:
-            scl.shamir_share_prg(f, secrets, t, n, seed, out=shares)
+        run_share(secrets, coeffs, shares)
         if timers:
             timers[0].stop()
             timers[1].start()
@@ -222,7 +287,7 @@ def main():
                    else f"shamir_share+reconstruct n={n} t={t} {FIELD_NAMES[args.field]} {N} secrets/GPU",
                    "field": FIELD_NAMES[args.field], "n": n, "t": t, "secrets_per_gpu": N,
                    "share_mode": args.share_mode, "layout": "SoA [party][secret]", "parallelism": f"shard{world}"},
-        "roofline": roofline, "kernels": kernels, "verified": verified,
+        "roofline": roofline, "kernels": kernels, "verified": verified, "placement_probe": placement,
         "reconstruct_only_per_s": N * world / (rec_ms * 1e-3), "share_only_per_s": N * world / (share_ms * 1e-3),
     }
     if world == 1 and args.cpu_sample > 0:
