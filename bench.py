@@ -171,7 +171,8 @@ def main():
         ][: max(2, args.placement_probes)]
         tm = scl.Timer()
         times = []
-        for (mo, io, oo) in lay:
+
+        def time_layout(mo, io, oo):
             inp = carve(io, 1 + tc)
             fill_inputs(inp[0], inp[1:])
             M, O_ = carve(mo, n), carve(oo, 1)[0]
@@ -181,8 +182,36 @@ def main():
                 run_share(inp[0], inp[1:], M)
                 scl.shamir_recover(f, M, lam, out=O_)
             tm.stop()
-            times.append(tm.elapsed_ms() / 2)
+            return tm.elapsed_ms() / 2
+
+        for l in lay:
+            times.append(time_layout(*l))
         best = min(range(len(lay)), key=times.__getitem__)
+        # second stage: with the matrix where it is, slide the reconstruct output and then the inputs over the free
+        # part of the arena (their position relative to the matrix decides which DRAM banks the lock-step read and
+        # write streams meet in)
+        if args.placement_probes >= 8:
+            def free_slots(size, taken, count=6):
+                cands = [up(int(top * k / (count + 1))) for k in range(count + 2)]
+                ok = []
+                for c in cands:
+                    c = min(c, top - size)
+                    if all(c + size <= a or c >= a + b for a, b in taken):
+                        ok.append(c)
+                return ok
+            mo, io, oo = lay[best]
+            bt = times[best]
+            for c in free_slots(o_bytes, [(mo, m_bytes), (io, i_bytes)]):
+                x = time_layout(mo, io, c)
+                lay.append((mo, io, c)); times.append(x)
+                if x < bt:
+                    bt, oo = x, c
+            for c in free_slots(i_bytes, [(mo, m_bytes), (oo, o_bytes)]):
+                x = time_layout(mo, c, oo)
+                lay.append((mo, c, oo)); times.append(x)
+                if x < bt:
+                    bt, io = x, c
+            best = min(range(len(lay)), key=times.__getitem__)
         mo, io, oo = lay[best]
         inp = carve(io, 1 + tc)
         fill_inputs(inp[0], inp[1:])
