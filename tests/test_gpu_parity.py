@@ -1042,3 +1042,50 @@ def test_full_size_round_trip(scl, port, f, n, t, N):
     # additive at size
     ad = scl.additive_share_prg(f, secrets, 3, b"big-add")
     assert scl.equals(f, scl.additive_recover(f, ad), secrets)
+
+
+def test_bench_contract_small(scl):
+    """bench.py end to end on a small batch: one JSON line with the contract's keys, the roofline and cpu_baseline objects,
+    a verified round trip, and the placement probe (arena arrangements) exercised."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--secrets", "300000", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "2000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["verified"] is True and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["cores"] == 1
+    assert line["placement_probe"] is None or len(line["placement_probe"]["step_ms"]) >= 2
+
+
+@pytest.mark.parametrize("n,t,N", [(128, 42, 3 * 256 * 32 + 17), (97, 5, 2 * 256 * 32 + 31), (128, 48, 256 * 32 + 1), (100, 33, 4 * 256 * 32)])
+def test_share_matrix_core_pipeline_many_trips(scl, port, n, t, N):
+    """k_share_mfma_m61_pipe with several trips per workgroup (the cross-block software pipeline: fetch two blocks ahead,
+    recode under the matrix instructions) and a ragged last block: bit-identical to the burst kernel, to the VALU kernels
+    and, on a sample of secrets, to the oracle's per-secret Horner."""
+    f, L = O.M61, 1
+    secrets = scl.vector_random(f, N, b"pipe-s")
+    coeffs = scl.vector_random(f, t * N, b"pipe-c").reshape(t, N, L)
+    outs = {}
+    for name, keys in (("pipe", {"mfma": 1, "mfma_pipe": 1}), ("burst", {"mfma": 1, "mfma_pipe": 0}), ("valu", {"mfma": -1})):
+        for k, v in keys.items():
+            scl.set_tuning(k, v)
+        try:
+            outs[name] = scl.shamir_share(f, secrets, coeffs, n)
+        finally:
+            scl.set_tuning("mfma", 0)
+            scl.set_tuning("mfma_pipe", 1)
+    assert scl.equals(f, outs["pipe"], outs["burst"])
+    assert scl.equals(f, outs["pipe"], outs["valu"])
+    hs, hc, got = host(scl, secrets), host(scl, coeffs), host(scl, outs["pipe"])
+    idx = sorted(set([0, 1, 31, 32, 33, 8191, 8192, N - 33, N - 2, N - 1] + list(range(N // 2, N // 2 + 40))))
+    sub_s = hs[idx]
+    sub_c = np.ascontiguousarray(np.transpose(hc[:, idx], (1, 0, 2)))
+    want = soa(port.shamir_share_coeffs(f, sub_s, sub_c, n))
+    assert np.array_equal(got[:, idx], want)
