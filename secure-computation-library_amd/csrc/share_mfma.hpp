@@ -521,6 +521,7 @@ __global__ __launch_bounds__(256, 1) void k_share_mfma_m61_pipe(u64* shares, siz
   };
 
   const unsigned char* brow = Bs + (size_t)r * ROWB + 16 * h;
+  const u32 brow_lds = (u32)reinterpret_cast<uintptr_t>(brow);  // LDS byte address of this lane's fragment row
   const unsigned char* arow = Atab + ((size_t)mt * 32 + r) * ROWB + 16 * h;
   v4i afrag[MF_LIMBS][KS], bfrag[MF_LIMBS][KS];
 #pragma unroll
@@ -552,8 +553,11 @@ __global__ __launch_bounds__(256, 1) void k_share_mfma_m61_pipe(u64* shares, siz
     for (int m = 0; m < MF_LIMBS; ++m)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        bfrag[m][ks] = *reinterpret_cast<const v4i*>(brow + (size_t)m * COLS * ROWB + ks * 32);
-        asm volatile("" : "=a"(bfrag[m][ks]) : "0"(bfrag[m][ks]));
+        // LDS -> accumulation registers in one instruction (the compiler would go through a VGPR and four
+        // v_accvgpr_write); the wait is the lgkmcnt(0) of the barrier below
+        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                     : "=a"(bfrag[m][ks])
+                     : "v"(brow_lds), "n"(m * COLS * ROWB + ks * 32));
       }
     mf_lds_barrier();
     // The next block's recode (its coefficients arrived during the previous block) and the fetch of the block after it
