@@ -455,7 +455,7 @@ def test_recover_detect(scl, port, f, name):
 
 
 @pytest.mark.parametrize("f", ALL_FIELDS)
-@pytest.mark.parametrize("t,N", [(1, 7), (2, 300), (4, 513), (5, 1001), (8, 257), (9, 600), (13, 333), (17, 64), (20, 129)])
+@pytest.mark.parametrize("t,N", [(1, 7), (2, 300), (4, 513), (5, 1001), (8, 257), (9, 600), (13, 333), (17, 64), (20, 129), (42, 70)])
 def test_recover_detect_row_blocks(scl, port, f, t, N):
     """shamirRecoverD over one, two and three row blocks of the check table (t rows: RB = 4 up to t = 4, 8 above; two
     rows per pass for the 256-bit field), odd batch sizes (the scalar tail of the 2-secrets-per-lane launch), errors in
