@@ -100,7 +100,8 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the sto
  *   force_table  1: no small-node / blocked / Vandermonde-table share kernels, 2: also no small-node Horner
  *   mfma         1: force the matrix-core share / matmul path, -1: never use it
  *   mfma_areg    (default 1) matrix-core kernel keeps V's digit fragments in registers for 97..128 parties
- *   mfma_pipe    (default 1) 97..128 parties run the software-pipelined one-wave-per-SIMD matrix-core kernel */
+ *   mfma_pipe    (default 2) matrix-core kernel for 97..128 parties: 2 = two software-pipelined waves per SIMD on
+ *                16x16x64 tiles (thresholds 32..63; smaller ones as 1), 1 = one pipelined wave per SIMD, 0 = word bursts */
 int scl_hip_set_tuning(const char* key, long value);
 
 /* ---- element-wise: scl::math::Vector<FF> members ------------------------- */

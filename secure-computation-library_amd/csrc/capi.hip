@@ -52,7 +52,8 @@ std::atomic<long> g_nontemporal{1};
 std::atomic<long> g_force_scalar{0};
 std::atomic<long> g_force_table{0};
 std::atomic<long> g_mfma_tpb{0};
-std::atomic<long> g_mfma_pipe{1};  // software-pipelined one-wave-per-SIMD kernel for the 4-row-tile shapes ("mfma_pipe")
+std::atomic<long> g_mfma_pipe{2};  // 4-row-tile shapes: 2 = two pipelined waves per SIMD on 16x16x64 tiles (33..64 coefficient
+                                   // rows; else as 1), 1 = one pipelined wave per SIMD, 0 = burst kernel ("mfma_pipe")
 std::atomic<long> g_mfma_areg{1};  // register-resident V fragments for the 4-row-tile shapes ("mfma_areg" tuning key)
 std::atomic<long> g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
 
@@ -441,6 +442,20 @@ int launch_share_mfma(u64* shares, size_t stride, const u64* secrets, const u64*
                       const unsigned char* tab, int t, int n, size_t N, hipStream_t st) {
   const bool areg = g_mfma_areg.load() != 0 && MT == 4;
   const long tpb_mode = g_mfma_tpb.load();
+  if constexpr (MT == 4 && KS == 2) {
+    if (g_mfma_pipe.load() >= 2) {
+      // k_share_mfma_m61_p16: one 8-wave workgroup per CU, 32 secrets per trip, two LDS images of the recoded block
+      const size_t shmem = 2 * mf_b_bytes(KS, MT, 1);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_mfma_m61_p16),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      const size_t nblocks = (N + 31) / 32;
+      const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
+      hipLaunchKernelGGL(k_share_mfma_m61_p16, dim3(grid), dim3(512), shmem, st, shares, stride, secrets, coeffs, cstride, tab,
+                         t, n, N);
+      HIP_TRY(hipGetLastError());
+      return SCL_OK;
+    }
+  }
   if constexpr (MT == 4) {
     if (g_mfma_pipe.load() != 0) {
       // k_share_mfma_m61_pipe: one 4-wave workgroup per CU, 32 secrets per trip

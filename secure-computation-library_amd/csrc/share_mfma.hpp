@@ -636,6 +636,228 @@ __global__ __launch_bounds__(256, 1) void k_share_mfma_m61_pipe(u64* shares, siz
   }
 }
 
+// ---- two pipelined waves per SIMD on 16x16x64 tiles ---------------------------------------------------------------
+// k_share_mfma_m61_pipe is bound by what a lone wave can issue (its VALU side alone takes longer than the matrix
+// instructions); a second wave on the SIMD needs the whole working set under 256 registers.  v_mfma_i32_16x16x64_i8
+// does that: the same multiply-accumulate rate, all 64 k-slots in one instruction, and a 16x16 tile is 4 accumulator
+// registers instead of 16.  Eight waves per workgroup; wave w owns parties 16w .. 16w+15 for the block's 32 secrets
+// (two tiles): accumulators 2 sets x 4 diagonals x 2 tiles x 4 = 64 VGPRs, V's digit fragments 32 and the block's
+// coefficient fragments 64 accumulation registers.  The product is taken transposed -- rows of the tile are secrets
+// (A operand: coefficient digits), columns are parties (B operand: V's digits) -- so that a lane ends up with four
+// consecutive secrets of one party: two 16-byte stores, no cross-lane exchange.  Same digit tables, same LDS image of
+// the recoded coefficients ([digit][32 columns][row of 64 k-bytes + pad]) as the kernels above.
+typedef int v4acc __attribute__((ext_vector_type(4)));
+struct MfOp16 {
+  int l, m, j, ct;
+};
+template <int A>
+__host__ __device__ constexpr MfOp16 mf16_word_op(int i) {
+  int c = 0;
+  for (int m = 0; m < MF_LIMBS; ++m)
+    for (int j = 0; j < 4; ++j) {
+      const int d = 4 * A + j, l = d - m;
+      if (d <= 2 * (MF_LIMBS - 1) && l >= 0 && l < MF_LIMBS) {
+        for (int ct = 0; ct < 2; ++ct) {
+          if (c == i) return MfOp16{l, m, j, ct};
+          ++c;
+        }
+      }
+    }
+  return MfOp16{-1, -1, c, -1};  // j = the number of instructions of the word
+}
+template <int A>
+__host__ __device__ constexpr int mf16_word_nops() { return mf16_word_op<A>(1 << 20).j; }
+template <int A>
+__host__ __device__ constexpr bool mf16_word_first(int i) {
+  for (int k = 0; k < i; ++k)
+    if (mf16_word_op<A>(k).j == mf16_word_op<A>(i).j && mf16_word_op<A>(k).ct == mf16_word_op<A>(i).ct) return false;
+  return true;
+}
+// recombination of word A as 40 unit operations: stage k = 0..3 adds diagonal 4A+k of the lane's eight elements
+// (tile ct = e / 4, register e % 4) into T, stage 4 rotates the finished words into S
+constexpr int MF16_UNITS = 40;
+template <int A, int U>
+__device__ __forceinline__ void mf16_recombine_unit(const v4acc (&acc)[4][2], const MfMul& mm, u64 (&T)[8], u64 (&S)[8]) {
+  constexpr int k = U / 8, e = U % 8, ct = e / 4, i = e % 4;
+  if constexpr (k == 0) T[e] = (u64)((long long)acc[0][ct][i] * mm.m0 + (long long)MF_WORD_BIAS);
+  if constexpr (k == 1) T[e] = (u64)((long long)acc[1][ct][i] * mm.m8 + (long long)T[e]);
+  if constexpr (k == 2) T[e] = (u64)((long long)acc[2][ct][i] * mm.m16 + (long long)T[e]);
+  if constexpr (k == 3 && 4 * A + 3 <= 2 * (MF_LIMBS - 1)) T[e] = (u64)((long long)acc[3][ct][i] * mm.m24 + (long long)T[e]);
+  if constexpr (k == 4) {
+    const u64 w = T[e];  // 0 < w < 2^51
+    if constexpr (A == 3) S[e] = rotl61(w, 35);   // 2^96
+    if constexpr (A == 2) S[e] += w << 3;         // 2^64
+    if constexpr (A == 1) S[e] += rotl61(w, 32);  // 2^32
+    if constexpr (A == 0) S[e] += w;
+    asm volatile("" : "+v"(S[e]));
+  }
+  asm volatile("" : "+v"(T[e]));  // pinned in place (see mf_recombine_unit)
+}
+template <int A, int U0, int U1>
+__device__ __forceinline__ void mf16_recombine_units(const v4acc (&acc)[4][2], const MfMul& mm, u64 (&T)[8], u64 (&S)[8]) {
+  if constexpr (U0 < U1) {
+    mf16_recombine_unit<A, U0>(acc, mm, T, S);
+    mf16_recombine_units<A, U0 + 1, U1>(acc, mm, T, S);
+  }
+}
+template <int A, int I, int NM, bool PREV, class Side>
+__device__ __forceinline__ void mf16_pipe_op(const v4i (&vfrag)[MF_LIMBS], const v4i (&cfrag)[2][MF_LIMBS], v4acc (&accN)[4][2],
+                                             const v4acc (&accP)[4][2], const MfMul& mm, u64 (&T)[8], u64 (&S)[8], Side& side) {
+  constexpr MfOp16 op = mf16_word_op<A>(I);
+  constexpr bool first = mf16_word_first<A>(I);
+  const v4acc zero = {0, 0, 0, 0};
+  accN[op.j][op.ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cfrag[op.ct][op.m], vfrag[op.l], first ? zero : accN[op.j][op.ct], 0, 0, 0);
+  if constexpr (PREV) mf16_recombine_units<A + 1, MF16_UNITS * I / NM, MF16_UNITS * (I + 1) / NM>(accP, mm, T, S);
+  side(std::integral_constant<int, A>{}, std::integral_constant<int, I>{}, std::integral_constant<int, NM>{});
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int A, bool PREV, class Side, int... Is>
+__device__ __forceinline__ void mf16_pipe_word(const v4i (&vfrag)[MF_LIMBS], const v4i (&cfrag)[2][MF_LIMBS], v4acc (&accN)[4][2],
+                                               const v4acc (&accP)[4][2], const MfMul& mm, u64 (&T)[8], u64 (&S)[8], Side& side,
+                                               std::integer_sequence<int, Is...>) {
+  (mf16_pipe_op<A, Is, (int)sizeof...(Is), PREV>(vfrag, cfrag, accN, accP, mm, T, S, side), ...);
+}
+
+// Atab: the KS = 2, MT = 4 table of mfma_table (rows = parties, 64 k-bytes + pad per row)
+__global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size_t stride, const u64* secrets,
+                                                               const u64* coeffs, size_t cstride, const unsigned char* Atab,
+                                                               int t, int n, size_t N) {
+  constexpr int KS = 2, MT = 4, COLS = 32;
+  constexpr int ROWB = mf_rowb(KS);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // two images [digit][32 cols][ROWB] of recoded coefficients: block i is read from image i & 1 while block i + 1 is
+  // recoded into the other one, so one barrier per block suffices
+  constexpr int IMG = MF_LIMBS * COLS * ROWB;
+  unsigned char* Bs = smem;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kb = lane >> 4, r32 = lane & 31, h = lane >> 5;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const size_t nblocks = (N + COLS - 1) / COLS;
+  const u64 P = M61::P;
+  const int party = 16 * w + r16;
+
+  // one (column, k-group) item per thread: column lane & 31 of k-group 2 wave + (lane >> 5)
+  u64 creg[4];
+  auto fetch = [&](size_t blk) {
+    const size_t s = blk * COLS + r32;
+    const bool full = blk * COLS + COLS <= N;  // block-uniform
+    const int kgw = 2 * wu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k_lo = 4 * kgw + j, k_hi = k_lo + 4;
+      const u64* p_lo = k_lo == 0 ? secrets : coeffs + (size_t)(k_lo - 1) * cstride;
+      const u64* p_hi = coeffs + (size_t)(k_hi - 1) * cstride;
+      const u64* p = (h ? p_hi : p_lo) + s;
+      creg[j] = 0;
+      if (full && k_hi <= t) {
+        creg[j] = __builtin_nontemporal_load(p);
+      } else if (k_lo <= t) {
+        if ((h ? k_hi : k_lo) <= t && s < N) creg[j] = __builtin_nontemporal_load(p);
+      }
+    }
+  };
+  auto recode = [&](int img) {
+    const int kg = 2 * w + h;
+    unsigned char* dst = Bs + (size_t)img * IMG + (size_t)r32 * ROWB + 4 * kg;
+    u32 lo[4], hi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u64 u = mf_recode(creg[j]);
+      lo[j] = (u32)u;
+      hi[j] = (u32)(u >> 32);
+    }
+#pragma unroll
+    for (int m = 0; m < MF_LIMBS; ++m) {
+      const u32* src = m < 4 ? lo : hi;
+      const u32 b = m & 3;
+      const u32 sel = 0x0c0c0000u | ((4 + b) << 8) | b;
+      const u32 p01 = __builtin_amdgcn_perm(src[1], src[0], sel);
+      const u32 p23 = __builtin_amdgcn_perm(src[3], src[2], sel);
+      *reinterpret_cast<u32*>(dst + (size_t)m * COLS * ROWB) = p01 | (p23 << 16);
+    }
+  };
+
+  // V's digit fragments of this wave's sixteen parties (B operand: k-block lane >> 4 of party lane & 15), kernel lifetime
+  v4i vfrag[MF_LIMBS], cfrag[2][MF_LIMBS];
+  {
+    const unsigned char* vrow = Atab + ((size_t)(party >> 5) * 32 + (party & 31)) * ROWB + 16 * kb;
+#pragma unroll
+    for (int l = 0; l < MF_LIMBS; ++l) {
+      vfrag[l] = *reinterpret_cast<const v4i*>(vrow + (size_t)l * MT * 32 * ROWB);
+      asm volatile("" : "=a"(vfrag[l]) : "0"(vfrag[l]));
+    }
+  }
+  const u32 crow_lds = (u32)reinterpret_cast<uintptr_t>(Bs + (size_t)r16 * ROWB + 16 * kb);  // secret lane & 15 of tile 0
+  MfMul mm{1, 256, 65536, 16777216};
+  asm volatile("" : "+s"(mm.m0), "+s"(mm.m8), "+s"(mm.m16), "+s"(mm.m24));
+  const bool rows_full = __builtin_amdgcn_readfirstlane(16 * w + 16 <= n);
+  const bool aligned_rows = (reinterpret_cast<uintptr_t>(shares) & 15) == 0 && (stride & 1) == 0;
+
+  size_t blk = blockIdx.x;
+  if (blk < nblocks) {
+    fetch(blk);
+    recode(0);
+  }
+  if (blk + gridDim.x < nblocks) fetch(blk + gridDim.x);
+
+  for (int img = 0; blk < nblocks; blk += gridDim.x, img ^= 1) {
+    const size_t s_base = blk * COLS;
+    mf_lds_barrier();  // this block's digits are complete in image img; everyone is done reading the other image
+    const u32 crow = crow_lds + (u32)img * IMG;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int m = 0; m < MF_LIMBS; ++m)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(cfrag[ct][m]) : "v"(crow), "n"(m * COLS * ROWB + ct * 16 * ROWB));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const bool have_next = blk + gridDim.x < nblocks, have_next2 = blk + 2 * (size_t)gridDim.x < nblocks;
+    auto side = [&](auto Ac, auto Ic, auto NMc) {
+      constexpr int A_ = decltype(Ac)::value, I_ = decltype(Ic)::value, NM_ = decltype(NMc)::value;
+      if constexpr (A_ == 2 && I_ == NM_ / 2) {
+        if (have_next) recode(img ^ 1);
+      }
+      if constexpr (A_ == 1 && I_ == NM_ / 4) {
+        if (have_next2) fetch(blk + 2 * (size_t)gridDim.x);
+      }
+    };
+    u64 S[8], T[8];
+    v4acc accX[4][2], accY[4][2];
+    mf16_pipe_word<3, false>(vfrag, cfrag, accX, accY, mm, T, S, side, std::make_integer_sequence<int, mf16_word_nops<3>()>{});
+    mf16_pipe_word<2, true>(vfrag, cfrag, accY, accX, mm, T, S, side, std::make_integer_sequence<int, mf16_word_nops<2>()>{});
+    mf16_pipe_word<1, true>(vfrag, cfrag, accX, accY, mm, T, S, side, std::make_integer_sequence<int, mf16_word_nops<1>()>{});
+    mf16_pipe_word<0, true>(vfrag, cfrag, accY, accX, mm, T, S, side, std::make_integer_sequence<int, mf16_word_nops<0>()>{});
+    mf16_recombine_units<0, 0, MF16_UNITS>(accY, mm, T, S);
+
+    // ---- fold and store: element e = 4 ct + i is secret s_base + 16 ct + 4 (lane >> 4) + i of party 16 w + (lane & 15)
+    const bool fast = rows_full && aligned_rows && s_base + COLS <= N;  // wave-uniform
+    u64* rowp = shares + (size_t)party * stride + s_base + 4 * kb;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      u64 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u64 sum = S[4 * ct + i] + (P - MF_TOTAL_BIAS);  // < 2^63
+        const u64 f = (sum & P) + (sum >> 61);
+        v[i] = f >= P ? f - P : f;
+      }
+      u64* dst = rowp + 16 * ct;
+      const size_t s0 = s_base + 16 * ct + 4 * kb;
+      u64x2 o0, o1;
+      o0.x = v[0];
+      o0.y = v[1];
+      o1.x = v[2];
+      o1.y = v[3];
+      if (fast) {
+        __builtin_nontemporal_store(o0, reinterpret_cast<u64x2*>(dst));
+        __builtin_nontemporal_store(o1, reinterpret_cast<u64x2*>(dst) + 1);
+      } else if (party < n) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (s0 + i < N) dst[i] = v[i];
+      }
+    }
+  }
+}
+
 // Digit planes of an arbitrary row-major matrix A[M x K] (device memory) in the A-table layout above, so
 // that Matrix::multiply (matrix.h:477-495) with a small left factor runs on the same kernel.  `tab` must be
 // zero-filled beforehand (padding rows / k-slots).

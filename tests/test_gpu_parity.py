@@ -1066,23 +1066,25 @@ def test_bench_contract_small(scl):
 
 @pytest.mark.parametrize("n,t,N", [(128, 42, 3 * 256 * 32 + 17), (97, 5, 2 * 256 * 32 + 31), (128, 48, 256 * 32 + 1), (100, 33, 4 * 256 * 32)])
 def test_share_matrix_core_pipeline_many_trips(scl, port, n, t, N):
-    """k_share_mfma_m61_pipe with several trips per workgroup (the cross-block software pipeline: fetch two blocks ahead,
+    """k_share_mfma_m61_p16 / k_share_mfma_m61_pipe with several trips per workgroup (the cross-block software pipeline: fetch two blocks ahead,
     recode under the matrix instructions) and a ragged last block: bit-identical to the burst kernel, to the VALU kernels
     and, on a sample of secrets, to the oracle's per-secret Horner."""
     f, L = O.M61, 1
     secrets = scl.vector_random(f, N, b"pipe-s")
     coeffs = scl.vector_random(f, t * N, b"pipe-c").reshape(t, N, L)
     outs = {}
-    for name, keys in (("pipe", {"mfma": 1, "mfma_pipe": 1}), ("burst", {"mfma": 1, "mfma_pipe": 0}), ("valu", {"mfma": -1})):
+    for name, keys in (("p16", {"mfma": 1, "mfma_pipe": 2}), ("pipe", {"mfma": 1, "mfma_pipe": 1}),
+                       ("burst", {"mfma": 1, "mfma_pipe": 0}), ("valu", {"mfma": -1})):
         for k, v in keys.items():
             scl.set_tuning(k, v)
         try:
             outs[name] = scl.shamir_share(f, secrets, coeffs, n)
         finally:
             scl.set_tuning("mfma", 0)
-            scl.set_tuning("mfma_pipe", 1)
+            scl.set_tuning("mfma_pipe", 2)
     assert scl.equals(f, outs["pipe"], outs["burst"])
     assert scl.equals(f, outs["pipe"], outs["valu"])
+    assert scl.equals(f, outs["pipe"], outs["p16"])
     hs, hc, got = host(scl, secrets), host(scl, coeffs), host(scl, outs["pipe"])
     idx = sorted(set([0, 1, 31, 32, 33, 8191, 8192, N - 33, N - 2, N - 1] + list(range(N // 2, N // 2 + 40))))
     sub_s = hs[idx]

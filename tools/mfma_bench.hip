@@ -82,6 +82,26 @@ int main(int argc, char** argv) {
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
     time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, 0, out1, N, c, c + N, N, tab, t, n, N); }, "k_share_mfma_m61_pipe");
   }
+  u64* out2;
+  CK(hipMalloc(&out2, (size_t)n * N * 8));
+  CK(hipMemset(out2, 0x33, (size_t)n * N * 8));
+  {
+    const size_t shmem = 2 * mf_b_bytes(KS, MT, 1);
+    auto kern = &k_share_mfma_m61_p16;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    const size_t nblocks = (N + 31) / 32;
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, 0, out2, N, c, c + N, N, tab, t, n, N); }, "k_share_mfma_m61_p16");
+    std::vector<u64> a0((size_t)n * N), a2((size_t)n * N);
+    CK(hipMemcpy(a0.data(), out0, a0.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(a2.data(), out2, a2.size() * 8, hipMemcpyDeviceToHost));
+    size_t d2 = 0, firstbad = (size_t)-1;
+    for (size_t i = 0; i < a0.size(); ++i)
+      if (a0[i] != a2[i]) { if (firstbad == (size_t)-1) firstbad = i; ++d2; }
+    std::printf("p16 vs bursts: %zu differing values", d2);
+    if (d2) std::printf(" (first at party %zu secret %zu: %llx vs %llx)", firstbad / N, firstbad % N, (unsigned long long)a2[firstbad], (unsigned long long)a0[firstbad]);
+    std::printf("\n");
+  }
   if (argc > 4) {  // ablations of the pipelined kernel (results are wrong by construction)
     const size_t shmem = mf_b_bytes(KS, MT, 1);
     const size_t nblocks = (N + 31) / 32;
