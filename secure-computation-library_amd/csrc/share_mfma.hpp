@@ -553,11 +553,12 @@ __global__ __launch_bounds__(256, 1) void k_share_mfma_m61_pipe(u64* shares, siz
     for (int m = 0; m < MF_LIMBS; ++m)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        // LDS -> accumulation registers in one instruction (the compiler would go through a VGPR and four
-        // v_accvgpr_write); the wait is the lgkmcnt(0) of the barrier below
-        asm volatile("ds_read_b128 %0, %1 offset:%2"
+        // load and wait in one asm statement each (nothing may touch the register before the data is in); straight
+        // into the accumulation registers -- the compiler would go through a VGPR and four v_accvgpr_write
+        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)"
                      : "=a"(bfrag[m][ks])
-                     : "v"(brow_lds), "n"(m * COLS * ROWB + ks * 32));
+                     : "v"(brow_lds), "n"(m * COLS * ROWB + ks * 32)
+                     : "memory");
       }
     mf_lds_barrier();
     // The next block's recode (its coefficients arrived during the previous block) and the fetch of the block after it
@@ -803,12 +804,23 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
     const size_t s_base = blk * COLS;
     mf_lds_barrier();  // this block's digits are complete in image img; everyone is done reading the other image
     const u32 crow = crow_lds + (u32)img * IMG;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int m = 0; m < MF_LIMBS; ++m)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(cfrag[ct][m]) : "v"(crow), "n"(m * COLS * ROWB + ct * 16 * ROWB));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the sixteen loads and their wait are ONE asm statement: nothing the compiler might insert (a copy, a spill)
+    // can touch a fragment register before its data has arrived
+    static_assert(MF_LIMBS == 8, "eight digit planes per tile below");
+#define MF16_LD(ct)                                                                                                    \
+  asm volatile("ds_read_b128 %0, %8 offset:%9\n\tds_read_b128 %1, %8 offset:%10\n\tds_read_b128 %2, %8 offset:%11\n\t"      \
+               "ds_read_b128 %3, %8 offset:%12\n\tds_read_b128 %4, %8 offset:%13\n\tds_read_b128 %5, %8 offset:%14\n\t"     \
+               "ds_read_b128 %6, %8 offset:%15\n\tds_read_b128 %7, %8 offset:%16\n\ts_waitcnt lgkmcnt(0)"                  \
+               : "=&a"(cfrag[ct][0]), "=&a"(cfrag[ct][1]), "=&a"(cfrag[ct][2]), "=&a"(cfrag[ct][3]), "=&a"(cfrag[ct][4]),     \
+                 "=&a"(cfrag[ct][5]), "=&a"(cfrag[ct][6]), "=&a"(cfrag[ct][7])                                                \
+               : "v"(crow), "n"(0 * COLS * ROWB + ct * 16 * ROWB), "n"(1 * COLS * ROWB + ct * 16 * ROWB),                    \
+                 "n"(2 * COLS * ROWB + ct * 16 * ROWB), "n"(3 * COLS * ROWB + ct * 16 * ROWB),                               \
+                 "n"(4 * COLS * ROWB + ct * 16 * ROWB), "n"(5 * COLS * ROWB + ct * 16 * ROWB),                               \
+                 "n"(6 * COLS * ROWB + ct * 16 * ROWB), "n"(7 * COLS * ROWB + ct * 16 * ROWB)                                \
+               : "memory")
+    MF16_LD(0);
+    MF16_LD(1);
+#undef MF16_LD
     const bool have_next = blk + gridDim.x < nblocks, have_next2 = blk + 2 * (size_t)gridDim.x < nblocks;
     auto side = [&](auto Ac, auto Ic, auto NMc) {
       constexpr int A_ = decltype(Ac)::value, I_ = decltype(Ic)::value, NM_ = decltype(NMc)::value;
