@@ -29,6 +29,10 @@ __device__ __forceinline__ void valu_group(long long (&t)[8], int x, int y) {
 template <int KV>
 __device__ __forceinline__ void body(bool do_m, bool do_v, int* out) {
   v4i a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, (int)threadIdx.x, 7};
+#ifdef AB_IN_AGPR
+  asm volatile("" : "=a"(a) : "0"(a));
+  asm volatile("" : "=a"(b) : "0"(b));
+#endif
   v16i acc[4];
   for (int j = 0; j < 4; ++j)
     for (int e = 0; e < 16; ++e) acc[j][e] = 0;
@@ -41,7 +45,13 @@ __device__ __forceinline__ void body(bool do_m, bool do_v, int* out) {
       for (int j = 0; j < 4; ++j) {
         acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef READ_ACC
+        // the VALU group's multiplicand comes from a tile finished two matrix instructions ago (as the share kernels'
+        // recombination reads the previous word's accumulators)
+        valu_group<KV>(t, acc[(j + 2) & 3][5], y);
+#else
         valu_group<KV>(t, x, y);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
