@@ -1436,8 +1436,10 @@ int scl_hip_shamir_recover_correct(int field, uint64_t* f_out, size_t f_stride, 
     SCL_TRY(scratch(tbytes + 64, &sc));
     unsigned* counters = static_cast<unsigned*>(sc);  // [0] queued, [1] failed
     KC* L_dev = reinterpret_cast<KC*>(static_cast<unsigned char*>(sc) + 64);
+    // the queue of inconsistent secrets lives in the per-thread temporary (kept and grown): a hipMalloc / hipFree pair
+    // per call costs more than the consistency pass of a few million secrets
     void* queue = nullptr;
-    HIP_TRY(hipMalloc(&queue, N * sizeof(unsigned)));
+    SCL_TRY(temp_acquire(N * sizeof(unsigned), S(stream), &queue));
     auto body = [&]() -> int {
       HIP_TRY(hipMemsetAsync(counters, 0, 8, S(stream)));
       HIP_TRY(hipMemcpyAsync(L_dev, Lk.data(), tbytes, hipMemcpyHostToDevice, S(stream)));
@@ -1471,7 +1473,7 @@ int scl_hip_shamir_recover_correct(int field, uint64_t* f_out, size_t f_stride, 
       return SCL_OK;
     };
     const int rc = body();
-    (void)hipFree(queue);
+    (void)temp_release(S(stream));
     return rc;
   });
 }
