@@ -1091,3 +1091,41 @@ def test_share_matrix_core_pipeline_many_trips(scl, port, n, t, N):
     sub_c = np.ascontiguousarray(np.transpose(hc[:, idx], (1, 0, 2)))
     want = soa(port.shamir_share_coeffs(f, sub_s, sub_c, n))
     assert np.array_equal(got[:, idx], want)
+
+
+@pytest.mark.parametrize("f", ALL_FIELDS)
+@pytest.mark.parametrize("d,t,extra,N", [(2, 3, 0, 200), (5, 4, 2, 333), (9, 9, 1, 129), (3, 1, 0, 64)])
+def test_recover_detect_general_overload(scl, port, f, d, t, extra, N):
+    """shamirRecoverD(shares, alphas, t, d, x) (shamir.h:116-139) with explicit nodes, degree d != t, an evaluation point
+    x != 0 and more shares than needed: the value is the interpolant of the first d+1 shares at x, shares d+1 .. d+t-1 are
+    checked against it, anything beyond index d+t-1 is ignored.  Expected values from the oracle's Polynomial::evaluate."""
+    L = O.LIMBS[f]
+    m = d + t + extra
+    nodes = rand_elems(port, f, m, b"gen-nodes-%d" % d)
+    x = rand_elems(port, f, 1, b"gen-x")[0]
+    coeffs = rand_elems(port, f, (d + 1) * N, b"gen-c").reshape(N, d + 1, L)
+    aos = np.stack([port.poly_eval(f, coeffs[s], nodes) for s in range(N)])          # [N][m][L]
+    want = np.stack([port.poly_eval(f, coeffs[s], x.reshape(1, L))[0] for s in range(N)])
+    junk = rand_elems(port, f, N, b"gen-junk")
+    rng = np.random.default_rng(d * 10 + t)
+    hit = rng.choice(N, N // 4, replace=False)
+    pos = {}
+    for k, s in enumerate(hit):
+        i = k % m
+        if not np.array_equal(aos[s, i], junk[s]):
+            aos[s, i] = junk[s]
+            pos[int(s)] = i
+    out, status, bad = scl.shamir_recover_detect(f, dev(scl, soa(aos)), t, d=d, alphas=nodes, x=x)
+    st, got = status.cpu().numpy(), host(scl, out)
+    for s in range(N):
+        i = pos.get(s)
+        if i is None or i >= d + t:                       # untouched, or a share the call never looks at
+            assert st[s] == 0 and np.array_equal(got[s], want[s]), (s, i)
+        elif i > d:                                       # a checked share disagrees with the interpolant
+            assert st[s] == 1 and not got[s].any(), (s, i)
+        elif t > 1:                                       # one of the d+1 interpolated shares is off: some check fails
+            assert st[s] == 1 and not got[s].any(), (s, i)
+    assert bad == int(st.sum())
+    with pytest.raises(scl.SclError) as ei:
+        scl.shamir_recover_detect(f, dev(scl, soa(aos))[: d + t - 1].contiguous(), t, d=d, alphas=nodes[: d + t - 1], x=x)
+    assert ei.value.reference_message == "not enough shares provided to detect errors"
