@@ -150,7 +150,11 @@ def main():
         free_b, _total = torch.cuda.mem_get_info()
         arena_bytes = min(int(free_b * 0.6), max(4 * need, 44 * GiB)) // 4096 * 4096
         if arena_bytes >= 2 * need + 3 * GiB:
-            arena = torch.empty(arena_bytes // 8, dtype=torch.int64, device="cuda")
+            try:
+                arena = torch.empty(arena_bytes // 8, dtype=torch.int64, device="cuda")
+            except RuntimeError:   # no room for the arena (another tenant on the card): plain allocations below
+                arena = None
+                torch.cuda.empty_cache()
 
     def carve(off_bytes, rows):
         assert off_bytes % 4096 == 0
