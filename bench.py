@@ -90,8 +90,9 @@ def main():
     ap.add_argument("--t", type=int, default=3)
     ap.add_argument("--secrets", type=int, default=100_000_000, help="secrets per GPU")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="secrets timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--placement-probes", type=int, default=8,
-                    help="arrangements of the operands inside one HBM arena to time before the warm-up (0 = plain allocations)")
+    ap.add_argument("--placement-probes", type=int, default=10,
+                    help="positions of the share matrix inside one HBM arena to try before the warm-up, each with its best "
+                         "output and input slots (0 = plain allocations)")
     ap.add_argument("--share-mode", default="coeffs", choices=["coeffs", "prg"],
                     help="coeffs: polynomial coefficients resident in HBM; prg: AES-CTR PRG inside the share kernel")
     args = ap.parse_args()
@@ -163,65 +164,59 @@ def main():
 
     if arena is not None:
         top = arena.numel() * 8
-        lay = [  # (matrix, inputs, output) byte offsets: packed low, output / matrix / inputs moved to the far end, ...
-            (i_bytes + o_bytes, 0, i_bytes),
-            (i_bytes, 0, top - o_bytes),
-            (top - m_bytes, 0, i_bytes),
-            (0, top - i_bytes - o_bytes, top - o_bytes),
-            (top - m_bytes, top - m_bytes - i_bytes - o_bytes, top - m_bytes - o_bytes),
-            (up(top // 2), 0, top - o_bytes),
-            (0, up(top // 2), up(top // 2) + i_bytes),
-            (up(top // 3), top - i_bytes, 0),
-        ][: max(2, args.placement_probes)]
         tm = scl.Timer()
-        times = []
 
-        def time_layout(mo, io, oo):
-            inp = carve(io, 1 + tc)
-            fill_inputs(inp[0], inp[1:])
-            M, O_ = carve(mo, n), carve(oo, 1)[0]
-            for rep in range(3):
-                if rep == 1:
-                    tm.start()
-                run_share(inp[0], inp[1:], M)
-                scl.shamir_recover(f, M, lam, out=O_)
+        def timed(fn):
+            fn()
+            tm.start()
+            fn()
+            fn()
             tm.stop()
             return tm.elapsed_ms() / 2
 
-        for l in lay:
-            times.append(time_layout(*l))
-        best = min(range(len(lay)), key=times.__getitem__)
-        # second stage: with the matrix where it is, slide the reconstruct output and then the inputs over the free
-        # part of the arena (their position relative to the matrix decides which DRAM banks the lock-step read and
-        # write streams meet in)
-        if args.placement_probes >= 8:
-            def free_slots(size, taken, count=6):
-                cands = [up(int(top * k / (count + 1))) for k in range(count + 2)]
-                ok = []
-                for c in cands:
-                    c = min(c, top - size)
-                    if all(c + size <= a or c >= a + b for a, b in taken):
-                        ok.append(c)
-                return ok
-            mo, io, oo = lay[best]
-            bt = times[best]
-            for c in free_slots(o_bytes, [(mo, m_bytes), (io, i_bytes)]):
-                x = time_layout(mo, io, c)
-                lay.append((mo, io, c)); times.append(x)
-                if x < bt:
-                    bt, oo = x, c
-            for c in free_slots(i_bytes, [(mo, m_bytes), (oo, o_bytes)]):
-                x = time_layout(mo, c, oo)
-                lay.append((mo, c, oo)); times.append(x)
-                if x < bt:
-                    bt, io = x, c
-            best = min(range(len(lay)), key=times.__getitem__)
-        mo, io, oo = lay[best]
+        def slots(size, taken, count):
+            """up to `count` evenly spread offsets for `size` bytes that avoid the `taken` (offset, size) ranges"""
+            out_ = []
+            for k in range(count + 2):
+                c = min(up(int(top * k / (count + 1))), top - size)
+                if all(c + size <= a_ or c >= a_ + b_ for a_, b_ in taken) and c not in out_:
+                    out_.append(c)
+            return out_
+
+        # The two kernels care about different pairs: reconstruct about (matrix, output), share about (inputs, matrix).
+        # For a few positions of the matrix, the best output slot is found with the reconstruct kernel alone and then
+        # the best input slot with the share kernel alone; the matrix position with the smallest sum is kept.
+        trials = []
+        src = scl.empty(f, 1 + tc, N)
+        fill_inputs(src[0], src[1:])
+        n_m = max(2, min(12, args.placement_probes))
+        for mo in slots(m_bytes, [], n_m)[:n_m + 2]:
+            M = carve(mo, n)
+            run_share(src[0], src[1:], M)                      # valid shares for the reconstruct trials
+            best_o = best_i = None
+            for oo in slots(o_bytes, [(mo, m_bytes)], 6):
+                O_ = carve(oo, 1)[0]
+                x = timed(lambda: scl.shamir_recover(f, M, lam, out=O_))
+                if best_o is None or x < best_o[0]:
+                    best_o = (x, oo)
+            for io in slots(i_bytes, [(mo, m_bytes), (best_o[1], o_bytes)], 6):
+                inp = carve(io, 1 + tc)
+                inp.copy_(src)
+                x = timed(lambda: run_share(inp[0], inp[1:], M))
+                if best_i is None or x < best_i[0]:
+                    best_i = (x, io)
+            trials.append((best_o[0] + best_i[0], mo, best_i[1], best_o[1], best_i[0], best_o[0]))
+        trials.sort()
+        _, mo, io, oo, _, _ = trials[0]
         inp = carve(io, 1 + tc)
-        fill_inputs(inp[0], inp[1:])
+        inp.copy_(src)
+        del src
         secrets, coeffs, shares, out = inp[0], (inp[1:] if tc else None), carve(mo, n), carve(oo, 1)[0]
-        placement = {"arena_GiB": round(top / GiB, 1), "layouts_GiB": [[round(x / GiB, 1) for x in l] for l in lay],
-                     "step_ms": [round(x, 4) for x in times], "chosen": best}
+        placement = {"arena_GiB": round(top / GiB, 1),
+                     "matrix_positions": [{"matrix_GiB": round(t_[1] / GiB, 1), "inputs_GiB": round(t_[2] / GiB, 1),
+                                           "output_GiB": round(t_[3] / GiB, 1), "share_ms": round(t_[4], 4),
+                                           "recover_ms": round(t_[5], 4)} for t_ in trials],
+                     "chosen": 0}
     else:
         secrets = scl.empty(f, N)
         coeffs = scl.empty(f, tc, N) if tc else None

@@ -1061,7 +1061,7 @@ def test_bench_contract_small(scl):
     assert line["verified"] is True and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["cores"] == 1
-    assert line["placement_probe"] is None or len(line["placement_probe"]["step_ms"]) >= 2
+    assert line["placement_probe"] is None or len(line["placement_probe"]["matrix_positions"]) >= 2
 
 
 @pytest.mark.parametrize("n,t,N", [(128, 42, 3 * 256 * 32 + 17), (97, 5, 2 * 256 * 32 + 31), (128, 48, 256 * 32 + 1), (100, 33, 4 * 256 * 32)])
