@@ -80,6 +80,24 @@ unsigned grid_aes(size_t work_items) {
   return (unsigned)blocks;
 }
 
+// The four-table AES kernels: one 1024-thread workgroup per CU (128 KiB of dynamic LDS), grid-strided.
+unsigned grid_aes4(size_t work_items) {
+  size_t blocks = (work_items + ABLOCK - 1) / ABLOCK;
+  long cap = g_aes_blocks.load();
+  if (cap <= 0) cap = AES4_GRID_CAP;
+  if (blocks > (size_t)cap) blocks = (size_t)cap;
+  if (blocks == 0) blocks = 1;
+  return (unsigned)blocks;
+}
+// launch KERN (a four-table AES kernel) with its 128 KiB of dynamic LDS
+#define AES4_LAUNCH(KERN, WORK, ST, ...)                                                                            \
+  do {                                                                                                              \
+    auto kern_ = &KERN;                                                                                             \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                AES4_LDS_BYTES));                                                                   \
+    hipLaunchKernelGGL(kern_, dim3(grid_aes4(WORK)), dim3(ABLOCK), AES4_LDS_BYTES, ST, __VA_ARGS__);                \
+  } while (0)
+
 // ---- Mont128 process-wide modulus ---------------------------------------------------------------
 std::mutex g_mont_mu;
 Mont128::Ctx g_mont = {0, 0, 0, 0};
@@ -947,8 +965,7 @@ int scl_hip_prg_blocks(unsigned char* dst, size_t nblocks, const unsigned char* 
   if (!aligned16(dst)) return fail(SCL_ERR_BAD_ARG, "dst not 16-byte aligned");
   AesKey key;
   make_aes_key(seed, seed_len, key);
-  hipLaunchKernelGGL(k_prg_blocks, dim3(grid_aes((nblocks + 3) / 4)), dim3(BLOCK), 0, S(stream), reinterpret_cast<u64*>(dst),
-                     key, (u64)counter0, nblocks);
+  AES4_LAUNCH(k_prg_blocks, (nblocks + 3) / 4, S(stream), reinterpret_cast<u64*>(dst), key, (u64)counter0, nblocks);
   LAUNCH_CHECK();
   return SCL_OK;
 }
@@ -1003,8 +1020,7 @@ int scl_hip_vector_random(int field, uint64_t* dst, size_t n, const unsigned cha
     AesKey key;
     make_aes_key(seed, seed_len, key);
     const size_t work = F::LIMBS == 4 ? (n + 1) / 2 : ((F::LIMBS == 1 ? (n + 1) / 2 : n) + 3) / 4;
-    hipLaunchKernelGGL((k_vector_random<F>), dim3(grid_aes(work)), dim3(BLOCK), 0, S(stream), ctx, dst, key,
-                       (u64)counter0, n);
+    AES4_LAUNCH((k_vector_random<F>), work, S(stream), ctx, dst, key, (u64)counter0, n);
     LAUNCH_CHECK();
     return SCL_OK;
   });
@@ -1233,9 +1249,9 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
           const int nblk = F::LIMBS == 1 ? (int)(t / 2 + 1) : (int)t;
 #define SPS_CASE(NB)                                                                                          \
   case NB:                                                                                                    \
-    hipLaunchKernelGGL((k_share_prg_small<F, VEC, NB>), dim3(grid_aes(npacks)), dim3(BLOCK), 0, S(stream),    \
-                       shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS, key,              \
-                       (u64)(counter0 + first * blocks_per_secret), sv, (int)t, (int)n, npacks);                              \
+    AES4_LAUNCH((k_share_prg_small<F, VEC, NB>), npacks, S(stream), shares + first * F::LIMBS, share_stride,   \
+                secrets + first * F::LIMBS, key, (u64)(counter0 + first * blocks_per_secret), sv, (int)t, (int)n,  \
+                npacks);                                                                                      \
     break;
           switch (nblk) {
             SPS_CASE(1) SPS_CASE(2) SPS_CASE(3) SPS_CASE(4)
@@ -1274,20 +1290,26 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
       constexpr int VEC = decltype(V)::value;
       u64* sh = shares + first * F::LIMBS;
       const u64* se = secrets + first * F::LIMBS;
-      const dim3 g(grid_aes(npacks)), blk(BLOCK);
+#define SHAREP_LAUNCH1(TREG, SX)                                                                                 \
+  do {                                                                                                           \
+    if constexpr (share_prg_four_tables<F, TREG>())                                                              \
+      AES4_LAUNCH((k_share_prg<F, VEC, TREG, SX>), npacks, S(stream), ctx, sh, share_stride, se, key,            \
+                  (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks, lane);                \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_share_prg<F, VEC, TREG, SX>), dim3(grid_aes(npacks)), dim3(BLOCK), 0, S(stream), ctx, \
+                         sh, share_stride, se, key, (u64)(counter0 + first * blocks_per_secret), al, (int)t,    \
+                         (int)n, npacks, lane);                                                                  \
+  } while (0)
 #define SHAREP_LAUNCH(TREG)                                                                                      \
   do {                                                                                                           \
-    if (smallx)                                                                                                  \
-      hipLaunchKernelGGL((k_share_prg<F, VEC, TREG, true>), g, blk, 0, S(stream), ctx, sh, share_stride, se,     \
-                         key, (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks, lane);    \
-    else                                                                                                         \
-      hipLaunchKernelGGL((k_share_prg<F, VEC, TREG, false>), g, blk, 0, S(stream), ctx, sh, share_stride, se,    \
-                         key, (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks, lane);    \
+    if (smallx) SHAREP_LAUNCH1(TREG, true);                                                                      \
+    else SHAREP_LAUNCH1(TREG, false);                                                                            \
   } while (0)
       if (t <= 4) SHAREP_LAUNCH(4);
       else if (t <= 16) SHAREP_LAUNCH(16);
       else SHAREP_LAUNCH(48);
 #undef SHAREP_LAUNCH
+#undef SHAREP_LAUNCH1
       LAUNCH_CHECK();
       return SCL_OK;
     });
@@ -1515,9 +1537,9 @@ int scl_hip_additive_share_prg(int field, uint64_t* shares, size_t share_stride,
     const int vec = vec_width<F>({shares, secrets}, {share_stride});
     return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;
-      hipLaunchKernelGGL((k_additive_share_prg<F, VEC>), dim3(grid_aes(npacks)), dim3(BLOCK), 0, S(stream), ctx,
-                         shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS, key,
-                         (u64)(counter0 + first * (n - 1) * ((F::LIMBS * 8 + 15) / 16)), (int)n, npacks);
+      AES4_LAUNCH((k_additive_share_prg<F, VEC>), npacks, S(stream), ctx, shares + first * F::LIMBS, share_stride,
+                  secrets + first * F::LIMBS, key, (u64)(counter0 + first * (n - 1) * ((F::LIMBS * 8 + 15) / 16)), (int)n,
+                  npacks);
       LAUNCH_CHECK();
       return SCL_OK;
     });

@@ -409,9 +409,9 @@ __device__ __forceinline__ void horner_rows(const typename F::Ctx& ctx, const Pa
 }
 
 // node table of a Horner kernel: full elements, or u32 images when SMALLX
-template <class F, bool SMALLX>
+template <class F, bool SMALLX, int THREADS = BLOCK>
 __device__ __forceinline__ void stage_nodes(const BigTable<F>& tab, int n, typename F::E* alpha, u32* alpha32) {
-  for (int i = threadIdx.x; i < n; i += BLOCK) {
+  for (int i = threadIdx.x; i < n; i += THREADS) {
     if constexpr (SMALLX) alpha32[i] = F::low32(tab.v[i]);
     else alpha[i] = tab.v[i];
   }
@@ -802,6 +802,97 @@ __device__ __forceinline__ void aes_ctr_multi(const u32* tl, const AesKey& key, 
 #undef SCL_T
 }
 
+// ---- four tables, no rotations -----------------------------------------------------------------------------------
+// The three rotations per output word of the single-table form are 20 % of its VALU work (tools/aes_bench.hip: 51.8 ->
+// 64.9 G blocks/s).  Four tables te_r[x] = rotl(te0[x], 8 r), each replicated 32 times as above, are 128 KiB of LDS:
+// one workgroup of ABLOCK = 1024 threads per CU shares them (dynamic LDS; the kernels that also keep a 32 KiB
+// Vandermonde table in LDS stay on the single-table form).  Word (r * 256 + x) * 32 + c holds entry x of table r, copy c.
+constexpr int ABLOCK = 1024;
+constexpr int AES4_LDS_BYTES = 4 * 256 * 32 * 4;
+constexpr int AES4_GRID_CAP = 256;  // one workgroup per CU; the kernels grid-stride
+
+struct Aes4 {  // the lane's copy of tables 0 / 1 (t0, t0 + 8192 words) and 2 / 3 (t2, t2 + 8192 words)
+  const u32* t0;
+  const u32* t2;
+  __device__ __forceinline__ void block(const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) const;
+};
+struct Aes1 {  // the single-table form above behind the same interface
+  const u32* tl;
+  __device__ __forceinline__ void block(const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) const {
+    aes_ctr_block(tl, key, counter, out_lo, out_hi);
+  }
+};
+
+#define SCL_T0(x) a.t0[(x) << 5]
+#define SCL_T1(x) a.t0[((x) << 5) + 8192]
+#define SCL_T2(x) a.t2[(x) << 5]
+#define SCL_T3(x) a.t2[((x) << 5) + 8192]
+#define SCL_SB(x) ((SCL_T0(x) >> 8) & 255u)
+template <int NB>
+__device__ __forceinline__ void aes4_ctr_multi(const Aes4& a, const AesKey& key, const u64 (&ctr)[NB], u64 (&lo)[NB],
+                                               u64 (&hi)[NB]) {
+  u32 s[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    s[b][0] = (u32)ctr[b] ^ key.rk[0];
+    s[b][1] = (u32)(ctr[b] >> 32) ^ key.rk[1];
+    s[b][2] = 0x89ABCDEFu ^ key.rk[2];
+    s[b][3] = 0x01234567u ^ key.rk[3];
+  }
+#pragma unroll 1
+  for (int r = 1; r < 10; ++r) {
+    const u32 k0 = key.rk[4 * r], k1 = key.rk[4 * r + 1], k2 = key.rk[4 * r + 2], k3 = key.rk[4 * r + 3];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const u32 s0 = s[b][0], s1 = s[b][1], s2 = s[b][2], s3 = s[b][3];
+      s[b][0] = SCL_T0(s0 & 255) ^ SCL_T1((s1 >> 8) & 255) ^ SCL_T2((s2 >> 16) & 255) ^ SCL_T3(s3 >> 24) ^ k0;
+      s[b][1] = SCL_T0(s1 & 255) ^ SCL_T1((s2 >> 8) & 255) ^ SCL_T2((s3 >> 16) & 255) ^ SCL_T3(s0 >> 24) ^ k1;
+      s[b][2] = SCL_T0(s2 & 255) ^ SCL_T1((s3 >> 8) & 255) ^ SCL_T2((s0 >> 16) & 255) ^ SCL_T3(s1 >> 24) ^ k2;
+      s[b][3] = SCL_T0(s3 & 255) ^ SCL_T1((s0 >> 8) & 255) ^ SCL_T2((s1 >> 16) & 255) ^ SCL_T3(s2 >> 24) ^ k3;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const u32 s0 = s[b][0], s1 = s[b][1], s2 = s[b][2], s3 = s[b][3];
+    const u32 o0 = (SCL_SB(s0 & 255) | (SCL_SB((s1 >> 8) & 255) << 8) | (SCL_SB((s2 >> 16) & 255) << 16) |
+                    (SCL_SB(s3 >> 24) << 24)) ^ key.rk[40];
+    const u32 o1 = (SCL_SB(s1 & 255) | (SCL_SB((s2 >> 8) & 255) << 8) | (SCL_SB((s3 >> 16) & 255) << 16) |
+                    (SCL_SB(s0 >> 24) << 24)) ^ key.rk[41];
+    const u32 o2 = (SCL_SB(s2 & 255) | (SCL_SB((s3 >> 8) & 255) << 8) | (SCL_SB((s0 >> 16) & 255) << 16) |
+                    (SCL_SB(s1 >> 24) << 24)) ^ key.rk[42];
+    const u32 o3 = (SCL_SB(s3 & 255) | (SCL_SB((s0 >> 8) & 255) << 8) | (SCL_SB((s1 >> 16) & 255) << 16) |
+                    (SCL_SB(s2 >> 24) << 24)) ^ key.rk[43];
+    lo[b] = (u64)o0 | ((u64)o1 << 32);
+    hi[b] = (u64)o2 | ((u64)o3 << 32);
+  }
+}
+#undef SCL_SB
+#undef SCL_T0
+#undef SCL_T1
+#undef SCL_T2
+#undef SCL_T3
+__device__ __forceinline__ void Aes4::block(const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) const {
+  const u64 ctr[1] = {counter};
+  u64 lo[1], hi[1];
+  aes4_ctr_multi<1>(*this, key, ctr, lo, hi);
+  out_lo = lo[0];
+  out_hi = hi[0];
+}
+
+// the workgroup (ABLOCK threads) builds the four replicated tables in dynamic LDS
+#define SCL_AES4_PROLOGUE(key)                                                                     \
+  extern __shared__ __align__(16) u32 aes4_lds[];                                                  \
+  for (int e_ = threadIdx.x; e_ < 4 * 256 * 32; e_ += ABLOCK) {                                    \
+    const int r_ = e_ >> 13;                                                                       \
+    const u32 v_ = (key).te0[(e_ >> 5) & 255];                                                     \
+    aes4_lds[e_] = r_ == 0 ? v_ : (v_ << (8 * r_)) | (v_ >> (32 - 8 * r_));                        \
+  }                                                                                                \
+  __syncthreads();                                                                                 \
+  const Aes4 aes{aes4_lds + (threadIdx.x & 31), aes4_lds + (threadIdx.x & 31) + 2 * 8192};
+
+#define SCL_AES4_GRID_STRIDE(q, npacks) \
+  for (size_t q = (size_t)blockIdx.x * ABLOCK + threadIdx.x; q < (npacks); q += (size_t)gridDim.x * ABLOCK)
+
 // FF::read over the AES stream: element bytes = F::LIMBS/2 consecutive blocks (128- and 256-bit fields)
 // RAW: the integer the bytes spell, not yet a residue (for kernels whose constant tables absorb the conversion)
 template <class F, bool RAW = false>
@@ -829,14 +920,14 @@ __device__ __forceinline__ typename F::E elem_from_blocks(const typename F::Ctx&
 
 // PRG::next as raw counter-addressed blocks (prg.cc:124-146); each lane computes 4 blocks a grid
 // stride apart so that every store instruction is a contiguous 1 KiB per wave.
-__global__ __launch_bounds__(BLOCK) void k_prg_blocks(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
-  SCL_AES_PROLOGUE(key)
-  const size_t G = (size_t)gridDim.x * BLOCK;
-  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nblocks; q += 4 * G) {
+__global__ __launch_bounds__(ABLOCK) void k_prg_blocks(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
+  SCL_AES4_PROLOGUE(key)
+  const size_t G = (size_t)gridDim.x * ABLOCK;
+  for (size_t q = (size_t)blockIdx.x * ABLOCK + threadIdx.x; q < nblocks; q += 4 * G) {
     u64 ctr[4], lo[4], hi[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) ctr[b] = counter0 + q + b * G;
-    aes_ctr_multi<4>(te0, key, ctr, lo, hi);
+    aes4_ctr_multi<4>(aes, key, ctr, lo, hi);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (q + b * G < nblocks) {
@@ -885,19 +976,19 @@ __global__ __launch_bounds__(BLOCK) void k_ring_from_bytes(typename F::Ctx ctx, 
 
 // Vector::random(n, prg) for a PRG at counter0 (vector.h:507-519): element e = bytes [e*bs,(e+1)*bs)
 template <class F>
-__global__ __launch_bounds__(BLOCK) void k_vector_random(typename F::Ctx ctx, u64* dst, AesKey key, u64 counter0,
-                                                         size_t n) {
-  SCL_AES_PROLOGUE(key)
-  const size_t G = (size_t)gridDim.x * BLOCK;
+__global__ __launch_bounds__(ABLOCK) void k_vector_random(typename F::Ctx ctx, u64* dst, AesKey key, u64 counter0,
+                                                          size_t n) {
+  SCL_AES4_PROLOGUE(key)
+  const size_t G = (size_t)gridDim.x * ABLOCK;
   constexpr int BPE = F::LIMBS >= 2 ? F::LIMBS / 2 : 1;        // AES blocks per element (wide fields)
   const size_t nb = F::LIMBS == 1 ? (n + 1) / 2 : n * BPE;    // AES blocks needed
   // 256-bit fields: q enumerates elements (two blocks each), two elements per trip
   const size_t units = F::LIMBS == 4 ? n : nb;
-  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < units; q += (F::LIMBS == 4 ? 2 : 4) * G) {
+  for (size_t q = (size_t)blockIdx.x * ABLOCK + threadIdx.x; q < units; q += (F::LIMBS == 4 ? 2 : 4) * G) {
     u64 ctr[4], lo[4], hi[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) ctr[b] = counter0 + (F::LIMBS == 4 ? 2 * (q + (b >> 1) * G) + (b & 1) : q + b * G);
-    aes_ctr_multi<4>(te0, key, ctr, lo, hi);
+    aes4_ctr_multi<4>(aes, key, ctr, lo, hi);
     if constexpr (F::LIMBS == 4) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -938,8 +1029,8 @@ struct ArrayLane {
   int W, lane;
 };
 
-template <class F, int VEC, int TREG, bool RAW = false>
-__device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, VEC> (&c)[TREG + 1], const u32* te0,
+template <class F, int VEC, int TREG, bool RAW = false, class AES>
+__device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, VEC> (&c)[TREG + 1], const AES& aes,
                                            const AesKey& key, u64 counter0, size_t q, int t, ArrayLane al = {1, 0}) {
   constexpr int BPE = F::LIMBS >= 2 ? F::LIMBS / 2 : 1;  // AES blocks per coefficient (wide fields)
   const u64 B = F::LIMBS == 1 ? ((u64)(t + 1) * al.W + 1) / 2 : (u64)(t + 1) * BPE * al.W;
@@ -953,7 +1044,7 @@ __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, V
           if (k <= t) {
             const u64 e = (u64)k * al.W + al.lane;
             u64 lo, hi;
-            aes_ctr_block(te0, key, ctr0 + (e >> 1), lo, hi);
+            aes.block(key, ctr0 + (e >> 1), lo, hi);
             c[k].v[v] = F::from_le_word(ctx, (e & 1) ? hi : lo);
           }
         }
@@ -964,7 +1055,7 @@ __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, V
       for (int j = 0; j <= TREG / 2; ++j) {
         if (2 * j <= t) {
           u64 lo, hi;
-          aes_ctr_block(te0, key, ctr0 + j, lo, hi);
+          aes.block(key, ctr0 + j, lo, hi);
           if (j > 0) c[2 * j].v[v] = F::from_le_word(ctx, lo);
           if (2 * j + 1 <= TREG && 2 * j + 1 <= t) c[2 * j + 1].v[v] = F::from_le_word(ctx, hi);
         }
@@ -977,7 +1068,7 @@ __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, V
           u64 lo[BPE], hi[BPE];
 #pragma unroll
           for (int b = 0; b < BPE; ++b)
-            aes_ctr_block(te0, key, ctr0 + ((u64)k * al.W + al.lane) * BPE + b, lo[b], hi[b]);
+            aes.block(key, ctr0 + ((u64)k * al.W + al.lane) * BPE + b, lo[b], hi[b]);
           c[k].v[v] = elem_from_blocks<F, RAW>(ctx, lo, hi);
         }
       }
@@ -987,20 +1078,35 @@ __device__ __forceinline__ void prg_coeffs(const typename F::Ctx& ctx, Pack<F, V
 
 // shamirSecretShare(secret_s, t, n, prg) for a whole batch, bit-identical to the per-secret calls on
 // ONE PRG (shamir.h:51-68); Horner evaluation at the default nodes 1..n.
+// Thresholds up to 16 (register-resident coefficients fit the 128 registers of a 1024-thread workgroup) run on the
+// four-table AES; the 48-coefficient form and the 256-bit field keep 256-thread workgroups and the single table.
+template <class F, int TREG>
+constexpr bool share_prg_four_tables() { return TREG <= 16 && F::LIMBS < 4; }
+
 template <class F, int VEC, int TREG, bool SMALLX>
-__global__ __launch_bounds__(BLOCK) void k_share_prg(typename F::Ctx ctx, u64* shares, size_t stride,
-                                                     const u64* secrets, AesKey key, u64 counter0,
-                                                     BigTable<F> tab, int t, int n, size_t npacks, ArrayLane al) {
-  SCL_AES_PROLOGUE(key)
+__global__ __launch_bounds__((share_prg_four_tables<F, TREG>() ? ABLOCK : BLOCK)) void k_share_prg(
+    typename F::Ctx ctx, u64* shares, size_t stride, const u64* secrets, AesKey key, u64 counter0, BigTable<F> tab, int t,
+    int n, size_t npacks, ArrayLane al) {
+  constexpr bool FOUR = share_prg_four_tables<F, TREG>();
+  constexpr int THREADS = FOUR ? ABLOCK : BLOCK;
   __shared__ typename F::E alpha[SMALLX ? 1 : BigTable<F>::CAP];
   __shared__ u32 alpha32[SMALLX ? BigTable<F>::CAP : 1];
-  stage_nodes<F, SMALLX>(tab, n, alpha, alpha32);
-  SCL_GRID_STRIDE(q, npacks) {
-    const size_t off = q * VEC * F::LIMBS;
-    Pack<F, VEC> c[TREG + 1];
-    c[0] = load_pack<F, VEC, true>(secrets + off);
-    prg_coeffs<F, VEC, TREG>(ctx, c, te0, key, counter0, q, t, al);
-    horner_rows<F, VEC, TREG, SMALLX>(ctx, c, t, alpha, alpha32, n, shares, stride, off);
+  auto body = [&](const auto& aes) {
+    stage_nodes<F, SMALLX, THREADS>(tab, n, alpha, alpha32);
+    for (size_t q = (size_t)blockIdx.x * THREADS + threadIdx.x; q < npacks; q += (size_t)gridDim.x * THREADS) {
+      const size_t off = q * VEC * F::LIMBS;
+      Pack<F, VEC> c[TREG + 1];
+      c[0] = load_pack<F, VEC, true>(secrets + off);
+      prg_coeffs<F, VEC, TREG, false>(ctx, c, aes, key, counter0, q, t, al);
+      horner_rows<F, VEC, TREG, SMALLX>(ctx, c, t, alpha, alpha32, n, shares, stride, off);
+    }
+  };
+  if constexpr (FOUR) {
+    SCL_AES4_PROLOGUE(key)
+    body(aes);
+  } else {
+    SCL_AES_PROLOGUE(key)
+    body(Aes1{te0});
   }
 }
 
@@ -1020,7 +1126,7 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg_vdm(typename F::Ctx ctx, u6
     const size_t off = q * F::LIMBS;
     Pack<F, 1> c[TREG + 1];
     c[0] = load_pack<F, 1, true>(secrets + off);
-    prg_coeffs<F, 1, TREG, true>(ctx, c, te0, key, counter0, q, t, al);  // raw integers: the table holds alpha^k * R
+    prg_coeffs<F, 1, TREG, true>(ctx, c, Aes1{te0}, key, counter0, q, t, al);  // raw integers: the table holds alpha^k * R
     vdm_rows<F, TREG>(ctx, c, t, V, n, shares, stride, off);
   }
 }
@@ -1029,16 +1135,16 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg_vdm(typename F::Ctx ctx, u6
 // blocks per secret that carry a used coefficient: t/2+1 for M61 (block j = c_2j, c_2j+1), t for the
 // 128-bit fields (block k = c_k, block 0 skipped).  All VEC*NBLK blocks of a lane run in lockstep.
 template <class F, int VEC, int NBLK>
-__global__ __launch_bounds__(BLOCK) void k_share_prg_small(u64* shares, size_t stride, const u64* secrets, AesKey key,
-                                                           u64 counter0, SmallVdm tab, int t, int n,
-                                                           size_t npacks) {
-  SCL_AES_PROLOGUE(key)
+__global__ __launch_bounds__(ABLOCK) void k_share_prg_small(u64* shares, size_t stride, const u64* secrets, AesKey key,
+                                                            u64 counter0, SmallVdm tab, int t, int n,
+                                                            size_t npacks) {
+  SCL_AES4_PROLOGUE(key)
   __shared__ u32 V[SmallVdm::CAP];
-  for (int i = threadIdx.x; i < n * (t + 1); i += BLOCK) V[i] = tab.v[i];
+  for (int i = threadIdx.x; i < n * (t + 1); i += ABLOCK) V[i] = tab.v[i];
   __syncthreads();
   const typename F::Ctx ctx{};
   const u64 B = F::LIMBS == 1 ? (u64)(t + 2) / 2 : (u64)(t + 1);
-  SCL_GRID_STRIDE(q, npacks) {
+  SCL_AES4_GRID_STRIDE(q, npacks) {
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> c[SmallVdm::TMAX + 1];
 #pragma unroll
@@ -1052,7 +1158,7 @@ __global__ __launch_bounds__(BLOCK) void k_share_prg_small(u64* shares, size_t s
 #pragma unroll
       for (int j = 0; j < NBLK; ++j)
         ctr[v * NBLK + j] = counter0 + (q * VEC + v) * B + j + (F::LIMBS == 1 ? 0 : 1);
-    aes_ctr_multi<VEC * NBLK>(te0, key, ctr, lo, hi);
+    aes4_ctr_multi<VEC * NBLK>(aes, key, ctr, lo, hi);
 #pragma unroll
     for (int v = 0; v < VEC; ++v)
 #pragma unroll
@@ -1089,11 +1195,11 @@ __global__ __launch_bounds__(BLOCK) void k_additive_share(typename F::Ctx ctx, u
 
 // PRG-driven: share i < n-1 of secret s = FF::random on counter counter0 + s*(n-1)+i (ff.h:72-76: one block each)
 template <class F, int VEC>
-__global__ __launch_bounds__(BLOCK) void k_additive_share_prg(typename F::Ctx ctx, u64* shares, size_t stride,
-                                                              const u64* secrets, AesKey key, u64 counter0, int n,
-                                                              size_t npacks) {
-  SCL_AES_PROLOGUE(key)
-  SCL_GRID_STRIDE(q, npacks) {
+__global__ __launch_bounds__(ABLOCK) void k_additive_share_prg(typename F::Ctx ctx, u64* shares, size_t stride,
+                                                               const u64* secrets, AesKey key, u64 counter0, int n,
+                                                               size_t npacks) {
+  SCL_AES4_PROLOGUE(key)
+  SCL_AES4_GRID_STRIDE(q, npacks) {
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> last = load_pack<F, VEC, true>(secrets + off);
     constexpr int BPE = F::LIMBS >= 2 ? F::LIMBS / 2 : 1;  // FF::random burns ceil(byteSize/16) blocks
@@ -1104,7 +1210,7 @@ __global__ __launch_bounds__(BLOCK) void k_additive_share_prg(typename F::Ctx ct
         u64 lo[BPE], hi[BPE];
         const u64 c0 = counter0 + ((q * VEC + v) * (u64)(n - 1) + i) * BPE;
 #pragma unroll
-        for (int b = 0; b < BPE; ++b) aes_ctr_block(te0, key, c0 + b, lo[b], hi[b]);
+        for (int b = 0; b < BPE; ++b) aes.block(key, c0 + b, lo[b], hi[b]);
         if constexpr (F::LIMBS == 1)
           r.v[v] = F::from_le_word(ctx, lo[0]);
         else
