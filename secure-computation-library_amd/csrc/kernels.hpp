@@ -871,12 +871,40 @@ __device__ __forceinline__ void aes4_ctr_multi(const Aes4& a, const AesKey& key,
 #undef SCL_T1
 #undef SCL_T2
 #undef SCL_T3
+// one block, rounds unrolled (as aes_ctr_block): consecutive independent blocks of a lane can be interleaved by the
+// scheduler
 __device__ __forceinline__ void Aes4::block(const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) const {
-  const u64 ctr[1] = {counter};
-  u64 lo[1], hi[1];
-  aes4_ctr_multi<1>(*this, key, ctr, lo, hi);
-  out_lo = lo[0];
-  out_hi = hi[0];
+  const Aes4& a = *this;
+#define SCL_T0(x) a.t0[(x) << 5]
+#define SCL_T1(x) a.t0[((x) << 5) + 8192]
+#define SCL_T2(x) a.t2[(x) << 5]
+#define SCL_T3(x) a.t2[((x) << 5) + 8192]
+#define SCL_SB(x) ((SCL_T0(x) >> 8) & 255u)
+  u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2 = 0x89ABCDEFu ^ key.rk[2],
+      s3 = 0x01234567u ^ key.rk[3];
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    const u32 t0 = SCL_T0(s0 & 255) ^ SCL_T1((s1 >> 8) & 255) ^ SCL_T2((s2 >> 16) & 255) ^ SCL_T3(s3 >> 24) ^ key.rk[4 * r + 0];
+    const u32 t1 = SCL_T0(s1 & 255) ^ SCL_T1((s2 >> 8) & 255) ^ SCL_T2((s3 >> 16) & 255) ^ SCL_T3(s0 >> 24) ^ key.rk[4 * r + 1];
+    const u32 t2 = SCL_T0(s2 & 255) ^ SCL_T1((s3 >> 8) & 255) ^ SCL_T2((s0 >> 16) & 255) ^ SCL_T3(s1 >> 24) ^ key.rk[4 * r + 2];
+    const u32 t3 = SCL_T0(s3 & 255) ^ SCL_T1((s0 >> 8) & 255) ^ SCL_T2((s1 >> 16) & 255) ^ SCL_T3(s2 >> 24) ^ key.rk[4 * r + 3];
+    s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+  }
+  const u32 o0 = (SCL_SB(s0 & 255) | (SCL_SB((s1 >> 8) & 255) << 8) | (SCL_SB((s2 >> 16) & 255) << 16) |
+                  (SCL_SB(s3 >> 24) << 24)) ^ key.rk[40];
+  const u32 o1 = (SCL_SB(s1 & 255) | (SCL_SB((s2 >> 8) & 255) << 8) | (SCL_SB((s3 >> 16) & 255) << 16) |
+                  (SCL_SB(s0 >> 24) << 24)) ^ key.rk[41];
+  const u32 o2 = (SCL_SB(s2 & 255) | (SCL_SB((s3 >> 8) & 255) << 8) | (SCL_SB((s0 >> 16) & 255) << 16) |
+                  (SCL_SB(s1 >> 24) << 24)) ^ key.rk[42];
+  const u32 o3 = (SCL_SB(s3 & 255) | (SCL_SB((s0 >> 8) & 255) << 8) | (SCL_SB((s1 >> 16) & 255) << 16) |
+                  (SCL_SB(s2 >> 24) << 24)) ^ key.rk[43];
+#undef SCL_SB
+#undef SCL_T0
+#undef SCL_T1
+#undef SCL_T2
+#undef SCL_T3
+  out_lo = (u64)o0 | ((u64)o1 << 32);
+  out_hi = (u64)o2 | ((u64)o3 << 32);
 }
 
 // the workgroup (ABLOCK threads) builds the four replicated tables in dynamic LDS
