@@ -33,6 +33,27 @@ __global__ __launch_bounds__(256) void k_prg_blocks1(u64* dst, AesKey key, u64 c
   }
 }
 
+// four tables, NB independent blocks per lane, each through the fully unrolled single-block form (Aes4::block)
+template <int NB>
+__global__ __launch_bounds__(ABLOCK) void k_prg_blocks4u(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
+  SCL_AES4_PROLOGUE(key)
+  const size_t G = (size_t)gridDim.x * ABLOCK;
+  for (size_t q = (size_t)blockIdx.x * ABLOCK + threadIdx.x; q < nblocks; q += NB * G) {
+    u64 lo[NB], hi[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) aes.block(key, counter0 + q + b * G, lo[b], hi[b]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (q + b * G < nblocks) {
+        u64x2 w;
+        w.x = lo[b];
+        w.y = hi[b];
+        *reinterpret_cast<u64x2*>(dst + 2 * (q + b * G)) = w;
+      }
+    }
+  }
+}
+
 int main() {
   const size_t nblocks = (size_t)1 << 28;
   AesKey key;
@@ -63,6 +84,15 @@ int main() {
     time_it([&] { hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, b, key, 12345ull, nblocks); },
             "four tables, 1024 threads per CU (k_prg_blocks)");
   }
+#define RUN4U(NB, name)                                                                                              \
+  {                                                                                                                      \
+    auto kern = &k_prg_blocks4u<NB>;                                                                                     \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AES4_LDS_BYTES)); \
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, b, key, 12345ull, nblocks); }, name); \
+  }
+  RUN4U(1, "four tables, unrolled rounds, 1 block/lane")
+  RUN4U(2, "four tables, unrolled rounds, 2 blocks/lane")
+  RUN4U(4, "four tables, unrolled rounds, 4 blocks/lane")
   CK(hipGetLastError());
   std::vector<u64> ha(1 << 20), hb(1 << 20);
   CK(hipMemcpy(ha.data(), a + (nblocks - (1 << 19)) * 2, ha.size() * 8, hipMemcpyDeviceToHost));
