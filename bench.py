@@ -4,19 +4,27 @@
 One "step" = one pass of the hot path over one batch: shamirSecretShare of N secrets
 (coefficients resident in HBM) followed by shamirRecoverP of all N from all n shares, for the
 configuration BASELINE.json quotes the metric on: Shamir (n=10, t=3) over Mersenne61, 100 M
-secrets per GPU.  Inputs are generated on the device before the timed region.
+secrets per GPU.  Inputs are generated on the device before the timed region, in plain allocations.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py                       one GPU, one JSON line
+    python bench.py --gpus N              starts N ranks itself (a child `python -m torch.distributed.run`,
+                                          before this process has touched torch or the GPU) and relays rank 0's line
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N     (what the driver does)
+    python bench.py --mode open [--gpus N]   times only the cross-party "open" step (RCCL all-gather + reconstruct)
 
 Multi-GPU: the batch of independent secrets shards across ranks (rank r owns its own N secrets,
-weak scaling, no data-path collective); time = max over ranks.
+weak scaling, no data-path collective); time = max over ranks.  The one exchange step of the path, the MPC
+"open" (reference: Network::send + Network::recv, include/scl/net/network.h:148-152,178-185), is timed after
+the headline region and reported under "open" with RCCL's bus bandwidth beside the reconstruct kernel's HBM rate.
 
 Prints ONE JSON line on rank 0 (fields described in DESIGN.md section "Measurement").
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +37,60 @@ FIELD_TAGS = {"m61": 0, "m127": 1, "mont128": 2, "gf2_128": 3, "secp256k1": 4}
 FIELD_NAMES = {"m61": "Mersenne61", "m127": "Mersenne127", "mont128": "Mont128", "gf2_128": "GF(2^128)",
                "secp256k1": "secp256k1_order"}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
+KERNEL_SOURCES = ("secure-computation-library_amd/csrc/kernels.hpp", "secure-computation-library_amd/csrc/capi.hip",
+                  "secure-computation-library_amd/csrc/share_mfma.hpp", "include/scl_hip/detail/field.hpp")
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="path", choices=["path", "open"],
+                    help="path: share + reconstruct per step (the headline); open: only the cross-party open step")
+    ap.add_argument("--field", default="m61", choices=sorted(FIELD_TAGS))
+    ap.add_argument("--n", type=int, default=10)
+    ap.add_argument("--t", type=int, default=3)
+    ap.add_argument("--secrets", type=int, default=100_000_000, help="secrets per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="secrets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--share-mode", default="coeffs", choices=["coeffs", "prg"],
+                    help="coeffs: polynomial coefficients resident in HBM; prg: AES-CTR PRG inside the share kernel")
+    ap.add_argument("--configs", type=int, default=1,
+                    help="1: after the headline, time the other BASELINE configurations at per-GPU shard size (one GPU only)")
+    ap.add_argument("--open", type=int, default=1, help="1: after the headline, time the open step (all ranks)")
+    ap.add_argument("--open-secrets", type=int, default=0,
+                    help="secrets opened per step in the C4 shape (default 12.5 M x ranks: 10^8 at 8 ranks)")
+    ap.add_argument("--open-chunk", type=int, default=1 << 24, help="secrets per all-gather")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --dry-run: the launcher / rendezvous / timing skeleton on CPU (tests)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: steps are empty (launcher test)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 started plainly: start the N ranks as a CHILD process and relay rank 0's line.  Runs before torch is
+    imported, so this process never initialises the GPU (a process that has must not start or become another)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = []
+    for ln in child.stdout:
+        ln = ln.rstrip("\n")
+        if ln.startswith("{") and '"metric"' in ln:
+            lines.append(ln)
+        elif ln:
+            print(ln, file=sys.stderr, flush=True)
+    rc = child.wait()
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: expected one result line from rank 0, got {len(lines)}", file=sys.stderr)
+        rc = 1
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    sys.exit(rc)
 
 
 def cpu_baseline(field_key, n, t, sample):
@@ -80,183 +142,293 @@ def cpu_baseline(field_key, n, t, sample):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--field", default="m61", choices=sorted(FIELD_TAGS))
-    ap.add_argument("--n", type=int, default=10)
-    ap.add_argument("--t", type=int, default=3)
-    ap.add_argument("--secrets", type=int, default=100_000_000, help="secrets per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="secrets timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--placement-probes", type=int, default=10,
-                    help="positions of the share matrix inside one HBM arena to try before the warm-up, each with its best "
-                         "output and input slots (0 = plain allocations)")
-    ap.add_argument("--share-mode", default="coeffs", choices=["coeffs", "prg"],
-                    help="coeffs: polynomial coefficients resident in HBM; prg: AES-CTR PRG inside the share kernel")
-    args = ap.parse_args()
+def kernel_source_hash():
+    """sha256 over the kernel sources: what profiles/pmc_traffic.json is stamped with (a rebuilt .so of the same
+    sources need not be byte-identical, the sources are)"""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
-    import torch
-    import torch.distributed as dist
+
+def pmc_traffic(dom, args):
+    """HBM bytes per launch of the dominant kernel from the committed PMC run -- only while that run still describes
+    the code: the file carries the configuration, the kernel symbols and a hash of the kernel sources it was taken
+    with; any mismatch gives null (bench.py cannot read PMCs itself)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        c = pmc["config"]
+        if (c["field"], c["n"], c["t"], c["secrets_per_gpu"], c["share_mode"]) != (
+                args.field, args.n, args.t, args.secrets, args.share_mode):
+            return None
+        if pmc.get("kernel_source_sha256_16") != kernel_source_hash():
+            return None
+        return pmc[dom]["bytes"]
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)          # never returns
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    dry = args.dry_run
+    if dry:
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            if not dry:
+                torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cpu" if dry or args.backend == "gloo" else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def timed_region(step, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
+        for _ in range(warmup):
+            step(None)
+        sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        sync()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    if dry:
+        elapsed = timed_region(lambda k: None, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps({"metric": "shamir_reconstructions_per_sec", "value": 0.0, "unit": "reconstructions/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "none (dry run)",
+                              "config": {"workload": "dry run of the launcher", "parallelism": f"shard{world}"}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import scl_amd as scl
+    from scl_amd import dist as sd
 
-    f = FIELD_TAGS[args.field]
-    L = scl.limbs(f)
+    def tag_limbs(fkey):
+        f_ = FIELD_TAGS[fkey]
+        return f_, scl.limbs(f_)
+
+    def fill_random(dst, f_, seed, counter0=0):
+        """uniform field elements from the device AES-CTR PRG straight into dst ([rows][N][L] or [N][L])"""
+        rows = dst if dst.dim() == 3 else dst.unsqueeze(0)
+        N_ = rows.shape[1]
+        per_row = (N_ * 8 * rows.shape[2] + 15) // 16
+        for k in range(rows.shape[0]):
+            scl.vector_random(f_, N_, seed, counter0=counter0 + k * per_row, out=rows[k])
+
+    def share_recover_config(fkey, n, t, N, steps, seed):
+        """one configuration end to end on this GPU: plain allocations, share + reconstruct timed with HIP events on the
+        launch stream, round trip verified.  Returns the per-kernel figures."""
+        f_, L = tag_limbs(fkey)
+        E = 8 * L
+        secrets = scl.empty(f_, N)
+        coeffs = scl.empty(f_, t, N)
+        fill_random(secrets, f_, seed + b"-secrets")
+        fill_random(coeffs, f_, seed + b"-coeffs")
+        shares = scl.empty(f_, n, N)
+        out = scl.empty(f_, N)
+        lam = scl.lagrange_basis(f_, n)
+        tms = [(scl.Timer(), scl.Timer()) for _ in range(steps)]
+        for k in range(-1, steps):
+            if k >= 0:
+                tms[k][0].start()
+            scl.shamir_share(f_, secrets, coeffs, n, out=shares)
+            if k >= 0:
+                tms[k][0].stop()
+                tms[k][1].start()
+            scl.shamir_recover(f_, shares, lam, out=out)
+            if k >= 0:
+                tms[k][1].stop()
+        torch.cuda.synchronize()
+        sm = sum(tm[0].elapsed_ms() for tm in tms) / steps
+        rm = sum(tm[1].elapsed_ms() for tm in tms) / steps
+        ok = bool(scl.equals(f_, out, secrets))
+        sb, rb = (1 + t + n) * E, (n + 1) * E
+        res = {"field": FIELD_NAMES[fkey], "n": n, "t": t, "secrets": N, "dtype": {1: "u64", 2: "u128", 4: "u256"}[L],
+               "share_ms": sm, "recover_ms": rm, "bytes_per_secret": {"share": sb, "recover": rb},
+               "share_GBps": sb * N / sm / 1e6, "recover_GBps": rb * N / rm / 1e6,
+               "share_frac": sb * N / sm / 1e6 / HBM_PEAK_GBPS, "recover_frac": rb * N / rm / 1e6 / HBM_PEAK_GBPS,
+               "round_trips_per_s": N / ((sm + rm) * 1e-3), "reconstructions_per_s": N / (rm * 1e-3), "verified": ok}
+        del secrets, coeffs, shares, out
+        torch.cuda.empty_cache()
+        return res
+
+    def open_step(fkey, n, t, N, chunk, steps, warmup, seed):
+        """The MPC open of N secrets: every rank holds ceil(n/G) parties' share vectors, one all-gather per chunk
+        brings all n rows to every rank, every rank reconstructs (as every MPC party does).  Timed three ways:
+        the collective alone, the reconstruct kernel alone (on gathered chunks), and the double-buffered pipeline."""
+        f_, L = tag_limbs(fkey)
+        E = 8 * L
+        per = sd.parties_per_rank(n, world)
+        first, cnt = sd.party_slab(n, rank, world)
+        # this rank's slab of a real sharing: all n rows are produced chunk-wise from the same seeds on every rank
+        # (identical bits everywhere) and only the rank's own rows are kept
+        secrets = scl.empty(f_, N)
+        fill_random(secrets, f_, seed + b"-open-secrets")
+        local = torch.zeros((per, N, L), dtype=torch.int64, device="cuda")
+        gen = min(N, chunk)
+        for s0 in range(0, N, gen):
+            c = min(gen, N - s0)
+            full = scl.shamir_share_prg(f_, secrets[s0:s0 + c], t, n, seed + b"-open", first_secret=s0)
+            if cnt:
+                local[:cnt, s0:s0 + c].copy_(full[first:first + cnt])
+            del full
+        lam = scl.lagrange_basis(f_, n)
+        c0 = min(chunk, N)
+        gathered = torch.empty((world * per, c0, L), dtype=torch.int64, device="cuda")
+        piece = local[:, :c0].contiguous()
+
+        def gather_only(k):
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, piece)
+            else:
+                gathered.copy_(piece)
+        t_gather = timed_region(gather_only, steps, warmup) / steps
+        out_c = scl.empty(f_, c0)
+        tm = scl.Timer()
+        scl.shamir_recover(f_, gathered[:n], lam, out=out_c)
+        tm.start()
+        for _ in range(steps):
+            scl.shamir_recover(f_, gathered[:n], lam, out=out_c)
+        tm.stop()
+        rec_ms = tm.elapsed_ms() / steps
+        result = {}
+
+        def pipeline(k):
+            result["out"] = sd.open_and_reconstruct(f_, local, n, lam, chunk=chunk) if world > 1 else \
+                sd.open_and_reconstruct_local(f_, local, n, lam, chunk=chunk)
+        t_pipe = timed_region(pipeline, steps, warmup) / steps
+        ok = bool(scl.equals(f_, result["out"], secrets))
+        gathered_bytes = world * per * c0 * E
+        res = {"field": FIELD_NAMES[fkey], "n": n, "t": t, "secrets": N, "chunk": c0, "parties_per_rank": per,
+               "collective": "all_gather_into_tensor" if world > 1 else "none (1 rank: local copy)",
+               "gather_ms_per_chunk": 1e3 * t_gather, "gathered_bytes_per_chunk": gathered_bytes,
+               "rccl_algbw_GBps": gathered_bytes / t_gather / 1e9,
+               "rccl_busbw_GBps": gathered_bytes / t_gather / 1e9 * (world - 1) / world,
+               "reconstruct_ms_per_chunk": rec_ms, "reconstruct_GBps": (n + 1) * E * c0 / rec_ms / 1e6,
+               "reconstruct_hbm_frac": (n + 1) * E * c0 / rec_ms / 1e6 / HBM_PEAK_GBPS,
+               "pipeline_ms": 1e3 * t_pipe, "opened_secrets_per_s": N / t_pipe, "verified": ok}
+        del secrets, local, gathered, piece, out_c, result
+        torch.cuda.empty_cache()
+        return res
+
+    def open_partial_sums(n, t, N, steps, warmup, seed):
+        """Mersenne61 alternative: canonical partial sums + ONE reduce-scatter(SUM)"""
+        f_ = scl.M61
+        first, cnt = sd.party_slab(n, rank, world)
+        secrets = scl.empty(f_, N)
+        fill_random(secrets, f_, seed + b"-ps-secrets")
+        full = scl.shamir_share_prg(f_, secrets, t, n, seed + b"-ps")
+        local = full[first:first + cnt].contiguous()
+        del full
+        lam = scl.lagrange_basis(f_, n)
+        result = {}
+
+        def run(k):
+            result["mine"] = sd.open_by_partial_sums(local, lam[first:first + cnt]) if world > 1 else \
+                scl.shamir_recover(f_, local, lam)
+        t_ps = timed_region(run, steps, warmup) / steps
+        lo = rank * (N // world)
+        ok = bool(scl.equals(f_, result["mine"].reshape(-1, 1), secrets[lo:lo + N // world]))
+        moved = N * 8
+        res = {"field": "Mersenne61", "n": n, "t": t, "secrets": N,
+               "collective": "reduce_scatter_tensor(SUM, int64)" if world > 1 else "none (1 rank)",
+               "ms": 1e3 * t_ps, "opened_secrets_per_s": N / t_ps, "reduce_scatter_input_bytes": moved,
+               "rccl_busbw_GBps": moved / t_ps / 1e9 * (world - 1) / world, "verified": ok}
+        del secrets, local, result
+        torch.cuda.empty_cache()
+        return res
+
+    def open_report():
+        N_open = args.open_secrets or 12_500_000 * world
+        N_ps = (args.secrets // world) * world
+        rep = {"c4_all_gather": open_step("gf2_128", 40, 13, N_open, args.open_chunk, 3, 1, b"scl-bench-open"),
+               "m61_partial_sums": open_partial_sums(10, 3, N_ps, 3, 1, b"scl-bench-open")}
+        return rep
+
+    if args.mode == "open":
+        rep = open_report()
+        if rank == 0:
+            c4 = rep["c4_all_gather"]
+            line = {"metric": "shamir_open_reconstructions_per_sec", "value": c4["opened_secrets_per_s"],
+                    "unit": "reconstructions/s", "n_gpus": world, "steps": 3, "warmup": 1,
+                    "ms_per_step": c4["pipeline_ms"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                    "dtype": "u128", "data": "synthetic",
+                    "config": {"workload": f"open (all-gather + reconstruct) n=40 t=13 GF(2^128) {c4['secrets']} secrets, "
+                                           f"{c4['parties_per_rank']} parties per rank (BASELINE configs[3] exchange step)",
+                               "parallelism": f"parties{world}"},
+                    "roofline": {"bound": "hbm", "kernel": "shamir_recover", "achieved": c4["reconstruct_GBps"],
+                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": c4["reconstruct_hbm_frac"], "traffic": None},
+                    "open": rep}
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # =============================================== headline ===============================================
+    f, L = tag_limbs(args.field)
     E = 8 * L
     n, t, N = args.n, args.t, args.secrets
-
-    # ---- synthetic inputs, generated on the device (uniform field elements from the AES-CTR PRG) ----
     seed = f"scl-bench-{args.field}-{rank}".encode()
     lam = scl.lagrange_basis(f, n)
     tc = t if args.share_mode == "coeffs" else 0
-    rowN = N * L                                   # int64 words per row of N elements
-    blocks_per_row = (N * E + 15) // 16
-
-    def fill_inputs(secrets, coeffs):
-        secrets.copy_(scl.vector_random(f, N, seed + b"-secrets"))
-        for k in range(tc):
-            coeffs[k].copy_(scl.vector_random(f, N, seed + b"-coeffs", counter0=k * blocks_per_row))
-
-    def run_share(secrets, coeffs, dst):
-        if args.share_mode == "coeffs":
-            scl.shamir_share(f, secrets, coeffs if tc else None, n, out=dst)
-        else:
-            scl.shamir_share_prg(f, secrets, t, n, seed, out=dst)
-
-    # ---- where the operands land in HBM.  The same two kernels run up to 10 % apart depending on which physical
-    # region the share matrix, the inputs and the reconstruct output occupy (tools/probe_placement*.py: it follows
-    # the region, not the row stride or small offsets; read-heavy and write-heavy kernels prefer different
-    # arrangements).  So the operands are carved out of one arena at a few spread-out arrangements, each is timed for
-    # two passes, and the fastest is kept -- all before the warm-up; --placement-probes 0 allocates plainly.
-    placement = None
-    GiB = 1 << 30
-    up = lambda x: (x + 4095) // 4096 * 4096       # operands start on 4 KiB boundaries and never overlap
-    m_bytes, i_bytes, o_bytes = up(n * rowN * 8), up((1 + tc) * rowN * 8), up(rowN * 8)
-    need = m_bytes + i_bytes + o_bytes
-    arena = None
-    if args.placement_probes > 0:
-        free_b, _total = torch.cuda.mem_get_info()
-        arena_bytes = min(int(free_b * 0.6), max(4 * need, 44 * GiB)) // 4096 * 4096
-        if arena_bytes >= 2 * need + 3 * GiB:
-            try:
-                arena = torch.empty(arena_bytes // 8, dtype=torch.int64, device="cuda")
-            except RuntimeError:   # no room for the arena (another tenant on the card): plain allocations below
-                arena = None
-                torch.cuda.empty_cache()
-
-    def carve(off_bytes, rows):
-        assert off_bytes % 4096 == 0
-        off = off_bytes // 8
-        return arena[off: off + rows * rowN].view(rows, N, L)
-
-    if arena is not None:
-        top = arena.numel() * 8
-        tm = scl.Timer()
-
-        def timed(fn):
-            fn()
-            tm.start()
-            fn()
-            fn()
-            tm.stop()
-            return tm.elapsed_ms() / 2
-
-        def slots(size, taken, count):
-            """up to `count` evenly spread offsets for `size` bytes that avoid the `taken` (offset, size) ranges"""
-            out_ = []
-            for k in range(count + 2):
-                c = min(up(int(top * k / (count + 1))), top - size)
-                if all(c + size <= a_ or c >= a_ + b_ for a_, b_ in taken) and c not in out_:
-                    out_.append(c)
-            return out_
-
-        # The two kernels care about different pairs: reconstruct about (matrix, output), share about (inputs, matrix).
-        # For a few positions of the matrix, the best output slot is found with the reconstruct kernel alone and then
-        # the best input slot with the share kernel alone; the matrix position with the smallest sum is kept.
-        trials = []
-        src = scl.empty(f, 1 + tc, N)
-        fill_inputs(src[0], src[1:])
-        n_m = max(2, min(12, args.placement_probes))
-        for mo in slots(m_bytes, [], n_m)[:n_m + 2]:
-            M = carve(mo, n)
-            run_share(src[0], src[1:], M)                      # valid shares for the reconstruct trials
-            best_o = best_i = None
-            for oo in slots(o_bytes, [(mo, m_bytes)], 6):
-                O_ = carve(oo, 1)[0]
-                x = timed(lambda: scl.shamir_recover(f, M, lam, out=O_))
-                if best_o is None or x < best_o[0]:
-                    best_o = (x, oo)
-            for io in slots(i_bytes, [(mo, m_bytes), (best_o[1], o_bytes)], 6):
-                inp = carve(io, 1 + tc)
-                inp.copy_(src)
-                x = timed(lambda: run_share(inp[0], inp[1:], M))
-                if best_i is None or x < best_i[0]:
-                    best_i = (x, io)
-            trials.append((best_o[0] + best_i[0], mo, best_i[1], best_o[1], best_i[0], best_o[0]))
-        trials.sort()
-        _, mo, io, oo, _, _ = trials[0]
-        inp = carve(io, 1 + tc)
-        inp.copy_(src)
-        del src
-        secrets, coeffs, shares, out = inp[0], (inp[1:] if tc else None), carve(mo, n), carve(oo, 1)[0]
-        placement = {"arena_GiB": round(top / GiB, 1),
-                     "matrix_positions": [{"matrix_GiB": round(t_[1] / GiB, 1), "inputs_GiB": round(t_[2] / GiB, 1),
-                                           "output_GiB": round(t_[3] / GiB, 1), "share_ms": round(t_[4], 4),
-                                           "recover_ms": round(t_[5], 4)} for t_ in trials],
-                     "chosen": 0}
-    else:
-        secrets = scl.empty(f, N)
-        coeffs = scl.empty(f, tc, N) if tc else None
-        fill_inputs(secrets, coeffs)
-        shares = scl.empty(f, n, N)
-        out = scl.empty(f, N)
-
-    def step(timers=None):
-        if timers:
-            timers[0].start()
-        run_share(secrets, coeffs, shares)
-        if timers:
-            timers[0].stop()
-            timers[1].start()
-        scl.shamir_recover(f, shares, lam, out=out)
-        if timers:
-            timers[1].stop()
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
+    secrets = scl.empty(f, N)
+    coeffs = scl.empty(f, tc, N) if tc else None
+    fill_random(secrets, f, seed + b"-secrets")
+    if tc:
+        fill_random(coeffs, f, seed + b"-coeffs")
+    shares = scl.empty(f, n, N)
+    out = scl.empty(f, N)
     timers = [(scl.Timer(), scl.Timer()) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(timers[k])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+
+    def step(k):
+        tm = timers[k] if k is not None else None
+        if tm:
+            tm[0].start()
+        if args.share_mode == "coeffs":
+            scl.shamir_share(f, secrets, coeffs, n, out=shares)
+        else:
+            scl.shamir_share_prg(f, secrets, t, n, seed, out=shares)
+        if tm:
+            tm[0].stop()
+            tm[1].start()
+        scl.shamir_recover(f, shares, lam, out=out)
+        if tm:
+            tm[1].stop()
+
+    elapsed = timed_region(step, args.steps, args.warmup)
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region -------------------
     share_ms = sum(tm[0].elapsed_ms() for tm in timers) / max(1, args.steps)
@@ -274,6 +446,10 @@ def main():
         scl.stream_copy(dst, src)
     tm.stop()
     copy_gbps = 2 * probe_bytes * 5 / (tm.elapsed_ms() * 1e-3) / 1e9
+    del secrets, coeffs, shares, out, src, dst
+    torch.cuda.empty_cache()
+
+    open_rep = open_report() if args.open else None      # every rank takes part in the collectives
 
     if rank != 0:
         if world > 1:
@@ -289,35 +465,42 @@ def main():
     }
     dom = "shamir_share" if share_ms >= rec_ms else "shamir_recover"
     ach = kernels[dom]["GBps"]
-    # HBM traffic per launch of the dominant kernel: PMC counters collected offline with rocprofv3 on this
-    # exact configuration (bench.py cannot read PMCs itself); null for any other configuration.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            pmc = json.load(fh)
-        c = pmc["config"]
-        if (c["field"], c["n"], c["t"], c["secrets_per_gpu"], c["share_mode"]) == (args.field, n, t, N, args.share_mode):
-            traffic = pmc[dom]["bytes"]
-    except Exception:
-        traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args),
                 "algorithmic_bytes": kernels[dom]["bytes_per_secret"] * N,
                 "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": ach / copy_gbps}
     total = N * world * args.steps
+    headline = (n, t, args.field, N) == (10, 3, "m61", 100_000_000)
     line = {
         "metric": "shamir_reconstructions_per_sec", "value": total / elapsed, "unit": "reconstructions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {1: "u64", 2: "u128", 4: "u256"}[L], "data": "synthetic",
-        "config": {"workload": f"shamir_share+reconstruct n={n} t={t} {FIELD_NAMES[args.field]} "
-                               f"{N} secrets/GPU (BASELINE configs[1])" if (n, t, args.field, N) == (10, 3, "m61", 100_000_000)
-                   else f"shamir_share+reconstruct n={n} t={t} {FIELD_NAMES[args.field]} {N} secrets/GPU",
+        "config": {"workload": f"shamir_share+reconstruct n={n} t={t} {FIELD_NAMES[args.field]} {N} secrets/GPU"
+                               + (" (BASELINE configs[1])" if headline else ""),
                    "field": FIELD_NAMES[args.field], "n": n, "t": t, "secrets_per_gpu": N,
-                   "share_mode": args.share_mode, "layout": "SoA [party][secret]", "parallelism": f"shard{world}"},
-        "roofline": roofline, "kernels": kernels, "verified": verified, "placement_probe": placement,
+                   "share_mode": args.share_mode, "layout": "SoA [party][secret]", "allocation": "plain",
+                   "parallelism": f"shard{world}"},
+        "roofline": roofline, "kernels": kernels, "verified": verified,
         "reconstruct_only_per_s": N * world / (rec_ms * 1e-3), "share_only_per_s": N * world / (share_ms * 1e-3),
     }
+    if open_rep is not None:
+        line["open"] = open_rep
+    if world == 1 and args.configs:
+        # the other BASELINE configurations at the size ONE GPU holds of them (C4, C5: an eighth), after the timed region
+        cfgs = {}
+        for key, (fk, n_, t_, N_, st) in {
+            "C3_mersenne127_10_3": ("m127", 10, 3, 10_000_000, 5),
+            "C3_mont128_10_3": ("mont128", 10, 3, 10_000_000, 5),
+            "C4_shard_gf2_128_40_13": ("gf2_128", 40, 13, 12_500_000, 3),
+            "C5_shard_mersenne61_128_42": ("m61", 128, 42, 125_000_000, 2),
+        }.items():
+            try:
+                cfgs[key] = share_recover_config(fk, n_, t_, N_, st, b"scl-bench-" + key.encode())
+            except Exception as e:  # a failed side configuration is reported, not hidden, and never fails the headline
+                cfgs[key] = {"error": str(e), "verified": False}
+                torch.cuda.empty_cache()
+        line["configs"] = cfgs
     if world == 1 and args.cpu_sample > 0:
         line["cpu_baseline"] = cpu_baseline(args.field, n, t, args.cpu_sample)
     print(json.dumps(line), flush=True)

@@ -1321,6 +1321,10 @@ int scl_hip_shamir_recover_detect(int field, uint64_t* out, unsigned char* statu
                                   const uint64_t* x_host, size_t* num_bad_host, void* stream) {
   // shamir.h:122-124: both the shares and the alphas must number at least d+t
   if (m < d + t) return fail(SCL_ERR_NOT_ENOUGH_SHARES, scl_hip_status_message(SCL_ERR_NOT_ENOUGH_SHARES));
+  // t = 0 passes that test with m = d, yet the interpolation below takes d + 1 shares and nodes.  The reference reads
+  // past the end of both vectors there (alphas.subVector(d + 1) only checks start <= end, shamir.h:127, vector.h:358-363):
+  // undefined behaviour, refused here with the text of its range check.
+  if (m < d + 1) return fail(SCL_ERR_INVALID_RANGE, scl_hip_status_message(SCL_ERR_INVALID_RANGE));
   if (num_bad_host) *num_bad_host = 0;
   if (N == 0) return SCL_OK;
   if (!out || !status || !shares) return fail(SCL_ERR_BAD_ARG, "NULL operand");

@@ -43,9 +43,38 @@ ADD, SUB, MUL, NEG, INV, DIV = range(6)
 OK, ERR_SIZE_MISMATCH, ERR_ZERO_INVERSE, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_ERROR_DETECTED, \
     ERR_NOT_ENOUGH_SHARES, ERR_MATMUL_DIMS, ERR_VANDERMONDE_XS, ERR_INVALID_RANGE = range(11)
 
-lib.scl_hip_last_error.restype = C.c_char_p
-lib.scl_hip_status_message.restype = C.c_char_p
-lib.scl_hip_field_name.restype = C.c_char_p
+
+
+def _declare_prototypes():
+    """argtypes / restype of every entry point, read from the prototypes of include/scl_hip.h (the boundary's one
+    source of truth): a forgotten c_size_t wrap or a swapped argument is then a ctypes.ArgumentError, not a wild
+    pointer.  Every pointer parameter is c_void_p (accepts ints, data_ptr() wrappers, bytes, byref() and None)."""
+    import re
+    hdr = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "scl_hip.h")
+    src = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    scalars = {"int": C.c_int, "long": C.c_long, "size_t": C.c_size_t, "uint64_t": C.c_uint64, "unsigned": C.c_uint,
+               "float": C.c_float}
+    rets = {"int": C.c_int, "size_t": C.c_size_t, "const char*": C.c_char_p}
+    n = 0
+    for m in re.finditer(r"\b(int|size_t|const char\s*\*)\s*(scl_hip_\w+)\s*\(([^;{]*?)\)\s*;", src):
+        ret, name, params = m.group(1).replace(" ", "").replace("constchar*", "const char*"), m.group(2), m.group(3)
+        fn = getattr(lib, name)
+        fn.restype = rets[ret]
+        argt = []
+        for prm in [x.strip() for x in params.split(",")]:
+            if prm in ("void", ""):
+                continue
+            if "*" in prm or "[" in prm:
+                argt.append(C.c_void_p)
+            else:
+                base = re.sub(r"\bconst\b", "", prm).split()
+                argt.append(scalars[base[0]])
+        fn.argtypes = argt
+        n += 1
+    return n
+
+
+_NPROTO = _declare_prototypes()
 
 _u64p = C.POINTER(C.c_uint64)
 
@@ -85,6 +114,29 @@ def _dev(t: torch.Tensor):
     if not t.is_contiguous():
         raise SclError(ERR_BAD_ARG, "tensor is not contiguous")
     return C.c_void_p(t.data_ptr())
+
+
+def _want(t: torch.Tensor, shape, what: str, like: torch.Tensor | None = None):
+    """out= / operand checks before a raw pointer crosses the boundary: exact shape, int64 limbs, contiguous, on the
+    same device as `like` -- a short buffer would otherwise be a silent out-of-bounds HBM access"""
+    if t.dtype != torch.int64:
+        raise SclError(ERR_BAD_ARG, f"{what}: dtype {t.dtype}, expected int64 limbs")
+    if tuple(t.shape) != tuple(shape):
+        raise SclError(ERR_SIZE_MISMATCH, f"{what}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if like is not None and t.device != like.device:
+        raise SclError(ERR_BAD_ARG, f"{what}: on {t.device}, expected {like.device}")
+    return t
+
+
+def _dev_rows(t: torch.Tensor):
+    """(device pointer, row stride in elements) of a share matrix [rows][N][L] whose rows are dense but may sit a pitch
+    apart -- a window of a larger matrix (a chunk, a shard), the C ABI's `stride >= N`"""
+    if not t.is_cuda:
+        raise SclError(ERR_BAD_ARG, "tensor is not on the GPU")
+    rows, N, L = t.shape
+    if N and (t.stride(2) != 1 or t.stride(1) != L or (rows > 1 and (t.stride(0) % L or t.stride(0) < N * L))):
+        raise SclError(ERR_BAD_ARG, "share matrix rows must be dense (a row pitch is allowed)")
+    return C.c_void_p(t.data_ptr()), (t.stride(0) // L if rows > 1 else max(N, 1))
 
 
 def _host(a) -> np.ndarray:
@@ -177,8 +229,11 @@ def from_bytes(field, raw: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def vector_random(field, n: int, seed: bytes, counter0: int = 0, device="cuda") -> torch.Tensor:
-    out = empty(field, n, device=device)
+def vector_random(field, n: int, seed: bytes, counter0: int = 0, device="cuda", out=None) -> torch.Tensor:
+    if out is None:
+        out = empty(field, n, device=device)
+    else:
+        _want(out, (n, limbs(field)), "vector_random out")
     _chk(lib.scl_hip_vector_random(field, _dev(out), C.c_size_t(n), seed, C.c_size_t(len(seed)),
                                    C.c_uint64(counter0), _stream()))
     return out
@@ -199,11 +254,14 @@ def shamir_share(field, secrets, coeffs, n: int, alphas=None, out=None):
     """secrets [N][L]; coeffs [t][N][L] (c_1..c_t) -> shares [n][N][L]"""
     L = limbs(field)
     N = secrets.shape[0]
+    _want(secrets, (N, L), "shamir_share secrets")
     t = 0 if coeffs is None else coeffs.shape[0]
-    if coeffs is not None and coeffs.shape[1] != N:
-        raise SclError(ERR_SIZE_MISMATCH, "")
+    if coeffs is not None:
+        _want(coeffs, (t, N, L), "shamir_share coeffs", secrets)
     if out is None:
         out = empty(field, n, N, device=secrets.device)
+    else:
+        _want(out, (n, N, L), "shamir_share out", secrets)
     al = _host(alphas).reshape(n, L) if alphas is not None else None
     _chk(lib.scl_hip_shamir_share(field, _dev(out), C.c_size_t(N), _dev(secrets),
                                   _dev(coeffs) if t else None, C.c_size_t(N), C.c_size_t(N), C.c_size_t(t),
@@ -220,10 +278,13 @@ def shamir_share_prg(field, secrets, t: int, n: int, seed: bytes, first_secret: 
     """first_secret: index of secrets[0] in a longer single-PRG run (counter0 = first_secret * B);
     counter0 overrides it with an explicit PRG block counter"""
     N = secrets.shape[0]
+    _want(secrets, (N, limbs(field)), "shamir_share_prg secrets")
     if counter0 is None:
         counter0 = first_secret * blocks_per_secret(field, t)
     if out is None:
         out = empty(field, n, N, device=secrets.device)
+    else:
+        _want(out, (n, N, limbs(field)), "shamir_share_prg out", secrets)
     _chk(lib.scl_hip_shamir_share_prg(field, _dev(out), C.c_size_t(N), _dev(secrets), C.c_size_t(N), C.c_size_t(t),
                                       C.c_size_t(n), seed, C.c_size_t(len(seed)), C.c_uint64(counter0),
                                       _stream()))
@@ -234,12 +295,16 @@ def shamir_recover(field, shares, lam=None, out=None):
     """shares [m][N][L] -> out [N][L]; lam defaults to the basis for nodes 1..m at x=0"""
     L = limbs(field)
     m, N = shares.shape[0], shares.shape[1]
+    _want(shares, (m, N, L), "shamir_recover shares")
     if lam is None:
         lam = lagrange_basis(field, m)
     lam = _host(lam).reshape(m, L)
     if out is None:
         out = empty(field, N, device=shares.device)
-    _chk(lib.scl_hip_shamir_recover(field, _dev(out), _dev(shares), C.c_size_t(N), _hp(lam), C.c_size_t(m),
+    else:
+        _want(out, (N, L), "shamir_recover out", shares)
+    sp, stride = _dev_rows(shares)
+    _chk(lib.scl_hip_shamir_recover(field, _dev(out), sp, C.c_size_t(stride), _hp(lam), C.c_size_t(m),
                                     C.c_size_t(N), _stream()))
     return out
 
@@ -295,9 +360,14 @@ def shamir_recover_correct(field, shares, alphas=None):
 
 # ---- additive ----------------------------------------------------------------------------------------------------
 def additive_share(field, secrets, rnd, n: int, out=None):
-    N = secrets.shape[0]
+    N, L = secrets.shape[0], limbs(field)
+    _want(secrets, (N, L), "additive_share secrets")
+    if rnd is not None:
+        _want(rnd, (n - 1, N, L), "additive_share rnd", secrets)
     if out is None:
         out = empty(field, n, N, device=secrets.device)
+    else:
+        _want(out, (n, N, L), "additive_share out", secrets)
     _chk(lib.scl_hip_additive_share(field, _dev(out), C.c_size_t(N), _dev(secrets),
                                     _dev(rnd) if rnd is not None else None, C.c_size_t(N), C.c_size_t(N),
                                     C.c_size_t(n), _stream()))
@@ -306,10 +376,13 @@ def additive_share(field, secrets, rnd, n: int, out=None):
 
 def additive_share_prg(field, secrets, n: int, seed: bytes, first_secret: int = 0, out=None, counter0=None):
     N = secrets.shape[0]
+    _want(secrets, (N, limbs(field)), "additive_share_prg secrets")
     if counter0 is None:
         counter0 = first_secret * (n - 1) * ((8 * limbs(field) + 15) // 16)  # FF::random burns whole blocks
     if out is None:
         out = empty(field, n, N, device=secrets.device)
+    else:
+        _want(out, (n, N, limbs(field)), "additive_share_prg out", secrets)
     _chk(lib.scl_hip_additive_share_prg(field, _dev(out), C.c_size_t(N), _dev(secrets), C.c_size_t(N), C.c_size_t(n),
                                         seed, C.c_size_t(len(seed)), C.c_uint64(counter0), _stream()))
     return out
@@ -317,8 +390,11 @@ def additive_share_prg(field, secrets, n: int, seed: bytes, first_secret: int = 
 
 def additive_recover(field, shares, out=None):
     n, N = shares.shape[0], shares.shape[1]
+    _want(shares, (n, N, limbs(field)), "additive_recover shares")
     if out is None:
         out = empty(field, N, device=shares.device)
+    else:
+        _want(out, (N, limbs(field)), "additive_recover out", shares)
     _chk(lib.scl_hip_additive_recover(field, _dev(out), _dev(shares), C.c_size_t(N), C.c_size_t(n), C.c_size_t(N),
                                       _stream()))
     return out

@@ -84,6 +84,19 @@ def open_and_reconstruct(field: int, local: torch.Tensor, n: int, lam, chunk: in
     return out
 
 
+def open_and_reconstruct_local(field: int, local: torch.Tensor, n: int, lam, chunk: int = 1 << 24, recover=None) -> torch.Tensor:
+    """World size 1: the one rank holds all n parties, so the open step is the chunked reconstruct alone (same chunking
+    and output as open_and_reconstruct, no collective)."""
+    if recover is None:
+        from . import shamir_recover as recover
+    N, L = local.shape[1], local.shape[2]
+    out = torch.empty((N, L), dtype=local.dtype, device=local.device)
+    for s0 in range(0, N, chunk):
+        c = min(chunk, N - s0)
+        recover(field, local[:n, s0:s0 + c], lam, out[s0:s0 + c])
+    return out
+
+
 def open_by_partial_sums(local: torch.Tensor, lam_local, group=None, partial=None, fold=None) -> torch.Tensor:
     """Mersenne61 only (the alternative to the all-gather): every rank reduces ITS parties
     to the canonical partial sum sum_j lambda_j * share_j (< p = 2^61 - 1), one reduce-scatter(SUM) over <= 8

@@ -100,3 +100,30 @@ def test_bench_cpu_baseline_leg():
     cb = bench.cpu_baseline("m61", 10, 3, 2000)
     assert cb["unit"] == "reconstructions/s" and cb["cores"] == 1 and cb["kind"] in ("reference", "port")
     assert cb["value"] > 1e4 and "2000 secrets" in cb["sample"]
+
+
+def test_recover_detect_refuses_a_node_range_it_does_not_have(scl):
+    """shamirRecoverD(shares, alphas, t = 0, d, x) with exactly d shares passes the reference's size test
+    (shares.size() >= d + t, shamir.h:122-124) and then interpolates from d + 1 shares and nodes -- past the end of
+    both vectors (alphas.subVector(d + 1) only checks start <= end).  The boundary refuses it with the text of the
+    range check before anything is launched; one share short of d + t is still "not enough shares"."""
+    dummy = (C.c_uint64 * 8)()
+    bad = C.c_size_t(7)
+    args = lambda m, t, d: (0, dummy, dummy, dummy, 4, m, 4, t, d, None, None, C.byref(bad), None)
+    assert scl.lib.scl_hip_shamir_recover_detect(*args(3, 0, 3)) == scl.ERR_INVALID_RANGE
+    assert scl.lib.scl_hip_last_error().decode() == "invalid range"
+    assert scl.lib.scl_hip_shamir_recover_detect(*args(1, 0, 1)) == scl.ERR_INVALID_RANGE
+    assert scl.lib.scl_hip_shamir_recover_detect(*args(5, 3, 3)) == scl.ERR_NOT_ENOUGH_SHARES
+    assert scl.lib.scl_hip_shamir_recover_detect(*args(0, 0, 0)) == scl.ERR_INVALID_RANGE
+
+
+def test_prototypes_come_from_the_header(scl):
+    """every entry point has argtypes / restype taken from include/scl_hip.h: a Python int in a pointer slot of the wrong
+    kind or a missing argument is an error at the call, not a wild pointer on the device"""
+    names = declared_symbols()
+    assert scl._NPROTO == len(names)
+    assert scl.lib.scl_hip_shamir_share.argtypes[2] is C.c_size_t and scl.lib.scl_hip_wire_size.restype is C.c_size_t
+    with pytest.raises((C.ArgumentError, TypeError)):
+        scl.lib.scl_hip_limbs()                      # too few arguments
+    with pytest.raises((C.ArgumentError, TypeError)):
+        scl.lib.scl_hip_limbs("m61")                 # not an int

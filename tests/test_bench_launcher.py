@@ -1,0 +1,47 @@
+"""bench.py's multi-rank plumbing on CPU: `--gpus N` started plainly must start N ranks itself (a child
+`python -m torch.distributed.run`, before torch or the GPU is touched) and print ONE line with n_gpus = N; a world
+size that disagrees with --gpus must fail.  `--backend gloo --dry-run` keeps the rendezvous, the barriers and the
+max-over-ranks timing and skips the GPU work (cf. the reference's exchange step, include/scl/net/network.h:148-185,
+which the real run times over RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_plain_start_with_gpus_2_launches_two_ranks():
+    r = _run(["--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["config"]["parallelism"] == "shard2"
+    assert line["metric"] == "shamir_reconstructions_per_sec" and line["scaling"] == "weak"
+
+
+def test_single_rank_dry_run_prints_one_line():
+    r = _run(["--dry-run", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1
+
+
+def test_world_size_that_disagrees_with_gpus_fails():
+    # what a mis-launched rank sees: WORLD_SIZE says 2, the command line says 4
+    r = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
+    r = _run(["--gpus", "1", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0

@@ -350,7 +350,11 @@ def test_reference_test_suite_kats(port):
         "0x10c9a04e00a8277a", "0xe0c7bcabdee0f5b", "0x129e3e74169f963"]
 
 
-@pytest.mark.parametrize("f,name", FIELDS)
+PLUGIN_FIELDS = [(O.MONT128, "Mont128"), (O.GF2_128, "GF(2^128)")]   # not in the reference; big-integer / shift-xor
+                                                                      # pins in test_plugin_field_pins.py
+
+
+@pytest.mark.parametrize("f,name", FIELDS + PLUGIN_FIELDS)
 def test_field_identities(port, f, name):
     """test/scl/math/test_ff.cc:64-227 restated: algebraic identities on PRG-seeded operands."""
     L = O.LIMBS[f]
@@ -368,6 +372,22 @@ def test_field_identities(port, f, name):
     assert E(port.ew(f, O.SUB, a, a), zero)
     assert E(port.ew(f, O.NEG, port.ew(f, O.SUB, a, b)), port.ew(f, O.SUB, b, a))
     assert E(port.ew(f, O.DIV, a, b), port.ew(f, O.INV, port.ew(f, O.DIV, b, a)))
+    # the rest of the suite: a + (-a) = 0, a - b = -b + a, a * 0 = 0, a * b != 0, a / a = 1, 0 / c = 0, c + 0 = c
+    assert E(port.ew(f, O.ADD, a, port.ew(f, O.NEG, a)), zero)
+    assert E(port.ew(f, O.SUB, a, b), port.ew(f, O.ADD, port.ew(f, O.NEG, b), a))
+    assert E(port.ew(f, O.MUL, a, zero), zero) and E(port.ew(f, O.ADD, c, zero), c)
+    assert all(v != 0 for v in O.to_ints(port.ew(f, O.MUL, a, b)))
+    assert E(port.ew(f, O.DIV, a, a), one) and E(port.ew(f, O.DIV, zero, c), zero)
+    assert E(port.ew(f, O.NEG, zero), zero)
+    with pytest.raises(O.OracleError) as err:            # test_ff.cc:168-171
+        port.ew(f, O.INV, zero[:1])
+    assert err.value.message == "0 not invertible modulo prime"
+    # FF Exp (test_ff.cc:214-227)
+    x = a[:1]
+    assert E(port.exp(f, x[0], 1)[None], x) and E(port.exp(f, x[0], 0)[None], one[:1])
+    x2 = port.ew(f, O.MUL, x, x)
+    assert E(port.exp(f, x[0], 2)[None], x2)
+    assert E(port.exp(f, x[0], 6)[None], port.ew(f, O.MUL, port.ew(f, O.MUL, x2, x2), x2))
     if f in O.P:
         assert all(v < O.P[f] for v in O.to_ints(a))
 
