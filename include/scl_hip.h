@@ -32,7 +32,11 @@
  *  - every function returns an scl_status; scl_hip_last_error() gives the
  *    thread's last diagnostic and scl_hip_status_message() the text of the
  *    exception the reference throws for that condition.
- *  - thread-safe: no shared mutable state except a per-thread scratch cache.
+ *  - thread-safe: callable concurrently from several host threads on different streams / devices.  The only
+ *    mutable state is per host thread (a scratch buffer, a temporary arena, the Mont128 modulus and the tuning
+ *    knobs: each thread sets its own and starts from the defaults) or immutable once built (device tables of
+ *    Vandermonde rows, behind a mutex, least-recently-used entries freed past 16).  A thread that exits calls
+ *    scl_hip_thread_cleanup() to release its device buffers.
  */
 #ifndef SCL_HIP_H
 #define SCL_HIP_H
@@ -95,14 +99,21 @@ int scl_hip_timer_destroy(void* timer);
 int scl_hip_timer_start(void* timer, void* stream);
 int scl_hip_timer_stop(void* timer, void* stream);
 int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the stop event */
-/* knobs for tuning and for the tests that pin a kernel path (0 = built-in default unless noted):
+/* knobs for tuning and for the tests that pin a kernel path (0 = built-in default unless noted); they belong to the
+ * calling host thread:
  *   max_blocks, aes_blocks   grid caps;  nontemporal (default 1);  force_scalar (no 16-byte packs)
- *   force_table  1: no small-node / blocked / Vandermonde-table share kernels, 2: also no small-node Horner
+ *   force_table  1: no small-node / blocked / Vandermonde-table share kernels, 2: also no small-node Horner,
+ *                3: GF(2^128) reconstruct on the shared-shift nibble tables instead of the position tables
+ *   stream_block (default 64) workgroup size of the (m <= 16) reconstruct kernel: 64 or 256
+ *   stream_waves (default 8) resident waves per CU that kernel is capped at; 0 = no cap
+ *   share_waves  (default 0) the same cap for the small-node share kernel (then also in stream_block workgroups)
  *   mfma         1: force the matrix-core share / matmul path, -1: never use it
  *   mfma_areg    (default 1) matrix-core kernel keeps V's digit fragments in registers for 97..128 parties
  *   mfma_pipe    (default 2) matrix-core kernel for 97..128 parties: 2 = two software-pipelined waves per SIMD on
  *                16x16x64 tiles (thresholds 32..63; smaller ones as 1), 1 = one pipelined wave per SIMD, 0 = word bursts */
 int scl_hip_set_tuning(const char* key, long value);
+/* frees the calling thread's device scratch and temporary arena (for host threads that exit; see Conventions) */
+int scl_hip_thread_cleanup(void);
 
 /* ---- element-wise: scl::math::Vector<FF> members ------------------------- */
 /* Vector::add / subtract / multiplyEntryWise (+InPlace) (vector.h:199-245,521-556),
@@ -273,7 +284,7 @@ int scl_hip_frame_unpack(int field, uint64_t* dst_dev, size_t capacity, const un
 /* plain device copy kernel (16 B per lane) used to measure achievable HBM bandwidth */
 int scl_hip_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 
-/* MONT128: choose the modulus (odd, < 2^128); default 2^128 - 159.  Process-wide. */
+/* MONT128: choose the modulus (odd, < 2^128) for the CALLING host thread; every thread starts at 2^128 - 159. */
 int scl_hip_mont128_set_prime(const uint64_t p[2]);
 int scl_hip_mont128_get_prime(uint64_t p[2]);
 

@@ -6,10 +6,11 @@
 // (detail/field.hpp), so a scalar computed on the host and a lane computed on the GPU agree by
 // construction.  Everything batch-shaped (Vector, Matrix, ss::*) goes through the C ABI.
 //
-// Field plug-in boundary: the reference extends fields by specialising ff::add/... for a traits
-// struct (include/scl/math/fields/ff_ops.h:35-118, worked example test/scl/gf7.cc:26-103).  Here a
-// field is a traits struct naming its device implementation: { ValueType, NAME, BYTE_SIZE, BIT_SIZE,
-// TAG (scl_field), Impl (struct in detail/field.hpp) }.
+// Field plug-in boundary: exactly the reference's -- a traits struct { ValueType, NAME, BYTE_SIZE, BIT_SIZE } plus the
+// eleven scl::math::ff:: specialisations of fields/ff_ops.h (include/scl/math/fields/ff_ops.h:35-118, worked example
+// test/scl/gf7.cc:26-103); FF<FIELD> below calls nothing else.  The five fields that have kernels are defined here
+// the same way: their traits additionally name TAG (scl_field) and Impl (detail/field.hpp), and their eleven
+// specialisations are stamped out by SCL_HIP_BUILTIN_FIELD_OPS over that Impl.
 #ifndef SCL_HIP_MATH_FF_H
 #define SCL_HIP_MATH_FF_H
 
@@ -24,6 +25,7 @@
 #include "../detail/call.h"
 #include "../detail/field.hpp"
 #include "../util/prg.h"
+#include "fields/ff_ops.h"
 
 namespace scl::math {
 
@@ -130,12 +132,130 @@ inline std::string hex64(std::uint64_t v) {
   return ss.str();
 }
 
+
+// ---- the eleven operations of a field that has an Impl (detail/field.hpp) ----------------------------------
+template <typename FIELD>
+inline void fromInt(typename FIELD::ValueType& out, int value) {  // negative: p - |v| (mersenne61.cc:37-40)
+  using Impl = typename FIELD::Impl;
+  const auto c = context<FIELD>();
+  const std::uint64_t mag = value < 0 ? (std::uint64_t)(-(std::int64_t)value) : (std::uint64_t)value;
+  out = Impl::from_u64(c, mag);
+  if (value < 0) out = Impl::neg(c, out);
+}
+
+template <typename FIELD>
+inline void fromString(typename FIELD::ValueType& out, const std::string& hexstr) {  // hex, reduced mod p (mersenne61.cc:42-46)
+  using Impl = typename FIELD::Impl;
+  using V = typename FIELD::ValueType;
+  const auto c = context<FIELD>();
+  if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
+    const V limbs = parseHexLimbs(hexstr);
+    out = hexstr.empty() ? limbs : Impl::to_mont(c, limbs);
+  } else {
+    const V raw = parseHex<V>(hexstr);
+    if constexpr (FIELD::TAG == SCL_MONT128) out = Impl::to_mont(c, raw);
+    else out = Impl::from_le_word(c, raw);
+  }
+}
+
+/// Mersenne61: std::hex of the word; Mersenne127: the top word (if non-zero) then the low word
+/// without zero padding -- the reference's formatting (src/scl/util/str.cc:23-39), kept as is.
+template <typename FIELD>
+inline std::string toStringOf(const typename FIELD::ValueType& value) {
+  using Impl = typename FIELD::Impl;
+  using V = typename FIELD::ValueType;
+  const auto c = context<FIELD>();
+  if constexpr (FIELD::TAG == SCL_M61) {
+    return hex64(value);
+  } else if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
+    // montyToString: the value out of Montgomery form, hex without leading zeros
+    const V v = Impl::from_mont(c, value);
+    std::string out;
+    for (int i = 3; i >= 0; --i) {
+      if (out.empty()) {
+        if (v.w[i] || i == 0) out = hex64(v.w[i]);
+      } else {
+        const std::string part = hex64(v.w[i]);
+        out += std::string(16 - part.size(), '0') + part;
+      }
+    }
+    return out;
+  } else {
+    V v = value;
+    if constexpr (FIELD::TAG == SCL_MONT128) v = Impl::from_mont(c, v);
+    const auto top = (std::uint64_t)(v >> 64), bot = (std::uint64_t)v;
+    if (v == 0) return "0";
+    std::string s;
+    if (top) s = hex64(top);
+    if (FIELD::TAG == SCL_M127 || !top) return s + hex64(bot);
+    std::string b = hex64(bot);
+    return s + std::string(16 - b.size(), '0') + b;
+  }
+}
+
+/// FF::write (ff.h:300-302).  Mersenne fields: the canonical little-endian word.  Mont128 follows
+/// the reference's Montgomery family (ff_ops_gmp.h:298-314): out of Montgomery form, big-endian.
+template <typename FIELD>
+inline void toBytesOf(unsigned char* dest, const typename FIELD::ValueType& value) {
+  using Impl = typename FIELD::Impl;
+  using V = typename FIELD::ValueType;
+  if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
+    const V v = Impl::to_be_image(context<FIELD>(), value);  // montyToBytes: value, big-endian
+    std::memcpy(dest, &v, sizeof v);
+  } else if constexpr (FIELD::TAG == SCL_MONT128) {
+    const V v = sclhip::bswap128(Impl::from_mont(context<FIELD>(), value));
+    std::memcpy(dest, &v, sizeof v);
+  } else {
+    std::memcpy(dest, &value, sizeof value);
+  }
+}
+
+/// FF::read (ff.h:63-67): byteSize() bytes, reduced into the field
+template <typename FIELD>
+inline void fromBytesOf(typename FIELD::ValueType& dest, const unsigned char* src) {
+  typename FIELD::ValueType raw;
+  std::memcpy(&raw, src, sizeof raw);
+  dest = FIELD::Impl::from_le_word(context<FIELD>(), raw);
+}
+
+template <typename FIELD>
+inline void invertOf(typename FIELD::ValueType& out) {
+  if (FIELD::Impl::is_zero(out)) scl::hip::detail::raise(SCL_ERR_ZERO_INVERSE);
+  out = FIELD::Impl::inv(context<FIELD>(), out);
+}
+
 }  // namespace detail
+
+// the eleven specialisations (fields/ff_ops.h) of a built-in field, over its Impl
+#define SCL_HIP_BUILTIN_FIELD_OPS(F)                                                                                      \
+  template <> inline void convertTo<F>(F::ValueType & out, int value) { detail::fromInt<F>(out, value); }                 \
+  template <> inline void convertTo<F>(F::ValueType & out, const std::string& src) { detail::fromString<F>(out, src); }   \
+  template <> inline void add<F>(F::ValueType & out, const F::ValueType& op) { out = F::Impl::add(detail::context<F>(), out, op); } \
+  template <> inline void subtract<F>(F::ValueType & out, const F::ValueType& op) { out = F::Impl::sub(detail::context<F>(), out, op); } \
+  template <> inline void multiply<F>(F::ValueType & out, const F::ValueType& op) { out = F::Impl::mul(detail::context<F>(), out, op); } \
+  template <> inline void negate<F>(F::ValueType & out) { out = F::Impl::neg(detail::context<F>(), out); }                \
+  template <> inline void invert<F>(F::ValueType & out) { detail::invertOf<F>(out); }                                     \
+  template <> inline bool equal<F>(const F::ValueType& in1, const F::ValueType& in2) { return F::Impl::eq(in1, in2); }    \
+  template <> inline void toBytes<F>(unsigned char* dest, const F::ValueType& src) { detail::toBytesOf<F>(dest, src); }   \
+  template <> inline void fromBytes<F>(F::ValueType & dest, const unsigned char* src) { detail::fromBytesOf<F>(dest, src); } \
+  template <> inline std::string toString<F>(const F::ValueType& in) { return detail::toStringOf<F>(in); }
+
+SCL_HIP_BUILTIN_FIELD_OPS(Mersenne61)
+SCL_HIP_BUILTIN_FIELD_OPS(Mersenne127)
+SCL_HIP_BUILTIN_FIELD_OPS(Secp256k1Scalar)
+SCL_HIP_BUILTIN_FIELD_OPS(Mont128)
+SCL_HIP_BUILTIN_FIELD_OPS(GF2_128)
+#undef SCL_HIP_BUILTIN_FIELD_OPS
+
 }  // namespace ff
+
+/// true for element types whose field (or ring) has kernels behind the C ABI: the batch-shaped members of Vector,
+/// Matrix and scl::ss go to the GPU for them and take the generic per-element host path otherwise
+template <typename T>
+concept OnDevice = requires { T::Field::TAG; };
 
 template <typename FIELD>
 class FF final {
-  using Impl = typename FIELD::Impl;
   using V = typename FIELD::ValueType;
 
  public:
@@ -147,9 +267,9 @@ class FF final {
 
   /// FF::read (ff.h:63-67): byteSize() bytes, reduced into the field
   static FF read(const unsigned char* src) {
-    V raw;
-    std::memcpy(&raw, src, sizeof raw);
-    return fromRaw(Impl::from_le_word(ctx(), raw));
+    FF e;
+    ff::fromBytes<FIELD>(e.m_value, src);
+    return e;
   }
 
   /// FF::random (ff.h:72-76): one prg.next(byteSize()) -- a whole AES block per element
@@ -161,33 +281,21 @@ class FF final {
 
   /// hex string, reduced mod p (mersenne61.cc:42-46)
   static FF fromString(const std::string& hexstr) {
-    if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
-      const V limbs = ff::detail::parseHexLimbs(hexstr);
-      return fromRaw(hexstr.empty() ? limbs : Impl::to_mont(ctx(), limbs));
-    } else {
-    const V raw = ff::detail::parseHex<V>(hexstr);
-    if constexpr (FIELD::TAG == SCL_MONT128)
-      return fromRaw(Impl::to_mont(ctx(), raw));
-    else
-      return fromRaw(Impl::from_le_word(ctx(), raw));
-    }
+    FF e;
+    ff::convertTo<FIELD>(e.m_value, hexstr);
+    return e;
   }
 
   static FF zero() { return FF(); }
   static FF one() { return FF(1); }
 
   /// FF(int): negative values wrap to p - |v| (mersenne61.cc:37-40)
-  explicit FF(int value) {
-    const auto c = ctx();
-    const std::uint64_t mag = value < 0 ? (std::uint64_t)(-(std::int64_t)value) : (std::uint64_t)value;
-    m_value = Impl::from_u64(c, mag);
-    if (value < 0) m_value = Impl::neg(c, m_value);
-  }
-  FF() : m_value(Impl::zero()) {}
+  explicit FF(int value) { ff::convertTo<FIELD>(m_value, value); }
+  FF() : FF(0) {}
 
-  FF& operator+=(const FF& o) { m_value = Impl::add(ctx(), m_value, o.m_value); return *this; }
-  FF& operator-=(const FF& o) { m_value = Impl::sub(ctx(), m_value, o.m_value); return *this; }
-  FF& operator*=(const FF& o) { m_value = Impl::mul(ctx(), m_value, o.m_value); return *this; }
+  FF& operator+=(const FF& o) { ff::add<FIELD>(m_value, o.m_value); return *this; }
+  FF& operator-=(const FF& o) { ff::subtract<FIELD>(m_value, o.m_value); return *this; }
+  FF& operator*=(const FF& o) { ff::multiply<FIELD>(m_value, o.m_value); return *this; }
   FF& operator/=(const FF& o) { return *this *= o.inverse(); }  // ff.h:203-205
   friend FF operator+(FF a, const FF& b) { return a += b; }
   friend FF operator-(FF a, const FF& b) { return a -= b; }
@@ -198,71 +306,33 @@ class FF final {
   FF& operator--() { return *this -= one(); }
   friend FF operator--(FF& e, int) { FF t(e); --e; return t; }
 
-  FF& negate() { m_value = Impl::neg(ctx(), m_value); return *this; }
+  FF& negate() { ff::negate<FIELD>(m_value); return *this; }
   FF negated() const { FF r(*this); return r.negate(); }
   friend FF operator-(const FF& e) { return e.negated(); }
 
   /// throws std::logic_error("0 not invertible modulo prime") on zero (test_ff.cc:168-171)
-  FF& invert() {
-    if (Impl::is_zero(m_value)) scl::hip::detail::raise(SCL_ERR_ZERO_INVERSE);
-    m_value = Impl::inv(ctx(), m_value);
-    return *this;
-  }
+  FF& invert() { ff::invert<FIELD>(m_value); return *this; }
   FF inverse() const { FF r(*this); return r.invert(); }
 
-  bool equal(const FF& o) const { return Impl::eq(m_value, o.m_value); }
+  bool equal(const FF& o) const { return ff::equal<FIELD>(m_value, o.m_value); }
   friend bool operator==(const FF& a, const FF& b) { return a.equal(b); }
   friend bool operator!=(const FF& a, const FF& b) { return !a.equal(b); }
 
-  /// Mersenne61: std::hex of the word; Mersenne127: the top word (if non-zero) then the low word
-  /// without zero padding -- the reference's formatting (src/scl/util/str.cc:23-39), kept as is.
-  std::string toString() const {
-    if constexpr (FIELD::TAG == SCL_M61) {
-      return ff::detail::hex64(m_value);
-    } else if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
-      // montyToString: the value out of Montgomery form, hex without leading zeros
-      const V v = Impl::from_mont(ctx(), m_value);
-      std::string out;
-      for (int i = 3; i >= 0; --i) {
-        if (out.empty()) {
-          if (v.w[i] || i == 0) out = ff::detail::hex64(v.w[i]);
-        } else {
-          const std::string part = ff::detail::hex64(v.w[i]);
-          out += std::string(16 - part.size(), '0') + part;
-        }
-      }
-      return out;
-    } else {
-      V v = m_value;
-      if constexpr (FIELD::TAG == SCL_MONT128) v = Impl::from_mont(ctx(), v);
-      const auto top = (std::uint64_t)(v >> 64), bot = (std::uint64_t)v;
-      if (v == 0) return "0";
-      std::string s;
-      if (top) s = ff::detail::hex64(top);
-      if (FIELD::TAG == SCL_M127 || !top) return s + ff::detail::hex64(bot);
-      std::string b = ff::detail::hex64(bot);
-      return s + std::string(16 - b.size(), '0') + b;
-    }
-  }
+  std::string toString() const { return ff::toString<FIELD>(m_value); }
   friend std::ostream& operator<<(std::ostream& os, const FF& e) { return os << e.toString(); }
 
-  /// FF::write (ff.h:300-302).  Mersenne fields: the canonical little-endian word.  Mont128 follows
-  /// the reference's Montgomery family (ff_ops_gmp.h:298-314): out of Montgomery form, big-endian.
-  void write(unsigned char* dest) const {
-    if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
-      const V v = Impl::to_be_image(ctx(), m_value);  // montyToBytes: value, big-endian
-      std::memcpy(dest, &v, sizeof v);
-    } else if constexpr (FIELD::TAG == SCL_MONT128) {
-      const V v = sclhip::bswap128(Impl::from_mont(ctx(), m_value));
-      std::memcpy(dest, &v, sizeof v);
-    } else {
-      std::memcpy(dest, &m_value, sizeof m_value);
-    }
-  }
+  /// FF::write (ff.h:300-302)
+  void write(unsigned char* dest) const { ff::toBytes<FIELD>(dest, m_value); }
 
-  /// the limb image the C ABI and the kernels use (internal representation, little-endian limbs)
-  void toLimbs(std::uint64_t* dest) const { std::memcpy(dest, &m_value, sizeof m_value); }
-  static FF fromLimbs(const std::uint64_t* src) {
+  /// the limb image the C ABI and the kernels use (internal representation, little-endian limbs); fields with kernels only
+  void toLimbs(std::uint64_t* dest) const
+    requires requires { FIELD::TAG; }
+  {
+    std::memcpy(dest, &m_value, sizeof m_value);
+  }
+  static FF fromLimbs(const std::uint64_t* src)
+    requires requires { FIELD::TAG; }
+  {
     FF e;
     std::memcpy(&e.m_value, src, sizeof e.m_value);
     return e;
@@ -272,12 +342,6 @@ class FF final {
   V& value() { return m_value; }
 
  private:
-  static typename Impl::Ctx ctx() { return ff::detail::context<FIELD>(); }
-  static FF fromRaw(V v) {
-    FF e;
-    e.m_value = v;
-    return e;
-  }
   V m_value;
 };
 

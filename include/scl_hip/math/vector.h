@@ -1,10 +1,11 @@
 // include/scl_hip/math/vector.h -- scl::math::Vector<T> with its batch members on the GPU.
 //
 // Surface of include/scl/math/vector.h:45-586 (names, SizeType, error text).  Storage is a host
-// std::vector like the reference's; every element-wise / reduction member uploads its operands,
-// runs the HIP kernel behind the C ABI and downloads the result -- a drop-in, PCIe-bound for large
-// vectors.  Code that wants the data to stay in HBM uses scl::hip::DeviceVector with the free
-// functions of scl::hip (same kernels, no transfers).
+// std::vector like the reference's; for element types with kernels (math::OnDevice: the built-in fields and rings)
+// every element-wise / reduction member uploads its operands, runs the HIP kernel behind the C ABI and downloads the
+// result -- a drop-in, PCIe-bound for large vectors.  Code that wants the data to stay in HBM uses
+// scl::hip::DeviceVector with the free functions of scl::hip (same kernels, no transfers).  An element type over a
+// user-defined field (fields/ff_ops.h) takes the reference's per-element loops on the host instead.
 #ifndef SCL_HIP_MATH_VECTOR_H
 #define SCL_HIP_MATH_VECTOR_H
 
@@ -29,6 +30,7 @@ namespace vec_detail {
 
 template <typename T>
 constexpr int tag() {
+  static_assert(OnDevice<T>, "this path needs a field or ring with kernels (math::OnDevice)");
   return T::Field::TAG;
 }
 
@@ -49,6 +51,11 @@ std::vector<T> runEw(int op, const std::vector<T>& a, const std::vector<T>* b) {
 /// innerProd (vector.h:45-52): sum of x_k * y_k over [xb, xe)
 template <typename T, typename IT0, typename IT1>
 T innerProd(IT0 xb, IT0 xe, IT1 yb) {
+  if constexpr (!OnDevice<T>) {  // v = 0; v += x_k * y_k in order (vector.h:45-52)
+    T v{};
+    for (; xb != xe; ++xb, ++yb) v += *xb * *yb;
+    return v;
+  } else {
   std::vector<T> x(xb, xe);
   std::vector<T> y(yb, yb + static_cast<std::ptrdiff_t>(x.size()));
   if (x.empty()) return T{};
@@ -56,6 +63,7 @@ T innerProd(IT0 xb, IT0 xe, IT1 yb) {
   std::uint64_t limbs[hip::limbsOf<T>()];
   hip::check(scl_hip_dot(vec_detail::tag<T>(), limbs, dx.data(), dy.data(), x.size(), nullptr));
   return T::fromLimbs(limbs);
+  }
 }
 
 template <typename ELEMENT>
@@ -72,12 +80,21 @@ class Vector final {
   /// as the device kernel on the PRG's counter; the PRG is advanced by ceil(n*byteSize/16) blocks.
   static Vector random(std::size_t n, util::PRG& prg) {
     if (n == 0) return Vector{};
+    if constexpr (!OnDevice<ELEMENT>) {  // one prg.next(n * byteSize), then ELEMENT::read per element
+      std::vector<unsigned char> buf(n * ELEMENT::byteSize());
+      prg.next(buf.data(), buf.size());
+      std::vector<ELEMENT> v;
+      v.reserve(n);
+      for (std::size_t i = 0; i < n; ++i) v.emplace_back(ELEMENT::read(buf.data() + i * ELEMENT::byteSize()));
+      return Vector(std::move(v));
+    } else {
     hip::DeviceVector<ELEMENT> d(n);
     const auto seed = prg.Seed();
     hip::check(scl_hip_vector_random(vec_detail::tag<ELEMENT>(), d.data(), n, seed.data(), seed.size(), prg.counter(),
                                      nullptr));
     prg.advance((n * ELEMENT::byteSize() + 15) / 16);
     return Vector(d.toHost());
+    }
   }
 
   /// Vector::range (vector.h:490-505): FF(int i) for i in [start, end)
@@ -117,19 +134,32 @@ class Vector final {
 
   ELEMENT sum() const {
     if (empty()) return ELEMENT{};
+    if constexpr (!OnDevice<ELEMENT>) {
+      ELEMENT v{};
+      for (const auto& e : m_values) v += e;
+      return v;
+    } else {
     hip::DeviceVector<ELEMENT> d(m_values);
     std::uint64_t limbs[hip::limbsOf<ELEMENT>()];
     hip::check(scl_hip_sum(vec_detail::tag<ELEMENT>(), limbs, d.data(), m_values.size(), nullptr));
     return ELEMENT::fromLimbs(limbs);
+    }
   }
 
   Vector scalarMultiply(const ELEMENT& scalar) const {
     if (empty()) return Vector{};
+    if constexpr (!OnDevice<ELEMENT>) {
+      std::vector<ELEMENT> r;
+      r.reserve(size());
+      for (const auto& e : m_values) r.emplace_back(scalar * e);
+      return Vector(std::move(r));
+    } else {
     hip::DeviceVector<ELEMENT> d(m_values), out(m_values.size());
     std::uint64_t limbs[hip::limbsOf<ELEMENT>()];
     scalar.toLimbs(limbs);
     hip::check(scl_hip_scalar_mul(vec_detail::tag<ELEMENT>(), out.data(), d.data(), limbs, m_values.size(), nullptr));
     return Vector(out.toHost());
+    }
   }
   Vector& scalarMultiplyInPlace(const ELEMENT& scalar) { return *this = scalarMultiply(scalar); }
 
@@ -137,10 +167,16 @@ class Vector final {
   bool equals(const Vector& o) const {
     if (size() != o.size()) return false;
     if (empty()) return true;
+    if constexpr (!OnDevice<ELEMENT>) {
+      bool eq = true;
+      for (std::size_t i = 0; i < m_values.size(); ++i) eq &= m_values[i] == o.m_values[i];
+      return eq;
+    } else {
     hip::DeviceVector<ELEMENT> a(m_values), b(o.m_values);
     int eq = 0;
     hip::check(scl_hip_equals(vec_detail::tag<ELEMENT>(), &eq, a.data(), b.data(), m_values.size(), nullptr));
     return eq != 0;
+    }
   }
   friend bool operator==(const Vector& l, const Vector& r) { return l.equals(r); }
   friend bool operator!=(const Vector& l, const Vector& r) { return !l.equals(r); }
@@ -190,7 +226,16 @@ class Vector final {
   Vector binary(int op, const Vector& o) const {
     ensureCompatible(o);
     if (empty()) return Vector{};
+    if constexpr (!OnDevice<ELEMENT>) {
+      std::vector<ELEMENT> r;
+      r.reserve(size());
+      for (std::size_t i = 0; i < m_values.size(); ++i)
+        r.emplace_back(op == SCL_OP_ADD ? m_values[i] + o.m_values[i]
+                                        : op == SCL_OP_SUB ? m_values[i] - o.m_values[i] : m_values[i] * o.m_values[i]);
+      return Vector(std::move(r));
+    } else {
     return Vector(vec_detail::runEw<ELEMENT>(op, m_values, &o.m_values));
+    }
   }
 
   std::vector<ELEMENT> m_values;

@@ -12,6 +12,8 @@
 
 #include "../hip/device.h"
 #include "../math/lagrange.h"
+#include "../math/matrix.h"
+#include "../math/poly.h"
 #include "../math/vector.h"
 #include "../util/prg.h"
 
@@ -119,9 +121,22 @@ hip::DeviceVector<T> shamirRecoverD(const hip::ShareMatrix<T>& shares, std::size
 /// shamirSecretShare(secret, t, n, prg) (shamir.h:51-68)
 template <typename T>
 math::Vector<T> shamirSecretShare(const T& secret, std::size_t t, std::size_t n, util::PRG& prg) {
+  if constexpr (!math::OnDevice<T>) {
+    // the reference's own steps for an element type without kernels (a user-defined field, an Array of them): random
+    // coefficients, c_0 = secret, evaluate at 1, 2, .. produced by x++ on T::one()
+    auto c = math::Vector<T>::random(t + 1, prg);
+    c[0] = secret;
+    const auto p = math::Polynomial<T>::create(c);
+    std::vector<T> shares;
+    shares.reserve(n);
+    T x = T::one();
+    for (std::size_t i = 0; i < n; ++i) shares.emplace_back(p.evaluate(x++));
+    return math::Vector<T>(std::move(shares));
+  } else {
   hip::DeviceVector<T> one(std::vector<T>{secret});
   const auto m = shamirSecretShare(one, t, n, prg);
   return math::Vector<T>(m.sharesOf(0));
+  }
 }
 
 namespace shamir_detail {
@@ -140,8 +155,13 @@ hip::ShareMatrix<T> upload(const math::Vector<T>& shares, std::size_t count) {
 /// with the shares in order, as innerProd does there
 template <typename T>
 T shamirRecoverP(const math::Vector<T>& shares, const math::Vector<T>& alphas, const T& x) {
+  if constexpr (!math::OnDevice<T>) {
+    const auto lb = math::computeLagrangeBasis(alphas, x);
+    return math::innerProd<T>(shares.begin(), shares.end(), lb.begin());
+  } else {
   const auto m = shamir_detail::upload(shares, shares.size());
   return shamir_detail::recoverWithBasis(m, math::computeLagrangeBasis(alphas, x)).toHost()[0];
+  }
 }
 
 /// shamirRecoverP(shares) (shamir.h:99-104): nodes 1..size, x = 0
@@ -155,6 +175,18 @@ template <typename T>
 T shamirRecoverD(const math::Vector<T>& shares, const math::Vector<T>& alphas, std::size_t t, std::size_t d,
                  const T& x) {
   if (shares.size() < d + t || alphas.size() < d + t) hip::detail::raise(SCL_ERR_NOT_ENOUGH_SHARES);
+  if (shares.size() < d + 1 || alphas.size() < d + 1) hip::detail::raise(SCL_ERR_INVALID_RANGE);  // t = 0 with d shares
+  if constexpr (!math::OnDevice<T>) {
+    const std::size_t m1 = d + 1;
+    const auto ns = alphas.subVector(m1);
+    for (std::size_t i = m1; i < d + t; ++i) {
+      const auto lb = math::computeLagrangeBasis(ns, alphas[i]);
+      if (math::innerProd<T>(shares.begin(), shares.begin() + static_cast<std::ptrdiff_t>(m1), lb.begin()) != shares[i])
+        hip::detail::raise(SCL_ERR_ERROR_DETECTED);
+    }
+    const auto lb = math::computeLagrangeBasis(ns, x);
+    return math::innerProd<T>(shares.begin(), shares.begin() + static_cast<std::ptrdiff_t>(m1), lb.begin());
+  } else {
   const std::size_t m = d + t;  // shares d+t .. are never looked at
   const auto sm = shamir_detail::upload(shares, m);
   const auto al = shamir_detail::toLimbs(alphas.subVector(m));
@@ -166,6 +198,7 @@ T shamirRecoverD(const math::Vector<T>& shares, const math::Vector<T>& alphas, s
   hip::check(scl_hip_shamir_recover_detect(T::Field::TAG, out.data(), static_cast<unsigned char*>(status.get()),
                                            sm.data(), 1, m, 1, t, d, al.data(), xl, &nbad, nullptr));
   return out.toHost()[0];
+  }
 }
 
 /// shamirRecoverD(shares, t) (shamir.h:150-155): n = 2t+1 nodes 1..n, d = t, x = 0
@@ -224,18 +257,91 @@ ErrorCorrectedBatch<T> shamirRecoverC(const hip::ShareMatrix<T>& shares, const m
   return out;
 }
 
+namespace shamir_detail {
+/// The unique solution of the n x n system A x = b, or false when A is singular (what the reference's
+/// solveLinearSystem answers for "unique solutions only", matrix.h:811-828).  Gauss-Jordan with row swaps; A and b are
+/// consumed.
+template <typename T>
+bool solveUnique(std::vector<std::vector<T>>& A, std::vector<T>& b, std::vector<T>& x) {
+  const std::size_t n = b.size();
+  for (std::size_t c = 0; c < n; ++c) {
+    std::size_t piv = c;
+    while (piv < n && A[piv][c] == T{}) ++piv;
+    if (piv == n) return false;
+    std::swap(A[piv], A[c]);
+    std::swap(b[piv], b[c]);
+    const T inv = A[c][c].inverse();
+    for (std::size_t j = c; j < n; ++j) A[c][j] *= inv;
+    b[c] *= inv;
+    for (std::size_t r = 0; r < n; ++r) {
+      if (r == c || A[r][c] == T{}) continue;
+      const T f = A[r][c];
+      for (std::size_t j = c; j < n; ++j) A[r][j] -= f * A[c][j];
+      b[r] -= f * b[c];
+    }
+  }
+  x = b;
+  return true;
+}
+
+/// Berlekamp-Welch on the host for element types without kernels (shamir.h:202-250): for e = t, t-1, .. 0 the system
+/// s_i E(a_i) = Q(a_i) with E monic of degree e and deg Q <= n-1-e; the first e whose system has a unique solution is
+/// taken, f = Q / E, and a non-zero remainder is "could not correct shares".
+template <typename T>
+ErrorCorrectedSecret<T> recoverCHost(const math::Vector<T>& shares, const math::Vector<T>& alphas) {
+  if (shares.empty()) throw std::invalid_argument("no shares");
+  const std::size_t t = (shares.size() - 1) / 3, n = 3 * t + 1;
+  std::vector<T> x;
+  std::size_t e = t;
+  for (;; --e) {
+    std::vector<std::vector<T>> A(n, std::vector<T>(n));
+    std::vector<T> b(n);
+    for (std::size_t i = 0; i < n; ++i) {
+      T pw = shares[i];  // s_i a_i^j for the e locator coefficients, then -a_i^(j-e) for Q's
+      for (std::size_t j = 0; j < e; ++j) {
+        A[i][j] = pw;
+        pw *= alphas[i];
+      }
+      b[i] = -pw;  // - s_i a_i^e: the monic term moved to the right-hand side
+      pw = -T(1);
+      for (std::size_t j = e; j < n; ++j) {
+        A[i][j] = pw;
+        pw *= alphas[i];
+      }
+    }
+    if (solveUnique(A, b, x)) break;
+    if (e == 0) throw std::logic_error("could not correct shares");  // duplicate nodes: not even interpolation is unique
+  }
+  std::vector<T> cE(x.begin(), x.begin() + static_cast<std::ptrdiff_t>(e));
+  cE.emplace_back(T(1));
+  const auto E = math::Polynomial<T>::create(math::Vector<T>(std::move(cE)));
+  const auto Q = math::Polynomial<T>::create(math::Vector<T>(x.begin() + static_cast<std::ptrdiff_t>(e), x.end()));
+  const auto qr = Q.divide(E);
+  if (!qr[1].isZero()) throw std::logic_error("could not correct shares");
+  return {qr[0], E};
+}
+}  // namespace shamir_detail
+
 /// shamirRecoverC(shares, alphas) (shamir.h:202-250)
 template <typename T>
 ErrorCorrectedSecret<T> shamirRecoverC(const math::Vector<T>& shares, const math::Vector<T>& alphas) {
+  if constexpr (!math::OnDevice<T>) {
+    return shamir_detail::recoverCHost(shares, alphas);
+  } else {
   const auto sm = shamir_detail::upload(shares, shares.size());
   return shamirRecoverC(sm, &alphas).at(0);
+  }
 }
 
 /// shamirRecoverC(shares) (shamir.h:255-259): nodes 1..size
 template <typename T>
 ErrorCorrectedSecret<T> shamirRecoverC(const math::Vector<T>& shares) {
+  if constexpr (!math::OnDevice<T>) {
+    return shamir_detail::recoverCHost(shares, math::Vector<T>::range(1, shares.size() + 1));
+  } else {
   const auto sm = shamir_detail::upload(shares, shares.size());
   return shamirRecoverC<T>(sm, nullptr).at(0);
+  }
 }
 
 }  // namespace scl::ss

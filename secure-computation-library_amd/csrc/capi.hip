@@ -7,6 +7,7 @@
 // HIP device is usable the calls fail with SCL_ERR_NO_DEVICE / SCL_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -47,15 +48,42 @@ int fail(int code, const std::string& msg) {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- tuning --------------------------------------------------------------------------------------
-std::atomic<long> g_max_blocks{0};
-std::atomic<long> g_nontemporal{1};
-std::atomic<long> g_force_scalar{0};
-std::atomic<long> g_force_table{0};
-std::atomic<long> g_mfma_tpb{0};
-std::atomic<long> g_mfma_pipe{2};  // 4-row-tile shapes: 2 = two pipelined waves per SIMD on 16x16x64 tiles (33..64 coefficient
+// Experiment knobs (scl_hip_set_tuning).  Per host thread, like the Mont128 modulus below: the library keeps no mutable
+// state that two host threads share, so concurrent callers with different settings cannot race (scl_hip.h, Conventions).
+struct Knob {
+  long v;
+  long load() const { return v; }
+  Knob& operator=(long x) {
+    v = x;
+    return *this;
+  }
+};
+thread_local Knob g_max_blocks{0};
+thread_local Knob g_nontemporal{1};
+thread_local Knob g_force_scalar{0};
+thread_local Knob g_force_table{0};
+thread_local Knob g_mfma_tpb{0};
+thread_local Knob g_mfma_pipe{2};  // 4-row-tile shapes: 2 = two pipelined waves per SIMD on 16x16x64 tiles (33..64 coefficient
                                    // rows; else as 1), 1 = one pipelined wave per SIMD, 0 = burst kernel ("mfma_pipe")
-std::atomic<long> g_mfma_areg{1};  // register-resident V fragments for the 4-row-tile shapes ("mfma_areg" tuning key)
-std::atomic<long> g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
+thread_local Knob g_mfma_areg{1};  // register-resident V fragments for the 4-row-tile shapes ("mfma_areg" tuning key)
+thread_local Knob g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
+// Headline streaming kernels (k_recover_fixed, k_share_small): workgroup size and resident waves per CU
+// (kernels.hpp, "Launch geometry"); "stream_block" 64 | 256, "stream_waves" 0 = no cap
+thread_local Knob g_stream_block{64};
+thread_local Knob g_stream_waves{8};
+thread_local Knob g_share_waves{0};  // the same cap for k_share_small ("share_waves"; 0 = none, the default)
+
+// dynamic LDS bytes that cap the residency of a kernel with `static_lds` bytes of its own at `waves` waves of
+// `block` threads per CU (160 KiB of LDS per CU; allocation granularity 512 B assumed, one granule of slack)
+size_t residency_pad(long waves, int block, size_t static_lds) {
+  if (waves <= 0) return 0;
+  const long groups = waves * 64 / block;
+  if (groups < 1) return 0;
+  const size_t per = (size_t)(160 * 1024) / (size_t)groups;      // what each resident workgroup may take
+  const size_t want = per - 1024;                                // strictly more than 160 KiB / (groups + 1) for groups <= 12
+  if (want <= static_lds || want > 64 * 1024) return 0;
+  return (want - static_lds) & ~(size_t)511;
+}
 
 unsigned grid_for(size_t work_items) {
   size_t blocks = (work_items + BLOCK - 1) / BLOCK;
@@ -68,9 +96,18 @@ unsigned grid_for(size_t work_items) {
   return (unsigned)blocks;
 }
 
+unsigned grid_for_block(size_t work_items, int block) {
+  size_t blocks = (work_items + block - 1) / block;
+  long cap = g_max_blocks.load();
+  if (cap <= 0) cap = 0x7fffffff;
+  if (blocks > (size_t)cap) blocks = (size_t)cap;
+  if (blocks == 0) blocks = 1;
+  return (unsigned)blocks;
+}
+
 // PRG kernels carry a 32 KiB replicated AES table per block: a fixed grid of resident blocks that
 // grid-strides amortises filling it.
-std::atomic<long> g_aes_blocks{0};
+thread_local Knob g_aes_blocks{0};
 unsigned grid_aes(size_t work_items) {
   size_t blocks = (work_items + BLOCK - 1) / BLOCK;
   long cap = g_aes_blocks.load();
@@ -98,25 +135,18 @@ unsigned grid_aes4(size_t work_items) {
     hipLaunchKernelGGL(kern_, dim3(grid_aes4(WORK)), dim3(ABLOCK), AES4_LDS_BYTES, ST, __VA_ARGS__);                \
   } while (0)
 
-// ---- Mont128 process-wide modulus ---------------------------------------------------------------
-std::mutex g_mont_mu;
-Mont128::Ctx g_mont = {0, 0, 0, 0};
+// ---- Mont128 modulus: per host thread ---------------------------------------------------------------
+// (two threads working over different primes must not see each other's; every thread starts at 2^128 - 159)
+thread_local Mont128::Ctx g_mont = {0, 0, 0, 0};
 
 int mont_set(u128 p) {
   if (!(p & 1) || p < 3) return fail(SCL_ERR_BAD_ARG, "mont128: modulus must be odd and >= 3");
-  const Mont128::Ctx c = Mont128::make_ctx(p);
-  std::lock_guard<std::mutex> lk(g_mont_mu);
-  g_mont = c;
+  g_mont = Mont128::make_ctx(p);
   return SCL_OK;
 }
 
 Mont128::Ctx mont_ctx() {
-  {
-    std::lock_guard<std::mutex> lk(g_mont_mu);
-    if (g_mont.p) return g_mont;
-  }
-  mont_set((((u128)0xFFFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFF61ull);  // 2^128 - 159
-  std::lock_guard<std::mutex> lk(g_mont_mu);
+  if (!g_mont.p) mont_set((((u128)0xFFFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFF61ull);  // 2^128 - 159
   return g_mont;
 }
 
@@ -422,19 +452,37 @@ struct MfmaTable {
   void* dev;
 };
 std::mutex g_mfma_mu;
-std::vector<MfmaTable> g_mfma_tables;  // immutable once built; never freed (a handful of (n,t) pairs)
+std::vector<MfmaTable> g_mfma_tables;  // immutable once built; most recently used last, at most TABLE_CACHE_CAP entries
+constexpr size_t TABLE_CACHE_CAP = 16;
+
+// Keeps a table cache bounded: a hit moves its entry to the back, a miss past the cap frees the front (least recently
+// used) entry.  hipFree waits for the device, so a kernel still reading the evicted table has finished by then.
+template <class Entry>
+void cache_touch(std::vector<Entry>& cache, size_t hit) {
+  if (hit + 1 != cache.size()) std::rotate(cache.begin() + hit, cache.begin() + hit + 1, cache.end());
+}
+template <class Entry>
+void cache_make_room(std::vector<Entry>& cache) {
+  while (cache.size() >= TABLE_CACHE_CAP) {
+    (void)hipFree(cache.front().dev);
+    cache.erase(cache.begin());
+  }
+}
 
 int mfma_table(const BigTable<M61>& al, size_t n, size_t t, int KS, int MT, const unsigned char** out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_mfma_mu);
-  for (const MfmaTable& e : g_mfma_tables) {
+  for (size_t k = 0; k < g_mfma_tables.size(); ++k) {
+    const MfmaTable& e = g_mfma_tables[k];
     if (e.device == dev && e.n == (int)n && e.t == (int)t && e.KS == KS && e.MT == MT &&
         std::equal(e.alphas.begin(), e.alphas.end(), al.v)) {
       *out = static_cast<const unsigned char*>(e.dev);
+      cache_touch(g_mfma_tables, k);
       return SCL_OK;
     }
   }
+  cache_make_room(g_mfma_tables);
   const int ROWB = mf_rowb(KS);
   std::vector<unsigned char> host(mf_a_bytes(KS, MT), 0);
   const M61::Ctx ctx{};
@@ -573,7 +621,7 @@ struct VdmTable {
   void* dev;
 };
 std::mutex g_vdm_mu;
-std::vector<VdmTable> g_vdm_tables;  // immutable once built; never freed
+std::vector<VdmTable> g_vdm_tables;  // immutable once built; bounded like g_mfma_tables
 
 template <class F>
 bool vdm_eligible(size_t n, size_t t) {
@@ -595,12 +643,15 @@ int vdm_table(const typename F::Ctx& ctx, const BigTable<F>& al, size_t n, size_
     key.insert(key.end(), w, w + F::LIMBS);
   }
   std::lock_guard<std::mutex> lk(g_vdm_mu);
-  for (const VdmTable& e : g_vdm_tables) {
+  for (size_t k = 0; k < g_vdm_tables.size(); ++k) {
+    const VdmTable& e = g_vdm_tables[k];
     if (e.device == dev && e.tag == (int)F::TAG && e.n == (int)n && e.t == (int)t && e.key == key) {
       *out = static_cast<const u64*>(e.dev);
+      cache_touch(g_vdm_tables, k);
       return SCL_OK;
     }
   }
+  cache_make_room(g_vdm_tables);
   std::vector<u64> host(n * t * F::LIMBS);
   for (size_t i = 0; i < n; ++i) {
     typename F::E v = al.v[i];  // alpha_i^k, Matrix::vandermonde (matrix.h:444-460)
@@ -640,12 +691,17 @@ struct RecoverFixed {
   static int run(const typename F::Ctx& ctx, u64* out, const u64* shares, size_t stride, const Table<F>& lam, int m,
                  size_t npacks, hipStream_t st) {
     if (m == M) {
-      if (g_nontemporal.load())
-        hipLaunchKernelGGL((k_recover_fixed<F, VEC, M, true>), dim3(grid_for(npacks)), dim3(BLOCK), 0, st, ctx, out,
-                           shares, stride, lam, npacks);
-      else
+      const bool wave_groups = g_stream_block.load() == 64;
+      const int blk = wave_groups ? 64 : BLOCK;
+      const size_t pad = residency_pad(g_stream_waves.load(), blk, 0);
+      const dim3 g(grid_for_block(npacks, blk));
+      if (!g_nontemporal.load())
         hipLaunchKernelGGL((k_recover_fixed<F, VEC, M, false>), dim3(grid_for(npacks)), dim3(BLOCK), 0, st, ctx, out,
                            shares, stride, lam, npacks);
+      else if (wave_groups)
+        hipLaunchKernelGGL((k_recover_fixed<F, VEC, M, true, 64>), g, dim3(64), pad, st, ctx, out, shares, stride, lam, npacks);
+      else
+        hipLaunchKernelGGL((k_recover_fixed<F, VEC, M, true>), g, dim3(BLOCK), pad, st, ctx, out, shares, stride, lam, npacks);
       return SCL_OK;
     }
     if constexpr (M > 1) return RecoverFixed<F, M - 1>::template run<VEC>(ctx, out, shares, stride, lam, m, npacks, st);
@@ -785,6 +841,23 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms) {
   return SCL_OK;
 }
 
+// Frees what the CALLING thread holds on the device: its scratch buffer and its temporary arena (both are kept and
+// grown across calls).  A host thread that is about to exit calls this; the buffers cannot be released from a
+// thread_local destructor, which may run after the HIP runtime has shut down.
+int scl_hip_thread_cleanup(void) {
+  if (g_scratch.dev) {
+    HIP_TRY(hipFree(g_scratch.dev));
+    g_scratch = Scratch{};
+  }
+  if (g_temp.dev) {
+    if (g_temp.pending) HIP_TRY(hipEventSynchronize(g_temp.done));
+    HIP_TRY(hipFree(g_temp.dev));
+    (void)hipEventDestroy(g_temp.done);
+    g_temp = TempArena{};
+  }
+  return SCL_OK;
+}
+
 int scl_hip_set_tuning(const char* key, long value) {
   if (!key) return fail(SCL_ERR_BAD_ARG, "key is NULL");
   const std::string k(key);
@@ -796,6 +869,9 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "mfma_pipe") g_mfma_pipe = value;
   else if (k == "mfma_tpb") g_mfma_tpb = value;
   else if (k == "aes_blocks") g_aes_blocks = value;
+  else if (k == "stream_block") g_stream_block = (value == 256 ? 256 : 64);
+  else if (k == "stream_waves") g_stream_waves = value;
+  else if (k == "share_waves") g_share_waves = value;
   else if (k == "mfma") g_mfma = value;
   else return fail(SCL_ERR_BAD_ARG, "unknown tuning key " + k);
   return SCL_OK;
@@ -892,14 +968,14 @@ static int reduce_impl(int field, uint64_t* out_host, const uint64_t* a, const u
     if (!a || (is_dot && !b)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
     SCL_TRY(check_align<F>({a, b}));
     const int vec = vec_width<F>({a, b}, {});
-    const unsigned maxg = 1024;
+    const unsigned maxg = 2048;  // 8 resident workgroups per CU, each lane with RED_UNROLL loads in flight
     void* sc;
     SCL_TRY(scratch((size_t)2 * (maxg + 1) * F::LIMBS * 8, &sc));
     u64* partial = static_cast<u64*>(sc);
     unsigned used = 0;
     SCL_TRY((split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;
-      unsigned g = grid_for(npacks);
+      unsigned g = grid_for((npacks + RED_UNROLL - 1) / RED_UNROLL);
       if (g > maxg) g = maxg;
       if (is_dot)
         hipLaunchKernelGGL((k_dot<F, VEC>), dim3(g), dim3(BLOCK), 0, S(stream), ctx, partial + (size_t)used * F::LIMBS,
@@ -1020,7 +1096,10 @@ int scl_hip_vector_random(int field, uint64_t* dst, size_t n, const unsigned cha
     AesKey key;
     make_aes_key(seed, seed_len, key);
     const size_t work = F::LIMBS == 4 ? (n + 1) / 2 : ((F::LIMBS == 1 ? (n + 1) / 2 : n) + 3) / 4;
-    AES4_LAUNCH((k_vector_random<F>), work, S(stream), ctx, dst, key, (u64)counter0, n);
+    if (F::LIMBS == 1 && !aligned16(dst))  // an 8-byte aligned window of a larger vector: element-wise stores
+      AES4_LAUNCH((k_vector_random<F, false>), work, S(stream), ctx, dst, key, (u64)counter0, n);
+    else
+      AES4_LAUNCH((k_vector_random<F, true>), work, S(stream), ctx, dst, key, (u64)counter0, n);
     LAUNCH_CHECK();
     return SCL_OK;
   });
@@ -1064,9 +1143,25 @@ int scl_hip_shamir_recover(int field, uint64_t* out, const uint64_t* shares, siz
       for (size_t i = 0; i < m; ++i) big.v[i] = F::ld(lambda_host + i * F::LIMBS);
     }
     if constexpr (F::TAG == 3) {
-      if (!g_force_table.load()) {  // GF(2^128): nibble-table kernel
-        hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
-                           (int)m, N);
+      const long ft = g_force_table.load();
+      if (!ft || ft == 3) {  // GF(2^128): nibble-table kernels ("force_table" 3: the shared-shift form at any m)
+        const size_t lds = gfpos_lds_bytes(m);
+        if (ft != 3 && lds <= 80 * 1024) {  // position tables, two 512-thread workgroups per CU
+          auto kern = &k_recover_gf128_pos<512, 2>;
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          const size_t blocks = (N + 511) / 512;
+          hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(512), lds, S(stream), out, shares, stride,
+                             big, (int)m, N);
+        } else if (ft != 3 && lds <= 160 * 1024) {  // one 1024-thread workgroup per CU
+          auto kern = &k_recover_gf128_pos<1024, 1>;
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          const size_t blocks = (N + 1023) / 1024;
+          hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(1024), lds, S(stream), out, shares, stride,
+                             big, (int)m, N);
+        } else {
+          hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
+                             (int)m, N);
+        }
         LAUNCH_CHECK();
         return SCL_OK;
       }
@@ -1129,9 +1224,20 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
       if (small) {
         return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
           constexpr int VEC = decltype(V)::value;
-          hipLaunchKernelGGL((k_share_small<F, VEC>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream),
-                             shares + first * F::LIMBS, share_stride, secrets + first * F::LIMBS,
-                             coeffs + first * F::LIMBS, coeff_stride, sv, (int)t, (int)n, npacks);
+          // the residency cap that gains reconstruct 6-7 % gains this kernel 2-3 % with the threshold and the party count
+          // compiled in (tools/streambench.hip) and LOSES 10 % with them at run time, as here (two waves per SIMD do not
+          // hide the per-term branches): 256-thread workgroups, no cap, unless "share_waves" asks for one
+          const long sw = g_share_waves.load();
+          const bool wave_groups = sw > 0 && g_stream_block.load() == 64;
+          const int blk = wave_groups ? 64 : BLOCK;
+          const size_t pad = residency_pad(sw, blk, sizeof(u32) * SmallVdm::CAP);
+          const dim3 g(grid_for_block(npacks, blk));
+          if (wave_groups)
+            hipLaunchKernelGGL((k_share_small<F, VEC, 64>), g, dim3(64), pad, S(stream), shares + first * F::LIMBS, share_stride,
+                               secrets + first * F::LIMBS, coeffs + first * F::LIMBS, coeff_stride, sv, (int)t, (int)n, npacks);
+          else
+            hipLaunchKernelGGL((k_share_small<F, VEC>), g, dim3(BLOCK), pad, S(stream), shares + first * F::LIMBS, share_stride,
+                               secrets + first * F::LIMBS, coeffs + first * F::LIMBS, coeff_stride, sv, (int)t, (int)n, npacks);
           LAUNCH_CHECK();
           return SCL_OK;
         });

@@ -157,19 +157,35 @@ __global__ __launch_bounds__(BLOCK) void k_scalar_mul(typename F::Ctx ctx, u64* 
   }
 }
 
-// ---- block reduction of canonical elements through LDS --------------------------------------
+// ---- block reduction of canonical elements: wavefront shuffles, then one LDS slot per wave ----------------
+// (an 8-level LDS tree with a barrier per level before: 5.3 TB/s for sum / dot; the north star asks for wavefront
+// shuffle reductions)
+template <class F>
+__device__ __forceinline__ typename F::E shfl_xor_elem(const typename F::E& v, int mask) {
+  constexpr int W = (int)(sizeof(typename F::E) / 4);
+  u32 w[W];
+  __builtin_memcpy(w, &v, sizeof v);
+#pragma unroll
+  for (int i = 0; i < W; ++i) w[i] = (u32)__shfl_xor((int)w[i], mask, 64);
+  typename F::E r;
+  __builtin_memcpy(&r, w, sizeof r);
+  return r;
+}
+
 template <class F>
 __device__ __forceinline__ typename F::E block_reduce_add(const typename F::Ctx& ctx, typename F::E x) {
-  __shared__ typename F::E red[BLOCK];
-  red[threadIdx.x] = x;
-  __syncthreads();
+  __shared__ typename F::E red[BLOCK / 64];
 #pragma unroll
-  for (int s = BLOCK / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = F::add(ctx, red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  return red[0];
+  for (int m = 32; m > 0; m >>= 1) x = F::add(ctx, x, shfl_xor_elem<F>(x, m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  typename F::E tot = red[0];
+#pragma unroll
+  for (int w = 1; w < BLOCK / 64; ++w) tot = F::add(ctx, tot, red[w]);
+  return tot;
 }
+
+constexpr int RED_UNROLL = 4;  // independent 16-byte loads in flight per lane and operand
 
 // Vector::sum (vector.h:261-267): per-block partial sums -> partial[blockIdx]
 template <class F, int VEC>
@@ -177,12 +193,21 @@ __global__ __launch_bounds__(BLOCK) void k_sum(typename F::Ctx ctx, u64* partial
   typename F::Acc acc = F::acc_zero();
   int terms = 0;
   typename F::E run = F::zero();
-  SCL_GRID_STRIDE(q, npacks) {
-    const Pack<F, VEC> x = load_pack<F, VEC, false>(a + q * VEC * F::LIMBS);
+  const size_t G = (size_t)gridDim.x * BLOCK;
+  for (size_t q0 = (size_t)blockIdx.x * BLOCK + threadIdx.x; q0 < npacks; q0 += RED_UNROLL * G) {
+    Pack<F, VEC> x[RED_UNROLL];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) F::acc_add(ctx, acc, x.v[v]);
-    terms += VEC;
-    if (terms + VEC > F::ACC_TERMS) {
+    for (int u = 0; u < RED_UNROLL; ++u)
+      if (q0 + u * G < npacks) x[u] = load_pack<F, VEC, true>(a + (q0 + u * G) * VEC * F::LIMBS);
+#pragma unroll
+    for (int u = 0; u < RED_UNROLL; ++u) {
+      if (q0 + u * G < npacks) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) F::acc_add(ctx, acc, x[u].v[v]);
+        terms += VEC;
+      }
+    }
+    if (terms + RED_UNROLL * VEC > F::ACC_TERMS) {
       run = F::add(ctx, run, F::acc_fold(ctx, acc));
       acc = F::acc_zero();
       terms = 0;
@@ -200,13 +225,26 @@ __global__ __launch_bounds__(BLOCK) void k_dot(typename F::Ctx ctx, u64* partial
   typename F::Acc acc = F::acc_zero();
   int terms = 0;
   typename F::E run = F::zero();
-  SCL_GRID_STRIDE(q, npacks) {
-    const size_t off = q * VEC * F::LIMBS;
-    const Pack<F, VEC> x = load_pack<F, VEC, false>(a + off), y = load_pack<F, VEC, false>(b + off);
+  const size_t G = (size_t)gridDim.x * BLOCK;
+  for (size_t q0 = (size_t)blockIdx.x * BLOCK + threadIdx.x; q0 < npacks; q0 += RED_UNROLL * G) {
+    Pack<F, VEC> x[RED_UNROLL], y[RED_UNROLL];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) F::mac(ctx, acc, x.v[v], y.v[v]);
-    terms += VEC;
-    if (terms + VEC > F::ACC_TERMS) {
+    for (int u = 0; u < RED_UNROLL; ++u) {
+      if (q0 + u * G < npacks) {
+        const size_t off = (q0 + u * G) * VEC * F::LIMBS;
+        x[u] = load_pack<F, VEC, true>(a + off);
+        y[u] = load_pack<F, VEC, true>(b + off);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RED_UNROLL; ++u) {
+      if (q0 + u * G < npacks) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) F::mac(ctx, acc, x[u].v[v], y[u].v[v]);
+        terms += VEC;
+      }
+    }
+    if (terms + RED_UNROLL * VEC > F::ACC_TERMS) {
       run = F::add(ctx, run, F::acc_fold(ctx, acc));
       acc = F::acc_zero();
       terms = 0;
@@ -240,10 +278,18 @@ __global__ __launch_bounds__(BLOCK) void k_count_diff_masked(unsigned long long*
 // shamirRecoverP with a hoisted basis (shamir.h:81-104, lagrange.h:54-71, vector.h:45-52):
 // out[s] = sum_i lambda[i] * shares[i][s].  M rows fully unrolled, lambda in scalar registers,
 // all M loads issued before the first multiply.
-template <class F, int VEC, int M, bool NT>
-__global__ __launch_bounds__(BLOCK) void k_recover_fixed(typename F::Ctx ctx, u64* out, const u64* shares,
-                                                         size_t stride, Table<F> lam, size_t npacks) {
-  SCL_GRID_STRIDE(q, npacks) {
+//
+// Launch geometry of the two headline streaming kernels (k_recover_fixed, k_share_small), measured on plain allocations
+// (tools/streambench.hip, profiles/r2_streambench_*.txt): SINGLE-WAVE workgroups (BLK = 64) and at most 8 of them
+// resident per CU -- the host passes a dynamic LDS size that nothing reads, only to cap the residency.  Each resident wave
+// keeps m + 1 (or t + 1 + n) DRAM streams open; with 32 waves per CU the chip walks ~90 K pages at once and the streams
+// evict each other's open rows, with 8 it still has 80 KiB of loads in flight per CU (enough for HBM latency) and
+// reconstruct gains 6-7 %, share 2-3 %, on every allocation tried.
+
+template <class F, int VEC, int M, bool NT, int BLK = BLOCK>
+__global__ __launch_bounds__(BLK) void k_recover_fixed(typename F::Ctx ctx, u64* out, const u64* shares,
+                                                       size_t stride, Table<F> lam, size_t npacks) {
+  for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < npacks; q += (size_t)gridDim.x * BLK) {
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> x[M];
 #pragma unroll
@@ -365,6 +411,124 @@ __global__ __launch_bounds__(BLOCK) void k_recover_gf128(u64* out, const u64* sh
     u64x2 o;
     o.x = (u64)total;
     o.y = (u64)(total >> 64);
+    __builtin_nontemporal_store(o, reinterpret_cast<u64x2*>(out + s * 2));
+  }
+}
+
+// GF(2^128) reconstruct, position tables.  T[i][p][j] = j(x) * lambda_i * x^(4p) for the 8 nibble positions p of a
+// 32-bit word: 2 KiB per party (80 KiB at n = 40, two 512-thread workgroups per CU).  The 8 nibbles of word w of every share
+// then add up with no shifting of the accumulator at all, and the four word sums are combined by three x^32 steps at the
+// very end -- k_recover_gf128 pays 32 x^4 steps per group of 8 parties -- so a group can be small (few registers, many
+// waves).  A lookup is one v_add_u32_sdwa (table base + a byte of the word masked to its high or low nibbles), one
+// conflict-free ds_read_b128 and four xors.  The LDS reads are issued by hand one batch (4 lookups) ahead of the xors that
+// consume them (s_waitcnt lgkmcnt(4): LDS returns in order; the compiler would wait for each batch right after issuing
+// it), and the next group's shares are fetched while this group is worked on.
+// Counters at (40,13), profiles/r2_pmc_gf128.txt: LDS array 68 % busy (4 cycles per ds_read_b128, no bank conflicts),
+// vector ALU 60 % (5.8 instructions per lookup); the two overlap only partly, so neither saturates:
+// 2.12 -> 2.44 TB/s.  At 100 % of the LDS array the form would reach 4.4 TB/s.
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+template <int B>
+__device__ __forceinline__ u32 add_byte(u32 base, u32 word) {  // base + byte B of word, one instruction
+  u32 d;
+  if constexpr (B == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(base), "v"(word));
+  if constexpr (B == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(base), "v"(word));
+  if constexpr (B == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(base), "v"(word));
+  if constexpr (B == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(base), "v"(word));
+  return d;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128(u32x4& d, u32 addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// batch IDX of a group of G parties: word wd = IDX / (2G), party j = (IDX / 2) % G, half = IDX & 1 (0: the odd nibbles)
+template <int G, int IDX>
+__device__ __forceinline__ void gfpos_issue4(u32x4 (&buf)[4], u32 gbase, const u32 (&w)[G][4]) {
+  constexpr int wd = IDX / (2 * G), j = (IDX / 2) % G, half = IDX & 1;
+  const u32 m = half ? ((w[j][wd] << 4) & 0xF0F0F0F0u) : (w[j][wd] & 0xF0F0F0F0u);
+  lds_read128<j * 2048 + (0 + (1 - half)) * 256>(buf[0], add_byte<0>(gbase, m));
+  lds_read128<j * 2048 + (2 + (1 - half)) * 256>(buf[1], add_byte<1>(gbase, m));
+  lds_read128<j * 2048 + (4 + (1 - half)) * 256>(buf[2], add_byte<2>(gbase, m));
+  lds_read128<j * 2048 + (6 + (1 - half)) * 256>(buf[3], add_byte<3>(gbase, m));
+}
+template <int G, int IDX>
+__device__ __forceinline__ void gfpos_pipe(u32x4 (&A)[4], u32x4 (&B)[4], u32x4 (&acc)[4], u32 gbase, const u32 (&w)[G][4]) {
+  constexpr int NB = 8 * G;
+  if constexpr (IDX < NB) {
+    if constexpr (IDX + 1 < NB) gfpos_issue4<G, IDX + 1>((IDX & 1) ? A : B, gbase, w);
+    u32x4(&cur)[4] = (IDX & 1) ? B : A;
+    if constexpr (IDX + 1 < NB) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+    acc[IDX / (2 * G)] ^= (cur[0] ^ cur[1]) ^ (cur[2] ^ cur[3]);
+    gfpos_pipe<G, IDX + 1>(A, B, acc, gbase, w);
+  }
+}
+__device__ __forceinline__ void gf_mulx32(u32 (&r)[4]) {  // r * x^32: the word that leaves the top times x^7 + x^2 + x + 1
+  const u32 t = r[3];
+  r[3] = r[2];
+  r[2] = r[1];
+  r[1] = r[0] ^ (t >> 31) ^ (t >> 30) ^ (t >> 25);
+  r[0] = t ^ (t << 1) ^ (t << 2) ^ (t << 7);
+}
+
+constexpr int GFPOS_G = 5;  // parties per group: 8 G batches of 4 lookups, 20 share words + 20 prefetched
+inline size_t gfpos_lds_bytes(size_t m) { return (m + GFPOS_G - 1) / GFPOS_G * GFPOS_G * 2048; }
+
+template <int BLK, int WPS>
+__global__ __launch_bounds__(BLK, WPS) void k_recover_gf128_pos(u64* out, const u64* shares, size_t stride,
+                                                                BigTable<Gf128> tab, int m, size_t N) {
+  constexpr int G = GFPOS_G;
+  extern __shared__ __align__(16) uint4 gfpos_T[];  // [mpad][8][16]; parties m .. mpad-1 are zero tables
+  const int mpad = (m + G - 1) / G * G;
+  for (int e = threadIdx.x; e < mpad * 128; e += BLK) {
+    const int i = e >> 7, p = (e >> 4) & 7, j = e & 15;
+    u128 l0 = i < m ? tab.v[i] : (u128)0;
+    for (int k = 0; k < p; ++k) l0 = Gf128::mulx4(l0);
+    const u128 l1 = Gf128::mulx(l0), l2 = Gf128::mulx(l1), l3 = Gf128::mulx(l2);
+    const u128 v = (j & 1 ? l0 : (u128)0) ^ (j & 2 ? l1 : (u128)0) ^ (j & 4 ? l2 : (u128)0) ^ (j & 8 ? l3 : (u128)0);
+    gfpos_T[e] = make_uint4((u32)v, (u32)(v >> 32), (u32)(v >> 64), (u32)(v >> 96));
+  }
+  __syncthreads();
+  const u32 tbase = (u32)(uintptr_t)gfpos_T;  // low half of the flat address = the LDS byte address
+  auto load_group = [&](u32(&w)[G][4], int i0, size_t s) {
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      u64x2 v;
+      v.x = v.y = 0;
+      if (i0 + j < m) v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(shares + ((size_t)(i0 + j) * stride + s) * 2));
+      w[j][0] = (u32)v.x;
+      w[j][1] = (u32)(v.x >> 32);
+      w[j][2] = (u32)v.y;
+      w[j][3] = (u32)(v.y >> 32);
+    }
+  };
+  for (size_t s = (size_t)blockIdx.x * BLK + threadIdx.x; s < N; s += (size_t)gridDim.x * BLK) {
+    u32x4 acc[4] = {0, 0, 0, 0};
+    u32 w[G][4], wn[G][4];
+    load_group(w, 0, s);
+    for (int i0 = 0; i0 < m; i0 += G) {
+      if (i0 + G < m) load_group(wn, i0 + G, s);
+      const u32 gbase = tbase + (u32)i0 * 2048u;
+      u32x4 A[4], B[4];
+      gfpos_issue4<G, 0>(A, gbase, w);
+      gfpos_pipe<G, 0>(A, B, acc, gbase, w);
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[j][c] = wn[j][c];
+    }
+    u32 r[4] = {acc[3].x, acc[3].y, acc[3].z, acc[3].w};
+#pragma unroll
+    for (int wd = 2; wd >= 0; --wd) {
+      gf_mulx32(r);
+      r[0] ^= acc[wd].x;
+      r[1] ^= acc[wd].y;
+      r[2] ^= acc[wd].z;
+      r[3] ^= acc[wd].w;
+    }
+    u64x2 o;
+    o.x = (u64)r[0] | ((u64)r[1] << 32);
+    o.y = (u64)r[2] | ((u64)r[3] << 32);
     __builtin_nontemporal_store(o, reinterpret_cast<u64x2*>(out + s * 2));
   }
 }
@@ -612,14 +776,14 @@ __device__ __forceinline__ void small_rows(const Pack<F, VEC> (&c)[SmallVdm::TMA
   }
 }
 
-template <class F, int VEC>
-__global__ __launch_bounds__(BLOCK) void k_share_small(u64* shares, size_t stride, const u64* secrets,
-                                                       const u64* coeffs, size_t cstride, SmallVdm tab, int t, int n,
-                                                       size_t npacks) {
+template <class F, int VEC, int BLK = BLOCK>
+__global__ __launch_bounds__(BLK) void k_share_small(u64* shares, size_t stride, const u64* secrets,
+                                                     const u64* coeffs, size_t cstride, SmallVdm tab, int t, int n,
+                                                     size_t npacks) {
   __shared__ u32 V[SmallVdm::CAP];
-  for (int i = threadIdx.x; i < n * (t + 1); i += BLOCK) V[i] = tab.v[i];
+  for (int i = threadIdx.x; i < n * (t + 1); i += BLK) V[i] = tab.v[i];
   __syncthreads();
-  SCL_GRID_STRIDE(q, npacks) {
+  for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < npacks; q += (size_t)gridDim.x * BLK) {
     const size_t off = q * VEC * F::LIMBS;
     Pack<F, VEC> c[SmallVdm::TMAX + 1];
     c[0] = load_pack<F, VEC, true>(secrets + off);
@@ -1011,7 +1175,8 @@ __global__ __launch_bounds__(BLOCK) void k_ring_from_bytes(typename F::Ctx ctx, 
 }
 
 // Vector::random(n, prg) for a PRG at counter0 (vector.h:507-519): element e = bytes [e*bs,(e+1)*bs)
-template <class F>
+// PAIRS: a Mersenne61 destination that is 16-byte aligned takes both elements of a block in one 16-byte store
+template <class F, bool PAIRS = true>
 __global__ __launch_bounds__(ABLOCK) void k_vector_random(typename F::Ctx ctx, u64* dst, AesKey key, u64 counter0,
                                                           size_t n) {
   SCL_AES4_PROLOGUE(key)
@@ -1039,10 +1204,15 @@ __global__ __launch_bounds__(ABLOCK) void k_vector_random(typename F::Ctx ctx, u
       if (blk < nb) {
         if constexpr (F::LIMBS == 1) {
           if (2 * blk + 1 < n) {
-            u64x2 w;
-            w.x = F::from_le_word(ctx, lo[b]);
-            w.y = F::from_le_word(ctx, hi[b]);
-            *reinterpret_cast<u64x2*>(dst + 2 * blk) = w;
+            if constexpr (PAIRS) {
+              u64x2 w;
+              w.x = F::from_le_word(ctx, lo[b]);
+              w.y = F::from_le_word(ctx, hi[b]);
+              *reinterpret_cast<u64x2*>(dst + 2 * blk) = w;
+            } else {
+              dst[2 * blk] = F::from_le_word(ctx, lo[b]);
+              dst[2 * blk + 1] = F::from_le_word(ctx, hi[b]);
+            }
           } else {
             dst[2 * blk] = F::from_le_word(ctx, lo[b]);
           }

@@ -15,6 +15,8 @@
 
 #include <scl_hip/scl.h>
 
+#include "gf7_field.h"
+
 using namespace scl;
 
 static int g_fail = 0, g_checks = 0;
@@ -334,6 +336,97 @@ TEST_CASE(matrix_host, "Matrix: identity / transpose / invert on scalars", false
 }
 
 // ---------------------------------------------------------------------------- GPU-backed
+// ---------------------------------------------------------------------------- a user-defined field (host)
+// The reference's field plug-in boundary (include/scl/math/fields/ff_ops.h:35-118): gf7_field.h defines GF(7) with the
+// traits struct and the eleven specialisations only; everything below runs through the generic host paths.
+using G7 = math::FF<usr::Gf7>;
+static_assert(!math::OnDevice<G7> && math::OnDevice<F61>, "GF(7) has no kernels; the built-in fields do");
+
+TEST_CASE(gf7_scalars, "user-defined field GF(7): FF<Gf7> over the eleven ff:: specialisations", false) {
+  REQUIRE(std::string(G7::name()) == "GF(7)" && G7::byteSize() == 1 && G7::bitSize() == 8);
+  for (int a = 0; a < 7; ++a)
+    for (int b = 0; b < 7; ++b) {
+      REQUIRE(G7(a) + G7(b) == G7((a + b) % 7));
+      REQUIRE(G7(a) - G7(b) == G7((a - b + 7) % 7));
+      REQUIRE(G7(a) * G7(b) == G7((a * b) % 7));
+      if (b) REQUIRE((G7(a) / G7(b)) * G7(b) == G7(a));
+    }
+  REQUIRE(G7(-1) == G7(6) && G7(-15) == G7(6) && G7(7) == G7::zero() && -G7(3) == G7(4) && -G7(0) == G7(0));
+  REQUIRE(G7(3).inverse() == G7(5) && G7(6).inverse() == G7(6));
+  REQUIRE_THROWS_MSG(G7(0).inverse(), std::logic_error, "0 not invertible modulo prime");  // test_ff.cc:168-171
+  REQUIRE(G7::fromString("0a") == G7(3) && G7(5).toString() == "5");
+  unsigned char byte = 0;
+  G7(4).write(&byte);
+  REQUIRE(byte == 4 && G7::read(&byte) == G7(4));
+  byte = 200;
+  REQUIRE(G7::read(&byte) == G7(200 % 7));
+  REQUIRE(math::exp(G7(3), 6) == G7(1) && math::exp(G7(3), 0) == G7(1) && math::exp(G7(3), 2) == G7(2));
+  G7 x = G7::one();
+  for (int i = 0; i < 6; ++i) x++;
+  REQUIRE(x == G7::zero());  // the x++ walk of shamirSecretShare wraps in a 7-element field
+}
+
+TEST_CASE(gf7_containers, "user-defined field GF(7): Vector / Matrix / Polynomial / Lagrange on the host", false) {
+  using V = math::Vector<G7>;
+  const V a = {G7(1), G7(2), G7(3)}, b = {G7(6), G7(5), G7(4)};
+  REQUIRE(a.add(b) == V({G7(0), G7(0), G7(0)}) && a.subtract(b) == V({G7(2), G7(4), G7(6)}));
+  REQUIRE(a.multiplyEntryWise(b) == V({G7(6), G7(3), G7(5)}) && a.dot(b) == G7((6 + 10 + 12) % 7));
+  REQUIRE(a.sum() == G7(6) && a.scalarMultiply(G7(3)) == V({G7(3), G7(6), G7(2)}) && a != b);
+  REQUIRE_THROWS_MSG(a.add(V({G7(1)})), std::invalid_argument, "Vec sizes mismatch");
+  REQUIRE(V::range(5, 9) == V({G7(5), G7(6), G7(0), G7(1)}));
+  // Vandermonde rows x_i^j and their product with a coefficient column = Horner at the same nodes
+  const auto vm = math::Matrix<G7>::vandermonde(4, 3);
+  REQUIRE(vm(0, 0) == G7(1) && vm(2, 2) == G7(2) && vm(3, 2) == G7(2) && vm(3, 1) == G7(4));
+  const V coeff = {G7(5), G7(1), G7(3)};  // 5 + x + 3x^2
+  const auto p = math::Polynomial<G7>::create(coeff);
+  const auto evals = vm.multiply(coeff);
+  for (int i = 0; i < 4; ++i) REQUIRE(evals[i] == p.evaluate(G7(i + 1)));
+  const auto prod = vm.multiply(coeff.toColumnMatrix());
+  REQUIRE(prod.rows() == 4 && prod.cols() == 1 && prod(1, 0) == p.evaluate(G7(2)));
+  // interpolation at 0 from three points of a degree-2 polynomial
+  const auto lb = math::computeLagrangeBasis(V::range(1, 4), 0);
+  REQUIRE(math::innerProd<G7>(evals.begin(), evals.begin() + 3, lb.begin()) == G7(5));
+  REQUIRE(ss::shamirRecoverP(evals.subVector(3)) == G7(5));
+  REQUIRE_THROWS_MSG(math::computeLagrangeBasis(V({G7(1), G7(8)}), 0), std::logic_error, "0 not invertible modulo prime");
+  // error detection (shamir.h:116-139), short overload: t = 2, five shares at nodes 1..5; it re-derives share t + 1 .. 2t - 1
+  // (index 3 only) from the first three -- the last share is never looked at (note E)
+  V five;
+  for (int i = 1; i <= 5; ++i) five.toStlVector().push_back(p.evaluate(G7(i)));
+  REQUIRE(ss::shamirRecoverD(five, 2) == G7(5));
+  V bad = five;
+  bad[3] += G7(1);
+  REQUIRE_THROWS_MSG(ss::shamirRecoverD(bad, 2), std::logic_error, "error detected during recovery");
+  bad = five;
+  bad[4] += G7(1);
+  REQUIRE(ss::shamirRecoverD(bad, 2) == G7(5));
+  REQUIRE_THROWS_MSG(ss::shamirRecoverD(five.subVector(3), 2), std::logic_error, "not enough shares provided to detect errors");
+  const auto him = math::Matrix<G7>::hyperInvertible(2, 2);
+  REQUIRE(him.rows() == 2 && !(him(0, 0) == him(1, 0) && him(0, 1) == him(1, 1)));
+  REQUIRE(math::Matrix<G7>::vandermonde(3, 3).multiply(math::Matrix<G7>::vandermonde(3, 3).invert()).isIdentity());
+}
+
+TEST_CASE(gf7_berlekamp_welch, "user-defined field GF(7): the Wikipedia Berlekamp-Welch case (test_shamir.cc:144-160)", false) {
+  // https://en.wikipedia.org/wiki/Berlekamp%E2%80%93Welch_algorithm#Example: seven shares of a degree-2 sharing,
+  // the ones at nodes 2 and 5 wrong
+  const math::Vector<G7> received = {G7(1), G7(5), G7(3), G7(6), G7(3), G7(2), G7(2)};
+  const math::Vector<G7> corrected = {G7(1), G7(6), G7(3), G7(6), G7(1), G7(2), G7(2)};
+  const auto s = ss::shamirRecoverC(received);
+  REQUIRE(s.err.evaluate(G7(2)) == G7::zero());
+  REQUIRE(s.err.evaluate(G7(5)) == G7::zero());
+  REQUIRE(s.err.degree() == 2 && s.f.degree() == 2);
+  for (std::size_t i = 0; i < received.size(); ++i) REQUIRE(s.f.evaluate(G7((int)i + 1)) == corrected[i]);
+  // nothing to correct: the locator is 1
+  const auto clean = ss::shamirRecoverC(corrected);
+  REQUIRE(clean.err.degree() == 0 && clean.err.constantTerm() == G7(1) && clean.f.constantTerm() == s.f.constantTerm());
+  // three errors are one too many for t = 2
+  math::Vector<G7> broken = corrected;
+  broken[0] = G7(0), broken[3] = G7(0), broken[6] = G7(0);
+  REQUIRE_THROWS_MSG(ss::shamirRecoverC(broken), std::logic_error, "could not correct shares");
+  // the same algebra through explicit nodes (shamir.h:202-250)
+  const auto s2 = ss::shamirRecoverC(received, math::Vector<G7>::range(1, 8));
+  REQUIRE(s2.f.constantTerm() == s.f.constantTerm());
+}
+
 TEST_CASE(prg_gpu, "util::PRG stream", true) {
   // test/scl/util/test_prg.cc:49-125 (determinism, reset, seed truncation) + known answers
   auto prg = util::PRG::create("shamir passive");

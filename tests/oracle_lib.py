@@ -411,6 +411,8 @@ class Port(_Base):
     has_err = False
 
     def __init__(self, path: str | None = None):
+        if path is None and os.environ.get("SCL_ORACLE_SO"):   # the sanitizer run points this at the instrumented build
+            path = os.environ["SCL_ORACLE_SO"]
         if path is None:
             path = PORT_SO if os.path.exists(PORT_SO) and os.path.getmtime(PORT_SO) >= os.path.getmtime(
                 os.path.join(ORACLE_DIR, "scl_oracle.c")) else build_port()

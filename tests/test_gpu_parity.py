@@ -1046,13 +1046,14 @@ def test_full_size_round_trip(scl, port, f, n, t, N):
 
 def test_bench_contract_small(scl):
     """bench.py end to end on a small batch: one JSON line with the contract's keys, the roofline and cpu_baseline objects,
-    a verified round trip, and the placement probe (arena arrangements) exercised."""
+    a verified round trip on plain allocations, the open-step report and (with --configs 0) no side configurations."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--secrets", "300000", "--steps", "2", "--warmup", "1",
-                        "--cpu-sample", "2000"], capture_output=True, text=True, timeout=600)
+                        "--cpu-sample", "2000", "--configs", "0", "--open-secrets", "50000", "--open-chunk", "20000"],
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -1061,7 +1062,32 @@ def test_bench_contract_small(scl):
     assert line["verified"] is True and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["cores"] == 1
-    assert line["placement_probe"] is None or len(line["placement_probe"]["matrix_positions"]) >= 2
+    assert line["config"]["allocation"] == "plain" and "configs" not in line
+    c4 = line["open"]["c4_all_gather"]
+    assert c4["verified"] is True and c4["secrets"] == 50000 and c4["chunk"] == 20000 and c4["parties_per_rank"] == 40
+    assert line["open"]["m61_partial_sums"]["verified"] is True
+    # the committed PMC traffic describes BASELINE configs[1] only: any other configuration reports null
+    assert line["roofline"]["traffic"] is None
+
+
+def test_bench_open_mode_line(scl):
+    """--mode open: the exchange step alone (reference: Network::send + Network::recv, include/scl/net/network.h:148-185),
+    with the collective's bandwidth fields beside the reconstruct kernel's HBM fraction"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "open", "--secrets", "200000",
+                        "--open-secrets", "70000", "--open-chunk", "1 << 15".replace("1 << 15", "32768")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["metric"] == "shamir_open_reconstructions_per_sec" and line["n_gpus"] == 1 and line["value"] > 0
+    c4 = line["open"]["c4_all_gather"]
+    for k in ("rccl_busbw_GBps", "rccl_algbw_GBps", "gather_ms_per_chunk", "reconstruct_hbm_frac", "pipeline_ms"):
+        assert k in c4, k
+    assert c4["verified"] and line["open"]["m61_partial_sums"]["verified"]
+    assert line["roofline"]["kernel"] == "shamir_recover" and 0 < line["roofline"]["frac"] < 1
 
 
 @pytest.mark.parametrize("n,t,N", [(128, 42, 3 * 256 * 32 + 17), (97, 5, 2 * 256 * 32 + 31), (128, 48, 256 * 32 + 1), (100, 33, 4 * 256 * 32)])
