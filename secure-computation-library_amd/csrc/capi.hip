@@ -434,7 +434,7 @@ bool small_nodes(const BigTable<F>& al, size_t n) {
 template <class F>
 int alpha_table(const typename F::Ctx& ctx, const u64* alphas_host, size_t n, BigTable<F>& tab) {
   if (n > (size_t)BigTable<F>::CAP)
-    return fail(SCL_ERR_BAD_ARG, "share: more parties than the table kernels hold (256 for M61, 128 for 128-bit fields)");
+    return fail(SCL_ERR_BAD_ARG, "share: internal party block too large");
   std::vector<typename F::E> nodes;
   if (alphas_host) load_host<F>(alphas_host, n, nodes);
   else default_nodes<F>(ctx, n, nodes);
@@ -708,6 +708,62 @@ struct RecoverFixed {
     return fail(SCL_ERR_BAD_ARG, "recover: m out of range");
   }
 };
+
+
+// the n nodes first_party+1 .. (default: FF(int) images, vector.h:490-505) or the caller's, as host limbs
+static int nodes_to_host(int field, const uint64_t* alphas_host, size_t n, size_t first_party, u64* out) {
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    for (size_t i = 0; i < n; ++i) {
+      if (alphas_host) F::st(out + i * F::LIMBS, F::ld(alphas_host + i * F::LIMBS));
+      else F::st(out + i * F::LIMBS, F::from_u64(ctx, (u64)(first_party + i + 1)));
+    }
+    return SCL_OK;
+  });
+}
+
+// Thresholds above 48 (k_share_chunk): Horner over chunks of the coefficient rows, top chunk first.  n <= the node table.
+// The node / node-power tables sit in the calling thread's temporary arena; the call synchronises (rarely used path).
+static int share_chunked(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, const uint64_t* coeffs,
+                         size_t coeff_stride, size_t N, size_t t, size_t n, const uint64_t* alphas_host, size_t first_party,
+                         void* stream) {
+  return with_field(field, [&](auto f, auto ctx) -> int {
+    using F = decltype(f);
+    typedef typename F::E E;
+    SCL_TRY(check_align<F>({shares, secrets, coeffs}));
+    if (n > (size_t)BigTable<F>::CAP) return fail(SCL_ERR_BAD_ARG, "share: internal party block too large");
+    constexpr size_t TC = (size_t)share_chunk_t<F>(), C = TC + 1;
+    std::vector<u64> nodes(n * F::LIMBS), tab(2 * n * F::LIMBS);
+    SCL_TRY(nodes_to_host(field, alphas_host, n, first_party, nodes.data()));
+    for (size_t i = 0; i < n; ++i) {
+      const E a = F::ld(nodes.data() + i * F::LIMBS);
+      E pw = F::one(ctx);
+      for (size_t k = 0; k < C; ++k) pw = F::mul(ctx, pw, a);
+      F::st(tab.data() + i * F::LIMBS, a);
+      F::st(tab.data() + (n + i) * F::LIMBS, pw);
+    }
+    void* dev = nullptr;
+    SCL_TRY(temp_acquire(tab.size() * 8, S(stream), &dev));
+    auto body = [&]() -> int {
+      HIP_TRY(hipMemcpyAsync(dev, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, S(stream)));
+      // chunks [0, TC], [C, C + TC], ..: the top one may be short and goes first
+      const size_t nchunks = t / C + 1;
+      for (size_t j = nchunks; j-- > 0;) {
+        const size_t k_lo = j * C, k_hi = (k_lo + TC < t) ? k_lo + TC : t;
+        const u64* c0 = k_lo == 0 ? secrets : coeffs + (k_lo - 1) * coeff_stride * F::LIMBS;
+        const u64* crest = coeffs + k_lo * coeff_stride * F::LIMBS;
+        hipLaunchKernelGGL((k_share_chunk<F>), dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), ctx, shares, share_stride, c0, crest,
+                           coeff_stride, static_cast<const u64*>(dev), (int)(k_hi - k_lo), (int)n, N, j + 1 != nchunks ? 1 : 0);
+        LAUNCH_CHECK();
+      }
+      HIP_TRY(hipStreamSynchronize(S(stream)));  // the host tables die with this frame
+      return SCL_OK;
+    };
+    const int rc = body();
+    (void)temp_release(S(stream));
+    return rc;
+  });
+}
 
 }  // namespace
 
@@ -1122,19 +1178,37 @@ int scl_hip_lagrange_basis(int field, uint64_t* lambda_host, const uint64_t* alp
   });
 }
 
+static int recover_block(int field, uint64_t* out, const uint64_t* shares, size_t stride, const uint64_t* lambda_host,
+                         size_t m, size_t N, const uint64_t* prev, void* stream);
+
 int scl_hip_shamir_recover(int field, uint64_t* out, const uint64_t* shares, size_t stride,
                            const uint64_t* lambda_host, size_t m, size_t N, void* stream) {
   if (N == 0) return SCL_OK;
   if (!out || !shares || !lambda_host) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (m == 0) return fail(SCL_ERR_BAD_ARG, "recover: need at least one share");
   if (stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "share_stride < N");
+  const int L = scl_hip_limbs(field);
+  if (L < 0 || is_ring(field)) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
+  // shamirRecoverP takes any number of shares (shamir.h:81-87); one launch holds 256 / limbs Lagrange coefficients.
+  // More parties are summed over several launches, each adding its block's terms to the canonical partial sum.
+  const size_t cap = (size_t)256 / (size_t)L;
+  for (size_t b0 = 0; b0 < m; b0 += cap) {
+    const size_t mb = m - b0 < cap ? m - b0 : cap;
+    SCL_TRY(recover_block(field, out, shares + b0 * stride * (size_t)L, stride, lambda_host + b0 * (size_t)L, mb, N,
+                          b0 ? out : nullptr, stream));
+  }
+  return SCL_OK;
+}
+
+static int recover_block(int field, uint64_t* out, const uint64_t* shares, size_t stride, const uint64_t* lambda_host,
+                         size_t m, size_t N, const uint64_t* prev, void* stream) {
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({out, shares}));
     const int vec = vec_width<F>({out, shares}, {stride});
     const bool nt = g_nontemporal.load() != 0;
-    const bool fixed = (m <= FIXED_M_MAX) && (F::TAG <= 1) && !g_force_table.load();
-    if (m > (size_t)BigTable<F>::CAP) return fail(SCL_ERR_BAD_ARG, "recover: more shares than the table kernels hold (256 for M61, 128 for 128-bit fields)");
+    const bool fixed = (m <= FIXED_M_MAX) && (F::TAG <= 1) && !g_force_table.load() && !prev;
+    if (m > (size_t)BigTable<F>::CAP) return fail(SCL_ERR_BAD_ARG, "recover: internal party block too large");
     Table<F> lam;
     BigTable<F> big;
     if (fixed) {
@@ -1146,7 +1220,10 @@ int scl_hip_shamir_recover(int field, uint64_t* out, const uint64_t* shares, siz
       const long ft = g_force_table.load();
       if (!ft || ft == 3) {  // GF(2^128): nibble-table kernels ("force_table" 3: the shared-shift form at any m)
         const size_t lds = gfpos_lds_bytes(m);
-        if (ft != 3 && lds <= 80 * 1024) {  // position tables, two 512-thread workgroups per CU
+        if (prev) {
+          hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
+                             (int)m, N, prev);
+        } else if (ft != 3 && lds <= 80 * 1024) {  // position tables, two 512-thread workgroups per CU
           auto kern = &k_recover_gf128_pos<512, 2>;
           HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           const size_t blocks = (N + 511) / 512;
@@ -1160,7 +1237,7 @@ int scl_hip_shamir_recover(int field, uint64_t* out, const uint64_t* shares, siz
                              big, (int)m, N);
         } else {
           hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
-                             (int)m, N);
+                             (int)m, N, (const u64*)nullptr);
         }
         LAUNCH_CHECK();
         return SCL_OK;
@@ -1176,10 +1253,10 @@ int scl_hip_shamir_recover(int field, uint64_t* out, const uint64_t* shares, siz
         }
       } else if (nt) {
         hipLaunchKernelGGL((k_recover_table<F, VEC, true>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx, o,
-                           sh, stride, big, (int)m, npacks);
+                           sh, stride, big, (int)m, npacks, prev ? prev + first * F::LIMBS : nullptr);
       } else {
         hipLaunchKernelGGL((k_recover_table<F, VEC, false>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx, o,
-                           sh, stride, big, (int)m, npacks);
+                           sh, stride, big, (int)m, npacks, prev ? prev + first * F::LIMBS : nullptr);
       }
       LAUNCH_CHECK();
       return SCL_OK;
@@ -1193,8 +1270,23 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
                          const uint64_t* alphas_host, void* stream) {
   if (N == 0 || n == 0) return SCL_OK;
   if (!shares || !secrets || (t > 0 && !coeffs)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
-  if (t > 48) return fail(SCL_ERR_BAD_ARG, "share: t > 48 not supported");
   if (share_stride < N || (t > 0 && coeff_stride < N)) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
+  {
+    // shamirSecretShare bounds neither n nor t (shamir.h:51-68).  One launch holds 256 / limbs nodes: more parties go
+    // block by block (parties are independent).  More than 48 coefficients go through the chunked Horner kernel.
+    const int L = scl_hip_limbs(field);
+    if (L < 0 || is_ring(field)) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
+    const size_t cap = (size_t)256 / (size_t)L;
+    if (n > cap) {
+      std::vector<u64> nodes(n * (size_t)L);
+      SCL_TRY(nodes_to_host(field, alphas_host, n, 0, nodes.data()));
+      for (size_t b0 = 0; b0 < n; b0 += cap)
+        SCL_TRY(scl_hip_shamir_share(field, shares + b0 * share_stride * (size_t)L, share_stride, secrets, coeffs, coeff_stride, N,
+                                     t, n - b0 < cap ? n - b0 : cap, nodes.data() + b0 * (size_t)L, stream));
+      return SCL_OK;
+    }
+    if (t > 48) return share_chunked(field, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, alphas_host, 0, stream);
+  }
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({shares, secrets, coeffs}));
@@ -1308,6 +1400,39 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
                           size_t n, const unsigned char* seed, size_t seed_len, uint64_t counter0, ArrayLane lane,
                           void* stream);
 
+// PRG-driven sharing beyond one launch's party / coefficient capacity
+static int share_prg_large(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N, size_t t,
+                           size_t n, const unsigned char* seed, size_t seed_len, uint64_t counter0, void* stream) {
+  const size_t L = (size_t)scl_hip_limbs(field), E = 8 * L;
+  const u64 B = ((u64)(t + 1) * E + 15) / 16;  // blocks per secret
+  size_t slab = t ? ((size_t)256 << 20) / (t * E) : N;
+  if (slab < 4096) slab = 4096;
+  if (slab > N) slab = N;
+  slab = (slab + 1) & ~(size_t)1;
+  void* rows_v = nullptr;
+  if (t) HIP_TRY(hipMalloc(&rows_v, t * slab * E));  // not the thread temporary: share_chunked takes that for its tables
+  u64* rows = static_cast<u64*>(rows_v);
+  AesKey key;
+  make_aes_key(seed, seed_len, key);
+  int rc = SCL_OK;
+  for (size_t s0 = 0; s0 < N && rc == SCL_OK; s0 += slab) {
+    const size_t c = N - s0 < slab ? N - s0 : slab;
+    if (t)
+      rc = with_field(field, [&](auto f, auto ctx) -> int {
+        using F = decltype(f);
+        hipLaunchKernelGGL((k_prg_coeff_rows<F>), dim3(grid_aes(c)), dim3(BLOCK), 0, S(stream), ctx, rows, slab, key,
+                           (u64)(counter0 + s0 * B), (int)t, c);
+        LAUNCH_CHECK();
+        return SCL_OK;
+      });
+    if (rc == SCL_OK)
+      rc = scl_hip_shamir_share(field, shares + s0 * L, share_stride, secrets + s0 * L, rows, slab, c, t, n, nullptr, stream);
+  }
+  (void)hipStreamSynchronize(S(stream));
+  if (rows_v) (void)hipFree(rows_v);
+  return rc;
+}
+
 int scl_hip_shamir_share_prg(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N,
                              size_t t, size_t n, const unsigned char* seed, size_t seed_len, uint64_t counter0,
                              void* stream) {
@@ -1335,8 +1460,18 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
                           void* stream) {
   if (N == 0 || n == 0) return SCL_OK;
   if (!shares || !secrets) return fail(SCL_ERR_BAD_ARG, "NULL operand");
-  if (t > 48) return fail(SCL_ERR_BAD_ARG, "share: t > 48 not supported");
   if (share_stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
+  {
+    const int L = scl_hip_limbs(field);
+    if (L < 0 || is_ring(field)) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
+    const size_t cap = (size_t)256 / (size_t)L;
+    if (n > cap || t > 48) {
+      // more parties than one node table or more coefficients than the register-resident kernels hold: the coefficient
+      // rows are drawn into the thread's temporary (slab by slab, at most 256 MiB) and shared from there
+      if (lane.W != 1) return fail(SCL_ERR_BAD_ARG, "share_prg_packed: n and t beyond one launch are not supported for W > 1");
+      return share_prg_large(field, shares, share_stride, secrets, N, t, n, seed, seed_len, counter0, stream);
+    }
+  }
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({shares, secrets}));

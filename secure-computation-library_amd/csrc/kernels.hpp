@@ -307,9 +307,12 @@ __global__ __launch_bounds__(BLK) void k_recover_fixed(typename F::Ctx ctx, u64*
 }
 
 // Any m <= BigTable::CAP: lambda staged in LDS, rows consumed 8 at a time.
+// prev != nullptr: out = prev + this block of parties' terms -- how more parties than one table holds are summed
+// over several launches (canonical partial sums add exactly)
 template <class F, int VEC, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_recover_table(typename F::Ctx ctx, u64* out, const u64* shares,
-                                                         size_t stride, BigTable<F> tab, int m, size_t npacks) {
+                                                         size_t stride, BigTable<F> tab, int m, size_t npacks,
+                                                         const u64* prev) {
   __shared__ typename F::E lam[BigTable<F>::CAP];
   for (int i = threadIdx.x; i < m; i += BLOCK) lam[i] = tab.v[i];
   __syncthreads();
@@ -321,6 +324,11 @@ __global__ __launch_bounds__(BLOCK) void k_recover_table(typename F::Ctx ctx, u6
     for (int v = 0; v < VEC; ++v) {
       acc[v] = F::acc_zero();
       run[v] = F::zero();
+    }
+    if (prev) {
+      const Pack<F, VEC> p0 = load_pack<F, VEC, false>(prev + off);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) run[v] = p0.v[v];
     }
     int i = 0, terms = 0;
     for (; i + 8 <= m; i += 8) {
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) void k_recover_table(typename F::Ctx ctx, u6
 // ds_read_b128 with data-dependent nibbles is conflict-free).  The x^4 shifts are shared across
 // parties: for nibble position k (high to low)  r = r * x^4  ^  XOR_i T_i[nib_k(s_i)].
 __global__ __launch_bounds__(BLOCK) void k_recover_gf128(u64* out, const u64* shares, size_t stride,
-                                                         BigTable<Gf128> tab, int m, size_t N) {
+                                                         BigTable<Gf128> tab, int m, size_t N, const u64* prev = nullptr) {
   __shared__ u128 T[BigTable<Gf128>::CAP * 16];
   for (int e = threadIdx.x; e < m * 16; e += BLOCK) {
     const u128 l0 = tab.v[e >> 4];
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(BLOCK) void k_recover_gf128(u64* out, const u64* sh
   __syncthreads();
   constexpr int G = 8;
   SCL_GRID_STRIDE(s, N) {
-    u128 total = 0;
+    u128 total = prev ? Gf128::ld(prev + s * 2) : (u128)0;
     for (int i0 = 0; i0 < m; i0 += G) {
       u32 w[G][4];
 #pragma unroll
@@ -1377,6 +1385,77 @@ __global__ __launch_bounds__(ABLOCK) void k_share_prg_small(u64* shares, size_t 
         }
       }
     small_rows<F, VEC>(c, V, t, n, shares, stride, off);
+  }
+}
+
+// ---- any threshold: the polynomial in chunks of at most SHARE_CHUNK_T + 1 coefficients, one launch per chunk -------
+// shamirSecretShare has no bound on t (shamir.h:51-68); the register-resident kernels above hold 49 coefficients.  A longer
+// polynomial f(x) = sum_j x^(C j) g_j(x), C = SHARE_CHUNK_T + 1, is evaluated by Horner over its chunks from the top: the
+// first launch writes g_top(alpha_i), every later one y_i <- y_i * alpha_i^C + g_j(alpha_i) (its chunk has exactly C
+// coefficients).  tables = [nodes | nodes^C] in device memory.  Generic full-width arithmetic: not a tuned path.
+template <class F>
+constexpr int share_chunk_t() { return F::LIMBS >= 4 ? 23 : 47; }
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_share_chunk(typename F::Ctx ctx, u64* shares, size_t stride, const u64* c0,
+                                                       const u64* crest, size_t cstride, const u64* tables, int tc, int n,
+                                                       size_t N, int accumulate) {
+  constexpr int TC = share_chunk_t<F>();
+  __shared__ typename F::E alpha[BigTable<F>::CAP], xpow[BigTable<F>::CAP];
+  for (int i = threadIdx.x; i < n; i += BLOCK) {
+    alpha[i] = F::ld(tables + (size_t)i * F::LIMBS);
+    xpow[i] = F::ld(tables + (size_t)(n + i) * F::LIMBS);
+  }
+  __syncthreads();
+  SCL_GRID_STRIDE(q, N) {
+    const size_t off = q * F::LIMBS;
+    Pack<F, 1> c[TC + 1];
+    c[0] = load_pack<F, 1, true>(c0 + off);
+#pragma unroll
+    for (int k = 1; k <= TC; ++k) {
+      if (k <= tc) c[k] = load_pack<F, 1, true>(crest + (size_t)(k - 1) * cstride * F::LIMBS + off);
+    }
+    for (int i = 0; i < n; ++i) {
+      const typename F::E x = alpha[i];
+      typename F::E y = F::zero();
+#pragma unroll
+      for (int k = TC; k >= 0; --k) {
+        if (k == tc) y = c[k].v[0];                                     // wave-uniform
+        else if (k < tc) y = F::add(ctx, F::mul(ctx, y, x), c[k].v[0]);
+      }
+      u64* dst = shares + (size_t)i * stride * F::LIMBS + off;
+      if (accumulate) y = F::add(ctx, F::mul(ctx, F::ld(dst), xpow[i]), y);
+      F::st(dst, y);
+    }
+  }
+}
+
+// Coefficient rows of a PRG-driven sharing (rows[k-1][s] = c_k of secret s, k = 1..t) under the reference's counter
+// discipline (prg_coeffs above), for thresholds the register-resident PRG kernels do not hold
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_prg_coeff_rows(typename F::Ctx ctx, u64* rows, size_t rstride, AesKey key,
+                                                          u64 counter0, int t, size_t N) {
+  SCL_AES_PROLOGUE(key)
+  const Aes1 aes{te0};
+  constexpr int BPE = F::LIMBS >= 2 ? F::LIMBS / 2 : 1;
+  const u64 B = F::LIMBS == 1 ? ((u64)(t + 1) + 1) / 2 : (u64)(t + 1) * BPE;
+  SCL_GRID_STRIDE(s, N) {
+    const u64 ctr0 = counter0 + s * B;
+    if constexpr (F::LIMBS == 1) {
+      for (int j = 0; 2 * j <= t; ++j) {  // block j = c_2j (low 8 bytes), c_2j+1 (high 8 bytes)
+        u64 lo, hi;
+        aes.block(key, ctr0 + j, lo, hi);
+        if (j > 0) rows[(size_t)(2 * j - 1) * rstride + s] = F::from_le_word(ctx, lo);
+        if (2 * j + 1 <= t) rows[(size_t)(2 * j) * rstride + s] = F::from_le_word(ctx, hi);
+      }
+    } else {
+      for (int k = 1; k <= t; ++k) {
+        u64 lo[BPE], hi[BPE];
+#pragma unroll
+        for (int b = 0; b < BPE; ++b) aes.block(key, ctr0 + (u64)k * BPE + b, lo[b], hi[b]);
+        F::st(rows + ((size_t)(k - 1) * rstride + s) * F::LIMBS, elem_from_blocks<F>(ctx, lo, hi));
+      }
+    }
   }
 }
 

@@ -219,8 +219,6 @@ def test_shamir_share_recover_vs_oracle(scl, port, f, n, t, N):
     L = O.LIMBS[f]
     if f in SLOW_ORACLE:
         N = min(N, 40)  # bit-serial / Fermat oracle is slow
-    if n > 256 // L:
-        pytest.skip("more parties than the table kernels hold for this field")
     secrets = rand_elems(port, f, N, b"secrets")
     seed = b"share-seed"
     # PRG-driven: bit-identical to per-secret shamirSecretShare on one PRG
@@ -265,6 +263,51 @@ def test_shamir_share_recover_vs_oracle(scl, port, f, n, t, N):
     # oracle's per-secret recompute-the-basis path gives the same values
     if f != O.GF2_128:
         assert np.array_equal(host(scl, rec), port.shamir_recover(f, np.ascontiguousarray(np.transpose(want2, (1, 0, 2)))))
+
+
+@pytest.mark.parametrize("f,n,t,N", [(O.M61, 300, 5, 33), (O.M61, 12, 100, 40), (O.M61, 300, 60, 9), (O.M61, 257, 49, 3),
+                                     (O.M127, 150, 50, 10), (O.MONT128, 130, 2, 7), (O.GF2_128, 140, 3, 6),
+                                     (O.GF2_128, 9, 55, 5), (O.SECP256K1_SCALAR, 70, 49, 5), (O.SECP256K1_SCALAR, 3, 30, 4)])
+def test_no_bound_on_parties_or_threshold(scl, port, f, n, t, N):
+    """shamirSecretShare / shamirRecoverP bound neither n nor t (include/scl/ss/shamir.h:51-104; the reference's own test
+    shares to 100 parties): beyond one launch's node table (256 / limbs parties) the share kernels go block by block over
+    the parties and the reconstruct kernels add canonical partial sums; beyond 48 coefficients the polynomial is evaluated
+    in chunks (k_share_chunk), PRG-driven coefficients first drawn into rows (k_prg_coeff_rows)."""
+    L = O.LIMBS[f]
+    secrets = rand_elems(port, f, N, b"big-secrets")
+    coeffs = rand_elems(port, f, t * N, b"big-coeffs").reshape(N, t, L)
+    dco = dev(scl, np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2))))
+    if f == O.GF2_128:
+        xs = O.from_ints(list(range(1, n + 1)), L)
+        want = soa(np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), xs) for s in range(N)]))
+    else:
+        want = soa(port.shamir_share_coeffs(f, secrets, coeffs, n))
+    got = scl.shamir_share(f, dev(scl, secrets), dco, n)
+    assert np.array_equal(host(scl, got), want)
+    if f != O.GF2_128:
+        want_prg = soa(port.shamir_share(f, b"big-seed", secrets, t, n))
+        assert np.array_equal(host(scl, scl.shamir_share_prg(f, dev(scl, secrets), t, n, b"big-seed")), want_prg)
+        k = N // 2
+        tail = scl.shamir_share_prg(f, dev(scl, secrets[k:]), t, n, b"big-seed", first_secret=k)
+        assert np.array_equal(host(scl, tail), want_prg[:, k:])
+    # explicit nodes far from 1..n
+    nodes = rand_elems(port, f, n, b"big-nodes")
+    want_x = soa(np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)]))
+    got_x = scl.shamir_share(f, dev(scl, secrets), dco, n, alphas=nodes)
+    assert np.array_equal(host(scl, got_x), want_x)
+    if n <= t:
+        return                                  # fewer shares than coefficients: nothing to reconstruct
+    # reconstruct from ALL n shares (the reference's semantics), default and explicit nodes
+    assert np.array_equal(host(scl, scl.shamir_recover(f, got)), secrets)
+    lam = port.lagrange_basis(f, nodes, port.from_int(f, 0))
+    assert np.array_equal(scl.lagrange_basis(f, n, nodes), lam)
+    assert np.array_equal(host(scl, scl.shamir_recover(f, got_x, lam)), secrets)
+    if f == O.GF2_128:   # the shared-shift nibble kernel on the same blocks
+        scl.set_tuning("force_table", 3)
+        try:
+            assert np.array_equal(host(scl, scl.shamir_recover(f, got_x, lam)), secrets)
+        finally:
+            scl.set_tuning("force_table", 0)
 
 
 @pytest.mark.parametrize("f", ALL_FIELDS)

@@ -136,16 +136,6 @@ __global__ __launch_bounds__(BLK, WPS) void k_rec_gf_v1(u64* out, const u64* sha
 // then add up with NO shifting of the accumulator (r_wd), and the four word sums combine by three x^32 steps at the very
 // end -- against 32 x^4 steps per group of parties in the library kernel -- so the group can be small (few registers, many
 // waves) at no cost.  A lookup is one v_add_u32_sdwa (table base + byte of the masked word), one ds_read_b128, four xors.
-// base + byte B of word, one instruction (sub-dword operand select)
-template <int B>
-__device__ __forceinline__ u32 add_byte(u32 base, u32 word) {
-  u32 d;
-  if constexpr (B == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(base), "v"(word));
-  if constexpr (B == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(base), "v"(word));
-  if constexpr (B == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(base), "v"(word));
-  if constexpr (B == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(base), "v"(word));
-  return d;
-}
 template <int B>
 __device__ __forceinline__ void gf_lookup2(u32 (&a)[4], const unsigned char* T, u32 gbase, u32 o, u32 e, int j) {
   const uint4 to = *reinterpret_cast<const uint4*>(T + add_byte<B>(gbase, o) + (j * 2048 + (2 * B + 1) * 256));
@@ -154,14 +144,6 @@ __device__ __forceinline__ void gf_lookup2(u32 (&a)[4], const unsigned char* T, 
   a[1] ^= to.y ^ te.y;
   a[2] ^= to.z ^ te.z;
   a[3] ^= to.w ^ te.w;
-}
-
-__device__ __forceinline__ void gf_mulx32(u32 (&r)[4]) {
-  const u32 t = r[3];
-  r[3] = r[2];
-  r[2] = r[1];
-  r[1] = r[0] ^ (t >> 31) ^ (t >> 30) ^ (t >> 25);
-  r[0] = t ^ (t << 1) ^ (t << 2) ^ (t << 7);
 }
 
 template <int G, int BLK, int WPS>
@@ -227,11 +209,6 @@ __global__ __launch_bounds__(BLK, WPS) void k_rec_gf_v2(u64* out, const u64* sha
 // ---- reconstruct variant 3: variant 2 with the LDS reads issued by hand, one batch (4 lookups) ahead of the xors -------
 // The compiler waits for a batch's reads right after issuing them; here batch b+1 is in flight while batch b is folded
 // in (s_waitcnt lgkmcnt(4): LDS returns in order).  PF: the next group's shares are fetched while this group is worked on.
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-template <int OFF>
-__device__ __forceinline__ void lds_read128(u32x4& d, u32 addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
 // batch IDX of a group of G parties: word wd = IDX / (2G), party j = (IDX / 2) % G, half = IDX & 1 (0: odd nibbles)
 template <int G, int IDX>
 __device__ __forceinline__ void gf_issue4(u32x4 (&buf)[4], u32 gbase, const u32 (&w)[G][4]) {
@@ -302,6 +279,87 @@ __global__ __launch_bounds__(BLK, WPS) void k_rec_gf_v3(u64* out, const u64* sha
       } else {
         if (i0 + G < m) load_group(w, i0 + G, s);
       }
+    }
+    u32 r[4] = {acc[3].x, acc[3].y, acc[3].z, acc[3].w};
+#pragma unroll
+    for (int wd = 2; wd >= 0; --wd) {
+      gf_mulx32(r);
+      r[0] ^= acc[wd].x;
+      r[1] ^= acc[wd].y;
+      r[2] ^= acc[wd].z;
+      r[3] ^= acc[wd].w;
+    }
+    u64x2 o;
+    o.x = (u64)r[0] | ((u64)r[1] << 32);
+    o.y = (u64)r[2] | ((u64)r[3] << 32);
+    __builtin_nontemporal_store(o, reinterpret_cast<u64x2*>(out + s * 2));
+  }
+}
+
+
+// ---- reconstruct variant 5: variant 3 squeezed under 64 registers (8 waves per SIMD) ---------------------------------
+// tools/oprate.hip: v_xor_b32 issues every ~2.7 cycles per SIMD only when >= 4 waves are ready to issue; with half of a
+// SIMD's 4 waves parked on LDS returns it drops to the ~4.6-cycle rate.  So: batches of 2 lookups (16 buffer registers),
+// groups of G = 2 parties with the next group prefetched, two 1024-thread workgroups per CU.
+template <int G, int IDX>
+__device__ __forceinline__ void gf5_issue2(u32x4 (&buf)[2], u32 gbase, const u32 (&w)[G][4]) {
+  // batch IDX: word wd = IDX / (4G), party j = (IDX / 4) % G, half = (IDX / 2) & 1 (0: odd nibbles), pair = IDX & 1 (bytes 0-1 / 2-3)
+  constexpr int wd = IDX / (4 * G), j = (IDX / 4) % G, half = (IDX / 2) & 1, pair = IDX & 1;
+  const u32 m = half ? ((w[j][wd] << 4) & 0xF0F0F0F0u) : (w[j][wd] & 0xF0F0F0F0u);
+  lds_read128<j * 2048 + (4 * pair + 0 + (1 - half)) * 256>(buf[0], add_byte<2 * pair>(gbase, m));
+  lds_read128<j * 2048 + (4 * pair + 2 + (1 - half)) * 256>(buf[1], add_byte<2 * pair + 1>(gbase, m));
+}
+template <int G, int IDX>
+__device__ __forceinline__ void gf5_pipe(u32x4 (&A)[2], u32x4 (&B)[2], u32x4 (&acc)[4], u32 gbase, const u32 (&w)[G][4]) {
+  constexpr int NB = 16 * G;
+  if constexpr (IDX < NB) {
+    if constexpr (IDX + 1 < NB) gf5_issue2<G, IDX + 1>((IDX & 1) ? A : B, gbase, w);
+    u32x4(&cur)[2] = (IDX & 1) ? B : A;
+    if constexpr (IDX + 1 < NB) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(cur[0]), "+v"(cur[1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]));
+    acc[IDX / (4 * G)] ^= cur[0] ^ cur[1];
+    gf5_pipe<G, IDX + 1>(A, B, acc, gbase, w);
+  }
+}
+
+template <int G, int BLK, int WPS>
+__global__ __launch_bounds__(BLK, WPS) void k_rec_gf_v5(u64* out, const u64* shares, size_t stride, const u128* lam, int m, size_t N) {
+  extern __shared__ uint4 Tdyn[];
+  const int mpad = (m + G - 1) / G * G;
+  for (int e = threadIdx.x; e < mpad * 128; e += BLK) {
+    const int i = e >> 7, p = (e >> 4) & 7, j = e & 15;
+    u128 l0 = i < m ? lam[i] : (u128)0;
+    for (int k = 0; k < p; ++k) l0 = Gf128::mulx4(l0);
+    const u128 l1 = Gf128::mulx(l0), l2 = Gf128::mulx(l1), l3 = Gf128::mulx(l2);
+    const u128 v = (j & 1 ? l0 : (u128)0) ^ (j & 2 ? l1 : (u128)0) ^ (j & 4 ? l2 : (u128)0) ^ (j & 8 ? l3 : (u128)0);
+    Tdyn[e] = make_uint4((u32)v, (u32)(v >> 32), (u32)(v >> 64), (u32)(v >> 96));
+  }
+  __syncthreads();
+  const u32 tbase = (u32)(uintptr_t)Tdyn;
+  for (size_t s = (size_t)blockIdx.x * BLK + threadIdx.x; s < N; s += (size_t)gridDim.x * BLK) {
+    u32x4 acc[4] = {0, 0, 0, 0};
+    u32 w[G][4], wn[G][4];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(shares + ((size_t)j * stride + s) * 2));
+      w[j][0] = (u32)v.x, w[j][1] = (u32)(v.x >> 32), w[j][2] = (u32)v.y, w[j][3] = (u32)(v.y >> 32);
+    }
+    for (int i0 = 0; i0 < m; i0 += G) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        u64x2 v;
+        v.x = v.y = 0;
+        if (i0 + G + j < m) v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(shares + ((size_t)(i0 + G + j) * stride + s) * 2));
+        wn[j][0] = (u32)v.x, wn[j][1] = (u32)(v.x >> 32), wn[j][2] = (u32)v.y, wn[j][3] = (u32)(v.y >> 32);
+      }
+      const u32 gbase = tbase + (u32)i0 * 2048u;
+      u32x4 A[2], B[2];
+      gf5_issue2<G, 0>(A, gbase, w);
+      gf5_pipe<G, 0>(A, B, acc, gbase, w);
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[j][c] = wn[j][c];
     }
     u32 r[4] = {acc[3].x, acc[3].y, acc[3].z, acc[3].w};
 #pragma unroll
@@ -549,7 +607,7 @@ int main(int argc, char** argv) {
     std::printf("v2 G=%2d block %4d wps %d grid %5zu lds %6zu   %8.3f ms  %6.2f TB/s  %6.2f G secrets/s  diff %zu\n", G, BLK, WPS, gb, lds, \
                 ms, rec_bytes / ms / 1e9, N / ms / 1e6, same(o0, o1, 2 * N));                                        \
   }
-  REC2(8, 512, 1, 2) REC2(4, 1024, 1, 1)
+  REC2(4, 1024, 1, 1)
 #undef REC2
 #define REC3(G, BLK, WPS, PF, GRIDPERCU)                                                                             \
   {                                                                                                                 \
@@ -564,9 +622,23 @@ int main(int argc, char** argv) {
     std::printf("v3 G=%2d block %4d wps %d pf %d grid %5zu lds %6zu %8.3f ms  %6.2f TB/s  %6.2f G secrets/s  diff %zu\n", G, BLK, WPS, (int)PF, \
                 gb, lds, ms, rec_bytes / ms / 1e9, N / ms / 1e6, same(o0, o1, 2 * N));                               \
   }
-  REC3(8, 512, 1, false, 2) REC3(8, 512, 1, true, 2) REC3(8, 1024, 1, false, 1) REC3(4, 1024, 1, true, 1) REC3(4, 512, 2, true, 2)
-  REC3(5, 512, 2, true, 2) REC3(8, 256, 1, true, 2) REC3(10, 512, 1, false, 2)
+  REC3(5, 512, 2, true, 2)
 #undef REC3
+#define REC5(G, BLK, WPS, GRIDPERCU)                                                                                 \
+  {                                                                                                                 \
+    auto kern = &k_rec_gf_v5<G, BLK, WPS>;                                                                          \
+    const int mpad = (M + G - 1) / G * G;                                                                           \
+    const size_t lds = (size_t)mpad * 2048;                                                                         \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    size_t gb = (N + BLK - 1) / BLK;                                                                                \
+    if (gb > 256 * GRIDPERCU) gb = 256 * GRIDPERCU;                                                                 \
+    CK(hipMemset(o1, 0, N * 16));                                                                                   \
+    const float ms = time_it([&] { hipLaunchKernelGGL(kern, dim3((unsigned)gb), dim3(BLK), lds, 0, o1, sh, N, lam_dev, M, N); }, 5); \
+    std::printf("v5 G=%2d block %4d wps %d grid %5zu lds %6zu      %8.3f ms  %6.2f TB/s  %6.2f G secrets/s  diff %zu\n", G, BLK, WPS, \
+                gb, lds, ms, rec_bytes / ms / 1e9, N / ms / 1e6, same(o0, o1, 2 * N));                               \
+  }
+  REC5(2, 1024, 8, 2) REC5(4, 1024, 8, 2) REC5(2, 1024, 4, 2) REC5(5, 1024, 4, 2) REC5(5, 512, 4, 2)
+#undef REC5
   std::printf("-- share, n = %d, t = %d, N = %zu (%.0f B per secret)\n", M, TT, N, share_bytes / N);
   u64* shares2;
   CK(hipMalloc(&shares2, (size_t)M * N * 16));
