@@ -1054,18 +1054,20 @@ def test_random_shapes_share_and_recover(scl, port, f):
 
 
 # ---------------------------------------------------------------------------------------------- full size properties
-@pytest.mark.parametrize("f,n,t,N", [(O.M61, 10, 3, 10_000_000), (O.M127, 10, 3, 2_000_000)])
+@pytest.mark.parametrize("f,n,t,N", [(O.M61, 10, 3, 100_000_000), (O.M127, 10, 3, 10_000_000), (O.MONT128, 10, 3, 10_000_000),
+                                     (O.GF2_128, 40, 13, 12_500_000)])
 def test_full_size_round_trip(scl, port, f, n, t, N):
-    """share -> reconstruct round trip, linearity and threshold consistency at bench-scale N
-    (size-independent properties; the oracle spot-checks a window)."""
+    """share -> reconstruct round trip, linearity and threshold consistency at the BASELINE sizes -- C2 (10^8), C3 (10^7,
+    Mersenne127 and the literal 128-bit Montgomery prime) and C4's per-GPU shard (1.25 * 10^7 at (40,13) over GF(2^128)) --
+    through size-independent properties; the oracle spot-checks a window."""
     L = O.LIMBS[f]
     secrets = scl.vector_random(f, N, b"big-secrets")
     other = scl.vector_random(f, N, b"big-secrets-2")
     sh = scl.shamir_share_prg(f, secrets, t, n, b"big-seed")
     assert scl.equals(f, scl.shamir_recover(f, sh), secrets)
     assert scl.equals(f, scl.shamir_recover(f, sh[: t + 1].contiguous()), secrets)
-    # any t+1 shares: parties 3,5,6,9 (nodes 4,6,7,10)
-    idx = [3, 5, 6, 9]
+    # any t+1 shares: parties 3,5,6,9 (nodes 4,6,7,10) for t = 3, every third party otherwise
+    idx = [3, 5, 6, 9] if t == 3 else list(range(0, 3 * (t + 1), 3))[: t + 1]
     nodes = np.stack([port.from_int(f, i + 1) for i in idx])
     lam = scl.lagrange_basis(f, len(idx), nodes)
     assert scl.equals(f, scl.shamir_recover(f, sh[idx].contiguous(), lam), secrets)
@@ -1073,8 +1075,11 @@ def test_full_size_round_trip(scl, port, f, n, t, N):
     sh2 = scl.shamir_share_prg(f, other, t, n, b"other-seed")
     ssum = scl.ew(f, O.ADD, sh, sh2)
     assert scl.equals(f, scl.shamir_recover(f, ssum), scl.ew(f, O.ADD, secrets, other))
+    del sh2, ssum
+    if f == O.GF2_128:   # (the oracle's shamirSecretShare walks x++ there; explicit nodes are covered at small sizes)
+        return
     # oracle window: coefficients of secret s come from PRG blocks [s*B, (s+1)*B)
-    w0, w = 1234567 % (N - 300), 300
+    w0, w = 1234567 % (N - 300), 300 if f == O.M61 else 40
     B = (t + 2) // 2 if L == 1 else t + 1
     elems = port.from_bytes(f, port.prg_blocks(b"big-seed", w0 * B, w * B)).reshape(w, -1, L)
     hs = host(scl, secrets[w0:w0 + w])
@@ -1085,6 +1090,34 @@ def test_full_size_round_trip(scl, port, f, n, t, N):
     # additive at size
     ad = scl.additive_share_prg(f, secrets, 3, b"big-add")
     assert scl.equals(f, scl.additive_recover(f, ad), secrets)
+
+
+def test_c5_shard_size(scl, port):
+    """BASELINE configs[4] at the size one of eight GPUs holds: (n, t) = (128, 42) over Mersenne61, 1.25 * 10^8 secrets --
+    128 GB of shares, 42 GB of coefficients generated on the device (addressing beyond 2^32 elements per matrix, the
+    matrix-core share kernel over thousands of trips per workgroup, the 128-row table reconstruct)."""
+    f, n, t, N = O.M61, 128, 42, 125_000_000
+    torch.cuda.empty_cache()
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 190 * (1 << 30):
+        pytest.skip("needs 190 GB of free HBM")
+    secrets = scl.vector_random(f, N, b"c5-secrets")
+    coeffs = scl.empty(f, t, N)
+    per_row = (N * 8 + 15) // 16
+    for k in range(t):
+        scl.vector_random(f, N, b"c5-coeffs", counter0=k * per_row, out=coeffs[k])
+    shares = scl.shamir_share(f, secrets, coeffs, n)
+    assert scl.equals(f, scl.shamir_recover(f, shares), secrets)
+    # the last t + 1 parties alone (rows past 2^32 elements into the matrix)
+    idx = list(range(n - t - 1, n))
+    lam = scl.lagrange_basis(f, len(idx), np.stack([port.from_int(f, i + 1) for i in idx]))
+    assert scl.equals(f, scl.shamir_recover(f, shares[n - t - 1:], lam), secrets)
+    # oracle windows at both ends and in the middle of the batch
+    for w0 in (0, N // 2 + 12345, N - 64):
+        hs = host(scl, secrets[w0:w0 + 64])
+        hc = np.ascontiguousarray(np.transpose(host(scl, coeffs[:, w0:w0 + 64].contiguous()), (1, 0, 2)))
+        want = soa(port.shamir_share_coeffs(f, hs, hc, n))
+        assert np.array_equal(host(scl, shares[:, w0:w0 + 64].contiguous()), want), w0
 
 
 def test_bench_contract_small(scl):
