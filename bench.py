@@ -191,9 +191,13 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-        torch.cuda.set_device(local_rank)
+        # SCL_BENCH_ONE_DEVICE=1: a rehearsal of the multi-rank logic on a one-GPU box (every rank on device 0, gloo
+        # collectives); never a measurement
+        one_device = os.environ.get("SCL_BENCH_ONE_DEVICE") == "1" and args.backend == "gloo"
+        dev_index = 0 if one_device else local_rank
+        torch.cuda.set_device(dev_index)
         if world > 1:
-            dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+            dist.init_process_group(args.backend, device_id=torch.device("cuda", dev_index) if args.backend == "nccl" else None)
 
     def sync():
         if not dry:

@@ -279,13 +279,12 @@ __global__ __launch_bounds__(BLOCK) void k_count_diff_masked(unsigned long long*
 // out[s] = sum_i lambda[i] * shares[i][s].  M rows fully unrolled, lambda in scalar registers,
 // all M loads issued before the first multiply.
 //
-// Launch geometry of the two headline streaming kernels (k_recover_fixed, k_share_small), measured on plain allocations
-// (tools/streambench.hip, profiles/r2_streambench_*.txt): SINGLE-WAVE workgroups (BLK = 64) and at most 8 of them
-// resident per CU -- the host passes a dynamic LDS size that nothing reads, only to cap the residency.  Each resident wave
-// keeps m + 1 (or t + 1 + n) DRAM streams open; with 32 waves per CU the chip walks ~90 K pages at once and the streams
-// evict each other's open rows, with 8 it still has 80 KiB of loads in flight per CU (enough for HBM latency) and
-// reconstruct gains 6-7 %, share 2-3 %, on every allocation tried.
-
+// Launch geometry (tools/streambench.hip on plain allocations, profiles/r2_streambench_*.txt): SINGLE-WAVE workgroups
+// (BLK = 64) and at most 8 of them resident per CU -- the host passes a dynamic LDS size that nothing reads, only to cap
+// the residency.  Each resident wave keeps m + 1 DRAM streams open; with 32 waves per CU the streams evict each other's
+// open rows, with 8 the CU still has 80 KiB of loads in flight (enough for HBM latency) and the kernel gains 6-7 % on
+// every allocation tried (1.52 / 1.49 -> 1.41 / 1.40 ms at (10,3), 10^8 secrets); 4 waves per CU lose.  The same cap is
+// available to k_share_small ("share_waves"), where it only pays with n and t compiled in.
 template <class F, int VEC, int M, bool NT, int BLK = BLOCK>
 __global__ __launch_bounds__(BLK) void k_recover_fixed(typename F::Ctx ctx, u64* out, const u64* shares,
                                                        size_t stride, Table<F> lam, size_t npacks) {

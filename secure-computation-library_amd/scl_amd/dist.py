@@ -121,7 +121,10 @@ def open_by_partial_sums(local: torch.Tensor, lam_local, group=None, partial=Non
 
         def fold(field, words):
             return from_bytes(field, words.view(torch.uint8).reshape(-1))
-    part = partial(M61, local, lam_local).reshape(N)              # canonical, < 2^61
+    if local.shape[0] == 0:   # more ranks than parties: this rank holds none and contributes zeros
+        part = torch.zeros(N, dtype=local.dtype, device=local.device)
+    else:
+        part = partial(M61, local, lam_local).reshape(N)          # canonical, < 2^61
     mine = torch.empty(N // world, dtype=part.dtype, device=part.device)
     dist.reduce_scatter_tensor(mine, part.contiguous(), op=dist.ReduceOp.SUM, group=group)
     return fold(M61, mine).reshape(N // world, 1)

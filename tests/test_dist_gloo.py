@@ -138,6 +138,27 @@ def _partial_sum_worker(rank, world, n, t, N):
     assert np.array_equal(mine.numpy().view(np.uint64), secrets[lo:lo + N // world])
 
 
-@pytest.mark.parametrize("world,n,t,N", [(2, 10, 3, 64), (3, 7, 2, 33), (2, 3, 1, 8)])
+@pytest.mark.parametrize("world,n,t,N", [(2, 10, 3, 64), (3, 7, 2, 33), (2, 3, 1, 8), (3, 2, 1, 9)])  # last: a rank with no party
 def test_open_by_partial_sums(world, n, t, N):
     _run(_partial_sum_worker, world, n, t, N)
+
+
+def test_open_on_one_rank_is_the_chunked_reconstruct():
+    """world size 1 (what bench.py times on a single GPU): no collective, same chunking and output"""
+    from scl_amd import dist as sd
+    port = O.Port()
+    f, n, t, N, chunk = O.M61, 5, 2, 77, 20
+    secrets = port.vector_random(f, b"one-rank", N)
+    full = _soa(port.shamir_share(f, b"one-rank-seed", secrets, t, n))
+    nodes = np.stack([port.from_int(f, i + 1) for i in range(n)])
+    lam = port.lagrange_basis(f, nodes, port.from_int(f, 0))
+    calls = []
+
+    def checker(field, shares, lam_, out):
+        sh = shares.numpy().view(np.uint64)
+        rec = port.shamir_recover_lambda(field, np.ascontiguousarray(np.transpose(sh, (1, 0, 2))), lam_)
+        out.copy_(torch.from_numpy(rec.view(np.int64)))
+        calls.append(sh.shape[1])
+
+    out = sd.open_and_reconstruct_local(f, torch.from_numpy(full.view(np.int64)), n, lam, chunk=chunk, recover=checker)
+    assert np.array_equal(out.numpy().view(np.uint64), secrets) and calls == [20, 20, 20, 17]

@@ -1166,6 +1166,32 @@ def test_bench_open_mode_line(scl):
     assert line["roofline"]["kernel"] == "shamir_recover" and 0 < line["roofline"]["frac"] < 1
 
 
+def test_bench_two_ranks_rehearsal_on_one_device(scl):
+    """bench.py's multi-rank logic with the HIP kernels: two ranks, both on this box's one GPU, gloo collectives on device
+    tensors (SCL_BENCH_ONE_DEVICE=1: a rehearsal, never a measurement; the driver's multi-GPU run uses RCCL, one rank per GPU).
+    Started plainly with --gpus 2, so the self-launcher runs too.  Covers the sharded headline, the all-gather open
+    (20 parties per rank) and the reduce-scatter partial-sum open; every round trip must verify."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCL_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--secrets", "1000000",
+                        "--open-secrets", "100000", "--open-chunk", "32768", "--configs", "0", "--cpu-sample", "0", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["config"]["parallelism"] == "shard2"
+    c4, ps = line["open"]["c4_all_gather"], line["open"]["m61_partial_sums"]
+    assert c4["verified"] and c4["parties_per_rank"] == 20 and c4["collective"] == "all_gather_into_tensor"
+    assert c4["rccl_busbw_GBps"] > 0 and ps["verified"] and ps["collective"].startswith("reduce_scatter_tensor")
+    assert "cpu_baseline" not in line and "configs" not in line
+
+
 @pytest.mark.parametrize("n,t,N", [(128, 42, 3 * 256 * 32 + 17), (97, 5, 2 * 256 * 32 + 31), (128, 48, 256 * 32 + 1), (100, 33, 4 * 256 * 32)])
 def test_share_matrix_core_pipeline_many_trips(scl, port, n, t, N):
     """k_share_mfma_m61_p16 / k_share_mfma_m61_pipe with several trips per workgroup (the cross-block software pipeline: fetch two blocks ahead,
