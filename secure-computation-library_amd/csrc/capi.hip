@@ -1024,30 +1024,46 @@ static int reduce_impl(int field, uint64_t* out_host, const uint64_t* a, const u
     if (!a || (is_dot && !b)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
     SCL_TRY(check_align<F>({a, b}));
     const int vec = vec_width<F>({a, b}, {});
-    const unsigned maxg = 2048;  // 8 resident workgroups per CU, each lane with RED_UNROLL loads in flight
+    // stage 1: one trip per thread where the batch allows (at most 2^20 workgroups, then they grid-stride); stage 2: the
+    // same kernel over the partials with at most 1024 workgroups; the host folds those
+    const unsigned max1 = 1u << 20, max2 = 1024;
     void* sc;
-    SCL_TRY(scratch((size_t)2 * (maxg + 1) * F::LIMBS * 8, &sc));
-    u64* partial = static_cast<u64*>(sc);
-    unsigned used = 0;
+    SCL_TRY(scratch(((size_t)max1 + 2 + 2 * (size_t)max2) * F::LIMBS * 8 + 64, &sc));
+    u64* part1 = static_cast<u64*>(sc);
+    unsigned used1 = 0;
     SCL_TRY((split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;
-      unsigned g = grid_for((npacks + RED_UNROLL - 1) / RED_UNROLL);
-      if (g > maxg) g = maxg;
+      size_t g = (npacks + (size_t)BLOCK * RED_UNROLL - 1) / ((size_t)BLOCK * RED_UNROLL);
+      const long cap = g_max_blocks.load();
+      if (cap > 0 && g > (size_t)cap) g = (size_t)cap;
+      if (g > max1) g = max1;
+      if (g == 0) g = 1;
       if (is_dot)
-        hipLaunchKernelGGL((k_dot<F, VEC>), dim3(g), dim3(BLOCK), 0, S(stream), ctx, partial + (size_t)used * F::LIMBS,
+        hipLaunchKernelGGL((k_dot<F, VEC>), dim3((unsigned)g), dim3(BLOCK), 0, S(stream), ctx, part1 + (size_t)used1 * F::LIMBS,
                            a + first * F::LIMBS, b + first * F::LIMBS, npacks);
       else
-        hipLaunchKernelGGL((k_sum<F, VEC>), dim3(g), dim3(BLOCK), 0, S(stream), ctx, partial + (size_t)used * F::LIMBS,
+        hipLaunchKernelGGL((k_sum<F, VEC>), dim3((unsigned)g), dim3(BLOCK), 0, S(stream), ctx, part1 + (size_t)used1 * F::LIMBS,
                            a + first * F::LIMBS, npacks);
       LAUNCH_CHECK();
-      used += g;
+      used1 += (unsigned)g;
       return SCL_OK;
     })));
-    std::vector<u64> host((size_t)used * F::LIMBS);
-    HIP_TRY(hipMemcpyAsync(host.data(), partial, host.size() * 8, hipMemcpyDeviceToHost, S(stream)));
+    const u64* fold_src = part1;
+    unsigned fold_n = used1;
+    if (used1 > 2 * max2) {  // second stage: the partials are canonical elements, summed like any vector
+      u64* part2 = part1 + ((size_t)max1 + 2) * F::LIMBS;
+      size_t g = ((size_t)used1 + (size_t)BLOCK * RED_UNROLL - 1) / ((size_t)BLOCK * RED_UNROLL);
+      if (g > max2) g = max2;
+      hipLaunchKernelGGL((k_sum<F, 1>), dim3((unsigned)g), dim3(BLOCK), 0, S(stream), ctx, part2, part1, (size_t)used1);
+      LAUNCH_CHECK();
+      fold_src = part2;
+      fold_n = (unsigned)g;
+    }
+    std::vector<u64> host((size_t)fold_n * F::LIMBS);
+    HIP_TRY(hipMemcpyAsync(host.data(), fold_src, host.size() * 8, hipMemcpyDeviceToHost, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
     typename F::E tot = F::zero();
-    for (unsigned i = 0; i < used; ++i) tot = F::add(ctx, tot, F::ld(host.data() + (size_t)i * F::LIMBS));
+    for (unsigned i = 0; i < fold_n; ++i) tot = F::add(ctx, tot, F::ld(host.data() + (size_t)i * F::LIMBS));
     F::st(out_host, tot);
     return SCL_OK;
   });

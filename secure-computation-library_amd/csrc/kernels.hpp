@@ -187,7 +187,11 @@ __device__ __forceinline__ typename F::E block_reduce_add(const typename F::Ctx&
 
 constexpr int RED_UNROLL = 4;  // independent 16-byte loads in flight per lane and operand
 
-// Vector::sum (vector.h:261-267): per-block partial sums -> partial[blockIdx]
+// Vector::sum (vector.h:261-267): per-block partial sums -> partial[blockIdx].  Launched with ONE trip per thread
+// (RED_UNROLL packs, a grid stride apart) wherever the batch allows: a read-only sweep by fresh workgroups reaches
+// 7.0 TB/s where a few thousand resident workgroups that grid-stride reach 5.7-6.0 (profiles/r1_membench_hbm_ceilings.txt;
+// issuing the next trip's loads ahead of this trip's adds did not help).  The partials -- up to 2^20 of them -- are
+// reduced by a second launch of the same kernel.
 template <class F, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_sum(typename F::Ctx ctx, u64* partial, const u64* a, size_t npacks) {
   typename F::Acc acc = F::acc_zero();
