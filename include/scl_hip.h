@@ -106,7 +106,8 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the sto
  *                3: GF(2^128) reconstruct on the shared-shift nibble tables instead of the position tables
  *   stream_block (default 64) workgroup size of the (m <= 16) reconstruct kernel: 64 or 256
  *   stream_waves (default 8) resident waves per CU that kernel is capped at; 0 = no cap
- *   share_waves  (default 0) the same cap for the small-node share kernel (then also in stream_block workgroups)
+ *   share_waves  (default 8) the same cap for the Mersenne61 small-node share kernel (threshold compiled in, stream_block
+ *                workgroups); 0 = the 256-thread kernel with the threshold at run time, no cap
  *   mfma         1: force the matrix-core share / matmul path, -1: never use it
  *   mfma_areg    (default 1) matrix-core kernel keeps V's digit fragments in registers for 97..128 parties
  *   mfma_pipe    (default 2) matrix-core kernel for 97..128 parties: 2 = two software-pipelined waves per SIMD on

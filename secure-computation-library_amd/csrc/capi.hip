@@ -71,7 +71,8 @@ thread_local Knob g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
 // (kernels.hpp, "Launch geometry"); "stream_block" 64 | 256, "stream_waves" 0 = no cap
 thread_local Knob g_stream_block{64};
 thread_local Knob g_stream_waves{8};
-thread_local Knob g_share_waves{0};  // the same cap for k_share_small ("share_waves"; 0 = none, the default)
+thread_local Knob g_share_waves{8};  // the same cap for the Mersenne61 small-node share kernel ("share_waves"; 0 = the
+                                     // 256-thread kernel without a cap)
 
 // dynamic LDS bytes that cap the residency of a kernel with `static_lds` bytes of its own at `waves` waves of
 // `block` threads per CU (160 KiB of LDS per CU; allocation granularity 512 B assumed, one granule of slack)
@@ -1332,20 +1333,31 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
       if (small) {
         return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
           constexpr int VEC = decltype(V)::value;
-          // the residency cap that gains reconstruct 6-7 % gains this kernel 2-3 % with the threshold and the party count
-          // compiled in (tools/streambench.hip) and LOSES 10 % with them at run time, as here (two waves per SIMD do not
-          // hide the per-term branches): 256-thread workgroups, no cap, unless "share_waves" asks for one
+          // Mersenne61: single-wave workgroups under the residency cap, threshold compiled in (k_share_small_t);
+          // "share_waves" 0 or "stream_block" 256 give the 256-thread kernel with the threshold at run time
           const long sw = g_share_waves.load();
-          const bool wave_groups = sw > 0 && g_stream_block.load() == 64;
-          const int blk = wave_groups ? 64 : BLOCK;
-          const size_t pad = residency_pad(sw, blk, sizeof(u32) * SmallVdm::CAP);
-          const dim3 g(grid_for_block(npacks, blk));
-          if (wave_groups)
-            hipLaunchKernelGGL((k_share_small<F, VEC, 64>), g, dim3(64), pad, S(stream), shares + first * F::LIMBS, share_stride,
-                               secrets + first * F::LIMBS, coeffs + first * F::LIMBS, coeff_stride, sv, (int)t, (int)n, npacks);
-          else
-            hipLaunchKernelGGL((k_share_small<F, VEC>), g, dim3(BLOCK), pad, S(stream), shares + first * F::LIMBS, share_stride,
-                               secrets + first * F::LIMBS, coeffs + first * F::LIMBS, coeff_stride, sv, (int)t, (int)n, npacks);
+          bool launched = false;
+          if constexpr (F::TAG == 0) {
+            if (sw > 0 && g_stream_block.load() == 64) {
+              const size_t pad = residency_pad(sw, 64, sizeof(u32) * SmallVdm::CAP);
+              const dim3 g(grid_for_block(npacks, 64));
+#define SST_CASE(TT)                                                                                                     \
+  case TT:                                                                                                               \
+    hipLaunchKernelGGL((k_share_small_t<F, VEC, TT, 64>), g, dim3(64), pad, S(stream), shares + first * F::LIMBS, share_stride, \
+                       secrets + first * F::LIMBS, coeffs + first * F::LIMBS, coeff_stride, sv, (int)n, npacks);         \
+    launched = true;                                                                                                     \
+    break;
+              switch (t) {
+                SST_CASE(1) SST_CASE(2) SST_CASE(3) SST_CASE(4) SST_CASE(5) SST_CASE(6) SST_CASE(7)
+                default: break;
+              }
+#undef SST_CASE
+            }
+          }
+          if (!launched)
+            hipLaunchKernelGGL((k_share_small<F, VEC>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), shares + first * F::LIMBS,
+                               share_stride, secrets + first * F::LIMBS, coeffs + first * F::LIMBS, coeff_stride, sv, (int)t, (int)n,
+                               npacks);
           LAUNCH_CHECK();
           return SCL_OK;
         });

@@ -806,6 +806,42 @@ __global__ __launch_bounds__(BLK) void k_share_small(u64* shares, size_t stride,
   }
 }
 
+// The same with the threshold T compiled in and single-wave workgroups under a residency cap (see "Launch geometry"
+// at k_recover_fixed): with at most 8 waves per CU nothing hides per-term control flow, so the party loop must be
+// straight-line -- then the cap gains 2-3 % on allocations the kernel writes fast and 9 % on those it writes slowly
+// (2.00 -> 1.83 ms at (10,3), 10^8 secrets; profiles/r2_streambench_pitch_and_regions.txt).  Mersenne61 only: Mersenne127's
+// heavier fold wants the occupancy.
+template <class F, int VEC, int T, int BLK>
+__global__ __launch_bounds__(BLK) void k_share_small_t(u64* shares, size_t stride, const u64* secrets, const u64* coeffs,
+                                                       size_t cstride, SmallVdm tab, int n, size_t npacks) {
+  __shared__ u32 V[SmallVdm::CAP];
+  for (int i = threadIdx.x; i < n * (T + 1); i += BLK) V[i] = tab.v[i];
+  __syncthreads();
+  for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < npacks; q += (size_t)gridDim.x * BLK) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> c[T + 1];
+    c[0] = load_pack<F, VEC, true>(secrets + off);
+#pragma unroll
+    for (int k = 1; k <= T; ++k) c[k] = load_pack<F, VEC, true>(coeffs + (size_t)(k - 1) * cstride * F::LIMBS + off);
+    for (int i = 0; i < n; ++i) {
+      const u32* row = V + i * (T + 1);
+      SmallAcc<F> acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v].init();
+#pragma unroll
+      for (int k = 1; k <= T; ++k) {
+        const u32 w = row[k];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v].mac(c[k].v[v], w);
+      }
+      Pack<F, VEC> y;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) y.v[v] = acc[v].fold(c[0].v[v]);  // V[i][0] = 1
+      store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
+    }
+  }
+}
+
 // Blocked form of the small-node evaluation for larger t: the polynomial is cut into groups of G coefficients,
 //   f(x) = sum_j x^(G j) * g_j(x),   g_j(x) = sum_{r<G} c_{Gj+r} x^r,
 // each g_j(x_i) summed lazily against the small powers x_i^r < 2^29 (one v_mad_u64_u32 per 32-bit limb and
