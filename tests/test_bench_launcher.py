@@ -45,3 +45,27 @@ def test_world_size_that_disagrees_with_gpus_fails():
     assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
     r = _run(["--gpus", "1", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0
+
+
+def test_pmc_traffic_is_stamped_and_only_quoted_for_its_own_kernels():
+    """profiles/pmc_traffic.json carries the configuration, the kernel symbols and a hash of the kernel sources it was measured
+    with; bench.py reports `roofline.traffic` only for that configuration and while the hash still matches -- a kernel edit
+    makes the number null instead of silently stale.  The committed file must describe the committed sources."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+        pmc = json.load(fh)
+    assert pmc["kernel_source_sha256_16"] == bench.kernel_source_hash(), "regenerate profiles/pmc_traffic.json (tools/make_pmc_traffic.py)"
+    assert "k_share_small" in pmc["shamir_share"]["kernel"] and "k_recover_fixed" in pmc["shamir_recover"]["kernel"]
+    args = bench.parse_args([])
+    share, rec = bench.pmc_traffic("shamir_share", args), bench.pmc_traffic("shamir_recover", args)
+    # algorithmic bytes of BASELINE configs[1]: 112 B and 88 B per secret; measured traffic within 0.5 % of them
+    assert abs(share / (112 * args.secrets) - 1) < 5e-3 and abs(rec / (88 * args.secrets) - 1) < 5e-3
+    assert bench.pmc_traffic("shamir_share", bench.parse_args(["--secrets", "1000"])) is None
+    assert bench.pmc_traffic("shamir_share", bench.parse_args(["--t", "4"])) is None
+    real = bench.kernel_source_hash
+    try:
+        bench.kernel_source_hash = lambda: "0" * 16      # what an edited kernel source looks like
+        assert bench.pmc_traffic("shamir_share", args) is None
+    finally:
+        bench.kernel_source_hash = real

@@ -54,6 +54,89 @@ __global__ __launch_bounds__(ABLOCK) void k_prg_blocks4u(u64* dst, AesKey key, u
   }
 }
 
+// ---- variant: table addresses from fast-class opcodes ----------------------------------------------------------------
+// tools/oprate.hip: v_bfe_u32 + v_lshl_add_u32 (4.4 + 4.5 cycles per wave instruction) is what the compiler makes of
+// te[(s >> 8k) & 255] with 128-byte entries; (s >> (8k - 7)) & 0x7F80 is v_lshrrev_b32 + v_and_b32 (2.4 + 2.5) and the base
+// goes in with a v_add_u32 (2.7) or folds into a v_and_or_b32 (4.6).
+struct Aes4f {
+  u32 b0, b2;  // LDS byte addresses of the lane's copy of table 0 and of table 2 (tables 1 / 3 sit 32 KiB above them)
+  // (word >> SH) & 0x7F80, + base: three fast-class instructions, written out because the compiler turns the C form
+  // back into v_bfe_u32 + v_lshl_add_u32.  SH < 0: shift left by -SH.
+  template <int SH>
+  static __device__ __forceinline__ u32 addr(u32 s, u32 base) {
+    u32 t;
+    if constexpr (SH >= 0) asm("v_lshrrev_b32 %0, %1, %2" : "=v"(t) : "n"(SH), "v"(s));
+    else asm("v_lshlrev_b32 %0, %1, %2" : "=v"(t) : "n"(-SH), "v"(s));
+    asm("v_and_b32 %0, 0x7f80, %0" : "+v"(t));
+    asm("v_add_u32 %0, %1, %0" : "+v"(t) : "v"(base));
+    return t;
+  }
+  template <int OFF>
+  static __device__ __forceinline__ u32 ld(u32 a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const __attribute__((address_space(3))) u32*>((uintptr_t)(a + OFF));
+#else
+    return a + OFF;
+#endif
+  }
+  __device__ __forceinline__ void block(const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) const {
+#define F_T0(s) ld<0>(addr<-7>(s, b0))
+#define F_T1(s) ld<32768>(addr<1>(s, b0))
+#define F_T2(s) ld<0>(addr<9>(s, b2))
+#define F_T3(s) ld<32768>(addr<17>(s, b2))
+#define F_SB0(s) ((ld<0>(addr<-7>(s, b0)) >> 8) & 255u)
+#define F_SB1(s) ((ld<0>(addr<1>(s, b0)) >> 8) & 255u)
+#define F_SB2(s) ((ld<0>(addr<9>(s, b0)) >> 8) & 255u)
+#define F_SB3(s) ((ld<0>(addr<17>(s, b0)) >> 8) & 255u)
+    u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2 = 0x89ABCDEFu ^ key.rk[2], s3 = 0x01234567u ^ key.rk[3];
+#pragma unroll
+    for (int r = 1; r < 10; ++r) {
+      const u32 u0 = F_T0(s0) ^ F_T1(s1) ^ F_T2(s2) ^ F_T3(s3) ^ key.rk[4 * r + 0];
+      const u32 u1 = F_T0(s1) ^ F_T1(s2) ^ F_T2(s3) ^ F_T3(s0) ^ key.rk[4 * r + 1];
+      const u32 u2 = F_T0(s2) ^ F_T1(s3) ^ F_T2(s0) ^ F_T3(s1) ^ key.rk[4 * r + 2];
+      const u32 u3 = F_T0(s3) ^ F_T1(s0) ^ F_T2(s1) ^ F_T3(s2) ^ key.rk[4 * r + 3];
+      s0 = u0; s1 = u1; s2 = u2; s3 = u3;
+    }
+    const u32 o0 = (F_SB0(s0) | (F_SB1(s1) << 8) | (F_SB2(s2) << 16) | (F_SB3(s3) << 24)) ^ key.rk[40];
+    const u32 o1 = (F_SB0(s1) | (F_SB1(s2) << 8) | (F_SB2(s3) << 16) | (F_SB3(s0) << 24)) ^ key.rk[41];
+    const u32 o2 = (F_SB0(s2) | (F_SB1(s3) << 8) | (F_SB2(s0) << 16) | (F_SB3(s1) << 24)) ^ key.rk[42];
+    const u32 o3 = (F_SB0(s3) | (F_SB1(s0) << 8) | (F_SB2(s1) << 16) | (F_SB3(s2) << 24)) ^ key.rk[43];
+    out_lo = (u64)o0 | ((u64)o1 << 32);
+    out_hi = (u64)o2 | ((u64)o3 << 32);
+#undef F_T0
+#undef F_T1
+#undef F_T2
+#undef F_T3
+#undef F_SB0
+#undef F_SB1
+#undef F_SB2
+#undef F_SB3
+  }
+};
+
+template <int NB>
+__global__ __launch_bounds__(ABLOCK) void k_prg_blocks4f(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
+  SCL_AES4_PROLOGUE(key)
+  (void)aes;
+  const u32 lane_base = (u32)(uintptr_t)aes4_lds + 4u * (threadIdx.x & 31);  // low half of the flat address = LDS byte address
+  const Aes4f af{lane_base, lane_base + 65536u};
+  const size_t G = (size_t)gridDim.x * ABLOCK;
+  for (size_t q = (size_t)blockIdx.x * ABLOCK + threadIdx.x; q < nblocks; q += NB * G) {
+    u64 lo[NB], hi[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) af.block(key, counter0 + q + b * G, lo[b], hi[b]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (q + b * G < nblocks) {
+        u64x2 w;
+        w.x = lo[b];
+        w.y = hi[b];
+        *reinterpret_cast<u64x2*>(dst + 2 * (q + b * G)) = w;
+      }
+    }
+  }
+}
+
 int main() {
   const size_t nblocks = (size_t)1 << 28;
   AesKey key;
@@ -93,6 +176,14 @@ int main() {
   RUN4U(1, "four tables, unrolled rounds, 1 block/lane")
   RUN4U(2, "four tables, unrolled rounds, 2 blocks/lane")
   RUN4U(4, "four tables, unrolled rounds, 4 blocks/lane")
+#define RUN4F(NB, name)                                                                                              \
+  {                                                                                                                      \
+    auto kern = &k_prg_blocks4f<NB>;                                                                                     \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AES4_LDS_BYTES)); \
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, b, key, 12345ull, nblocks); }, name); \
+  }
+  RUN4F(2, "four tables, fast-opcode addresses, 2 blocks/lane")
+  RUN4F(4, "four tables, fast-opcode addresses, 4 blocks/lane")
   CK(hipGetLastError());
   std::vector<u64> ha(1 << 20), hb(1 << 20);
   CK(hipMemcpy(ha.data(), a + (nblocks - (1 << 19)) * 2, ha.size() * 8, hipMemcpyDeviceToHost));
