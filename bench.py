@@ -33,9 +33,9 @@ for p in (os.path.join(ROOT, "secure-computation-library_amd"), os.path.join(ROO
     if p not in sys.path:
         sys.path.insert(0, p)
 
-FIELD_TAGS = {"m61": 0, "m127": 1, "mont128": 2, "gf2_128": 3, "secp256k1": 4}
+FIELD_TAGS = {"m61": 0, "m127": 1, "mont128": 2, "gf2_128": 3, "secp256k1": 4, "secp256k1_field": 5}
 FIELD_NAMES = {"m61": "Mersenne61", "m127": "Mersenne127", "mont128": "Mont128", "gf2_128": "GF(2^128)",
-               "secp256k1": "secp256k1_order"}
+               "secp256k1": "secp256k1_order", "secp256k1_field": "secp256k1_field"}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
 KERNEL_SOURCES = ("secure-computation-library_amd/csrc/kernels.hpp", "secure-computation-library_amd/csrc/capi.hip",
                   "secure-computation-library_amd/csrc/share_mfma.hpp", "include/scl_hip/detail/field.hpp")

@@ -12,7 +12,9 @@
  *  - field tags: SCL_M61 = scl::math::ff::Mersenne61 (1 uint64 limb),
  *    SCL_M127 = Mersenne127 (2 limbs, little-endian, 16-byte aligned),
  *    SCL_SECP256K1_SCALAR = scl::math::ff::Secp256k1Scalar, the secp256k1 group
- *    order (4 limbs, 16-byte aligned); SCL_MONT128 / SCL_GF2_128 are plug-in
+ *    order, and SCL_SECP256K1_FIELD = scl::math::ff::Secp256k1Field, the prime the
+ *    curve is defined over (src/scl/math/fields/secp256k1_field.cc:43-135) -- the
+ *    two N = 4 instances of the reference's Montgomery family (4 limbs, 16-byte aligned); SCL_MONT128 / SCL_GF2_128 are plug-in
  *    fields the reference does not have (2 limbs).  An element's limbs are the
  *    in-memory image of FF::m_value (what std::vector<FF>::data() holds): the
  *    canonical integer for the Mersenne fields, the Montgomery residue
@@ -48,7 +50,8 @@
 extern "C" {
 #endif
 
-typedef enum { SCL_M61 = 0, SCL_M127 = 1, SCL_MONT128 = 2, SCL_GF2_128 = 3, SCL_SECP256K1_SCALAR = 4 } scl_field;
+typedef enum { SCL_M61 = 0, SCL_M127 = 1, SCL_MONT128 = 2, SCL_GF2_128 = 3, SCL_SECP256K1_SCALAR = 4,
+               SCL_SECP256K1_FIELD = 5 } scl_field;
 /* Rings scl::math::Z2k<K> (include/scl/math/z2k.h:39-320, z2k/z2k_ops.h:32-150), 1 <= K <= 128: tag
  * SCL_Z2K(K).  One limb for K <= 64, two above (Z2k::ValueType); values are taken modulo 2^K on entry and are
  * returned masked.  Accepted by the entry points that make sense in a ring: scl_hip_ew (INV / DIV need odd

@@ -654,32 +654,57 @@ struct Gf128 {
   }
 };
 
-// --------------------------------------------------------------- secp256k1 group order
-// FF<Secp256k1Scalar> of the reference (include/scl/math/fields/secp256k1_scalar.h,
-// src/scl/math/fields/secp256k1_scalar.cc:47-135): the field Feldman / Pedersen VSS share over.  Four
-// 64-bit limbs holding the Montgomery residue x*2^256 mod p exactly like the reference's m_value, with the
-// arithmetic of its mpn Montgomery family (include/scl/math/fields/ff_ops_gmp.h:44-314).
+// --------------------------------------------------------------- 256-bit Montgomery primes (N = 4)
+// The reference's mpn Montgomery family (include/scl/math/fields/ff_ops_gmp.h:44-314) instantiated for four 64-bit limbs:
+//   FF<Secp256k1Scalar>  the order of the secp256k1 group (src/scl/math/fields/secp256k1_scalar.cc:47-135): the field
+//                        Feldman / Pedersen VSS share over
+//   FF<Secp256k1Field>   the prime the curve is defined over, 2^256 - 2^32 - 977 (src/scl/math/fields/secp256k1_field.cc:43-135)
+// Four limbs holding the Montgomery residue x*2^256 mod p exactly like the reference's m_value.  PRM supplies the prime,
+// -p^-1 mod 2^64 (low limb of RedParams::mc), 2^256 mod p, 2^512 mod p and the 32-bit limbs of 2^256 - p.
 struct U256 {
   u64 w[4];
 };
 
-struct Secp256k1Scalar {
-  typedef U256 E;
-  struct Ctx {};
-  enum { LIMBS = 4, ACC_TERMS = 1 << 24, TAG = 4, SMALL_BITS = 0 };
-
-  static SCL_HD u64 P(int i) {  // p = FFFFFFFF FFFFFFFF FFFFFFFF FFFFFFFE BAAEDCE6 AF48A03B BFD25E8C D0364141
+struct SecpOrderParams {  // p = FFFFFFFF FFFFFFFF FFFFFFFF FFFFFFFE BAAEDCE6 AF48A03B BFD25E8C D0364141
+  enum { TAG = 4 };
+  static SCL_HD u64 P(int i) {
     return i == 0 ? 0xBFD25E8CD0364141ull : i == 1 ? 0xBAAEDCE6AF48A03Bull : i == 2 ? 0xFFFFFFFFFFFFFFFEull : 0xFFFFFFFFFFFFFFFFull;
   }
-  static constexpr u64 MC0 = 0x4B0DFF665588B13Full;  // -p^-1 mod 2^64 (low limb of RedParams::mc, secp256k1_scalar.cc:62-67)
+  static constexpr u64 MC0 = 0x4B0DFF665588B13Full;  // secp256k1_scalar.cc:62-67
+  static SCL_HD u64 ONE(int i) { return i == 0 ? 0x402DA1732FC9BEBFull : i == 1 ? 0x4551231950B75FC4ull : i == 2 ? 1ull : 0ull; }
+  static SCL_HD u64 R2(int i) {
+    return i == 0 ? 0x896CF21467D7D140ull : i == 1 ? 0x741496C20E7CF878ull : i == 2 ? 0xE697F5E45BCD07C6ull : 0x9D671CD581C69BC5ull;
+  }
+  static SCL_HD u32 C32(int j) {  // 2^256 - p = 1 45512319 50B75FC4 402DA173 2FC9BEBF
+    return j == 0 ? 0x2FC9BEBFu : j == 1 ? 0x402DA173u : j == 2 ? 0x50B75FC4u : j == 3 ? 0x45512319u : j == 4 ? 1u : 0u;
+  }
+};
+
+struct SecpFieldParams {  // p = 2^256 - 2^32 - 977 = FFFFFFFF ... FFFFFFFE FFFFFC2F
+  enum { TAG = 7 };       // (5 and 6 are the rings' internal tags)
+  static SCL_HD u64 P(int i) { return i == 0 ? 0xFFFFFFFEFFFFFC2Full : 0xFFFFFFFFFFFFFFFFull; }
+  static constexpr u64 MC0 = 0xD838091DD2253531ull;  // secp256k1_field.cc:53-58 (low limb)
+  static SCL_HD u64 ONE(int i) { return i == 0 ? 0x1000003D1ull : 0ull; }                                   // 2^256 mod p (the ONE of :93-94)
+  static SCL_HD u64 R2(int i) { return i == 0 ? 0x000007A2000E90A1ull : i == 1 ? 1ull : 0ull; }              // (2^32 + 977)^2
+  static SCL_HD u32 C32(int j) { return j == 0 ? 0x000003D1u : j == 1 ? 1u : 0u; }                          // 2^256 - p = 2^32 + 977
+};
+
+template <class PRM>
+struct Mont256 {
+  typedef U256 E;
+  struct Ctx {};
+  enum { LIMBS = 4, ACC_TERMS = 1 << 24, TAG = PRM::TAG, SMALL_BITS = 0 };
+
+  static SCL_HD u64 P(int i) { return PRM::P(i); }
+  static constexpr u64 MC0 = PRM::MC0;
   static SCL_HD E make(u64 a, u64 b, u64 c, u64 d) {
     E r;
     r.w[0] = a; r.w[1] = b; r.w[2] = c; r.w[3] = d;
     return r;
   }
   static SCL_HD E zero() { return make(0, 0, 0, 0); }
-  static SCL_HD E one(const Ctx&) { return make(0x402DA1732FC9BEBFull, 0x4551231950B75FC4ull, 1, 0); }  // 2^256 mod p
-  static SCL_HD E r2() { return make(0x896CF21467D7D140ull, 0x741496C20E7CF878ull, 0xE697F5E45BCD07C6ull, 0x9D671CD581C69BC5ull); }  // 2^512 mod p
+  static SCL_HD E one(const Ctx&) { return make(PRM::ONE(0), PRM::ONE(1), PRM::ONE(2), PRM::ONE(3)); }  // 2^256 mod p
+  static SCL_HD E r2() { return make(PRM::R2(0), PRM::R2(1), PRM::R2(2), PRM::R2(3)); }               // 2^512 mod p
   static SCL_HD bool is_zero(const E& a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
   static SCL_HD bool eq(const E& a, const E& b) {
     return ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3])) == 0;
@@ -812,9 +837,7 @@ struct Secp256k1Scalar {
   }
   static SCL_HD void acc_add(const Ctx& c, Acc& acc, const E& a) { acc.e = add(c, acc.e, a); }
   static SCL_HD u32 P32(int j) { return (u32)(P(j >> 1) >> (32 * (j & 1))); }
-  static SCL_HD u32 C32(int j) {  // 2^256 - p = 1 45512319 50B75FC4 402DA173 2FC9BEBF
-    return j == 0 ? 0x2FC9BEBFu : j == 1 ? 0x402DA173u : j == 2 ? 0x50B75FC4u : j == 3 ? 0x45512319u : j == 4 ? 1u : 0u;
-  }
+  static SCL_HD u32 C32(int j) { return PRM::C32(j); }  // 32-bit limbs of 2^256 - p
   static SCL_HD u32 fold_top(u32* r, u32 h) {  // r[0..8) += h * (2^256 - p); returns the carry out
     u64 cy = 0;
 #pragma unroll
@@ -852,6 +875,9 @@ struct Secp256k1Scalar {
     return is_zero(a) ? zero() : r;
   }
 };
+
+typedef Mont256<SecpOrderParams> Secp256k1Scalar;
+typedef Mont256<SecpFieldParams> Secp256k1Field;
 
 // ------------------------------------------------------------------------------- rings Z2k<K>
 // scl::math::Z2k<K> of the reference (include/scl/math/z2k.h:39-320, include/scl/math/z2k/z2k_ops.h:32-150):

@@ -58,6 +58,15 @@ struct Secp256k1Scalar {  // include/scl/math/fields/secp256k1_scalar.h: the ord
   constexpr static int TAG = SCL_SECP256K1_SCALAR;
 };
 
+struct Secp256k1Field {  // include/scl/math/fields/secp256k1_field.h: the prime the secp256k1 curve is defined over
+  using ValueType = sclhip::U256;
+  using Impl = sclhip::Secp256k1Field;
+  constexpr static const char* NAME = "secp256k1_field";
+  constexpr static std::size_t BYTE_SIZE = 32;
+  constexpr static std::size_t BIT_SIZE = 256;
+  constexpr static int TAG = SCL_SECP256K1_FIELD;
+};
+
 struct Mont128 {  // plug-in: generic 128-bit prime, Montgomery form (not in the reference)
   using ValueType = __uint128_t;
   using Impl = sclhip::Mont128;
@@ -148,7 +157,7 @@ inline void fromString(typename FIELD::ValueType& out, const std::string& hexstr
   using Impl = typename FIELD::Impl;
   using V = typename FIELD::ValueType;
   const auto c = context<FIELD>();
-  if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
+  if constexpr (FIELD::Impl::LIMBS == 4) {
     const V limbs = parseHexLimbs(hexstr);
     out = hexstr.empty() ? limbs : Impl::to_mont(c, limbs);
   } else {
@@ -167,7 +176,7 @@ inline std::string toStringOf(const typename FIELD::ValueType& value) {
   const auto c = context<FIELD>();
   if constexpr (FIELD::TAG == SCL_M61) {
     return hex64(value);
-  } else if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
+  } else if constexpr (FIELD::Impl::LIMBS == 4) {
     // montyToString: the value out of Montgomery form, hex without leading zeros
     const V v = Impl::from_mont(c, value);
     std::string out;
@@ -199,7 +208,7 @@ template <typename FIELD>
 inline void toBytesOf(unsigned char* dest, const typename FIELD::ValueType& value) {
   using Impl = typename FIELD::Impl;
   using V = typename FIELD::ValueType;
-  if constexpr (FIELD::TAG == SCL_SECP256K1_SCALAR) {
+  if constexpr (FIELD::Impl::LIMBS == 4) {
     const V v = Impl::to_be_image(context<FIELD>(), value);  // montyToBytes: value, big-endian
     std::memcpy(dest, &v, sizeof v);
   } else if constexpr (FIELD::TAG == SCL_MONT128) {
@@ -243,6 +252,7 @@ inline void invertOf(typename FIELD::ValueType& out) {
 SCL_HIP_BUILTIN_FIELD_OPS(Mersenne61)
 SCL_HIP_BUILTIN_FIELD_OPS(Mersenne127)
 SCL_HIP_BUILTIN_FIELD_OPS(Secp256k1Scalar)
+SCL_HIP_BUILTIN_FIELD_OPS(Secp256k1Field)
 SCL_HIP_BUILTIN_FIELD_OPS(Mont128)
 SCL_HIP_BUILTIN_FIELD_OPS(GF2_128)
 #undef SCL_HIP_BUILTIN_FIELD_OPS

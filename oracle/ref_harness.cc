@@ -14,6 +14,7 @@
 // Share matrices are AoS [secret][party], the layout the reference returns
 // (one Vector of n shares per secret, include/scl/ss/shamir.h:52-68).
 
+#include <scl/math/fields/secp256k1_field.h>
 #include <scl/math/fields/secp256k1_scalar.h>
 #include <scl/math/fp.h>
 #include <scl/math/lagrange.h>
@@ -40,6 +41,7 @@ namespace {
 using F61 = scl::math::Fp<61>;
 using F127 = scl::math::Fp<127>;
 using F256 = scl::math::FF<scl::math::ff::Secp256k1Scalar>;  // field tag 4 (4 limbs, Montgomery form)
+using F256F = scl::math::FF<scl::math::ff::Secp256k1Field>;  // field tag 5: the prime the curve is defined over
 using scl::math::Matrix;
 using scl::math::Vector;
 using scl::util::PRG;
@@ -225,6 +227,9 @@ void storeMat(std::uint64_t* p, const Matrix<F>& m) {
     } else if ((field) == 4) {     \
       using F = F256;              \
       __VA_ARGS__;                 \
+    } else if ((field) == 5) {     \
+      using F = F256F;             \
+      __VA_ARGS__;                 \
     } else {                       \
       return -2;                   \
     }                              \
@@ -263,11 +268,11 @@ extern "C" {
 
 int sclref_limbs(int field) {
   if (field > 0x100 && field <= 0x100 + 128) return field - 0x100 <= 64 ? 1 : 2;
-  return field == 0 ? 1 : field == 1 ? 2 : field == 4 ? 4 : -1;
+  return field == 0 ? 1 : field == 1 ? 2 : (field == 4 || field == 5) ? 4 : -1;
 }
 
 const char* sclref_field_name(int field) {
-  return field == 0 ? F61::name() : field == 1 ? F127::name() : field == 4 ? F256::name() : "";
+  return field == 0 ? F61::name() : field == 1 ? F127::name() : field == 4 ? F256::name() : field == 5 ? F256F::name() : "";
 }
 
 // returns 0 ok, 1 if the reference threw (message copied to err, NUL terminated)

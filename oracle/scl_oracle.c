@@ -484,13 +484,19 @@ static inline int gf128_is_zero(u128 v) { return v == 0; }
 #undef FN
 #undef LIMBS
 
-/* ======================================================== secp256k1 group order */
-/* FF<Secp256k1Scalar> (include/scl/math/fields/secp256k1_scalar.h, src/scl/math/fields/secp256k1_scalar.cc:47-135):
+/* ======================================================== the two 256-bit Montgomery primes of secp256k1 */
+/* FF<Secp256k1Scalar> (include/scl/math/fields/secp256k1_scalar.h, src/scl/math/fields/secp256k1_scalar.cc:47-135) and
+ * FF<Secp256k1Field> (secp256k1_field.h, src/scl/math/fields/secp256k1_field.cc:43-135):
  * 4 x 64-bit limbs, values held in Montgomery form x*2^256 mod p, arithmetic from the mpn Montgomery family
- * include/scl/math/fields/ff_ops_gmp.h:44-314.  Prime p = the order of the secp256k1 group. */
+ * include/scl/math/fields/ff_ops_gmp.h:44-314.  Prime p = the order of the secp256k1 group, or the prime the curve is
+ * defined over (2^256 - 2^32 - 977).  One set of routines; secpq_select() points it at either prime and re-derives the
+ * Montgomery constants from it (this oracle is single-threaded test infrastructure). */
 typedef struct { uint64_t w[4]; } fe256;
-static const uint64_t SQ_P[4] = {0xBFD25E8CD0364141ULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFEULL, 0xFFFFFFFFFFFFFFFFULL};
-static uint64_t g_sq_mc0 = 0; /* -p^{-1} mod 2^64 (low limb of RedParams::mc, secp256k1_scalar.cc:62-67) */
+static const uint64_t SQ_PRIMES[2][4] = {
+    {0xBFD25E8CD0364141ULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFEULL, 0xFFFFFFFFFFFFFFFFULL},   /* group order */
+    {0xFFFFFFFEFFFFFC2FULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL}};  /* field prime */
+static const uint64_t* SQ_P = SQ_PRIMES[0];
+static uint64_t g_sq_mc0 = 0; /* -p^{-1} mod 2^64 (low limb of RedParams::mc, secp256k1_scalar.cc:62-67, secp256k1_field.cc:53-58) */
 static fe256 g_sq_one, g_sq_r2;
 
 static int sq_geq_p(const uint64_t a[4]) {
@@ -594,6 +600,16 @@ static void secpq_ensure(void) {
   }
   g_sq_r2 = r;
 }
+
+static void secpq_select(int field) { /* SCLO_SECP256K1_SCALAR or SCLO_SECP256K1_FIELD */
+  const uint64_t* want = SQ_PRIMES[field == SCLO_SECP256K1_FIELD ? 1 : 0];
+  if (want != SQ_P) {
+    SQ_P = want;
+    g_sq_mc0 = 0;
+  }
+  secpq_ensure();
+}
+#define IS_SECP256(field) ((field) == SCLO_SECP256K1_SCALAR || (field) == SCLO_SECP256K1_FIELD)
 
 #define FE fe256
 #define FN(name) secpq_##name
@@ -732,7 +748,7 @@ static int ring_matmul(int K, const uint64_t* A, const uint64_t* B, size_t n, si
 
 int sclo_limbs(int field) {
   if (SCLO_IS_RING(field)) return (int)ring_limbs(RING_K(field));
-  return field == SCLO_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : field == SCLO_SECP256K1_SCALAR ? 4 : -1;
+  return field == SCLO_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : IS_SECP256(field) ? 4 : -1;
 }
 
 const char* sclo_field_name(int field) {
@@ -742,6 +758,7 @@ const char* sclo_field_name(int field) {
     case SCLO_MONT128: return "Mont128";
     case SCLO_GF2_128: return "GF(2^128)";
     case SCLO_SECP256K1_SCALAR: return "secp256k1_order"; /* secp256k1_scalar.h NAME */
+    case SCLO_SECP256K1_FIELD: return "secp256k1_field";  /* secp256k1_field.h NAME */
     default: return "";
   }
 }
@@ -767,7 +784,8 @@ const char* sclo_status_message(int status) {
     case SCLO_M127: { BODY(m127_) } break;                 \
     case SCLO_MONT128: { mont128_ensure(); BODY(mont128_) } break; \
     case SCLO_GF2_128: { BODY(gf128_) } break;             \
-    case SCLO_SECP256K1_SCALAR: { secpq_ensure(); BODY(secpq_) } break; \
+    case SCLO_SECP256K1_SCALAR: { secpq_select(field); BODY(secpq_) } break; \
+    case SCLO_SECP256K1_FIELD: { secpq_select(field); BODY(secpq_) } break; \
     default: break;                                        \
   }                                                        \
   return SCLO_BAD_ARG;
@@ -838,11 +856,11 @@ static int hex_parse256(const char* s, fe256* out) {
 }
 
 int sclo_from_hex(int field, const char* hex, uint64_t* dst) {
-  if (field == SCLO_SECP256K1_SCALAR) {
+  if (IS_SECP256(field)) {
     fe256 t;
     int st256 = hex_parse256(hex, &t);
     if (st256) return st256;
-    secpq_ensure();
+    secpq_select(field);
     secpq_st(dst, hex[0] ? secpq_to_mont(t) : t);
     return SCLO_OK;
   }
@@ -862,8 +880,8 @@ int sclo_from_hex(int field, const char* hex, uint64_t* dst) {
  * the top word (if non-zero) then the low word WITHOUT zero padding
  * (src/scl/util/str.cc:23-39) -- reproduced as is. */
 int sclo_to_hex(int field, const uint64_t* a, char* out, size_t outlen) {
-  if (field == SCLO_SECP256K1_SCALAR) { /* montyToString: value out of Montgomery form, hex without leading zeros */
-    secpq_ensure();
+  if (IS_SECP256(field)) { /* montyToString: value out of Montgomery form, hex without leading zeros */
+    secpq_select(field);
     const fe256 v = secpq_from_mont(secpq_ld(a));
     char tmp[65];
     int len = 0, started = 0;
@@ -1054,8 +1072,8 @@ size_t sclo_wire_vector(int field, const uint64_t* elems, size_t n, unsigned cha
     const uint32_t cnt = (uint32_t)n;
     memcpy(out, &cnt, 4);
     for (size_t i = 0; i < n; ++i) {
-      if (field == SCLO_SECP256K1_SCALAR) { /* montyToBytes: out of Montgomery form, big-endian (ff_ops_gmp.h:298-314) */
-        secpq_ensure();
+      if (IS_SECP256(field)) { /* montyToBytes: out of Montgomery form, big-endian (ff_ops_gmp.h:298-314) */
+        secpq_select(field);
         const fe256 v = secpq_from_mont(secpq_ld(elems + i * L));
         for (int b = 0; b < 32; ++b) out[4 + i * bs + b] = (unsigned char)(v.w[3 - b / 8] >> (8 * (7 - b % 8)));
       } else if (field == SCLO_MONT128) { /* gmp family: out of Montgomery form, big-endian (ff_ops_gmp.h:298-314) */

@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-enum { SCLO_M61 = 0, SCLO_M127 = 1, SCLO_MONT128 = 2, SCLO_GF2_128 = 3, SCLO_SECP256K1_SCALAR = 4 };
+enum { SCLO_M61 = 0, SCLO_M127 = 1, SCLO_MONT128 = 2, SCLO_GF2_128 = 3, SCLO_SECP256K1_SCALAR = 4,
+       SCLO_SECP256K1_FIELD = 5 };
 /* rings Z2k<K> (include/scl/math/z2k.h): element-wise ops, from_bytes, vector_random, additive sharing, sum, dot,
  * scalar_mul and matmul take these tags; one limb for K <= 64, two above */
 #define SCLO_Z2K(K) (0x100 + (K))

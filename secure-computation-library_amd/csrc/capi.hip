@@ -159,6 +159,7 @@ int with_field(int field, Fn&& fn) {
     case SCL_MONT128: return fn(Mont128{}, mont_ctx());
     case SCL_GF2_128: return fn(Gf128{}, Gf128::Ctx{});
     case SCL_SECP256K1_SCALAR: return fn(Secp256k1Scalar{}, Secp256k1Scalar::Ctx{});
+    case SCL_SECP256K1_FIELD: return fn(Secp256k1Field{}, Secp256k1Field::Ctx{});
     default: return fail(SCL_ERR_BAD_ARG, "unknown field tag");
   }
 }
@@ -626,7 +627,7 @@ std::vector<VdmTable> g_vdm_tables;  // immutable once built; bounded like g_mfm
 
 template <class F>
 bool vdm_eligible(size_t n, size_t t) {
-  return (F::TAG == 2 || F::TAG == 4) && t >= 1 && t <= 16 && n * t * F::LIMBS <= (size_t)VdmLds::WORDS;
+  return (F::TAG == 2 || F::LIMBS == 4) && t >= 1 && t <= 16 && n * t * F::LIMBS <= (size_t)VdmLds::WORDS;
 }
 
 template <class F>
@@ -795,7 +796,7 @@ const char* scl_hip_status_message(int status) {
 
 int scl_hip_limbs(int field) {
   if (is_ring(field)) return field - 0x100 <= 64 ? 1 : 2;
-  return field == SCL_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : field == SCL_SECP256K1_SCALAR ? 4 : -1;
+  return field == SCL_M61 ? 1 : (field >= 1 && field <= 3) ? 2 : (field == SCL_SECP256K1_SCALAR || field == SCL_SECP256K1_FIELD) ? 4 : -1;
 }
 
 const char* scl_hip_field_name(int field) {
@@ -806,6 +807,7 @@ const char* scl_hip_field_name(int field) {
     case SCL_MONT128: return "Mont128";
     case SCL_GF2_128: return "GF(2^128)";
     case SCL_SECP256K1_SCALAR: return "secp256k1_order";  // secp256k1_scalar.h NAME
+    case SCL_SECP256K1_FIELD: return "secp256k1_field";   // secp256k1_field.h NAME
     default: return "";
   }
 }
@@ -985,7 +987,7 @@ int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64
       HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, S(stream)));
       HIP_TRY(hipStreamSynchronize(S(stream)));
       if (h) {
-        const int code = F::TAG >= 5 ? SCL_ERR_NOT_INVERTIBLE_2K : SCL_ERR_ZERO_INVERSE;
+        const int code = (F::TAG == 5 || F::TAG == 6) ? SCL_ERR_NOT_INVERTIBLE_2K : SCL_ERR_ZERO_INVERSE;
         return fail(code, scl_hip_status_message(code));
       }
     }
@@ -1124,7 +1126,7 @@ static int ring_from_bytes(int field, uint64_t* dst, const unsigned char* src, s
   const int bs = (field - 0x100 - 1) / 8 + 1;
   return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
-    if constexpr (F::TAG >= 5) {
+    if constexpr (F::TAG == 5 || F::TAG == 6) {
       SCL_TRY(check_align<F>({dst}));
       hipLaunchKernelGGL((k_ring_from_bytes<F>), dim3(grid_for(n)), dim3(BLOCK), 0, st, ctx, dst, src, n, bs);
       LAUNCH_CHECK();
@@ -1384,7 +1386,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
         });
       }
     }
-    if constexpr (F::TAG == 2 || F::TAG == 4) {
+    if constexpr (F::TAG == 2 || F::LIMBS == 4) {
       if (vdm_eligible<F>(n, t) && !g_force_table.load()) {
         const u64* vdm = nullptr;
         SCL_TRY((vdm_table<F>(ctx, al, n, t, false, &vdm)));
@@ -1540,7 +1542,7 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
         });
       }
     }
-    if constexpr (F::TAG == 2 || F::TAG == 4) {
+    if constexpr (F::TAG == 2 || F::LIMBS == 4) {
       if (vdm_eligible<F>(n, t) && !g_force_table.load()) {
         const u64* vdm = nullptr;
         SCL_TRY((vdm_table<F>(ctx, al, n, t, true, &vdm)));

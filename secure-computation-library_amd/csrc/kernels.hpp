@@ -113,7 +113,7 @@ struct BigTable {
 // what FF::invert / Z2k::invert refuse: zero in a field (small_ff.h:61-70), even values in a ring (z2k_ops.h:81-83)
 template <class F>
 __device__ __forceinline__ bool not_invertible(const typename F::E& a) {
-  if constexpr (F::TAG >= 5) return (F::low32(a) & 1u) == 0;
+  if constexpr (F::TAG == 5 || F::TAG == 6) return (F::low32(a) & 1u) == 0;  // the rings Z2k64 / Z2k128
   else return F::is_zero(a);
 }
 

@@ -25,7 +25,7 @@ if not os.path.exists(_SO):
         "(python -c 'import __graft_entry__ as g; g.build()' or make -C secure-computation-library_amd/csrc)")
 lib = C.CDLL(_SO)
 
-M61, M127, MONT128, GF2_128, SECP256K1_SCALAR = 0, 1, 2, 3, 4
+M61, M127, MONT128, GF2_128, SECP256K1_SCALAR, SECP256K1_FIELD = 0, 1, 2, 3, 4, 5
 
 
 def Z2K(bits: int) -> int:

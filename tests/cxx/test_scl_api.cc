@@ -152,6 +152,23 @@ TEST_CASE(ff_secp256k1_scalar, "FF<Secp256k1Scalar> identities + metadata", fals
   REQUIRE_THROWS_MSG(FS::fromString(std::string(66, 'f')), std::invalid_argument, "hex string too large to parse");
 }
 
+TEST_CASE(ff_secp256k1_field, "FF<Secp256k1Field> identities + metadata", false) {
+  // the prime the curve is defined over, 2^256 - 2^32 - 977 (src/scl/math/fields/secp256k1_field.cc:43-135)
+  using FP = math::FF<math::ff::Secp256k1Field>;
+  field_identities<FP>("p");
+  REQUIRE(std::string(FP::name()) == "secp256k1_field");
+  REQUIRE(FP::byteSize() == 32 && FP::bitSize() == 256);
+  REQUIRE(FP(123).toString() == "7b");
+  REQUIRE(FP(-1).toString() == "fffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2e");  // p - 1
+  REQUIRE(FP::fromString("fffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2f") == FP(0));  // p = 0
+  REQUIRE(FP::fromString("fffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc30") == FP(1));
+  REQUIRE(FP(2).inverse() * FP(2) == FP::one());
+  REQUIRE(FP::one().value().w[0] == 0x1000003D1ull && FP::one().value().w[1] == 0);  // the ONE of secp256k1_field.cc:93-94
+  unsigned char buf[32];
+  FP(-2).write(buf);
+  REQUIRE(buf[0] == 0xff && buf[27] == 0xfe && buf[31] == 0x2d && FP::read(buf) == FP(-2));  // value, big-endian
+}
+
 TEST_CASE(ff_plugins, "plug-in fields: Mont128, GF(2^128) identities", false) {
   field_identities<math::FF<math::ff::Mont128>>("c");
   using G = math::FF<math::ff::GF2_128>;

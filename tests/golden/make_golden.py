@@ -401,6 +401,25 @@ def main():
         json.dump(doc, fh_, indent=0, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")
 
+    # FF<Secp256k1Field> (src/scl/math/fields/secp256k1_field.cc:43-135), the second N = 4 instance of the Montgomery
+    # family: its own small fixture file, same sections as secp256k1_order
+    f = O.SECP256K1_FIELD
+    fd = gen_montgomery_field(ref, f)
+    fd["recover_c"] = gen_recover_c(ref, f, np.random.default_rng(77 + f))
+    L = O.LIMBS[f]
+    rng = np.random.default_rng(99 + f)
+    pk = []
+    for (W, n, t, N, seed) in ((2, 4, 3, 5, b"pedersen"), (3, 5, 2, 3, b"array3")):
+        sec = ref.from_bytes(f, rng.bytes(8 * L * W * N)).reshape(N, W, L)
+        pk.append({"W": W, "n": n, "t": t, "seed": seed.hex(), "secrets": hx(sec.reshape(-1, L)),
+                   "shares": hx(ref.shamir_share_packed(f, seed, sec, t, n).reshape(-1, L))})
+    fd["shamir_packed"] = pk
+    doc2 = {"generator": doc["generator"], "source": doc["source"], "fields": {"secp256k1_field": fd}}
+    path2 = os.path.join(HERE, "golden_secp256k1_field.json")
+    with open(path2, "w") as fh_:
+        json.dump(doc2, fh_, indent=0, separators=(",", ":"))
+    print("wrote", path2, os.path.getsize(path2), "bytes")
+
 
 if __name__ == "__main__":
     main()

@@ -21,7 +21,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 PORT_SO = os.path.join(ORACLE_DIR, "_build", "libscl_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libscl_ref.so")
 
-M61, M127, MONT128, GF2_128, SECP256K1_SCALAR = 0, 1, 2, 3, 4
+M61, M127, MONT128, GF2_128, SECP256K1_SCALAR, SECP256K1_FIELD = 0, 1, 2, 3, 4, 5
 ADD, SUB, MUL, NEG, INV, DIV = range(6)
 
 
@@ -45,7 +45,7 @@ class _Limbs(dict):
         raise KeyError(field)
 
 
-LIMBS = _Limbs({M61: 1, M127: 2, MONT128: 2, GF2_128: 2, SECP256K1_SCALAR: 4})
+LIMBS = _Limbs({M61: 1, M127: 2, MONT128: 2, GF2_128: 2, SECP256K1_SCALAR: 4, SECP256K1_FIELD: 4})
 
 
 def byte_size(field: int) -> int:

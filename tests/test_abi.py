@@ -34,10 +34,11 @@ def test_every_declared_symbol_is_exported(scl):
 
 def test_metadata_and_messages(scl):
     assert scl.lib.scl_hip_abi_version() == 1
-    assert [scl.limbs(f) for f in range(5)] == [1, 2, 2, 2, 4]
+    assert [scl.limbs(f) for f in range(6)] == [1, 2, 2, 2, 4, 4]
     # names pinned by test/scl/math/test_mersenne61.cc:28-33, test_mersenne127.cc:28-33
     assert scl.field_name(0) == "Mersenne61" and scl.field_name(1) == "Mersenne127"
     assert scl.field_name(4) == "secp256k1_order"  # include/scl/math/fields/secp256k1_scalar.h
+    assert scl.field_name(5) == "secp256k1_field"  # include/scl/math/fields/secp256k1_field.h
     msg = lambda s: scl.lib.scl_hip_status_message(s).decode()
     assert msg(scl.ERR_ZERO_INVERSE) == "0 not invertible modulo prime"
     assert msg(scl.ERR_SIZE_MISMATCH) == "Vec sizes mismatch"
@@ -48,14 +49,14 @@ def test_metadata_and_messages(scl):
     assert msg(scl.ERR_INVALID_RANGE) == "invalid range"
 
 
-@pytest.mark.parametrize("f", [O.M61, O.M127, O.MONT128, O.GF2_128, O.SECP256K1_SCALAR])
+@pytest.mark.parametrize("f", [O.M61, O.M127, O.MONT128, O.GF2_128, O.SECP256K1_SCALAR, O.SECP256K1_FIELD])
 def test_host_lagrange_basis_matches_oracle(scl, f):
     """the hoisted basis (host table code in csrc/capi.hip, Fermat inverses) == the oracle's
     per-factor Euclid divisions (lagrange.h:54-71)"""
     port = O.Port()
     L = O.LIMBS[f]
     for m in (1, 2, 4, 10, 40, 128):
-        if f in (O.MONT128, O.GF2_128, O.SECP256K1_SCALAR) and m > 40:
+        if f in (O.MONT128, O.GF2_128, O.SECP256K1_SCALAR, O.SECP256K1_FIELD) and m > 40:
             continue
         nodes = O.from_ints(list(range(1, m + 1)), L) if f == O.GF2_128 else np.stack(
             [port.from_int(f, i + 1) for i in range(m)])

@@ -16,10 +16,13 @@ torch = pytest.importorskip("torch")
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "golden_v1.json")) as fh:
     GOLD = json.load(fh)
+with open(os.path.join(HERE, "golden", "golden_secp256k1_field.json")) as fh:   # FF<Secp256k1Field>, same generator
+    GOLD["fields"].update(json.load(fh)["fields"])
 
-FIELDS = [(O.M61, "Mersenne61"), (O.M127, "Mersenne127"), (O.SECP256K1_SCALAR, "secp256k1_order")]
-ALL_FIELDS = [O.M61, O.M127, O.MONT128, O.GF2_128, O.SECP256K1_SCALAR]
-SLOW_ORACLE = (O.MONT128, O.GF2_128, O.SECP256K1_SCALAR)  # bit-serial / Fermat inversions in the C oracle
+FIELDS = [(O.M61, "Mersenne61"), (O.M127, "Mersenne127"), (O.SECP256K1_SCALAR, "secp256k1_order"),
+          (O.SECP256K1_FIELD, "secp256k1_field")]
+ALL_FIELDS = [O.M61, O.M127, O.MONT128, O.GF2_128, O.SECP256K1_SCALAR, O.SECP256K1_FIELD]
+SLOW_ORACLE = (O.MONT128, O.GF2_128, O.SECP256K1_SCALAR, O.SECP256K1_FIELD)  # bit-serial / Fermat inversions in the C oracle
 
 
 @pytest.fixture(scope="module")
@@ -425,7 +428,7 @@ def test_recover_fixed_and_table_kernels_agree(scl, port, f):
 def test_worst_case_lazy_accumulation(scl, port):
     """all operands p-1: the lazy 128-bit accumulators must not wrap (M61: 64-term bound); for the Montgomery
     fields the unreduced column sums and their single reduction at the largest residue"""
-    for f in (O.M61, O.M127, O.MONT128, O.SECP256K1_SCALAR):
+    for f in (O.M61, O.M127, O.MONT128, O.SECP256K1_SCALAR, O.SECP256K1_FIELD):
         L = O.LIMBS[f]
         for m in (16, 64, 65, 128, 200 if f == O.M61 else 128):
             if m > 256 // L:
@@ -647,7 +650,7 @@ def test_vandermonde_matmul_is_sharing(scl, port):
 def test_wire_image(scl, port, f):
     """seri::Serializer<Vector<FF>>: u32 count || FF::write images; golden bytes from the reference"""
     L = O.LIMBS[f]
-    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order"}.get(f)
+    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order", O.SECP256K1_FIELD: "secp256k1_field"}.get(f)
     if name:
         for c in GOLD["fields"][name]["wire"]:
             el = O.from_ints(ints(c["elems"]), L) if c["elems"] else np.zeros((0, L), np.uint64)
@@ -672,7 +675,7 @@ def test_wire_image(scl, port, f):
 def test_wire_matrix_image(scl, port, f):
     """seri::Serializer<Matrix<FF>>: u32 rows || u32 cols || vector image; golden bytes from the reference"""
     L = O.LIMBS[f]
-    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order"}.get(f)
+    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order", O.SECP256K1_FIELD: "secp256k1_field"}.get(f)
     if name:
         for c in GOLD["fields"][name]["wire_matrix"]:
             m = O.from_ints(ints(c["elems"]), L).reshape(c["rows"], c["cols"], L) if c["elems"] else None
@@ -703,7 +706,7 @@ def test_shamir_over_arrays(scl, port, f):
     """shamirSecretShare<Array<FF, W>> (pedersen.h:138): golden shares from the reference, then the oracle at more
     shapes; every component reconstructs on its own"""
     L = O.LIMBS[f]
-    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order"}.get(f)
+    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order", O.SECP256K1_FIELD: "secp256k1_field"}.get(f)
     cases = []
     if name:
         for c in GOLD["fields"][name]["shamir_packed"]:
@@ -726,7 +729,7 @@ def test_shamir_over_arrays(scl, port, f):
 def test_tcp_frames(scl, port, f):
     """TcpChannel frame = u32 packet size || Packet bytes (tcp_channel.h:125-160); golden frames from the reference"""
     L = O.LIMBS[f]
-    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order"}.get(f)
+    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order", O.SECP256K1_FIELD: "secp256k1_field"}.get(f)
     if name:
         for c in GOLD["fields"][name]["frame"]:
             if c["kind"] == "vector":
@@ -786,7 +789,7 @@ def test_recover_correct_golden(scl, port, f, name):
 def test_recover_correct_vs_oracle(scl, port, f, n, t, N):
     if f in SLOW_ORACLE and n >= 40:
         N = min(N, 6 if n == 40 else 2)
-    if f == O.SECP256K1_SCALAR and n > 40:
+    if O.LIMBS[f] == 4 and n > 40:
         pytest.skip("node table of the 256-bit field holds 64 entries but the oracle takes minutes here")
     L = O.LIMBS[f]
     rng = np.random.default_rng(n * 100 + t)

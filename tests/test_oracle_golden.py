@@ -13,8 +13,11 @@ import oracle_lib as O
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "golden_v1.json")) as fh:
     GOLD = json.load(fh)
+with open(os.path.join(HERE, "golden", "golden_secp256k1_field.json")) as fh:   # FF<Secp256k1Field>, same generator
+    GOLD["fields"].update(json.load(fh)["fields"])
 
-FIELDS = [(O.M61, "Mersenne61"), (O.M127, "Mersenne127"), (O.SECP256K1_SCALAR, "secp256k1_order")]
+FIELDS = [(O.M61, "Mersenne61"), (O.M127, "Mersenne127"), (O.SECP256K1_SCALAR, "secp256k1_order"),
+          (O.SECP256K1_FIELD, "secp256k1_field")]
 
 
 @pytest.fixture(scope="module")
