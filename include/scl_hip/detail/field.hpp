@@ -805,8 +805,53 @@ struct Mont256 {
     const E v = from_mont(c, a);
     return make(__builtin_bswap64(v.w[3]), __builtin_bswap64(v.w[2]), __builtin_bswap64(v.w[1]), __builtin_bswap64(v.w[0]));
   }
-  static SCL_HD E muladd_small(const Ctx& c, const E& y, u32, const E& a) { return add(c, y, a); }
-  static SCL_HD E muladd_small_lazy(const E& y, u32, const E&) { return y; }
+  // ---- products with SMALL plain integers --------------------------------------------------------------------
+  // (x R) * v = (x v) R as integers: a residue in Montgomery form times a plain integer v stays in Montgomery form and
+  // needs no Montgomery reduction at all, only "mod p" of a 288-bit integer -- which for these primes (2^256 minus a
+  // short constant) is fold_top.  With v < 2^29 (the powers of the default nodes 1..n at small thresholds) a term is
+  // eight 32 x 32 multiply-adds into per-limb 64-bit sums (seven terms cannot overflow them) against the 64 multiply-adds
+  // and a share of an eight-round reduction of a full product: what k_share_small / k_share_blocked run on.
+  struct SAcc {
+    u64 a[8];
+  };
+  static SCL_HD void sacc_zero(SAcc& s) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.a[j] = 0;
+  }
+  static SCL_HD void sacc_mac(SAcc& s, const E& c, u32 v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mad32(s.a[2 * i], (u32)c.w[i], v);
+      mad32(s.a[2 * i + 1], (u32)(c.w[i] >> 32), v);
+    }
+  }
+  // c0 + sum_j a_j 2^(32 j) mod p, canonical; the sum is < 2^288 (at most 7 terms of < p * 2^29, plus c0 < p)
+  static SCL_HD E sacc_fold(const SAcc& s, const E& c0) {
+    u32 r[9];
+    u64 cy = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const u64 t = (u64)(u32)s.a[j] + (j ? (s.a[j - 1] >> 32) : 0) + (u32)(c0.w[j >> 1] >> (32 * (j & 1))) + cy;  // < 2^35
+      r[j] = (u32)t;
+      cy = t >> 32;
+    }
+    r[8] = (u32)((s.a[7] >> 32) + cy);  // < 2^32: the whole sum is < 2^288
+    const u32 again = fold_top(r, r[8]);
+    fold_top(r, again);
+    E v = make((u64)r[0] | ((u64)r[1] << 32), (u64)r[2] | ((u64)r[3] << 32), (u64)r[4] | ((u64)r[5] << 32),
+               (u64)r[6] | ((u64)r[7] << 32));
+    if (geq_p(v)) sub_n(v, v, prime());
+    return v;
+  }
+  enum { SMALL_NODE_VALUE_BITS = 29 };
+  // y * x + c for a plain x < 2^32, canonical (the Horner step between the groups of k_share_blocked)
+  static SCL_HD E muladd_small(const Ctx&, const E& y, u32 x, const E& c) {
+    SAcc s;
+    sacc_zero(s);
+    sacc_mac(s, y, x);
+    return sacc_fold(s, c);
+  }
+  static SCL_HD E muladd_small_lazy(const E& y, u32 x, const E& c) { return muladd_small(Ctx{}, y, x, c); }
   static SCL_HD E canon(const E& r) { return r; }
 
   // Lazy accumulator: products summed unreduced (LazyCols), plain elements summed modularly beside them.

@@ -368,13 +368,29 @@ int check_align(std::initializer_list<const void*> ptrs) {
   return SCL_OK;
 }
 
+// The plain integer a node stands for, if it is one that fits 64 bits: the element itself for the Mersenne fields, the
+// value out of Montgomery form for the 256-bit primes.
+template <class F>
+bool node_value(const typename F::Ctx& ctx, const typename F::E& e, u128& out) {
+  if constexpr (F::LIMBS == 4) {
+    const typename F::E v = F::from_mont(ctx, e);
+    if (v.w[1] | v.w[2] | v.w[3]) return false;
+    out = v.w[0];
+    return true;
+  } else {
+    out = (u128)e;
+    return true;
+  }
+}
+
 // Small-node test: every power alpha_i^k, k <= t, as an integer (no reduction) stays below 2^29.
 template <class F>
-bool small_vandermonde(const BigTable<F>& al, size_t n, size_t t, SmallVdm& sv) {
+bool small_vandermonde(const typename F::Ctx& ctx, const BigTable<F>& al, size_t n, size_t t, SmallVdm& sv) {
   if (g_force_table.load() || t > (size_t)SmallVdm::TMAX || n * (t + 1) > (size_t)SmallVdm::CAP) return false;
   const u128 lim = (u128)1 << 29;
   for (size_t i = 0; i < n; ++i) {
-    const u128 a = al.v[i];
+    u128 a;
+    if (!node_value<F>(ctx, al.v[i], a)) return false;
     u128 pw = 1;
     for (size_t k = 0; k <= t; ++k) {
       if (pw >= lim) return false;
@@ -391,14 +407,14 @@ bool small_vandermonde(const BigTable<F>& al, size_t n, size_t t, SmallVdm& sv) 
 // Blocked small-node form (k_share_blocked): the largest group size G in {8, 6, 4} with every alpha_i^(G-1) < 2^29
 // and every alpha_i^G < 2^32 as integers; 0 if none fits.
 template <class F>
-int blocked_vandermonde(const BigTable<F>& al, size_t n, BlockVdm& bv) {
+int blocked_vandermonde(const typename F::Ctx& ctx, const BigTable<F>& al, size_t n, BlockVdm& bv) {
   if (g_force_table.load()) return 0;
   for (int G : {8, 6, 4}) {
     if (n * (size_t)(G + 1) > (size_t)BlockVdm::CAP) continue;
     bool ok = true;
     for (size_t i = 0; i < n && ok; ++i) {
-      const u128 a = al.v[i];
-      if (a >> 29) {
+      u128 a;
+      if (!node_value<F>(ctx, al.v[i], a) || (a >> 29)) {
         ok = false;
         break;
       }
@@ -1323,15 +1339,15 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
       // blocked small-node kernel applies (t <= 16, small nodes) that one is ahead up to about 1024
       // ((40,13): 2.5 vs 4.0 ms, (64,16): 2.4 vs 2.0 ms)
       BlockVdm bprobe;
-      const bool blocked = t <= (size_t)BlockVdm::TMAX && blocked_vandermonde<F>(al, n, bprobe) != 0;
+      const bool blocked = t <= (size_t)BlockVdm::TMAX && blocked_vandermonde<F>(ctx, al, n, bprobe) != 0;
       const size_t work_min = blocked ? 1024 : 512;
-      if (eligible && (mode > 0 || (mode == 0 && n * (t + 1) >= work_min && !small_vandermonde<F>(al, n, t, probe) &&
+      if (eligible && (mode > 0 || (mode == 0 && n * (t + 1) >= work_min && !small_vandermonde<F>(ctx, al, n, t, probe) &&
                                     !g_force_table.load())))
         return share_mfma(al, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, S(stream));
     }
-    if constexpr (F::TAG <= 1) {
+    if constexpr (F::TAG <= 1 || F::LIMBS == 4) {  // the Mersenne fields and the 256-bit Montgomery primes
       SmallVdm sv;
-      const bool small = t >= 1 && small_vandermonde<F>(al, n, t, sv);
+      const bool small = t >= 1 && small_vandermonde<F>(ctx, al, n, t, sv);
       if (small) {
         return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
           constexpr int VEC = decltype(V)::value;
@@ -1365,9 +1381,9 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
         });
       }
     }
-    if constexpr (F::TAG == 0) {  // Mersenne127 gains nothing here (its lazy Horner step is already 4 multiplies + a fold)
+    if constexpr (F::TAG == 0 || F::LIMBS == 4) {  // Mersenne127 gains nothing here (its lazy Horner step is already 4 multiplies + a fold)
       BlockVdm bv;
-      const int G = (t >= 1 && t <= (size_t)BlockVdm::TMAX) ? blocked_vandermonde<F>(al, n, bv) : 0;
+      const int G = (t >= 1 && t <= (size_t)BlockVdm::TMAX) ? blocked_vandermonde<F>(ctx, al, n, bv) : 0;
       if (G) {
         return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
           constexpr int VEC = decltype(V)::value;
@@ -1514,7 +1530,7 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
     const u64 blocks_per_secret = ((u64)(t + 1) * lane.W * F::LIMBS * 8 + 15) / 16;  // ceil((t+1)*W*byteSize/16)
     if constexpr (F::TAG <= 1) {
       SmallVdm sv;
-      if (lane.W == 1 && t >= 1 && small_vandermonde<F>(al, n, t, sv)) {
+      if (lane.W == 1 && t >= 1 && small_vandermonde<F>(ctx, al, n, t, sv)) {
         return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
           constexpr int VEC = decltype(V)::value;
           const int nblk = F::LIMBS == 1 ? (int)(t / 2 + 1) : (int)t;

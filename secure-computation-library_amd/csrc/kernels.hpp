@@ -764,6 +764,15 @@ struct SmallAcc<M127> {
   }
 };
 
+// The 256-bit Montgomery primes: (x R) * v = (x v) R needs no Montgomery reduction (field.hpp, Mont256::SAcc)
+template <class PRM>
+struct SmallAcc<Mont256<PRM>> {
+  typename Mont256<PRM>::SAcc s;
+  __device__ __forceinline__ void init() { Mont256<PRM>::sacc_zero(s); }
+  __device__ __forceinline__ void mac(const U256& c, u32 v) { Mont256<PRM>::sacc_mac(s, c, v); }
+  __device__ __forceinline__ U256 fold(const U256& c0) const { return Mont256<PRM>::sacc_fold(s, c0); }
+};
+
 template <class F, int VEC>
 __device__ __forceinline__ void small_rows(const Pack<F, VEC> (&c)[SmallVdm::TMAX + 1], const u32* V, int t, int n,
                                            u64* shares, size_t stride, size_t off) {
