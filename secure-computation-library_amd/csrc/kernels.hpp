@@ -1022,19 +1022,51 @@ __device__ __forceinline__ void aes_ctr_multi(const u32* tl, const AesKey& key, 
 #undef SCL_T
 }
 
-// ---- four tables, no rotations -----------------------------------------------------------------------------------
+// ---- four tables, no rotations, one instruction per table address -------------------------------------------------
 // The three rotations per output word of the single-table form are 20 % of its VALU work (tools/aes_bench.hip: 51.8 ->
-// 64.9 G blocks/s).  Four tables te_r[x] = rotl(te0[x], 8 r), each replicated 32 times as above, are 128 KiB of LDS:
-// one workgroup of ABLOCK = 1024 threads per CU shares them (dynamic LDS; the kernels that also keep a 32 KiB
-// Vandermonde table in LDS stay on the single-table form).  Word (r * 256 + x) * 32 + c holds entry x of table r, copy c.
+// 64.9 G blocks/s), so four tables te_r[x] = rotl(te0[x], 8 r) are kept, each replicated 32 times (a lane reads copy
+// lane % 32: no bank conflicts whatever the 64 indices are).  128 KiB of LDS: one workgroup of ABLOCK = 1024 threads per CU
+// shares them (dynamic LDS; the kernels that also keep a 32 KiB Vandermonde table in LDS stay on the single-table form).
+//
+// Layout: a 256-byte row per byte value x = [table 0, copies 0..31 | table 1, copies 0..31]; tables 2 / 3 the same 64 KiB
+// higher.  A lane's address register is then (region << 16) | (x << 8) | 4 * copy, and a lookup's whole address
+// computation is ONE v_mov_b32_sdwa that drops byte n of the state word into byte 1 of that register
+// (dst_unused:UNUSED_PRESERVE keeps the other three); the table select (0 / 128) rides in the ds_read offset field.  The
+// compiler's form of te[(s >> 8n) & 255] is v_bfe_u32 + v_lshl_add_u32, two slow-class instructions per lookup
+// (tools/oprate.hip): 526 -> 342 vector instructions per block, 66 -> 81 G blocks/s (profiles/r2_aes_sdwa.txt).
+// For byte 1 of the register to be the row, the tables must start at LDS address 0: these kernels declare no static
+// __shared__ and carve whatever else they stage from the dynamic block above the tables (AES4_EXTRA_BYTES).
 constexpr int ABLOCK = 1024;
-constexpr int AES4_LDS_BYTES = 4 * 256 * 32 * 4;
+constexpr int AES4_TABLE_WORDS = 4 * 256 * 32;
+constexpr int AES4_EXTRA_BYTES = 4096;
+constexpr int AES4_LDS_BYTES = AES4_TABLE_WORDS * 4 + AES4_EXTRA_BYTES;
 constexpr int AES4_GRID_CAP = 256;  // one workgroup per CU; the kernels grid-stride
 
-struct Aes4 {  // the lane's copy of tables 0 / 1 (t0, t0 + 8192 words) and 2 / 3 (t2, t2 + 8192 words)
-  const u32* t0;
-  const u32* t2;
+struct Aes4 {
+  u32 lane;  // 4 * (the lane's copy)
   __device__ __forceinline__ void block(const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) const;
+  // table word at LDS address a + OFF
+  template <int OFF>
+  static __device__ __forceinline__ u32 ld(u32 a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const __attribute__((address_space(3))) u32*>((uintptr_t)(a + OFF));
+#else
+    return a + OFF;
+#endif
+  }
+  // byte BYTE of s becomes the row of address register a; the word at table select OFF (0 or 128) of that row
+  template <int BYTE, int OFF>
+  static __device__ __forceinline__ u32 look(u32& a, u32 s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (BYTE == 0) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(a) : "v"(s));
+    if constexpr (BYTE == 1) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(a) : "v"(s));
+    if constexpr (BYTE == 2) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(a) : "v"(s));
+    if constexpr (BYTE == 3) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(a) : "v"(s));
+#else
+    a = (a & ~0xFF00u) | (((s >> (8 * BYTE)) & 255u) << 8);
+#endif
+    return ld<OFF>(a);
+  }
 };
 struct Aes1 {  // the single-table form above behind the same interface
   const u32* tl;
@@ -1043,86 +1075,30 @@ struct Aes1 {  // the single-table form above behind the same interface
   }
 };
 
-#define SCL_T0(x) a.t0[(x) << 5]
-#define SCL_T1(x) a.t0[((x) << 5) + 8192]
-#define SCL_T2(x) a.t2[(x) << 5]
-#define SCL_T3(x) a.t2[((x) << 5) + 8192]
-#define SCL_SB(x) ((SCL_T0(x) >> 8) & 255u)
-template <int NB>
-__device__ __forceinline__ void aes4_ctr_multi(const Aes4& a, const AesKey& key, const u64 (&ctr)[NB], u64 (&lo)[NB],
-                                               u64 (&hi)[NB]) {
-  u32 s[NB][4];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    s[b][0] = (u32)ctr[b] ^ key.rk[0];
-    s[b][1] = (u32)(ctr[b] >> 32) ^ key.rk[1];
-    s[b][2] = 0x89ABCDEFu ^ key.rk[2];
-    s[b][3] = 0x01234567u ^ key.rk[3];
-  }
-#pragma unroll 1
-  for (int r = 1; r < 10; ++r) {
-    const u32 k0 = key.rk[4 * r], k1 = key.rk[4 * r + 1], k2 = key.rk[4 * r + 2], k3 = key.rk[4 * r + 3];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const u32 s0 = s[b][0], s1 = s[b][1], s2 = s[b][2], s3 = s[b][3];
-      s[b][0] = SCL_T0(s0 & 255) ^ SCL_T1((s1 >> 8) & 255) ^ SCL_T2((s2 >> 16) & 255) ^ SCL_T3(s3 >> 24) ^ k0;
-      s[b][1] = SCL_T0(s1 & 255) ^ SCL_T1((s2 >> 8) & 255) ^ SCL_T2((s3 >> 16) & 255) ^ SCL_T3(s0 >> 24) ^ k1;
-      s[b][2] = SCL_T0(s2 & 255) ^ SCL_T1((s3 >> 8) & 255) ^ SCL_T2((s0 >> 16) & 255) ^ SCL_T3(s1 >> 24) ^ k2;
-      s[b][3] = SCL_T0(s3 & 255) ^ SCL_T1((s0 >> 8) & 255) ^ SCL_T2((s1 >> 16) & 255) ^ SCL_T3(s2 >> 24) ^ k3;
-    }
-  }
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const u32 s0 = s[b][0], s1 = s[b][1], s2 = s[b][2], s3 = s[b][3];
-    const u32 o0 = (SCL_SB(s0 & 255) | (SCL_SB((s1 >> 8) & 255) << 8) | (SCL_SB((s2 >> 16) & 255) << 16) |
-                    (SCL_SB(s3 >> 24) << 24)) ^ key.rk[40];
-    const u32 o1 = (SCL_SB(s1 & 255) | (SCL_SB((s2 >> 8) & 255) << 8) | (SCL_SB((s3 >> 16) & 255) << 16) |
-                    (SCL_SB(s0 >> 24) << 24)) ^ key.rk[41];
-    const u32 o2 = (SCL_SB(s2 & 255) | (SCL_SB((s3 >> 8) & 255) << 8) | (SCL_SB((s0 >> 16) & 255) << 16) |
-                    (SCL_SB(s1 >> 24) << 24)) ^ key.rk[42];
-    const u32 o3 = (SCL_SB(s3 & 255) | (SCL_SB((s0 >> 8) & 255) << 8) | (SCL_SB((s1 >> 16) & 255) << 16) |
-                    (SCL_SB(s2 >> 24) << 24)) ^ key.rk[43];
-    lo[b] = (u64)o0 | ((u64)o1 << 32);
-    hi[b] = (u64)o2 | ((u64)o3 << 32);
-  }
-}
-#undef SCL_SB
-#undef SCL_T0
-#undef SCL_T1
-#undef SCL_T2
-#undef SCL_T3
 // one block, rounds unrolled (as aes_ctr_block): consecutive independent blocks of a lane can be interleaved by the
-// scheduler
+// scheduler.  Four address registers (one per table), each a chain of byte-1 replacements.
 __device__ __forceinline__ void Aes4::block(const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) const {
-  const Aes4& a = *this;
-#define SCL_T0(x) a.t0[(x) << 5]
-#define SCL_T1(x) a.t0[((x) << 5) + 8192]
-#define SCL_T2(x) a.t2[(x) << 5]
-#define SCL_T3(x) a.t2[((x) << 5) + 8192]
-#define SCL_SB(x) ((SCL_T0(x) >> 8) & 255u)
+  u32 a0 = lane, a1 = lane, a2 = lane + 65536u, a3 = lane + 65536u;
   u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2 = 0x89ABCDEFu ^ key.rk[2],
       s3 = 0x01234567u ^ key.rk[3];
 #pragma unroll
   for (int r = 1; r < 10; ++r) {
-    const u32 t0 = SCL_T0(s0 & 255) ^ SCL_T1((s1 >> 8) & 255) ^ SCL_T2((s2 >> 16) & 255) ^ SCL_T3(s3 >> 24) ^ key.rk[4 * r + 0];
-    const u32 t1 = SCL_T0(s1 & 255) ^ SCL_T1((s2 >> 8) & 255) ^ SCL_T2((s3 >> 16) & 255) ^ SCL_T3(s0 >> 24) ^ key.rk[4 * r + 1];
-    const u32 t2 = SCL_T0(s2 & 255) ^ SCL_T1((s3 >> 8) & 255) ^ SCL_T2((s0 >> 16) & 255) ^ SCL_T3(s1 >> 24) ^ key.rk[4 * r + 2];
-    const u32 t3 = SCL_T0(s3 & 255) ^ SCL_T1((s0 >> 8) & 255) ^ SCL_T2((s1 >> 16) & 255) ^ SCL_T3(s2 >> 24) ^ key.rk[4 * r + 3];
-    s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+    const u32 u0 = look<0, 0>(a0, s0) ^ look<1, 128>(a1, s1) ^ look<2, 0>(a2, s2) ^ look<3, 128>(a3, s3) ^ key.rk[4 * r + 0];
+    const u32 u1 = look<0, 0>(a0, s1) ^ look<1, 128>(a1, s2) ^ look<2, 0>(a2, s3) ^ look<3, 128>(a3, s0) ^ key.rk[4 * r + 1];
+    const u32 u2 = look<0, 0>(a0, s2) ^ look<1, 128>(a1, s3) ^ look<2, 0>(a2, s0) ^ look<3, 128>(a3, s1) ^ key.rk[4 * r + 2];
+    const u32 u3 = look<0, 0>(a0, s3) ^ look<1, 128>(a1, s0) ^ look<2, 0>(a2, s1) ^ look<3, 128>(a3, s2) ^ key.rk[4 * r + 3];
+    s0 = u0; s1 = u1; s2 = u2; s3 = u3;
   }
-  const u32 o0 = (SCL_SB(s0 & 255) | (SCL_SB((s1 >> 8) & 255) << 8) | (SCL_SB((s2 >> 16) & 255) << 16) |
-                  (SCL_SB(s3 >> 24) << 24)) ^ key.rk[40];
-  const u32 o1 = (SCL_SB(s1 & 255) | (SCL_SB((s2 >> 8) & 255) << 8) | (SCL_SB((s3 >> 16) & 255) << 16) |
-                  (SCL_SB(s0 >> 24) << 24)) ^ key.rk[41];
-  const u32 o2 = (SCL_SB(s2 & 255) | (SCL_SB((s3 >> 8) & 255) << 8) | (SCL_SB((s0 >> 16) & 255) << 16) |
-                  (SCL_SB(s1 >> 24) << 24)) ^ key.rk[42];
-  const u32 o3 = (SCL_SB(s3 & 255) | (SCL_SB((s0 >> 8) & 255) << 8) | (SCL_SB((s1 >> 16) & 255) << 16) |
-                  (SCL_SB(s2 >> 24) << 24)) ^ key.rk[43];
-#undef SCL_SB
-#undef SCL_T0
-#undef SCL_T1
-#undef SCL_T2
-#undef SCL_T3
+  // last round (SubBytes + ShiftRows only): te0[x] = (2s, s, s, 3s) from the top byte down, so the S-box byte already sits in
+  // byte 0 of table 3, byte 1 of table 0, byte 2 of table 1 and byte 3 of table 2
+  const u32 o0 = ((look<0, 128>(a3, s0) & 0xFFu) | (look<1, 0>(a0, s1) & 0xFF00u) | (look<2, 128>(a1, s2) & 0xFF0000u) |
+                  (look<3, 0>(a2, s3) & 0xFF000000u)) ^ key.rk[40];
+  const u32 o1 = ((look<0, 128>(a3, s1) & 0xFFu) | (look<1, 0>(a0, s2) & 0xFF00u) | (look<2, 128>(a1, s3) & 0xFF0000u) |
+                  (look<3, 0>(a2, s0) & 0xFF000000u)) ^ key.rk[41];
+  const u32 o2 = ((look<0, 128>(a3, s2) & 0xFFu) | (look<1, 0>(a0, s3) & 0xFF00u) | (look<2, 128>(a1, s0) & 0xFF0000u) |
+                  (look<3, 0>(a2, s1) & 0xFF000000u)) ^ key.rk[42];
+  const u32 o3 = ((look<0, 128>(a3, s3) & 0xFFu) | (look<1, 0>(a0, s0) & 0xFF00u) | (look<2, 128>(a1, s1) & 0xFF0000u) |
+                  (look<3, 0>(a2, s2) & 0xFF000000u)) ^ key.rk[43];
   out_lo = (u64)o0 | ((u64)o1 << 32);
   out_hi = (u64)o2 | ((u64)o3 << 32);
 }
@@ -1135,16 +1111,20 @@ __device__ __forceinline__ void aes4_blocks(const Aes4& a, const AesKey& key, co
   for (int b = 0; b < NB; ++b) a.block(key, ctr[b], lo[b], hi[b]);
 }
 
-// the workgroup (ABLOCK threads) builds the four replicated tables in dynamic LDS
+// the workgroup (ABLOCK threads) builds the four replicated tables at the bottom of its dynamic LDS: word e belongs to
+// region e >> 14, row (e >> 6) & 255, table 2 * region + ((e >> 5) & 1).  aes4_extra = the AES4_EXTRA_BYTES above them.
 #define SCL_AES4_PROLOGUE(key)                                                                     \
   extern __shared__ __align__(16) u32 aes4_lds[];                                                  \
-  for (int e_ = threadIdx.x; e_ < 4 * 256 * 32; e_ += ABLOCK) {                                    \
-    const int r_ = e_ >> 13;                                                                       \
-    const u32 v_ = (key).te0[(e_ >> 5) & 255];                                                     \
+  if ((u32)(uintptr_t)aes4_lds != 0) __builtin_trap(); /* a static __shared__ crept into the kernel */ \
+  for (int e_ = threadIdx.x; e_ < AES4_TABLE_WORDS; e_ += ABLOCK) {                                \
+    const int r_ = 2 * (e_ >> 14) + ((e_ >> 5) & 1);                                               \
+    const u32 v_ = (key).te0[(e_ >> 6) & 255];                                                     \
     aes4_lds[e_] = r_ == 0 ? v_ : (v_ << (8 * r_)) | (v_ >> (32 - 8 * r_));                        \
   }                                                                                                \
   __syncthreads();                                                                                 \
-  const Aes4 aes{aes4_lds + (threadIdx.x & 31), aes4_lds + (threadIdx.x & 31) + 2 * 8192};
+  u32* const aes4_extra = aes4_lds + AES4_TABLE_WORDS;                                             \
+  (void)aes4_extra;                                                                                \
+  const Aes4 aes{4u * (threadIdx.x & 31)};
 
 #define SCL_AES4_GRID_STRIDE(q, npacks) \
   for (size_t q = (size_t)blockIdx.x * ABLOCK + threadIdx.x; q < (npacks); q += (size_t)gridDim.x * ABLOCK)
@@ -1351,9 +1331,8 @@ __global__ __launch_bounds__((share_prg_four_tables<F, TREG>() ? ABLOCK : BLOCK)
     int n, size_t npacks, ArrayLane al) {
   constexpr bool FOUR = share_prg_four_tables<F, TREG>();
   constexpr int THREADS = FOUR ? ABLOCK : BLOCK;
-  __shared__ typename F::E alpha[SMALLX ? 1 : BigTable<F>::CAP];
-  __shared__ u32 alpha32[SMALLX ? BigTable<F>::CAP : 1];
-  auto body = [&](const auto& aes) {
+  constexpr int NALPHA = SMALLX ? 1 : BigTable<F>::CAP, NALPHA32 = SMALLX ? BigTable<F>::CAP : 1;
+  auto body = [&](const auto& aes, typename F::E* alpha, u32* alpha32) {
     stage_nodes<F, SMALLX, THREADS>(tab, n, alpha, alpha32);
     for (size_t q = (size_t)blockIdx.x * THREADS + threadIdx.x; q < npacks; q += (size_t)gridDim.x * THREADS) {
       const size_t off = q * VEC * F::LIMBS;
@@ -1363,12 +1342,16 @@ __global__ __launch_bounds__((share_prg_four_tables<F, TREG>() ? ABLOCK : BLOCK)
       horner_rows<F, VEC, TREG, SMALLX>(ctx, c, t, alpha, alpha32, n, shares, stride, off);
     }
   };
-  if constexpr (FOUR) {
+  if constexpr (FOUR) {  // no static __shared__ here: the node table goes above the AES tables
+    static_assert(NALPHA * sizeof(typename F::E) + NALPHA32 * 4 <= AES4_EXTRA_BYTES, "node table outgrew the dynamic block");
     SCL_AES4_PROLOGUE(key)
-    body(aes);
+    typename F::E* alpha = reinterpret_cast<typename F::E*>(aes4_extra);
+    body(aes, alpha, reinterpret_cast<u32*>(alpha + NALPHA));
   } else {
+    __shared__ typename F::E alpha[NALPHA];
+    __shared__ u32 alpha32[NALPHA32];
     SCL_AES_PROLOGUE(key)
-    body(Aes1{te0});
+    body(Aes1{te0}, alpha, alpha32);
   }
 }
 
@@ -1400,8 +1383,9 @@ template <class F, int VEC, int NBLK>
 __global__ __launch_bounds__(ABLOCK) void k_share_prg_small(u64* shares, size_t stride, const u64* secrets, AesKey key,
                                                             u64 counter0, SmallVdm tab, int t, int n,
                                                             size_t npacks) {
+  static_assert(SmallVdm::CAP * 4 <= AES4_EXTRA_BYTES, "Vandermonde table outgrew the dynamic block");
   SCL_AES4_PROLOGUE(key)
-  __shared__ u32 V[SmallVdm::CAP];
+  u32* const V = aes4_extra;  // (no static __shared__: the AES tables must start at LDS address 0)
   for (int i = threadIdx.x; i < n * (t + 1); i += ABLOCK) V[i] = tab.v[i];
   __syncthreads();
   const typename F::Ctx ctx{};

@@ -1,6 +1,8 @@
 // tools/aes_bench.hip -- AES-128-CTR block rate of the single-table form (one T-table + rotations, 32 KiB of LDS per
-// 256-thread workgroup) against the library's four-table PRG kernel (no rotations; 128 KiB of LDS, one 1024-thread workgroup per CU).
-// The table contents are arbitrary here: both kernels compute the same function of them, and are compared word for word.
+// 256-thread workgroup) against the library's four-table PRG kernel (no rotations, one SDWA move per table address; 128 KiB
+// of LDS, one 1024-thread workgroup per CU) and against the four-table forms it replaced (kept here only: the compiler's
+// v_bfe_u32 + v_lshl_add_u32 addressing, and the same addresses from three fast-class opcodes).
+// The table contents are arbitrary here: all kernels compute the same function of them, and are compared word for word.
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/_build/aes_bench tools/aes_bench.hip
 #include <hip/hip_runtime.h>
 
@@ -33,10 +35,50 @@ __global__ __launch_bounds__(256) void k_prg_blocks1(u64* dst, AesKey key, u64 c
   }
 }
 
-// four tables, NB independent blocks per lane, each through the fully unrolled single-block form (Aes4::block)
-template <int NB>
-__global__ __launch_bounds__(ABLOCK) void k_prg_blocks4u(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
-  SCL_AES4_PROLOGUE(key)
+// ---- the four-table form the library shipped before: word (r * 256 + x) * 32 + c = entry x of table r, copy c ------------
+#define OLD_AES4_PROLOGUE(key)                                                                     \
+  extern __shared__ __align__(16) u32 aes4_lds[];                                                  \
+  for (int e_ = threadIdx.x; e_ < 4 * 256 * 32; e_ += ABLOCK) {                                    \
+    const int r_ = e_ >> 13;                                                                       \
+    const u32 v_ = (key).te0[(e_ >> 5) & 255];                                                     \
+    aes4_lds[e_] = r_ == 0 ? v_ : (v_ << (8 * r_)) | (v_ >> (32 - 8 * r_));                        \
+  }                                                                                                \
+  __syncthreads();
+struct OldAes4 {  // the lane's copy of tables 0 / 1 (t0, t0 + 8192 words) and 2 / 3 (t2, t2 + 8192 words)
+  const u32* t0;
+  const u32* t2;
+  __device__ __forceinline__ void block(const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) const {
+#define O_T0(x) t0[(x) << 5]
+#define O_T1(x) t0[((x) << 5) + 8192]
+#define O_T2(x) t2[(x) << 5]
+#define O_T3(x) t2[((x) << 5) + 8192]
+#define O_SB(x) ((O_T0(x) >> 8) & 255u)
+    u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2 = 0x89ABCDEFu ^ key.rk[2], s3 = 0x01234567u ^ key.rk[3];
+#pragma unroll
+    for (int r = 1; r < 10; ++r) {
+      const u32 u0 = O_T0(s0 & 255) ^ O_T1((s1 >> 8) & 255) ^ O_T2((s2 >> 16) & 255) ^ O_T3(s3 >> 24) ^ key.rk[4 * r + 0];
+      const u32 u1 = O_T0(s1 & 255) ^ O_T1((s2 >> 8) & 255) ^ O_T2((s3 >> 16) & 255) ^ O_T3(s0 >> 24) ^ key.rk[4 * r + 1];
+      const u32 u2 = O_T0(s2 & 255) ^ O_T1((s3 >> 8) & 255) ^ O_T2((s0 >> 16) & 255) ^ O_T3(s1 >> 24) ^ key.rk[4 * r + 2];
+      const u32 u3 = O_T0(s3 & 255) ^ O_T1((s0 >> 8) & 255) ^ O_T2((s1 >> 16) & 255) ^ O_T3(s2 >> 24) ^ key.rk[4 * r + 3];
+      s0 = u0; s1 = u1; s2 = u2; s3 = u3;
+    }
+    const u32 o0 = (O_SB(s0 & 255) | (O_SB((s1 >> 8) & 255) << 8) | (O_SB((s2 >> 16) & 255) << 16) | (O_SB(s3 >> 24) << 24)) ^ key.rk[40];
+    const u32 o1 = (O_SB(s1 & 255) | (O_SB((s2 >> 8) & 255) << 8) | (O_SB((s3 >> 16) & 255) << 16) | (O_SB(s0 >> 24) << 24)) ^ key.rk[41];
+    const u32 o2 = (O_SB(s2 & 255) | (O_SB((s3 >> 8) & 255) << 8) | (O_SB((s0 >> 16) & 255) << 16) | (O_SB(s1 >> 24) << 24)) ^ key.rk[42];
+    const u32 o3 = (O_SB(s3 & 255) | (O_SB((s0 >> 8) & 255) << 8) | (O_SB((s1 >> 16) & 255) << 16) | (O_SB(s2 >> 24) << 24)) ^ key.rk[43];
+    out_lo = (u64)o0 | ((u64)o1 << 32);
+    out_hi = (u64)o2 | ((u64)o3 << 32);
+#undef O_T0
+#undef O_T1
+#undef O_T2
+#undef O_T3
+#undef O_SB
+  }
+};
+
+// NB independent blocks per lane through AES (OldAes4 / Aes4f over the old layout, or the library's Aes4)
+template <int NB, class AES>
+__device__ __forceinline__ void run_blocks(const AES& aes, u64* dst, const AesKey& key, u64 counter0, size_t nblocks) {
   const size_t G = (size_t)gridDim.x * ABLOCK;
   for (size_t q = (size_t)blockIdx.x * ABLOCK + threadIdx.x; q < nblocks; q += NB * G) {
     u64 lo[NB], hi[NB];
@@ -52,6 +94,12 @@ __global__ __launch_bounds__(ABLOCK) void k_prg_blocks4u(u64* dst, AesKey key, u
       }
     }
   }
+}
+
+template <int NB>
+__global__ __launch_bounds__(ABLOCK) void k_prg_blocks4u(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
+  OLD_AES4_PROLOGUE(key)
+  run_blocks<NB>(OldAes4{aes4_lds + (threadIdx.x & 31), aes4_lds + (threadIdx.x & 31) + 2 * 8192}, dst, key, counter0, nblocks);
 }
 
 // ---- variant: table addresses from fast-class opcodes ----------------------------------------------------------------
@@ -116,25 +164,16 @@ struct Aes4f {
 
 template <int NB>
 __global__ __launch_bounds__(ABLOCK) void k_prg_blocks4f(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
-  SCL_AES4_PROLOGUE(key)
-  (void)aes;
+  OLD_AES4_PROLOGUE(key)
   const u32 lane_base = (u32)(uintptr_t)aes4_lds + 4u * (threadIdx.x & 31);  // low half of the flat address = LDS byte address
-  const Aes4f af{lane_base, lane_base + 65536u};
-  const size_t G = (size_t)gridDim.x * ABLOCK;
-  for (size_t q = (size_t)blockIdx.x * ABLOCK + threadIdx.x; q < nblocks; q += NB * G) {
-    u64 lo[NB], hi[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) af.block(key, counter0 + q + b * G, lo[b], hi[b]);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (q + b * G < nblocks) {
-        u64x2 w;
-        w.x = lo[b];
-        w.y = hi[b];
-        *reinterpret_cast<u64x2*>(dst + 2 * (q + b * G)) = w;
-      }
-    }
-  }
+  run_blocks<NB>(Aes4f{lane_base, lane_base + 65536u}, dst, key, counter0, nblocks);
+}
+
+// ---- the library's form (kernels.hpp, Aes4): one SDWA move per table address, at 1 / 2 / 4 blocks per lane ------------------
+template <int NB>
+__global__ __launch_bounds__(ABLOCK) void k_prg_blocks4p(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
+  SCL_AES4_PROLOGUE(key)
+  run_blocks<NB>(aes, dst, key, counter0, nblocks);
 }
 
 int main() {
@@ -165,7 +204,7 @@ int main() {
     auto kern = &k_prg_blocks;  // the library's kernel: four tables, one 1024-thread workgroup per CU
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AES4_LDS_BYTES));
     time_it([&] { hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, b, key, 12345ull, nblocks); },
-            "four tables, 1024 threads per CU (k_prg_blocks)");
+            "library: k_prg_blocks (four tables, SDWA addresses)");
   }
 #define RUN4U(NB, name)                                                                                              \
   {                                                                                                                      \
@@ -173,9 +212,9 @@ int main() {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AES4_LDS_BYTES)); \
     time_it([&] { hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, b, key, 12345ull, nblocks); }, name); \
   }
-  RUN4U(1, "four tables, unrolled rounds, 1 block/lane")
-  RUN4U(2, "four tables, unrolled rounds, 2 blocks/lane")
-  RUN4U(4, "four tables, unrolled rounds, 4 blocks/lane")
+  RUN4U(1, "four tables, compiler addresses, 1 block/lane")
+  RUN4U(2, "four tables, compiler addresses, 2 blocks/lane")
+  RUN4U(4, "four tables, compiler addresses, 4 blocks/lane")
 #define RUN4F(NB, name)                                                                                              \
   {                                                                                                                      \
     auto kern = &k_prg_blocks4f<NB>;                                                                                     \
@@ -184,6 +223,15 @@ int main() {
   }
   RUN4F(2, "four tables, fast-opcode addresses, 2 blocks/lane")
   RUN4F(4, "four tables, fast-opcode addresses, 4 blocks/lane")
+#define RUN4P(NB, name)                                                                                              \
+  {                                                                                                                      \
+    auto kern = &k_prg_blocks4p<NB>;                                                                                     \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AES4_LDS_BYTES)); \
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, b, key, 12345ull, nblocks); }, name); \
+  }
+  RUN4P(1, "four tables, one SDWA move per address, 1 block/lane")
+  RUN4P(2, "four tables, one SDWA move per address, 2 blocks/lane")
+  RUN4P(4, "four tables, one SDWA move per address, 4 blocks/lane")
   CK(hipGetLastError());
   std::vector<u64> ha(1 << 20), hb(1 << 20);
   CK(hipMemcpy(ha.data(), a + (nblocks - (1 << 19)) * 2, ha.size() * 8, hipMemcpyDeviceToHost));
