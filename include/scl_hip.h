@@ -204,14 +204,15 @@ int scl_hip_shamir_recover_detect(int field, uint64_t* out_dev, unsigned char* s
 
 /* Batched shamirRecoverC(shares, alphas) -- Berlekamp-Welch error correction (shamir.h:202-259, with
  * solveLinearSystem matrix.h:811-828 and Polynomial::divide poly.h:261-278).  t = (m - 1) / 3 and only the first
- * n = 3t + 1 shares are used, as in the reference; n <= 64.  Per secret s:
+ * n = 3t + 1 shares are used, as in the reference; n is unbounded, as there.  Per secret s:
  *   f_dev[k * f_stride + s], k < n      coefficients of the corrected polynomial f (zero padded); the secret is
  *                                       f(0) = row 0
  *   e_dev[k * e_stride + s], k <= t     the monic error locator E (zero padded); nerr_dev[s] = its degree
  *   status_dev[s]                       1 where the reference throws std::logic_error("could not correct shares")
  *                                       (f, E and nerr zeroed there)
  * Secrets whose n shares already lie on one polynomial of degree <= t take a streaming kernel (E = 1); the rest are
- * queued and solved one wavefront each.  Synchronous.  *num_queued_host = secrets that needed the solver,
+ * queued and solved one workgroup each (one wavefront up to 64 shares; the systems in LDS while they fit, in device
+ * memory beyond that).  Synchronous.  *num_queued_host = secrets that needed the solver,
  * *num_failed_host = how many of them could not be corrected (either may be NULL).  alphas_host NULL = 1..n. */
 int scl_hip_shamir_recover_correct(int field, uint64_t* f_dev, size_t f_stride, uint64_t* e_dev, size_t e_stride,
                                    unsigned char* status_dev, unsigned* nerr_dev, const uint64_t* shares_dev,

@@ -1691,12 +1691,10 @@ int scl_hip_shamir_recover_correct(int field, uint64_t* f_out, size_t f_stride, 
   if (stride < N || f_stride < N || e_stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
   if (N > 0xFFFFFFFFull) return fail(SCL_ERR_BAD_ARG, "recover_correct: at most 2^32 - 1 secrets per call");
   const size_t t = (m - 1) / 3, n = 3 * t + 1, d1 = t + 1, nchk = n - d1;  // shamir.h:205-206: the first 3t+1 shares
-  if (n > (size_t)BW_WAVE) return fail(SCL_ERR_BAD_ARG, "recover_correct: at most 64 shares (t <= 21)");
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     typedef typename F::E E;
     SCL_TRY(check_align<F>({f_out, e_out, shares}));
-    if (n > (size_t)BigTable<F>::CAP) return fail(SCL_ERR_BAD_ARG, "recover_correct: too many shares for this field's node table");
     std::vector<E> alphas;
     if (alphas_host) load_host<F>(alphas_host, n, alphas);
     else default_nodes<F>(ctx, n, alphas);
@@ -1741,21 +1739,29 @@ int scl_hip_shamir_recover_correct(int field, uint64_t* f_out, size_t f_stride, 
     std::vector<KC> Lk(nblk * d1 * RB, F::kc_make(ctx, F::zero()));
     for (size_t r = 0; r < rows; ++r)
       for (size_t k = 0; k < d1; ++k) Lk[((r / RB) * d1 + k) * RB + r % RB] = F::kc_make(ctx, L[r * d1 + k]);
-    const size_t tbytes = Lk.size() * sizeof(KC), lbytes = d1 * RB * sizeof(KC);
-    const size_t solve_bytes = bw_lds_elems(n) * sizeof(E);
-    if (lbytes > 150 * 1024 || solve_bytes > 150 * 1024)
-      return fail(SCL_ERR_BAD_ARG, "recover_correct: the systems for this many shares exceed LDS");
+    const size_t tbytes = (Lk.size() * sizeof(KC) + 63) / 64 * 64, lbytes = d1 * RB * sizeof(KC);
+    const size_t solve_bytes = bw_lds_elems(n) * sizeof(E), nbytes = n * sizeof(E);
+    if (lbytes > 150 * 1024) return fail(SCL_ERR_BAD_ARG, "recover_correct: the interpolation rows for this many shares exceed LDS");
+    // the systems of one secret live in the workgroup's LDS while they fit (n <= 136 / 95 / 66 shares by element size) and
+    // in a slice of device memory per workgroup beyond that
+    const bool in_lds = solve_bytes <= 150 * 1024;
+    const size_t max_groups = in_lds ? 8192 : std::max<size_t>(1, std::min<size_t>(1024, ((size_t)512 << 20) / solve_bytes));
+    const size_t groups_cap = std::min<size_t>(N, max_groups);
     void* sc;
-    SCL_TRY(scratch(tbytes + 64, &sc));
+    SCL_TRY(scratch(tbytes + nbytes + 64, &sc));
     unsigned* counters = static_cast<unsigned*>(sc);  // [0] queued, [1] failed
     KC* L_dev = reinterpret_cast<KC*>(static_cast<unsigned char*>(sc) + 64);
-    // the queue of inconsistent secrets lives in the per-thread temporary (kept and grown): a hipMalloc / hipFree pair
-    // per call costs more than the consistency pass of a few million secrets
+    u64* nodes_dev = reinterpret_cast<u64*>(static_cast<unsigned char*>(sc) + 64 + tbytes);
+    // the queue of inconsistent secrets (and the out-of-LDS work area) lives in the per-thread temporary (kept and grown):
+    // a hipMalloc / hipFree pair per call costs more than the consistency pass of a few million secrets
+    const size_t qbytes = (N * sizeof(unsigned) + 255) / 256 * 256;
     void* queue = nullptr;
-    SCL_TRY(temp_acquire(N * sizeof(unsigned), S(stream), &queue));
+    SCL_TRY(temp_acquire(qbytes + (in_lds ? 0 : groups_cap * solve_bytes), S(stream), &queue));
+    u64* work = in_lds ? nullptr : reinterpret_cast<u64*>(static_cast<unsigned char*>(queue) + qbytes);
     auto body = [&]() -> int {
       HIP_TRY(hipMemsetAsync(counters, 0, 8, S(stream)));
-      HIP_TRY(hipMemcpyAsync(L_dev, Lk.data(), tbytes, hipMemcpyHostToDevice, S(stream)));
+      HIP_TRY(hipMemcpyAsync(L_dev, Lk.data(), Lk.size() * sizeof(KC), hipMemcpyHostToDevice, S(stream)));
+      HIP_TRY(hipMemcpyAsync(nodes_dev, alphas.data(), nbytes, hipMemcpyHostToDevice, S(stream)));
       auto kern = &k_bw_consistent<F, RB>;
       if (lbytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1770,15 +1776,15 @@ int scl_hip_shamir_recover_correct(int field, uint64_t* f_out, size_t f_stride, 
       HIP_TRY(hipStreamSynchronize(S(stream)));
       if (num_queued_host) *num_queued_host = h[0];
       if (h[0] == 0) return SCL_OK;
-      BigTable<F> nodes;
-      for (size_t i = 0; i < n; ++i) nodes.v[i] = alphas[i];
-      if (solve_bytes > 48 * 1024)
+      const size_t lds = in_lds ? solve_bytes : 0;
+      if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bw_solve<F>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_bytes));
-      const unsigned grid = h[0] < 8192u ? h[0] : 8192u;
-      hipLaunchKernelGGL((k_bw_solve<F>), dim3(grid), dim3(BW_WAVE), solve_bytes, S(stream), ctx, f_out, f_stride, e_out,
-                         e_stride, status, nerr, shares, stride, nodes, (int)n, static_cast<const unsigned*>(queue), h[0],
-                         counters + 1);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const unsigned grid = (unsigned)std::min<size_t>(h[0], groups_cap);
+      const unsigned threads = (unsigned)std::min<size_t>(1024, (n + BW_WAVE - 1) / BW_WAVE * BW_WAVE);  // threads over rows
+      hipLaunchKernelGGL((k_bw_solve<F>), dim3(grid), dim3(threads), lds, S(stream), ctx, f_out, f_stride, e_out, e_stride,
+                         status, nerr, shares, stride, nodes_dev, (int)n, static_cast<const unsigned*>(queue), h[0],
+                         counters + 1, work);
       LAUNCH_CHECK();
       HIP_TRY(hipMemcpyAsync(h, counters, 8, hipMemcpyDeviceToHost, S(stream)));
       HIP_TRY(hipStreamSynchronize(S(stream)));

@@ -1763,35 +1763,40 @@ __global__ __launch_bounds__(BLOCK) void k_bw_consistent(typename F::Ctx ctx, u6
 
 constexpr int BW_WAVE = 64;
 
-// LDS elements k_bw_solve needs for n shares (t = (n-1)/3): the augmented matrix, the nodes, the shares, the
+// elements of k_bw_solve's work area for n shares (t = (n-1)/3): the augmented matrix, the nodes, the shares, the
 // quotient and the locator
-inline size_t bw_lds_elems(size_t n) { return n * (n + 1) + 3 * n + (n - 1) / 3 + 1; }
+__host__ __device__ inline size_t bw_lds_elems(size_t n) { return n * (n + 1) + 3 * n + (n - 1) / 3 + 1; }
 
+// One workgroup per queued secret, threads over rows (a thread owns rows tid, tid + blockDim.x, ..: one wavefront while
+// n <= 64).  The work area is the workgroup's dynamic LDS when it fits and a slice of `work` (global memory, one slice
+// per workgroup) when it does not -- shamirRecoverC has no bound on the number of shares.
 template <class F>
-__global__ __launch_bounds__(BW_WAVE) void k_bw_solve(typename F::Ctx ctx, u64* f_out, size_t f_stride, u64* e_out,
-                                                      size_t e_stride, unsigned char* status, unsigned* nerr,
-                                                      const u64* shares, size_t stride, BigTable<F> nodes, int n,
-                                                      const unsigned* queue, unsigned nqueued, unsigned* failed) {
+__global__ __launch_bounds__(1024) void k_bw_solve(typename F::Ctx ctx, u64* f_out, size_t f_stride, u64* e_out,
+                                                   size_t e_stride, unsigned char* status, unsigned* nerr,
+                                                   const u64* shares, size_t stride, const u64* nodes, int n,
+                                                   const unsigned* queue, unsigned nqueued, unsigned* failed, u64* work) {
   typedef typename F::E E;
   extern __shared__ unsigned char smem_raw[];
-  const int t = (n - 1) / 3, m = n + 1, lane = threadIdx.x;
-  E* M = reinterpret_cast<E*>(smem_raw);  // [n][m]
-  E* al = M + (size_t)n * m;              // [n]
-  E* sh = al + n;                         // [n]
-  E* fq = sh + n;                         // [n] quotient
-  E* ec = fq + n;                         // [t+1] locator
-  if (lane < n) al[lane] = nodes.v[lane];
+  __shared__ int pivot_row;
+  __shared__ int all_ok;
+  const int t = (n - 1) / 3, m = n + 1, tid = threadIdx.x, T = blockDim.x;
+  E* M = work ? reinterpret_cast<E*>(work) + (size_t)blockIdx.x * bw_lds_elems(n) : reinterpret_cast<E*>(smem_raw);  // [n][m]
+  E* al = M + (size_t)n * m;  // [n]
+  E* sh = al + n;             // [n]
+  E* fq = sh + n;             // [n] quotient
+  E* ec = fq + n;             // [t+1] locator
+  for (int r = tid; r < n; r += T) al[r] = F::ld(nodes + (size_t)r * F::LIMBS);
   for (unsigned item = blockIdx.x; item < nqueued; item += gridDim.x) {
     const size_t s = queue[item];
     __syncthreads();
-    if (lane < n) sh[lane] = F::ld(shares + ((size_t)lane * stride + s) * F::LIMBS);
+    for (int r = tid; r < n; r += T) sh[r] = F::ld(shares + ((size_t)r * stride + s) * F::LIMBS);
     __syncthreads();
     int e = t;
     for (; e >= 0; --e) {
       // row i of [A | b] (shamir.h:217-231): s a^j for j < e, -1 at e, -a^(j-e) above, b = -s a^e
-      if (lane < n) {
-        E* row = M + (size_t)lane * m;
-        const E a = al[lane], si = sh[lane];
+      for (int r = tid; r < n; r += T) {
+        E* row = M + (size_t)r * m;
+        const E a = al[r], si = sh[r];
         E v = si;
         for (int j = 0; j < e; ++j) {
           row[j] = v;
@@ -1804,20 +1809,25 @@ __global__ __launch_bounds__(BW_WAVE) void k_bw_solve(typename F::Ctx ctx, u64* 
           v = F::mul(ctx, v, a);
         }
       }
-      __syncthreads();
       // Division-free Gauss-Jordan: rows k != c become row_k * pivot - row_c * M[k][c], which keeps the solution
       // set (the pivot is non-zero) and needs no inversion to decide the rank; the matrix ends up diagonal.
       bool singular = false;
       for (int c = 0; c < n; ++c) {
-        const bool nz = lane >= c && lane < n && !F::is_zero(M[(size_t)lane * m + c]);
-        const unsigned long long cand = __ballot(nz);
-        if (cand == 0) {  // wave-uniform: no pivot in this column, the matrix is singular
+        if (tid == 0) pivot_row = n;
+        __syncthreads();  // (also: the rows written above / by the previous column are visible)
+        for (int r = c + tid; r < n; r += T)
+          if (!F::is_zero(M[(size_t)r * m + c])) {
+            atomicMin(&pivot_row, r);
+            break;  // a thread's rows ascend
+          }
+        __syncthreads();
+        const int p = pivot_row;
+        if (p >= n) {  // workgroup-uniform: no pivot in this column, the matrix is singular
           singular = true;
           break;
         }
-        const int p = __ffsll((long long)cand) - 1;
         if (p != c) {
-          for (int j = lane; j < m; j += BW_WAVE) {
+          for (int j = tid; j < m; j += T) {
             const E tmp = M[(size_t)p * m + j];
             M[(size_t)p * m + j] = M[(size_t)c * m + j];
             M[(size_t)c * m + j] = tmp;
@@ -1825,48 +1835,53 @@ __global__ __launch_bounds__(BW_WAVE) void k_bw_solve(typename F::Ctx ctx, u64* 
           __syncthreads();
         }
         const E pv = M[(size_t)c * m + c];
-        if (lane < n && lane != c) {
-          E* row = M + (size_t)lane * m;
+        for (int r = tid; r < n; r += T) {
+          if (r == c) continue;
+          E* row = M + (size_t)r * m;
           const E nt = F::neg(ctx, row[c]);
           row[c] = F::zero();
           // columns left of c: zero in row c, so only the scaling by the pivot remains (rows above c carry their
           // own diagonal entry there)
-          if (lane < c) row[lane] = F::mul(ctx, row[lane], pv);
+          if (r < c) row[r] = F::mul(ctx, row[r], pv);
           for (int j = c + 1; j < m; ++j) row[j] = F::add(ctx, F::mul(ctx, row[j], pv), F::mul(ctx, M[(size_t)c * m + j], nt));
         }
-        __syncthreads();
+        __syncthreads();  // every thread has read pivot_row and finished its rows before the next column resets it
       }
-      if (!singular) break;
       __syncthreads();
+      if (!singular) break;
     }
     // the e = 0 system is a Vandermonde system, nonsingular for distinct nodes (the host checks them)
     const bool solved = e >= 0;
     if (!solved) e = 0;
-    // the system is diagonal now: x_j = M[j][n] / M[j][j], every lane inverting its own diagonal entry at once
-    if (solved && lane < n) M[(size_t)lane * m + n] = F::mul(ctx, M[(size_t)lane * m + n], F::inv(ctx, M[(size_t)lane * m + lane]));
+    // the system is diagonal now: x_j = M[j][n] / M[j][j], every thread inverting its own diagonal entries
+    if (solved)
+      for (int r = tid; r < n; r += T) M[(size_t)r * m + n] = F::mul(ctx, M[(size_t)r * m + n], F::inv(ctx, M[(size_t)r * m + r]));
     __syncthreads();
     // E = x[0..e) then 1, Q = x[e..n)
-    bool ok = solved;
-    if (lane == 0 && solved) {
-      for (int j = 0; j <= t; ++j) ec[j] = j < e ? M[(size_t)j * m + n] : (j == e ? F::one(ctx) : F::zero());
-      const int qn = n - e;  // Q has qn coefficients; reuse column n of M as the running remainder
-      for (int j = 0; j < n; ++j) fq[j] = F::zero();
-      for (int d = qn - 1 - e; d >= 0; --d) {  // synthetic division by the monic E
-        const E lead = M[(size_t)(e + d + e) * m + n];
-        fq[d] = lead;
-        for (int j = 0; j < e; ++j) {
-          E& r = M[(size_t)(e + d + j) * m + n];
-          r = F::sub(ctx, r, F::mul(ctx, lead, ec[j]));
+    if (tid == 0) {
+      bool ok = solved;
+      if (solved) {
+        for (int j = 0; j <= t; ++j) ec[j] = j < e ? M[(size_t)j * m + n] : (j == e ? F::one(ctx) : F::zero());
+        const int qn = n - e;  // Q has qn coefficients; reuse column n of M as the running remainder
+        for (int j = 0; j < n; ++j) fq[j] = F::zero();
+        for (int d = qn - 1 - e; d >= 0; --d) {  // synthetic division by the monic E
+          const E lead = M[(size_t)(e + d + e) * m + n];
+          fq[d] = lead;
+          for (int j = 0; j < e; ++j) {
+            E& r = M[(size_t)(e + d + j) * m + n];
+            r = F::sub(ctx, r, F::mul(ctx, lead, ec[j]));
+          }
         }
+        const int rem = qn - 1 - e >= 0 ? e : qn;  // remainder coefficients left in Q[0..rem)
+        for (int j = 0; j < rem; ++j) ok = ok && F::is_zero(M[(size_t)(e + j) * m + n]);
       }
-      const int rem = qn - 1 - e >= 0 ? e : qn;  // remainder coefficients left in Q[0..rem)
-      for (int j = 0; j < rem; ++j) ok = ok && F::is_zero(M[(size_t)(e + j) * m + n]);
+      all_ok = ok ? 1 : 0;
     }
-    ok = __shfl((int)ok, 0) != 0;
     __syncthreads();
-    for (int k = lane; k < n; k += BW_WAVE) F::st(f_out + ((size_t)k * f_stride + s) * F::LIMBS, ok ? fq[k] : F::zero());
-    for (int k = lane; k <= t; k += BW_WAVE) F::st(e_out + ((size_t)k * e_stride + s) * F::LIMBS, ok ? ec[k] : F::zero());
-    if (lane == 0) {
+    const bool ok = all_ok != 0;
+    for (int k = tid; k < n; k += T) F::st(f_out + ((size_t)k * f_stride + s) * F::LIMBS, ok ? fq[k] : F::zero());
+    for (int k = tid; k <= t; k += T) F::st(e_out + ((size_t)k * e_stride + s) * F::LIMBS, ok ? ec[k] : F::zero());
+    if (tid == 0) {
       status[s] = ok ? 0 : 1;
       nerr[s] = ok ? (unsigned)e : 0u;
       if (!ok) atomicAdd(failed, 1u);

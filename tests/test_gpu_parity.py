@@ -849,9 +849,32 @@ def test_recover_correct_edges(scl, port):
         scl.shamir_recover_correct(f, dev(scl, soa(sh)), np.stack([al[0]] * 7))
     with pytest.raises(scl.SclError):      # rings have no Berlekamp-Welch
         scl.shamir_recover_correct(scl.Z2K(62), dev(scl, soa(sh)))
-    big = rand_elems(port, f, 67 * 3, b"bwb").reshape(3, 67, L)
-    with pytest.raises(scl.SclError):      # 3t+1 = 67 > 64 shares
-        scl.shamir_recover_correct(f, dev(scl, soa(big)))
+
+
+@pytest.mark.parametrize("f,n,N", [(O.M61, 67, 9), (O.M61, 100, 8), (O.M61, 148, 5), (O.M127, 70, 6), (O.M127, 97, 4),
+                                   (O.MONT128, 130, 3), (O.SECP256K1_SCALAR, 67, 3)])
+def test_recover_correct_has_no_bound_on_shares(scl, port, f, n, N):
+    """shamirRecoverC takes any number of shares (shamir.h:202-259).  Beyond 64 the systems of a secret are solved by a
+    workgroup with threads over rows, in LDS while they fit (M61: 136 shares, 128-bit fields: 95, 256-bit: 66) and in a
+    device-memory slice per workgroup after that -- every case against the oracle, output for output."""
+    L = O.LIMBS[f]
+    t = (n - 1) // 3
+    rng = np.random.default_rng(n)
+    secrets = rand_elems(port, f, N, b"bwL-s")
+    coeffs = rand_elems(port, f, t * N, b"bwL-c").reshape(N, t, L)
+    nodes = np.stack([port.from_int(f, i + 1) for i in range(n)])
+    shares = np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)])
+    junk = rand_elems(port, f, N * n, b"bwL-j").reshape(N, n, L)
+    nbad = [0, 1, t, t + 1, t // 2, 2, 3, t - 1, 5][:N]      # clean, inside the radius, at it, beyond it
+    for s in range(N):
+        for i in rng.choice(n, size=nbad[s], replace=False):
+            shares[s, i] = junk[s, i]
+    r, (fo, eo, st, ne) = _check_recover_c(scl, port, f, shares)
+    used = 3 * t + 1
+    for s in range(N):
+        if nbad[s] <= t and n == used:
+            assert st[s] == 0 and ne[s] == nbad[s] and np.array_equal(fo[s, 0], secrets[s])
+    assert r["queued"] == sum(1 for k in nbad if k > 0)
 
 
 # ------------------------------------------------------------------------------------------------------- rings Z2k<K>
