@@ -213,6 +213,7 @@ struct M61 {
     return (s & P) + (s >> 61);
   }
   static SCL_HD E canon(u64 r) { return r >= P ? r - P : r; }       // r < 2^61 + P
+  static SCL_HD u64 muladd_small_lazy(const Ctx&, u64 y, u32 x, u64 c) { return muladd_small_lazy(y, x, c); }
   static SCL_HD E muladd_small(const Ctx&, E y, u32 x, E c) { return canon(muladd_small_lazy(y, x, c)); }
 
   struct Acc {
@@ -432,6 +433,7 @@ struct Mont128 {
   struct Ctx {
     u128 p, mc, one, r2;  // modulus, -p^-1 mod R, R mod p, R^2 mod p
     u128 k32;             // 2^32 * R mod p (undoes the extra word of the lazy accumulator's reduction)
+    u64 bmu;              // floor(2^160 / p) for a full-width modulus (p >= 2^127), else 0: the small-node quotient estimate
   };
   enum { LIMBS = 2, ACC_TERMS = 1 << 24, TAG = 2 };
 
@@ -451,6 +453,21 @@ struct Mont128 {
     }
     c.r2 = r;
     c.k32 = mul(c, (u128)1 << 32, c.r2);
+    c.bmu = 0;
+    if (p >> 127) {  // long division of 2^160 by p: the quotient has 33 or 34 bits
+      u128 rem = 1;
+      u64 q = 0;
+      for (int i = 0; i < 160; ++i) {
+        const bool top = (rem >> 127) != 0;
+        rem <<= 1;
+        q <<= 1;
+        if (top || rem >= p) {
+          rem -= p;
+          q |= 1;
+        }
+      }
+      c.bmu = q;
+    }
     return c;
   }
 
@@ -483,9 +500,71 @@ struct Mont128 {
   }
   static SCL_HD E mul(const Ctx& c, E a, E b) { return redc(c, mulwide(a, b)); }
   static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
-  enum { SMALL_BITS = 0 };  // Montgomery residues are never small
-  static SCL_HD E muladd_small(const Ctx& c, E y, u32, E a) { return add(c, y, a); }
-  static SCL_HD E muladd_small_lazy(E y, u32, E) { return y; }
+  enum { SMALL_BITS = 0 };  // Montgomery residues are never small (the SMALLX Horner kernels do not apply)
+
+  // Small-node sharing.  A node power v that is a small plain integer multiplies a residue without leaving
+  // Montgomery form, (x R) v = (x v) R, so share_i = sum_k c_k v_ik needs no Montgomery product: four 32 x 32
+  // multiply-adds per term into per-limb 64-bit sums (seven terms of v < 2^29 cannot overflow them), then ONE reduction
+  // of the < 2^160 sum S.  For a full-width modulus (2^127 <= p < 2^128, Ctx::bmu != 0) that is a Barrett step:
+  // q' = floor(floor(S / 2^96) * bmu / 2^64) satisfies q - 2 <= q' <= q for q = floor(S / p) < 2^32, so
+  // S - q' p < 3p takes two conditional subtractions.  (ff_ops_gmp.h:174-191 reaches the same residue one
+  // montyModMul and one montyModAdd at a time.)
+  struct SAcc {
+    u64 a[4];
+  };
+  static SCL_HD void sacc_zero(SAcc& s) { s.a[0] = s.a[1] = s.a[2] = s.a[3] = 0; }
+  static SCL_HD void sacc_mac(SAcc& s, E c, u32 v) {
+    mad32(s.a[0], (u32)c, v);
+    mad32(s.a[1], (u32)(c >> 32), v);
+    mad32(s.a[2], (u32)(c >> 64), v);
+    mad32(s.a[3], (u32)(c >> 96), v);
+  }
+  // c0 + sum_j a_j 2^(32 j) mod p, canonical; the sum is < p * 2^32
+  static SCL_HD E sacc_fold(const Ctx& c, const SAcc& s, E c0) {
+    u64 l0 = (u64)(u32)s.a[0] + (u32)c0;
+    u64 l1 = (s.a[0] >> 32) + (u64)(u32)s.a[1] + (u32)(c0 >> 32);
+    u64 l2 = (s.a[1] >> 32) + (u64)(u32)s.a[2] + (u32)(c0 >> 64);
+    u64 l3 = (s.a[2] >> 32) + (u64)(u32)s.a[3] + (u32)(c0 >> 96);
+    u64 l4 = (s.a[3] >> 32);
+    l1 += l0 >> 32;
+    l2 += l1 >> 32;
+    l3 += l2 >> 32;
+    l4 += l3 >> 32;  // < 2^32: S < p * 2^32 < 2^160
+    const u128 slo = (u128)((u64)(u32)l0 | (l1 << 32)) | ((u128)((u64)(u32)l2 | (l3 << 32)) << 64);
+    const u64 sh = (u64)(u32)l3 | (l4 << 32);  // floor(S / 2^96)
+    const u32 q = (u32)(u64)(((u128)sh * c.bmu) >> 64);
+    const u32 p0 = (u32)c.p, p1 = (u32)(c.p >> 32), p2 = (u32)(c.p >> 64), p3 = (u32)(c.p >> 96);
+    u64 t0 = 0, t1, t2, t3;
+    mad32(t0, q, p0);
+    t1 = t0 >> 32;
+    mad32(t1, q, p1);
+    t2 = t1 >> 32;
+    mad32(t2, q, p2);
+    t3 = t2 >> 32;
+    mad32(t3, q, p3);
+    const u128 qlo = (u128)((u64)(u32)t0 | (t1 << 32)) | ((u128)((u64)(u32)t2 | (t3 << 32)) << 64);
+    u128 r = slo - qlo;
+    u32 rh = (u32)l4 - (u32)(t3 >> 32) - (slo < qlo ? 1u : 0u);  // S - q p < 3p: rh <= 2
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (rh || r >= c.p) {
+        rh -= r < c.p ? 1u : 0u;
+        r -= c.p;
+      }
+    }
+    return r;
+  }
+  enum { SMALL_NODE_VALUE_BITS = 29 };
+  static SCL_HD bool small_nodes_ok(const Ctx& c) { return c.bmu != 0; }
+  // y * x + a for a plain x < 2^32, canonical (the Horner step between the groups of k_share_blocked)
+  static SCL_HD E muladd_small(const Ctx& c, E y, u32 x, E a) {
+    SAcc s;
+    sacc_zero(s);
+    sacc_mac(s, y, x);
+    return sacc_fold(c, s, a);
+  }
+  static SCL_HD E muladd_small_lazy(const Ctx& c, E y, u32 x, E a) { return muladd_small(c, y, x, a); }
+  static SCL_HD E muladd_small_lazy(E y, u32, E) { return y; }  // (SMALLX instantiations only; never run: SMALL_BITS = 0)
   static SCL_HD E canon(E r) { return r; }
   static SCL_HD E to_mont(const Ctx& c, u128 x) { return mul(c, x, c.r2); }
   static SCL_HD u128 from_mont(const Ctx& c, E a) { return mul(c, a, 1); }
@@ -852,6 +931,7 @@ struct Mont256 {
     return sacc_fold(s, c);
   }
   static SCL_HD E muladd_small_lazy(const E& y, u32 x, const E& c) { return muladd_small(Ctx{}, y, x, c); }
+  static SCL_HD E muladd_small_lazy(const Ctx&, const E& y, u32 x, const E& c) { return muladd_small(Ctx{}, y, x, c); }
   static SCL_HD E canon(const E& r) { return r; }
 
   // Lazy accumulator: products summed unreduced (LazyCols), plain elements summed modularly beside them.

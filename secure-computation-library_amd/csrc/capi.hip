@@ -377,6 +377,10 @@ bool node_value(const typename F::Ctx& ctx, const typename F::E& e, u128& out) {
     if (v.w[1] | v.w[2] | v.w[3]) return false;
     out = v.w[0];
     return true;
+  } else if constexpr (F::TAG == 2) {  // Mont128: only a full-width modulus has the small-node reduction (Ctx::bmu)
+    if (!F::small_nodes_ok(ctx)) return false;
+    out = F::from_mont(ctx, e);
+    return true;
   } else {
     out = (u128)e;
     return true;
@@ -1345,7 +1349,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
                                     !g_force_table.load())))
         return share_mfma(al, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, S(stream));
     }
-    if constexpr (F::TAG <= 1 || F::LIMBS == 4) {  // the Mersenne fields and the 256-bit Montgomery primes
+    if constexpr (F::TAG <= 2 || F::LIMBS == 4) {  // the Mersenne fields and the Montgomery primes (Mont128: of full width)
       SmallVdm sv;
       const bool small = t >= 1 && small_vandermonde<F>(ctx, al, n, t, sv);
       if (small) {
@@ -1361,7 +1365,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
               const dim3 g(grid_for_block(npacks, 64));
 #define SST_CASE(TT)                                                                                                     \
   case TT:                                                                                                               \
-    hipLaunchKernelGGL((k_share_small_t<F, VEC, TT, 64>), g, dim3(64), pad, S(stream), shares + first * F::LIMBS, share_stride, \
+    hipLaunchKernelGGL((k_share_small_t<F, VEC, TT, 64>), g, dim3(64), pad, S(stream), ctx, shares + first * F::LIMBS, share_stride, \
                        secrets + first * F::LIMBS, coeffs + first * F::LIMBS, coeff_stride, sv, (int)n, npacks);         \
     launched = true;                                                                                                     \
     break;
@@ -1373,7 +1377,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
             }
           }
           if (!launched)
-            hipLaunchKernelGGL((k_share_small<F, VEC>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), shares + first * F::LIMBS,
+            hipLaunchKernelGGL((k_share_small<F, VEC>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx, shares + first * F::LIMBS,
                                share_stride, secrets + first * F::LIMBS, coeffs + first * F::LIMBS, coeff_stride, sv, (int)t, (int)n,
                                npacks);
           LAUNCH_CHECK();
@@ -1381,7 +1385,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
         });
       }
     }
-    if constexpr (F::TAG == 0 || F::LIMBS == 4) {  // Mersenne127 gains nothing here (its lazy Horner step is already 4 multiplies + a fold)
+    if constexpr (F::TAG == 0 || F::TAG == 2 || F::LIMBS == 4) {  // Mersenne127 gains nothing here (its lazy Horner step is already 4 multiplies + a fold)
       BlockVdm bv;
       const int G = (t >= 1 && t <= (size_t)BlockVdm::TMAX) ? blocked_vandermonde<F>(ctx, al, n, bv) : 0;
       if (G) {
@@ -1392,7 +1396,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
           const u64* co = coeffs + first * F::LIMBS;
           const dim3 g(grid_for(npacks)), blk(BLOCK);
 #define BLK_LAUNCH(GG) \
-  hipLaunchKernelGGL((k_share_blocked<F, VEC, GG>), g, blk, 0, S(stream), sh, share_stride, se, co, coeff_stride, bv, (int)t, (int)n, npacks)
+  hipLaunchKernelGGL((k_share_blocked<F, VEC, GG>), g, blk, 0, S(stream), ctx, sh, share_stride, se, co, coeff_stride, bv, (int)t, (int)n, npacks)
           if (G == 8) BLK_LAUNCH(8);
           else if (G == 6) BLK_LAUNCH(6);
           else BLK_LAUNCH(4);

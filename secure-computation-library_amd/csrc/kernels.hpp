@@ -727,7 +727,7 @@ struct SmallAcc<M61> {
     a1 += (u64)(u32)(c >> 32) * v;  // c_hi < 2^29, * v < 2^58
   }
   // c0 + a0 + a1*2^32 mod p, with 2^61 = 1: a1*2^32 = (a1 >> 29) + ((a1 & (2^29-1)) << 32)
-  __device__ __forceinline__ u64 fold(u64 c0) const {
+  __device__ __forceinline__ u64 fold(const M61::Ctx&, u64 c0) const {
     const u64 P = M61::P;
     const u64 s = (a0 & P) + (a0 >> 61) + c0 + (a1 >> 29) + ((a1 & 0x1FFFFFFFull) << 32);  // < 2^63
     const u64 r = (s & P) + (s >> 61);
@@ -747,7 +747,7 @@ struct SmallAcc<M127> {
   }
   // c0 + sum_j a_j 2^(32j) mod p: the four accumulators overlap by 32 bits, so sum them limb-wise (each limb
   // sum < 2^34), ripple the carries once, then 2^128 = 2 (mod p)
-  __device__ __forceinline__ u128 fold(u128 c0) const {
+  __device__ __forceinline__ u128 fold(const M127::Ctx&, u128 c0) const {
     u64 l0 = (u64)(u32)a[0] + (u32)c0;
     u64 l1 = (a[0] >> 32) + (u64)(u32)a[1] + (u32)(c0 >> 32);
     u64 l2 = (a[1] >> 32) + (u64)(u32)a[2] + (u32)(c0 >> 64);
@@ -770,12 +770,21 @@ struct SmallAcc<Mont256<PRM>> {
   typename Mont256<PRM>::SAcc s;
   __device__ __forceinline__ void init() { Mont256<PRM>::sacc_zero(s); }
   __device__ __forceinline__ void mac(const U256& c, u32 v) { Mont256<PRM>::sacc_mac(s, c, v); }
-  __device__ __forceinline__ U256 fold(const U256& c0) const { return Mont256<PRM>::sacc_fold(s, c0); }
+  __device__ __forceinline__ U256 fold(const typename Mont256<PRM>::Ctx&, const U256& c0) const { return Mont256<PRM>::sacc_fold(s, c0); }
+};
+
+// The 128-bit Montgomery prime of full width: the same, with a Barrett step for the one reduction (field.hpp, Mont128::SAcc)
+template <>
+struct SmallAcc<Mont128> {
+  Mont128::SAcc s;
+  __device__ __forceinline__ void init() { Mont128::sacc_zero(s); }
+  __device__ __forceinline__ void mac(u128 c, u32 v) { Mont128::sacc_mac(s, c, v); }
+  __device__ __forceinline__ u128 fold(const Mont128::Ctx& ctx, u128 c0) const { return Mont128::sacc_fold(ctx, s, c0); }
 };
 
 template <class F, int VEC>
-__device__ __forceinline__ void small_rows(const Pack<F, VEC> (&c)[SmallVdm::TMAX + 1], const u32* V, int t, int n,
-                                           u64* shares, size_t stride, size_t off) {
+__device__ __forceinline__ void small_rows(const typename F::Ctx& ctx, const Pack<F, VEC> (&c)[SmallVdm::TMAX + 1],
+                                           const u32* V, int t, int n, u64* shares, size_t stride, size_t off) {
   for (int i = 0; i < n; ++i) {
     const u32* row = V + i * (t + 1);
     SmallAcc<F> acc[VEC];
@@ -791,13 +800,13 @@ __device__ __forceinline__ void small_rows(const Pack<F, VEC> (&c)[SmallVdm::TMA
     }
     Pack<F, VEC> y;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) y.v[v] = acc[v].fold(c[0].v[v]);  // V[i][0] = 1
+    for (int v = 0; v < VEC; ++v) y.v[v] = acc[v].fold(ctx, c[0].v[v]);  // V[i][0] = 1
     store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
   }
 }
 
 template <class F, int VEC, int BLK = BLOCK>
-__global__ __launch_bounds__(BLK) void k_share_small(u64* shares, size_t stride, const u64* secrets,
+__global__ __launch_bounds__(BLK) void k_share_small(typename F::Ctx ctx, u64* shares, size_t stride, const u64* secrets,
                                                      const u64* coeffs, size_t cstride, SmallVdm tab, int t, int n,
                                                      size_t npacks) {
   __shared__ u32 V[SmallVdm::CAP];
@@ -811,7 +820,7 @@ __global__ __launch_bounds__(BLK) void k_share_small(u64* shares, size_t stride,
     for (int k = 1; k <= SmallVdm::TMAX; ++k) {
       if (k <= t) c[k] = load_pack<F, VEC, true>(coeffs + (size_t)(k - 1) * cstride * F::LIMBS + off);
     }
-    small_rows<F, VEC>(c, V, t, n, shares, stride, off);
+    small_rows<F, VEC>(ctx, c, V, t, n, shares, stride, off);
   }
 }
 
@@ -821,8 +830,9 @@ __global__ __launch_bounds__(BLK) void k_share_small(u64* shares, size_t stride,
 // (2.00 -> 1.83 ms at (10,3), 10^8 secrets; profiles/r2_streambench_pitch_and_regions.txt).  Mersenne61 only: Mersenne127's
 // heavier fold wants the occupancy.
 template <class F, int VEC, int T, int BLK>
-__global__ __launch_bounds__(BLK) void k_share_small_t(u64* shares, size_t stride, const u64* secrets, const u64* coeffs,
-                                                       size_t cstride, SmallVdm tab, int n, size_t npacks) {
+__global__ __launch_bounds__(BLK) void k_share_small_t(typename F::Ctx ctx, u64* shares, size_t stride, const u64* secrets,
+                                                       const u64* coeffs, size_t cstride, SmallVdm tab, int n,
+                                                       size_t npacks) {
   __shared__ u32 V[SmallVdm::CAP];
   for (int i = threadIdx.x; i < n * (T + 1); i += BLK) V[i] = tab.v[i];
   __syncthreads();
@@ -845,7 +855,7 @@ __global__ __launch_bounds__(BLK) void k_share_small_t(u64* shares, size_t strid
       }
       Pack<F, VEC> y;
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) y.v[v] = acc[v].fold(c[0].v[v]);  // V[i][0] = 1
+      for (int v = 0; v < VEC; ++v) y.v[v] = acc[v].fold(ctx, c[0].v[v]);  // V[i][0] = 1
       store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
     }
   }
@@ -864,8 +874,8 @@ struct BlockVdm {
 
 // One pack, exact threshold T known at compile time: no per-term control flow in the party loop.
 template <class F, int VEC, int G, int T>
-__device__ __forceinline__ void blocked_pack(u64* shares, size_t stride, const u64* secrets, const u64* coeffs,
-                                             size_t cstride, const u32* V, int n, size_t off) {
+__device__ __forceinline__ void blocked_pack(const typename F::Ctx& ctx, u64* shares, size_t stride, const u64* secrets,
+                                             const u64* coeffs, size_t cstride, const u32* V, int n, size_t off) {
   Pack<F, VEC> c[T + 1];
   c[0] = load_pack<F, VEC, true>(secrets + off);
 #pragma unroll
@@ -888,10 +898,10 @@ __device__ __forceinline__ void blocked_pack(u64* shares, size_t stride, const u
       } else {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          const typename F::E gv = acc[v].fold(c[k].v[v]);  // g_j(x_i), canonical
+          const typename F::E gv = acc[v].fold(ctx, c[k].v[v]);  // g_j(x_i), canonical
           acc[v].init();
           if (k / G == T / G) y.v[v] = gv;
-          else y.v[v] = F::muladd_small_lazy(y.v[v], xg, gv);
+          else y.v[v] = F::muladd_small_lazy(ctx, y.v[v], xg, gv);
         }
       }
     }
@@ -902,9 +912,9 @@ __device__ __forceinline__ void blocked_pack(u64* shares, size_t stride, const u
 }
 
 template <class F, int VEC, int G>
-__global__ __launch_bounds__(BLOCK) void k_share_blocked(u64* shares, size_t stride, const u64* secrets,
-                                                         const u64* coeffs, size_t cstride, BlockVdm tab, int t, int n,
-                                                         size_t npacks) {
+__global__ __launch_bounds__(BLOCK) void k_share_blocked(typename F::Ctx ctx, u64* shares, size_t stride,
+                                                         const u64* secrets, const u64* coeffs, size_t cstride,
+                                                         BlockVdm tab, int t, int n, size_t npacks) {
   static_assert(G >= 2 && G <= 8, "at most 7 lazy terms per group (SmallAcc bound)");
   __shared__ u32 V[BlockVdm::CAP];
   for (int i = threadIdx.x; i < n * (G + 1); i += BLOCK) V[i] = tab.v[i];
@@ -912,7 +922,7 @@ __global__ __launch_bounds__(BLOCK) void k_share_blocked(u64* shares, size_t str
   SCL_GRID_STRIDE(q, npacks) {
     const size_t off = q * VEC * F::LIMBS;
 #define SCL_BLK_CASE(T) \
-  case T: blocked_pack<F, VEC, G, T>(shares, stride, secrets, coeffs, cstride, V, n, off); break;
+  case T: blocked_pack<F, VEC, G, T>(ctx, shares, stride, secrets, coeffs, cstride, V, n, off); break;
     switch (t) {  // wave-uniform; BlockVdm::TMAX cases
       SCL_BLK_CASE(1) SCL_BLK_CASE(2) SCL_BLK_CASE(3) SCL_BLK_CASE(4) SCL_BLK_CASE(5) SCL_BLK_CASE(6) SCL_BLK_CASE(7)
       SCL_BLK_CASE(8) SCL_BLK_CASE(9) SCL_BLK_CASE(10) SCL_BLK_CASE(11) SCL_BLK_CASE(12) SCL_BLK_CASE(13)
@@ -1416,7 +1426,7 @@ __global__ __launch_bounds__(ABLOCK) void k_share_prg_small(u64* shares, size_t 
           c[j + 1].v[v] = F::from_le_word(ctx, ((u128)hi[v * NBLK + j] << 64) | lo[v * NBLK + j]);
         }
       }
-    small_rows<F, VEC>(c, V, t, n, shares, stride, off);
+    small_rows<F, VEC>(ctx, c, V, t, n, shares, stride, off);
   }
 }
 

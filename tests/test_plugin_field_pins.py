@@ -283,6 +283,20 @@ def test_gpu_mont128_against_python_big_integers(scl, p):
                 want_row = [(s + sum(c[j] * pow(x, k + 1, p) for k, c in enumerate(cs))) % p for j, s in enumerate(sec)]
                 assert O.to_ints(scl.to_host(shares[i])) == to_mont(want_row, p), f"party {i}"
             assert O.to_ints(scl.to_host(scl.shamir_recover(f, shares))) == to_mont(sec, p)
+            # the small-node kernels (one Barrett step per share for a full-width modulus; the blocked form at t = 13):
+            # extreme coefficients -- every residue p - 1, 0, 1 or a top-heavy value -- so that the lazy sums reach their
+            # bound p * sum(v) and the quotient estimate its corner cases
+            edge = [p - 1, 0, 1, p - 2, (p >> 1) + 1, (1 << 127) % p, (p - 1) ^ 0xFFFFFFFF, p - (1 << 96) if p > (1 << 96) else 3]
+            for n2, t2 in ((10, 7), (10, 3), (40, 13), (64, 16), (6, 5)):
+                N2 = 64
+                sec2 = [edge[j % len(edge)] % p for j in range(N2)]
+                cs2 = [[edge[(j * 3 + k) % len(edge)] % p if (j // 8) % 2 else p - 1 for j in range(N2)] for k in range(t2)]
+                sh2 = scl.shamir_share(f, scl.to_device(O.from_ints(to_mont(sec2, p), 2)),
+                                       torch.stack([scl.to_device(O.from_ints(to_mont(c, p), 2)) for c in cs2]), n2)
+                for i in range(n2):
+                    x = i + 1
+                    want_row = [(s0 + sum(c[j] * pow(x, k + 1, p) for k, c in enumerate(cs2))) % p for j, s0 in enumerate(sec2)]
+                    assert O.to_ints(scl.to_host(sh2[i])) == to_mont(want_row, p), f"({n2},{t2}) party {i}"
     finally:
         scl.set_mont128_prime(R - 159)
 

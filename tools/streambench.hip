@@ -256,7 +256,7 @@ int main(int argc, char** argv) {
   const double sb = 112.0 * N, rb = 88.0 * N;
   {
     const unsigned g = (unsigned)((npacks + 255) / 256);
-    hipLaunchKernelGGL((k_share_small<M61, 2>), dim3(g), dim3(256), 0, 0, ref_sh, N, secrets[0], coeffs[0], N, sv, TT, NP, npacks);
+    hipLaunchKernelGGL((k_share_small<M61, 2>), dim3(g), dim3(256), 0, 0, M61::Ctx{}, ref_sh, N, secrets[0], coeffs[0], N, sv, TT, NP, npacks);
     hipLaunchKernelGGL((k_recover_fixed<M61, 2, NP, true>), dim3(g), dim3(256), 0, 0, M61::Ctx{}, ref_out, ref_sh, N, lamt, npacks);
     CK(hipDeviceSynchronize());
     std::printf("reference round trip: diff %zu\n", diff(ref_out, secrets[0], N));
@@ -270,7 +270,7 @@ int main(int argc, char** argv) {
       const unsigned g = (unsigned)((npacks + 255) / 256);
       float ms[2];
       for (int a = 0; a < 2; ++a)
-        ms[a] = time_it([&] { hipLaunchKernelGGL((k_share_small<M61, 2>), dim3(g), dim3(256), 0, 0, shares[a], N, secrets[a], coeffs[a], N, sv, TT, NP, npacks); }, 10);
+        ms[a] = time_it([&] { hipLaunchKernelGGL((k_share_small<M61, 2>), dim3(g), dim3(256), 0, 0, M61::Ctx{}, shares[a], N, secrets[a], coeffs[a], N, sv, TT, NP, npacks); }, 10);
       report("share", "library k_share_small b256", ms[0], ms[1], sb, diff(ref_sh, shares[0], (size_t)NP * N) + diff(ref_sh, shares[1], (size_t)NP * N));
     }
 #define SHR2(BLK, NTS, PK, LDSB)                                                                                     \
@@ -330,7 +330,7 @@ int main(int argc, char** argv) {
       const unsigned g = (unsigned)((npacks + 255) / 256), g64 = (unsigned)((npacks + 63) / 64);
       float ms_s[2], ms_r[2];
       for (int a = 0; a < 2; ++a) {
-        ms_s[a] = time_it([&] { hipLaunchKernelGGL((k_share_small<M61, 2>), dim3(g), dim3(256), 0, 0, pitched[a], pitch, secrets[a], coeffs[a], N, sv, TT, NP, npacks); }, 10);
+        ms_s[a] = time_it([&] { hipLaunchKernelGGL((k_share_small<M61, 2>), dim3(g), dim3(256), 0, 0, M61::Ctx{}, pitched[a], pitch, secrets[a], coeffs[a], N, sv, TT, NP, npacks); }, 10);
         ms_r[a] = time_it([&] { hipLaunchKernelGGL((k_recover_fixed<M61, 2, NP, true, 64>), dim3(g64), dim3(64), 19456, 0, M61::Ctx{}, out[a], pitched[a], pitch, lamt, npacks); }, 10);
       }
       std::printf("pitch N + %9zu B: share %7.3f / %7.3f ms  recover(b64, 8 waves/CU) %7.3f / %7.3f ms  diff %zu\n", pad_bytes, ms_s[0], ms_s[1],
