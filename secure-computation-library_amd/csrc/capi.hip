@@ -70,7 +70,8 @@ thread_local Knob g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
 // Headline streaming kernels (k_recover_fixed, k_share_small): workgroup size and resident waves per CU
 // (kernels.hpp, "Launch geometry"); "stream_block" 64 | 256, "stream_waves" 0 = no cap
 thread_local Knob g_stream_block{64};
-thread_local Knob g_stream_waves{8};
+thread_local Knob g_stream_waves{-1};  // -1 = by element size: 10 for one-word elements, 12 for wider ones
+                                        // (profiles/r2_probe_cap_rec.txt, r2_probe_c3_waves.txt)
 thread_local Knob g_share_waves{8};  // the same cap for the Mersenne61 small-node share kernel ("share_waves"; 0 = the
                                      // 256-thread kernel without a cap)
 
@@ -594,16 +595,21 @@ int launch_share_mfma(u64* shares, size_t stride, const u64* secrets, const u64*
 
 // C[M x N] = A[M x K] * B[K x N] over Mersenne61 on the matrix cores: A's digit planes are built on the
 // device into a stream-ordered temporary, B's rows play the role of the coefficient rows.
+// the digit planes of A into `tab` (mf_a_bytes(KS, MT) bytes of device memory the caller owns)
+template <int KS, int MT>
+int mfma_planes_of(void* tab, const u64* A, size_t lda, size_t M, size_t K, hipStream_t st) {
+  HIP_TRY(hipMemsetAsync(tab, 0, mf_a_bytes(KS, MT), st));
+  hipLaunchKernelGGL((k_mfma_planes_from_matrix<KS, MT>), dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, st,
+                     static_cast<unsigned char*>(tab), A, lda, (int)M, (int)K);
+  return hipGetLastError() == hipSuccess ? SCL_OK : fail(SCL_ERR_HIP, "k_mfma_planes_from_matrix launch failed");
+}
+
 template <int KS, int MT>
 int matmul_mfma_impl(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M, size_t K,
                      size_t N, hipStream_t st) {
   void* tab = nullptr;
-  const size_t bytes = mf_a_bytes(KS, MT);
-  SCL_TRY(temp_acquire(bytes, st, &tab));
-  HIP_TRY(hipMemsetAsync(tab, 0, bytes, st));
-  hipLaunchKernelGGL((k_mfma_planes_from_matrix<KS, MT>), dim3((unsigned)((M * K + 255) / 256)), dim3(256), 0, st,
-                     static_cast<unsigned char*>(tab), A, lda, (int)M, (int)K);
-  int rc = hipGetLastError() == hipSuccess ? SCL_OK : fail(SCL_ERR_HIP, "k_mfma_planes_from_matrix launch failed");
+  SCL_TRY(temp_acquire(mf_a_bytes(KS, MT), st, &tab));
+  int rc = mfma_planes_of<KS, MT>(tab, A, lda, M, K, st);
   if (rc == SCL_OK)
     rc = launch_share_mfma<KS, MT>(C, ldc, B, B + ldb, ldb, static_cast<const unsigned char*>(tab), (int)K - 1, (int)M, N,
                                    st);
@@ -614,12 +620,55 @@ int matmul_mfma_impl(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B,
 int matmul_mfma(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M, size_t K, size_t N,
                 hipStream_t st) {
   const int KS = K <= 32 ? 1 : 2;
-  const int MT = M <= 32 ? 1 : M <= 64 ? 2 : 4;
+  // (one row tile with two k-steps would need 160 KiB for the staged right factor: such shapes take two row tiles)
+  const int MT = (M <= 32 && KS == 1) ? 1 : M <= 64 ? 2 : 4;
 #define MM_CASE(ks, mt) \
   if (KS == ks && MT == mt) return matmul_mfma_impl<ks, mt>(C, ldc, A, lda, B, ldb, M, K, N, st);
-  MM_CASE(1, 1) MM_CASE(1, 2) MM_CASE(1, 4) MM_CASE(2, 1) MM_CASE(2, 2) MM_CASE(2, 4)
+  MM_CASE(1, 1) MM_CASE(1, 2) MM_CASE(1, 4) MM_CASE(2, 2) MM_CASE(2, 4)
 #undef MM_CASE
   return fail(SCL_ERR_BAD_ARG, "matmul_mfma: unsupported shape");
+}
+
+// shamirRecoverD as a contraction (k_detect_compare): L [rows x d1] host elements, rows = nchk + 1.  The product Y is kept
+// for a slab of secrets at a time in the per-thread temporary, next to L and its digit planes.
+template <int KS, int MT>
+int detect_mfma_impl(u64* out, unsigned char* status, const u64* shares, size_t stride, const std::vector<u64>& L,
+                     size_t rows, size_t d1, size_t N, unsigned long long* cnt, hipStream_t st) {
+  const size_t slab = std::min<size_t>(N, (size_t)1 << 22);
+  const size_t ldy = (slab + 63) / 64 * 64;
+  const size_t abytes = (mf_a_bytes(KS, MT) + 255) / 256 * 256, lbytes = (rows * d1 * 8 + 255) / 256 * 256;
+  void* tmp = nullptr;
+  SCL_TRY(temp_acquire(abytes + lbytes + rows * ldy * 8, st, &tmp));
+  unsigned char* base = static_cast<unsigned char*>(tmp);
+  u64* L_dev = reinterpret_cast<u64*>(base + abytes);
+  u64* Y = reinterpret_cast<u64*>(base + abytes + lbytes);
+  auto body = [&]() -> int {
+    HIP_TRY(hipMemcpyAsync(L_dev, L.data(), rows * d1 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // L is a host temporary of the caller
+    SCL_TRY((mfma_planes_of<KS, MT>(base, L_dev, d1, rows, d1, st)));
+    for (size_t s0 = 0; s0 < N; s0 += slab) {
+      const size_t ns = std::min(slab, N - s0);
+      SCL_TRY((launch_share_mfma<KS, MT>(Y, ldy, shares + s0, shares + stride + s0, stride, base, (int)d1 - 1, (int)rows, ns, st)));
+      hipLaunchKernelGGL((k_detect_compare<M61>), dim3(grid_for(ns)), dim3(BLOCK), 0, st, out + s0, status + s0, Y, ldy,
+                         shares + d1 * stride + s0, stride, (int)rows - 1, ns, cnt);
+      HIP_TRY(hipGetLastError());
+    }
+    return SCL_OK;
+  };
+  const int rc = body();
+  (void)temp_release(st);
+  return rc;
+}
+
+int detect_mfma(u64* out, unsigned char* status, const u64* shares, size_t stride, const std::vector<u64>& L, size_t rows,
+                size_t d1, size_t N, unsigned long long* cnt, hipStream_t st) {
+  const int KS = d1 <= 32 ? 1 : 2;
+  const int MT = (rows <= 32 && KS == 1) ? 1 : rows <= 64 ? 2 : 4;
+#define DM_CASE(ks, mt) \
+  if (KS == ks && MT == mt) return detect_mfma_impl<ks, mt>(out, status, shares, stride, L, rows, d1, N, cnt, st);
+  DM_CASE(1, 1) DM_CASE(1, 2) DM_CASE(1, 4) DM_CASE(2, 2) DM_CASE(2, 4)
+#undef DM_CASE
+  return fail(SCL_ERR_BAD_ARG, "detect_mfma: unsupported shape");
 }
 
 int share_mfma(const BigTable<M61>& al, u64* shares, size_t stride, const u64* secrets, const u64* coeffs,
@@ -715,7 +764,8 @@ struct RecoverFixed {
     if (m == M) {
       const bool wave_groups = g_stream_block.load() == 64;
       const int blk = wave_groups ? 64 : BLOCK;
-      const size_t pad = residency_pad(g_stream_waves.load(), blk, 0);
+      const long sw = g_stream_waves.load();
+      const size_t pad = residency_pad(sw < 0 ? (F::LIMBS == 1 ? 10 : 12) : sw, blk, 0);
       const dim3 g(grid_for_block(npacks, blk));
       if (!g_nontemporal.load())
         hipLaunchKernelGGL((k_recover_fixed<F, VEC, M, false>), dim3(grid_for(npacks)), dim3(BLOCK), 0, st, ctx, out,
@@ -1631,9 +1681,28 @@ int scl_hip_shamir_recover_detect(int field, uint64_t* out, unsigned char* statu
     std::vector<typename F::E> ns(alphas.begin(), alphas.begin() + d1), L((nchk + 1) * d1);
     for (size_t r = 0; r < nchk; ++r) SCL_TRY(lagrange<F>(ctx, ns, alphas[d1 + r], L.data() + r * d1));
     SCL_TRY(lagrange<F>(ctx, ns, x_host ? F::ld(x_host) : F::zero(), L.data() + nchk * d1));
+    const size_t rows = nchk + 1;
+    if constexpr (F::TAG == 0) {
+      // many rows over many shares (large t and d): the rows-times-shares product on the matrix cores, then one compare
+      // pass -- 1.26 G secrets/s for the vector-ALU kernel at t = d = 42 (profiles/r2_probe_detect.txt)
+      const long mode = g_mfma.load();
+      if (rows <= 128 && d1 >= 2 && d1 <= 64 && (mode > 0 || (mode == 0 && rows * d1 >= 512 && N >= 4096))) {
+        void* sc;
+        SCL_TRY(scratch(64, &sc));
+        unsigned long long* cnt = static_cast<unsigned long long*>(sc);
+        HIP_TRY(hipMemsetAsync(cnt, 0, 8, S(stream)));
+        std::vector<u64> Lw(L.begin(), L.end());
+        SCL_TRY(detect_mfma(out, status, shares, stride, Lw, rows, d1, N, cnt, S(stream)));
+        unsigned long long h = 0;
+        HIP_TRY(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, S(stream)));
+        HIP_TRY(hipStreamSynchronize(S(stream)));
+        if (num_bad_host) *num_bad_host = (size_t)h;
+        if (h) return fail(SCL_ERR_ERROR_DETECTED, scl_hip_status_message(SCL_ERR_ERROR_DETECTED));
+        return SCL_OK;
+      }
+    }
     // device image of L as prepared constants: [row block][k][RB], zero rows pad the last block (k_recover_detect)
     typedef typename F::KC KC;
-    const size_t rows = nchk + 1;
     // rows per pass: the 256-bit field's accumulators are 24 registers each (two rows), the others take four or eight
     // (sixteen rows per pass with one secret per lane was measured for Mersenne61: no faster -- the kernel is
     // bound by multiply issue, not by the re-reads)

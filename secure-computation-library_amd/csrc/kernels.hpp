@@ -1720,6 +1720,25 @@ __global__ __launch_bounds__(BLOCK) void k_recover_detect(typename F::Ctx ctx, u
   }
 }
 
+// shamirRecoverD at large (t, d) over Mersenne61 as a contraction (shamir.h:129-136 is nchk + 1 Lagrange rows applied to the
+// same d + 1 shares): Y = L * S runs on the matrix cores (share_mfma.hpp, the kernel that evaluates V * C when sharing);
+// this pass compares rows 0 .. nchk-1 of Y with the shares they re-derive and hands out row nchk, the value at x.
+// Same outputs as k_recover_detect: status 1 and a zero result where a check fails, the failures counted.
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_detect_compare(u64* out, unsigned char* status, const u64* Y, size_t ldy,
+                                                          const u64* checked, size_t stride, int nchk, size_t N,
+                                                          unsigned long long* bad_count) {
+  static_assert(F::LIMBS == 1, "one-word elements");
+  SCL_GRID_STRIDE(s, N) {
+    bool bad = false;
+    for (int r = 0; r < nchk; ++r) bad |= Y[(size_t)r * ldy + s] != checked[(size_t)r * stride + s];
+    out[s] = bad ? 0 : Y[(size_t)nchk * ldy + s];
+    status[s] = bad ? 1 : 0;
+    const unsigned long long nb = __popcll(__ballot(bad));
+    if (nb && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(bad)) - 1)) atomicAdd(bad_count, nb);
+  }
+}
+
 // ---- error-correcting recovery: shamirRecoverC (Berlekamp-Welch, shamir.h:202-259) ----------------------------
 // What the reference computes per secret is fixed by algebra, not by its elimination order: for e = t, t-1, .. 0
 // it builds the n x n system  s_i E(a_i) = Q(a_i)  (E monic of degree e, deg Q <= n-1-e, n = 3t+1) and takes the

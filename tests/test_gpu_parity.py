@@ -500,6 +500,54 @@ def test_recover_detect(scl, port, f, name):
     assert ei.value.reference_message == "not enough shares provided to detect errors"
 
 
+@pytest.mark.parametrize("t,d,extra,N", [(42, 42, 0, 5000), (23, 23, 1, 4100), (30, 20, 3, 4500), (63, 63, 0, 4200), (10, 60, 0, 4097)])
+def test_recover_detect_on_matrix_cores(scl, port, t, d, extra, N):
+    """shamirRecoverD over Mersenne61 with many check rows over many shares: the rows-times-shares product runs on the matrix
+    cores (k_share_mfma_* as a matmul) and k_detect_compare does the checks.  Same statuses, values and count as the oracle
+    and as the vector-ALU kernel ("mfma" -1), errors in checked rows, in the interpolated rows and in ignored shares."""
+    f, L = O.M61, 1
+    m = d + t + extra
+    nodes = np.stack([port.from_int(f, i + 1) for i in range(m)])
+    coeffs = rand_elems(port, f, (d + 1) * N, b"mcd-c").reshape(N, d + 1, L)
+    # shares of N polynomials of degree d at 1..m, through the library's own matmul (Vandermonde rows times coefficients)
+    V = O.from_ints([pow(i + 1, k, (1 << 61) - 1) for i in range(m) for k in range(d + 1)], L).reshape(m, d + 1, L)
+    soa_sh = scl.matmul(f, dev(scl, V), dev(scl, soa(coeffs)))
+    aos = np.ascontiguousarray(host(scl, soa_sh).transpose(1, 0, 2))
+    some = [0, 1, N // 2, N - 1]
+    for s in some:
+        assert np.array_equal(aos[s], port.poly_eval(f, coeffs[s], nodes))
+    junk = rand_elems(port, f, N, b"mcd-j")
+    rng = np.random.default_rng(t * 100 + d)
+    hit = rng.choice(N, N // 6, replace=False)
+    for k, s in enumerate(hit):
+        aos[s, k % m] = junk[s]
+    shares = dev(scl, soa(aos))
+    x = port.from_int(f, 0)
+    res = {}
+    for mode in (1, -1):
+        scl.set_tuning("mfma", mode)
+        try:
+            res[mode] = scl.shamir_recover_detect(f, shares, t, d=d, alphas=nodes, x=x) if (d != t or extra) else scl.shamir_recover_detect(f, shares, t)
+        finally:
+            scl.set_tuning("mfma", 0)
+    (o1, s1, b1), (o0, s0, b0) = res[1], res[-1]
+    assert b1 == b0 and np.array_equal(s1.cpu().numpy(), s0.cpu().numpy()) and np.array_equal(host(scl, o1), host(scl, o0))
+    st = s1.cpu().numpy()
+    sub = np.concatenate([hit[:40], np.setdiff1d(np.arange(N), hit)[:40]])      # against the oracle on a sample
+    if d == t and extra == 0:
+        want_out, want_st = port.shamir_recover_d(f, aos[sub], t)
+        assert np.array_equal(st[sub], want_st) and np.array_equal(host(scl, o1)[sub], want_out)
+    for k, s in enumerate(hit):
+        i = k % m
+        if d + 1 <= i < d + t and not np.array_equal(junk[s], port.poly_eval(f, coeffs[s], nodes[i:i + 1])[0]):
+            assert st[s] == 1
+        if i >= d + t:
+            assert st[s] == 0 and np.array_equal(host(scl, o1)[s], coeffs[s, 0])
+    clean = np.setdiff1d(np.arange(N), hit)
+    assert not st[clean].any() and np.array_equal(host(scl, o1)[clean], coeffs[clean, 0])
+    assert b1 == int(st.sum())
+
+
 @pytest.mark.parametrize("f", ALL_FIELDS)
 @pytest.mark.parametrize("t,N", [(1, 7), (2, 300), (4, 513), (5, 1001), (8, 257), (9, 600), (13, 333), (17, 64), (20, 129), (42, 70)])
 def test_recover_detect_row_blocks(scl, port, f, t, N):
@@ -616,7 +664,7 @@ def test_matmul_vs_oracle(scl, port, f, M, K, N):
     assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), port.matmul(f, A, B))
 
 
-@pytest.mark.parametrize("M,K,N", [(128, 43, 5000), (64, 22, 4099), (100, 64, 300), (1, 1, 70), (33, 5, 129)])
+@pytest.mark.parametrize("M,K,N", [(128, 43, 5000), (64, 22, 4099), (100, 64, 300), (1, 1, 70), (33, 5, 129), (16, 40, 4500), (32, 64, 700)])
 def test_matmul_on_matrix_cores(scl, port, M, K, N):
     """Matrix::multiply with a small left factor through the i8-digit MFMA kernel == the oracle's i-k-j loop"""
     f, L = O.M61, 1

@@ -32,9 +32,11 @@ def timed(fn):
     return tm.elapsed_ms() / 10
 
 
+caps = [int(v) for v in sys.argv[1:] if not v.startswith("-")] or [0, 8]
+share_fixed = "--share-8" in sys.argv      # sweep the reconstruct kernel's cap only
 for rnd in range(2):
-    for sw in (0, 8):
-        scl.set_tuning("share_waves", sw)
+    for sw in caps:
+        scl.set_tuning("share_waves", 8 if share_fixed else sw)
         scl.set_tuning("stream_waves", sw)
         row = []
         for secrets, coeffs, shares, out in sets:
