@@ -1486,7 +1486,19 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
       hipLaunchKernelGGL((k_share<F, VEC, TREG, false>), g, blk, 0, S(stream), ctx, sh, share_stride, se, co,     \
                          coeff_stride, al, (int)t, (int)n, npacks);                                               \
   } while (0)
-      if (t <= 4) SHARE_LAUNCH(4);
+      bool launched = false;
+      if constexpr (F::TAG == 3) {
+        if (smallx && t >= 5 && t <= 16 && !g_force_table.load()) {  // per-node Horner code ("force_table" 1: the tested-bits form)
+          // a few persistent workgroups per CU keep the waves of a CU on the same few nodes' code (4.91 against 5.06 ms at
+          // C4's shard size with one pack per thread; profiles/r2_gf128_node_horner.txt)
+          const dim3 gg(g_max_blocks.load() > 0 ? g.x : std::min<unsigned>(g.x, 4096u));
+          hipLaunchKernelGGL(k_share_gf_nodes, gg, blk, 0, S(stream), sh, share_stride, se, co, coeff_stride, al, (int)t, (int)n,
+                             npacks);
+          launched = true;
+        }
+      }
+      if (launched) {
+      } else if (t <= 4) SHARE_LAUNCH(4);
       else if (t <= 16) SHARE_LAUNCH(16);
       else SHARE_LAUNCH(48);
 #undef SHARE_LAUNCH

@@ -593,6 +593,147 @@ __device__ __forceinline__ void stage_nodes(const BigTable<F>& tab, int n, typen
   __syncthreads();
 }
 
+// ---- GF(2^128) Horner at a node known at compile time ---------------------------------------------------------------------
+// Gf128::muladd_small tests the bits of the (wave-uniform) node with a scalar branch each and reduces after every step:
+// at (40,13) a Horner step costs 152 SIMD-cycles per wave for ~108 cycles of vector work (7 scalar test-and-branch pairs per
+// step; profiles/r2_gf128_node_horner.txt).  With the node A a template parameter a step is straight-line -- one shifted copy
+// of y per set bit, no tests -- and y lives in FIVE words: the bits shifted past x^127 collect in the fifth (deg A <= 5 per
+// step) and come back down through x^128 = x^7 + x^2 + x + 1 once per 32 / deg A steps instead of every step.
+__device__ __forceinline__ void gf_fold5(u32 (&y)[5]) {
+  const u32 t = y[4];
+  y[0] ^= t ^ (t << 1) ^ (t << 2) ^ (t << 7);
+  y[1] ^= (t >> 31) ^ (t >> 30) ^ (t >> 25);
+  y[4] = 0;
+}
+template <u32 A>
+__device__ __forceinline__ void gf_node_step(u32 (&y)[5], u128 c) {
+  u32 r0 = (u32)c, r1 = (u32)(c >> 32), r2 = (u32)(c >> 64), r3 = (u32)(c >> 96), r4 = 0;
+  if constexpr (A & 1u) {
+    r0 ^= y[0];
+    r1 ^= y[1];
+    r2 ^= y[2];
+    r3 ^= y[3];
+    r4 ^= y[4];
+  }
+#define SCL_GFN_BIT(B)                                        \
+  if constexpr ((A >> B) & 1u) {                              \
+    r0 ^= y[0] << B;                                          \
+    r1 ^= __builtin_amdgcn_alignbit(y[1], y[0], 32 - B);      \
+    r2 ^= __builtin_amdgcn_alignbit(y[2], y[1], 32 - B);      \
+    r3 ^= __builtin_amdgcn_alignbit(y[3], y[2], 32 - B);      \
+    r4 ^= __builtin_amdgcn_alignbit(y[4], y[3], 32 - B);      \
+  }
+  SCL_GFN_BIT(1) SCL_GFN_BIT(2) SCL_GFN_BIT(3) SCL_GFN_BIT(4) SCL_GFN_BIT(5)
+#undef SCL_GFN_BIT
+  y[0] = r0;
+  y[1] = r1;
+  y[2] = r2;
+  y[3] = r3;
+  y[4] = r4;
+}
+// The coefficients of one secret as two 32-word register vectors (word 4k + j of coefficient k: k < 8 in lo, 8 <= k < 16 in
+// hi), so that the Horner loop can stay a LOOP: a wave-uniform k indexes them through the register-index mode
+// (s_set_gpr_idx / v_movrel), four moves per step.  Why a loop: with the steps unrolled, the code of one (node, threshold)
+// pair is 2.6 KB that a wave runs once per party -- 63 nodes of it is 1.4 MB per kernel, every wave streams 100 KB of
+// instructions per secret and the kernel becomes instruction-fetch-bound (10.0 ms against 6.3 for the branchy form, at any
+// occupancy; profiles/r2_gf128_node_horner.txt).  Rolled, a node's code is ~0.5 KB and all 63 stay in the instruction cache.
+typedef u32 v32u __attribute__((ext_vector_type(32)));
+struct GfCoeffs {
+  v32u lo, hi;
+};
+// coefficient k of the pack at `off`: the secret for k = 0, row k - 1 of the coefficient matrix above that
+__device__ __forceinline__ u128 gf_load_coeff(const u64* secrets, const u64* coeffs, size_t cstride, size_t off, int k) {
+  const Pack<Gf128, 1> p = k == 0 ? load_pack<Gf128, 1, true>(secrets + off)
+                                  : load_pack<Gf128, 1, true>(coeffs + (size_t)(k - 1) * cstride * Gf128::LIMBS + off);
+  return p.v[0];
+}
+template <int T>
+__device__ __forceinline__ GfCoeffs gf_load_coeffs(const u64* secrets, const u64* coeffs, size_t cstride, size_t off) {
+  GfCoeffs cf;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const u128 v = k < T ? gf_load_coeff(secrets, coeffs, cstride, off, k) : (u128)0;
+    if (k < 8) {
+      cf.lo[4 * k] = (u32)v;
+      cf.lo[4 * k + 1] = (u32)(v >> 32);
+      cf.lo[4 * k + 2] = (u32)(v >> 64);
+      cf.lo[4 * k + 3] = (u32)(v >> 96);
+    } else {
+      cf.hi[4 * (k - 8)] = (u32)v;
+      cf.hi[4 * (k - 8) + 1] = (u32)(v >> 32);
+      cf.hi[4 * (k - 8) + 2] = (u32)(v >> 64);
+      cf.hi[4 * (k - 8) + 3] = (u32)(v >> 96);
+    }
+  }
+  return cf;
+}
+template <int T, u32 A>
+__device__ __forceinline__ u128 gf_horner_node(u128 top, const GfCoeffs& cf) {
+  static_assert(A >= 1 && A < 64 && T >= 1 && T <= 16, "nodes of degree <= 5, at most 16 steps");
+  constexpr int DEG = A >= 32 ? 5 : A >= 16 ? 4 : A >= 8 ? 3 : A >= 4 ? 2 : A >= 2 ? 1 : 0;
+  constexpr int EVERY = DEG ? 32 / DEG : (1 << 30);  // steps the fifth word can take before it must come down
+  u32 y[5] = {(u32)top, (u32)(top >> 32), (u32)(top >> 64), (u32)(top >> 96), 0};
+  int since = 0;
+  if constexpr (T > 8) {
+#pragma unroll 1
+    for (int b = 4 * (T - 9); b >= 0; b -= 4) {
+      const u128 ck = (u128)cf.hi[b] | ((u128)cf.hi[b + 1] << 32) | ((u128)cf.hi[b + 2] << 64) | ((u128)cf.hi[b + 3] << 96);
+      gf_node_step<A>(y, ck);
+      if (++since == EVERY) {
+        gf_fold5(y);
+        since = 0;
+      }
+    }
+  }
+#pragma unroll 1
+  for (int b = 4 * ((T < 8 ? T : 8) - 1); b >= 0; b -= 4) {
+    const u128 ck = (u128)cf.lo[b] | ((u128)cf.lo[b + 1] << 32) | ((u128)cf.lo[b + 2] << 64) | ((u128)cf.lo[b + 3] << 96);
+    gf_node_step<A>(y, ck);
+    if (++since == EVERY) {
+      gf_fold5(y);
+      since = 0;
+    }
+  }
+  gf_fold5(y);
+  return (u128)y[0] | ((u128)y[1] << 32) | ((u128)y[2] << 64) | ((u128)y[3] << 96);
+}
+// the share at node a (wave-uniform): nodes 1..63 through their own code, anything else by the tested-bits form
+template <int T>
+__device__ __forceinline__ u128 gf_horner_at(u32 a, u128 top, const GfCoeffs& cf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  a = __builtin_amdgcn_readfirstlane(a);
+#endif
+  switch (a) {
+#define SCL_GFN(A) \
+  case A:          \
+    return gf_horner_node<T, A>(top, cf);
+    SCL_GFN(1) SCL_GFN(2) SCL_GFN(3) SCL_GFN(4) SCL_GFN(5) SCL_GFN(6) SCL_GFN(7) SCL_GFN(8) SCL_GFN(9) SCL_GFN(10) SCL_GFN(11) SCL_GFN(12) SCL_GFN(13) SCL_GFN(14) SCL_GFN(15) SCL_GFN(16) SCL_GFN(17) SCL_GFN(18) SCL_GFN(19) SCL_GFN(20) SCL_GFN(21) SCL_GFN(22) SCL_GFN(23) SCL_GFN(24) SCL_GFN(25) SCL_GFN(26) SCL_GFN(27) SCL_GFN(28) SCL_GFN(29) SCL_GFN(30) SCL_GFN(31) SCL_GFN(32) SCL_GFN(33) SCL_GFN(34) SCL_GFN(35) SCL_GFN(36) SCL_GFN(37) SCL_GFN(38) SCL_GFN(39) SCL_GFN(40) SCL_GFN(41) SCL_GFN(42) SCL_GFN(43) SCL_GFN(44) SCL_GFN(45) SCL_GFN(46) SCL_GFN(47) SCL_GFN(48) SCL_GFN(49) SCL_GFN(50) SCL_GFN(51) SCL_GFN(52) SCL_GFN(53) SCL_GFN(54) SCL_GFN(55) SCL_GFN(56) SCL_GFN(57) SCL_GFN(58) SCL_GFN(59) SCL_GFN(60) SCL_GFN(61) SCL_GFN(62) SCL_GFN(63)
+#undef SCL_GFN
+    default: break;
+  }
+  u128 y = top;
+#pragma unroll
+  for (int k = T - 1; k >= 0; --k) {
+    const u128 ck = k < 8 ? ((u128)cf.lo[4 * k] | ((u128)cf.lo[4 * k + 1] << 32) | ((u128)cf.lo[4 * k + 2] << 64) | ((u128)cf.lo[4 * k + 3] << 96))
+                          : ((u128)cf.hi[4 * (k - 8)] | ((u128)cf.hi[4 * (k - 8) + 1] << 32) | ((u128)cf.hi[4 * (k - 8) + 2] << 64) |
+                             ((u128)cf.hi[4 * (k - 8) + 3] << 96));
+    y = Gf128::muladd_small_lazy(y, a, ck);
+  }
+  return y;
+}
+// the GF(2^128) form of horner_pack_exact at small nodes
+template <int T>
+__device__ __forceinline__ void gf_horner_pack_exact(u64* shares, size_t stride, const u64* secrets, const u64* coeffs,
+                                                     size_t cstride, const u32* alpha32_lds, int n, size_t off) {
+  const GfCoeffs cf = gf_load_coeffs<T>(secrets, coeffs, cstride, off);
+  const u128 top = gf_load_coeff(secrets, coeffs, cstride, off, T);
+  for (int i = 0; i < n; ++i) {
+    Pack<Gf128, 1> y;
+    y.v[0] = gf_horner_at<T>(alpha32_lds[i], top, cf);
+    store_pack<Gf128, 1, true>(shares + (size_t)i * stride * Gf128::LIMBS + off, y);
+  }
+}
+
 // One pack with the threshold T known at compile time: the party loop carries no per-term control flow (the
 // wave-uniform "k <= t" tests of horner_rows cost about as much as the arithmetic at t ~ 10).
 template <class F, int VEC, int T, bool SMALLX>
@@ -624,6 +765,28 @@ __device__ __forceinline__ void horner_pack_exact(const typename F::Ctx& ctx, u6
       }
     }
     store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
+  }
+}
+
+// shamirSecretShare over GF(2^128) at small nodes (every node < 2^16 as a bit pattern), 5 <= t <= 16: per-node Horner code
+// over register-indexed coefficients (gf_horner_at).  Four waves per SIMD asked of the register allocator: the two
+// 32-word coefficient vectors and a dozen temporaries need no more.
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_share_gf_nodes(
+    u64* shares, size_t stride, const u64* secrets, const u64* coeffs, size_t cstride, BigTable<Gf128> tab, int t, int n,
+    size_t npacks) {
+  __shared__ u32 alpha32[BigTable<Gf128>::CAP];
+  for (int i = threadIdx.x; i < n; i += BLOCK) alpha32[i] = Gf128::low32(tab.v[i]);
+  __syncthreads();
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * Gf128::LIMBS;
+#define SCL_GFX_CASE(T) \
+  case T: gf_horner_pack_exact<T>(shares, stride, secrets, coeffs, cstride, alpha32, n, off); break;
+    switch (t) {  // wave-uniform
+      SCL_GFX_CASE(5) SCL_GFX_CASE(6) SCL_GFX_CASE(7) SCL_GFX_CASE(8) SCL_GFX_CASE(9) SCL_GFX_CASE(10) SCL_GFX_CASE(11)
+      SCL_GFX_CASE(12) SCL_GFX_CASE(13) SCL_GFX_CASE(14) SCL_GFX_CASE(15) SCL_GFX_CASE(16)
+      default: break;
+    }
+#undef SCL_GFX_CASE
   }
 }
 
