@@ -112,7 +112,9 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the sto
  *                elements and 12 for wider ones
  *   share_waves  (default 8) the same cap for the Mersenne61 small-node share kernel (threshold compiled in, stream_block
  *                workgroups); 0 = the 256-thread kernel with the threshold at run time, no cap
- *   mfma         1: force the matrix-core share / matmul path, -1: never use it
+ *   mfma         1: force the matrix-core share / matmul / recover_detect path, -1: never use it
+ *   prg_two_pass PRG-driven sharing: 1 = always draw the coefficient rows into a temporary and share from there, -1 = always the
+ *                fused kernels (where one exists), 0 (default) = by shape and field
  *   mfma_areg    (default 1) matrix-core kernel keeps V's digit fragments in registers for 97..128 parties
  *   mfma_pipe    (default 2) matrix-core kernel for 97..128 parties: 2 = two software-pipelined waves per SIMD on
  *                16x16x64 tiles (thresholds 32..63; smaller ones as 1), 1 = one pipelined wave per SIMD, 0 = word bursts */

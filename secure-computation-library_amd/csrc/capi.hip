@@ -67,6 +67,7 @@ thread_local Knob g_mfma_pipe{2};  // 4-row-tile shapes: 2 = two pipelined waves
                                    // rows; else as 1), 1 = one pipelined wave per SIMD, 0 = burst kernel ("mfma_pipe")
 thread_local Knob g_mfma_areg{1};  // register-resident V fragments for the 4-row-tile shapes ("mfma_areg" tuning key)
 thread_local Knob g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
+thread_local Knob g_prg_two_pass{0};  // PRG-driven sharing: 0 auto, 1 always two passes, -1 always the fused kernels
 // Headline streaming kernels (k_recover_fixed, k_share_small): workgroup size and resident waves per CU
 // (kernels.hpp, "Launch geometry"); "stream_block" 64 | 256, "stream_waves" 0 = no cap
 thread_local Knob g_stream_block{64};
@@ -217,12 +218,14 @@ struct TempArena {
   hipEvent_t done = nullptr;
   bool pending = false;
 };
-thread_local TempArena g_temp;
+// arena 0: tables, queues and products of one call; arena 1: the coefficient rows of a two-pass PRG sharing (whose second
+// pass may take arena 0 itself)
+thread_local TempArena g_temps[2];
 
-int temp_acquire(size_t bytes, hipStream_t st, void** out) {
+int temp_acquire(size_t bytes, hipStream_t st, void** out, int which = 0) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  TempArena& a = g_temp;
+  TempArena& a = g_temps[which];
   if (a.dev && (a.device != dev || a.bytes < bytes)) {
     if (a.pending) HIP_TRY(hipEventSynchronize(a.done));
     (void)hipFree(a.dev);
@@ -240,9 +243,9 @@ int temp_acquire(size_t bytes, hipStream_t st, void** out) {
   return SCL_OK;
 }
 
-int temp_release(hipStream_t st) {
-  HIP_TRY(hipEventRecord(g_temp.done, st));
-  g_temp.pending = true;
+int temp_release(hipStream_t st, int which = 0) {
+  HIP_TRY(hipEventRecord(g_temps[which].done, st));
+  g_temps[which].pending = true;
   return SCL_OK;
 }
 
@@ -674,12 +677,12 @@ int detect_mfma(u64* out, unsigned char* status, const u64* shares, size_t strid
 int share_mfma(const BigTable<M61>& al, u64* shares, size_t stride, const u64* secrets, const u64* coeffs,
                size_t cstride, size_t N, size_t t, size_t n, hipStream_t st) {
   const int KS = t + 1 <= 32 ? 1 : 2;
-  const int MT = n <= 32 ? 1 : n <= 64 ? 2 : 4;
+  const int MT = (n <= 32 && KS == 1) ? 1 : n <= 64 ? 2 : 4;  // (as matmul_mfma: no one-row-tile form with two k-steps)
   const unsigned char* tab = nullptr;
   SCL_TRY(mfma_table(al, n, t, KS, MT, &tab));
 #define MF_CASE(ks, mt) \
   if (KS == ks && MT == mt) return launch_share_mfma<ks, mt>(shares, stride, secrets, coeffs, cstride, tab, (int)t, (int)n, N, st);
-  MF_CASE(1, 1) MF_CASE(1, 2) MF_CASE(1, 4) MF_CASE(2, 1) MF_CASE(2, 2) MF_CASE(2, 4)
+  MF_CASE(1, 1) MF_CASE(1, 2) MF_CASE(1, 4) MF_CASE(2, 2) MF_CASE(2, 4)
 #undef MF_CASE
   return fail(SCL_ERR_BAD_ARG, "share_mfma: unsupported shape");
 }
@@ -978,7 +981,8 @@ int scl_hip_thread_cleanup(void) {
     HIP_TRY(hipFree(g_scratch.dev));
     g_scratch = Scratch{};
   }
-  if (g_temp.dev) {
+  for (TempArena& g_temp : g_temps) {
+    if (!g_temp.dev) continue;
     if (g_temp.pending) HIP_TRY(hipEventSynchronize(g_temp.done));
     HIP_TRY(hipFree(g_temp.dev));
     (void)hipEventDestroy(g_temp.done);
@@ -995,6 +999,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "force_scalar") g_force_scalar = value;
   else if (k == "force_table") g_force_table = value;
   else if (k == "mfma_areg") g_mfma_areg = value;
+  else if (k == "prg_two_pass") g_prg_two_pass = value;
   else if (k == "mfma_pipe") g_mfma_pipe = value;
   else if (k == "mfma_tpb") g_mfma_tpb = value;
   else if (k == "aes_blocks") g_aes_blocks = value;
@@ -1513,35 +1518,37 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
                           void* stream);
 
 // PRG-driven sharing beyond one launch's party / coefficient capacity
-static int share_prg_large(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N, size_t t,
-                           size_t n, const unsigned char* seed, size_t seed_len, uint64_t counter0, void* stream) {
+// Two-pass PRG-driven sharing: the coefficient rows of a slab of secrets are drawn into arena 1 (k_prg_coeff_rows: AES at
+// the rate of the four-table kernel), then shared from there by whatever explicit-coefficient kernel fits the shape.  At most
+// 256 MiB of rows per slab; everything is stream-ordered, the arena is kept and grown by the calling thread.
+static int share_prg_two_pass(int field, uint64_t* shares, size_t share_stride, const uint64_t* secrets, size_t N, size_t t,
+                              size_t n, const unsigned char* seed, size_t seed_len, uint64_t counter0, ArrayLane lane,
+                              void* stream) {
   const size_t L = (size_t)scl_hip_limbs(field), E = 8 * L;
-  const u64 B = ((u64)(t + 1) * E + 15) / 16;  // blocks per secret
-  size_t slab = t ? ((size_t)256 << 20) / (t * E) : N;
+  const u64 B = ((u64)(t + 1) * (u64)lane.W * E + 15) / 16;  // blocks per secret
+  if (t == 0) return scl_hip_shamir_share(field, shares, share_stride, secrets, nullptr, 0, N, 0, n, nullptr, stream);
+  size_t slab = ((size_t)256 << 20) / (t * E);
   if (slab < 4096) slab = 4096;
   if (slab > N) slab = N;
   slab = (slab + 1) & ~(size_t)1;
   void* rows_v = nullptr;
-  if (t) HIP_TRY(hipMalloc(&rows_v, t * slab * E));  // not the thread temporary: share_chunked takes that for its tables
+  SCL_TRY(temp_acquire(t * slab * E, S(stream), &rows_v, 1));
   u64* rows = static_cast<u64*>(rows_v);
   AesKey key;
   make_aes_key(seed, seed_len, key);
   int rc = SCL_OK;
   for (size_t s0 = 0; s0 < N && rc == SCL_OK; s0 += slab) {
     const size_t c = N - s0 < slab ? N - s0 : slab;
-    if (t)
-      rc = with_field(field, [&](auto f, auto ctx) -> int {
-        using F = decltype(f);
-        hipLaunchKernelGGL((k_prg_coeff_rows<F>), dim3(grid_aes(c)), dim3(BLOCK), 0, S(stream), ctx, rows, slab, key,
-                           (u64)(counter0 + s0 * B), (int)t, c);
-        LAUNCH_CHECK();
-        return SCL_OK;
-      });
+    rc = with_field(field, [&](auto f, auto ctx) -> int {
+      using F = decltype(f);
+      AES4_LAUNCH((k_prg_coeff_rows<F>), c, S(stream), ctx, rows, slab, key, (u64)(counter0 + s0 * B), (int)t, c, lane);
+      LAUNCH_CHECK();
+      return SCL_OK;
+    });
     if (rc == SCL_OK)
       rc = scl_hip_shamir_share(field, shares + s0 * L, share_stride, secrets + s0 * L, rows, slab, c, t, n, nullptr, stream);
   }
-  (void)hipStreamSynchronize(S(stream));
-  if (rows_v) (void)hipFree(rows_v);
+  (void)temp_release(S(stream), 1);
   return rc;
 }
 
@@ -1577,12 +1584,19 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
     const int L = scl_hip_limbs(field);
     if (L < 0 || is_ring(field)) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
     const size_t cap = (size_t)256 / (size_t)L;
-    if (n > cap || t > 48) {
-      // more parties than one node table or more coefficients than the register-resident kernels hold: the coefficient
-      // rows are drawn into the thread's temporary (slab by slab, at most 256 MiB) and shared from there
-      if (lane.W != 1) return fail(SCL_ERR_BAD_ARG, "share_prg_packed: n and t beyond one launch are not supported for W > 1");
-      return share_prg_large(field, shares, share_stride, secrets, N, t, n, seed, seed_len, counter0, stream);
-    }
+    // One fused kernel (coefficients drawn into registers, evaluated in place) or two passes (rows drawn into a temporary,
+    // then the explicit-coefficient kernel of the shape).  Fused wins where its kernel is small and the evaluation cheap: the
+    // small-node kernels of the Mersenne fields (t <= 7) and GF(2^128) up to t = 11.  Beyond that the fused kernels unroll
+    // 9 .. 25 AES blocks per lane (100 - 260 KB of code) and evaluate by plain Horner, and the Montgomery fields' fused
+    // kernels multiply by full-width Vandermonde entries: (40,13) Mersenne61 3.0 -> 2.1 ms, (128,42) 6.4 -> 1.6 ms,
+    // secp256k1 (10,3) 1.9 -> 1.0 ms per 5 * 10^6 (profiles/r2_probe_prg_share.txt).  "prg_two_pass": 1 always, -1 never
+    // (where a fused kernel exists).
+    const bool must = n > cap || t > 48;  // more parties than one node table / more coefficients than registers hold
+    const long pref = g_prg_two_pass.load();
+    const bool montgomery = field == SCL_MONT128 || L == 4;
+    const bool want = t >= 1 && (montgomery || (field == SCL_GF2_128 ? t >= 12 : t >= 8));
+    if (must || pref > 0 || (pref == 0 && want))
+      return share_prg_two_pass(field, shares, share_stride, secrets, N, t, n, seed, seed_len, counter0, lane, stream);
   }
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);

@@ -1636,28 +1636,43 @@ __global__ __launch_bounds__(BLOCK) void k_share_chunk(typename F::Ctx ctx, u64*
 }
 
 // Coefficient rows of a PRG-driven sharing (rows[k-1][s] = c_k of secret s, k = 1..t) under the reference's counter
-// discipline (prg_coeffs above), for thresholds the register-resident PRG kernels do not hold
+// discipline (prg_coeffs above; al = component `lane` of an Array<FF, W> draw).  The first pass of the two-pass form
+// of shamirSecretShare(secret, t, n, prg): AES at the rate of the four-table kernel with a rolled block loop (a fused
+// kernel that keeps 17 or 49 coefficients in registers unrolls 9 .. 25 AES blocks per lane -- 100 to 260 KB of code per
+// launch, beyond the instruction cache), the explicit-coefficient kernel of the shape (small-node, blocked, matrix cores,
+// per-node GF(2^128)) as the second (profiles/r2_probe_prg_share.txt).
 template <class F>
-__global__ __launch_bounds__(BLOCK) void k_prg_coeff_rows(typename F::Ctx ctx, u64* rows, size_t rstride, AesKey key,
-                                                          u64 counter0, int t, size_t N) {
-  SCL_AES_PROLOGUE(key)
-  const Aes1 aes{te0};
+__global__ __launch_bounds__(ABLOCK) void k_prg_coeff_rows(typename F::Ctx ctx, u64* rows, size_t rstride, AesKey key,
+                                                           u64 counter0, int t, size_t N, ArrayLane al) {
+  SCL_AES4_PROLOGUE(key)
   constexpr int BPE = F::LIMBS >= 2 ? F::LIMBS / 2 : 1;
-  const u64 B = F::LIMBS == 1 ? ((u64)(t + 1) + 1) / 2 : (u64)(t + 1) * BPE;
-  SCL_GRID_STRIDE(s, N) {
+  const u64 B = F::LIMBS == 1 ? ((u64)(t + 1) * al.W + 1) / 2 : (u64)(t + 1) * BPE * al.W;
+  SCL_AES4_GRID_STRIDE(s, N) {
     const u64 ctr0 = counter0 + s * B;
     if constexpr (F::LIMBS == 1) {
-      for (int j = 0; 2 * j <= t; ++j) {  // block j = c_2j (low 8 bytes), c_2j+1 (high 8 bytes)
-        u64 lo, hi;
-        aes.block(key, ctr0 + j, lo, hi);
-        if (j > 0) rows[(size_t)(2 * j - 1) * rstride + s] = F::from_le_word(ctx, lo);
-        if (2 * j + 1 <= t) rows[(size_t)(2 * j) * rstride + s] = F::from_le_word(ctx, hi);
+      if (al.W == 1) {
+#pragma unroll 1
+        for (int j = 0; 2 * j <= t; ++j) {  // block j = c_2j (low 8 bytes), c_2j+1 (high 8 bytes)
+          u64 lo, hi;
+          aes.block(key, ctr0 + j, lo, hi);
+          if (j > 0) rows[(size_t)(2 * j - 1) * rstride + s] = F::from_le_word(ctx, lo);
+          if (2 * j + 1 <= t) rows[(size_t)(2 * j) * rstride + s] = F::from_le_word(ctx, hi);
+        }
+      } else {
+#pragma unroll 1
+        for (int k = 1; k <= t; ++k) {  // element e = k*W + lane is half (e & 1) of block e >> 1
+          const u64 e = (u64)k * al.W + al.lane;
+          u64 lo, hi;
+          aes.block(key, ctr0 + (e >> 1), lo, hi);
+          rows[(size_t)(k - 1) * rstride + s] = F::from_le_word(ctx, (e & 1) ? hi : lo);
+        }
       }
     } else {
+#pragma unroll 1
       for (int k = 1; k <= t; ++k) {
         u64 lo[BPE], hi[BPE];
 #pragma unroll
-        for (int b = 0; b < BPE; ++b) aes.block(key, ctr0 + (u64)k * BPE + b, lo[b], hi[b]);
+        for (int b = 0; b < BPE; ++b) aes.block(key, ctr0 + ((u64)k * al.W + al.lane) * BPE + b, lo[b], hi[b]);
         F::st(rows + ((size_t)(k - 1) * rstride + s) * F::LIMBS, elem_from_blocks<F>(ctx, lo, hi));
       }
     }

@@ -233,6 +233,17 @@ def test_shamir_share_recover_vs_oracle(scl, port, f, n, t, N):
         if N > 9:
             tail = scl.shamir_share_prg(f, dev(scl, secrets[7:]), t, n, seed, first_secret=7)
             assert np.array_equal(host(scl, tail), want[:, 7:])
+        # both forms of the PRG-driven sharing whatever the automatic choice is: the fused kernels (coefficients drawn into
+        # registers) and the two passes (rows drawn into a temporary, then the explicit-coefficient kernel of the shape)
+        for mode in (1, -1):
+            scl.set_tuning("prg_two_pass", mode)
+            try:
+                assert np.array_equal(host(scl, scl.shamir_share_prg(f, dev(scl, secrets), t, n, seed)), want), mode
+                if N > 9:
+                    tail = scl.shamir_share_prg(f, dev(scl, secrets[7:]), t, n, seed, first_secret=7)
+                    assert np.array_equal(host(scl, tail), want[:, 7:]), mode
+            finally:
+                scl.set_tuning("prg_two_pass", 0)
     # explicit coefficients
     coeffs = rand_elems(port, f, t * N, b"coeffs").reshape(N, t, L) if t else np.zeros((N, 0, L), np.uint64)
     if f == O.GF2_128:
@@ -768,6 +779,13 @@ def test_shamir_over_arrays(scl, port, f):
     for sec, t, n, seed, want in cases:
         got = scl.shamir_share_prg_packed(f, dev(scl, np.ascontiguousarray(sec.transpose(1, 0, 2))), t, n, seed)
         assert np.array_equal(host(scl, got), want.transpose(2, 1, 0, 3)), (t, n)     # [W][n][N][L]
+        for mode in (1, -1):     # two passes / the fused kernels, whatever the automatic choice was
+            scl.set_tuning("prg_two_pass", mode)
+            try:
+                again = scl.shamir_share_prg_packed(f, dev(scl, np.ascontiguousarray(sec.transpose(1, 0, 2))), t, n, seed)
+            finally:
+                scl.set_tuning("prg_two_pass", 0)
+            assert scl.equals(f, again.reshape(-1, L), got.reshape(-1, L)), (t, n, mode)
         lam = scl.lagrange_basis(f, n)
         for j in range(sec.shape[1]):
             assert np.array_equal(host(scl, scl.shamir_recover(f, got[j], lam)), sec[:, j])
