@@ -1527,12 +1527,18 @@ static int share_prg_two_pass(int field, uint64_t* shares, size_t share_stride, 
   const size_t L = (size_t)scl_hip_limbs(field), E = 8 * L;
   const u64 B = ((u64)(t + 1) * (u64)lane.W * E + 15) / 16;  // blocks per secret
   if (t == 0) return scl_hip_shamir_share(field, shares, share_stride, secrets, nullptr, 0, N, 0, n, nullptr, stream);
-  size_t slab = ((size_t)256 << 20) / (t * E);
-  if (slab < 4096) slab = 4096;
+  // slab: at most 1 GiB of rows; a whole number of passes of the AES grid (256 workgroups of 1024 lanes: a 3.05-pass slab
+  // runs at 76 % of the 4-pass rate) and 8 KiB-aligned slab origins in every row (the matrix-core kernel runs at half speed on
+  // share rows that start 32 bytes into a 128-byte line; profiles/r2_prg_two_pass_trace.txt)
+  size_t slab = ((size_t)1 << 30) / (t * E);
+  const size_t pass = (size_t)AES4_GRID_CAP * ABLOCK;
+  if (slab >= pass) slab -= slab % pass;
+  else if (slab >= 4096) slab &= ~(size_t)1023;
+  else slab = 4096;
   if (slab > N) slab = N;
-  slab = (slab + 1) & ~(size_t)1;
+  const size_t rstride = (slab + 1) & ~(size_t)1;
   void* rows_v = nullptr;
-  SCL_TRY(temp_acquire(t * slab * E, S(stream), &rows_v, 1));
+  SCL_TRY(temp_acquire(t * rstride * E, S(stream), &rows_v, 1));
   u64* rows = static_cast<u64*>(rows_v);
   AesKey key;
   make_aes_key(seed, seed_len, key);
@@ -1541,12 +1547,12 @@ static int share_prg_two_pass(int field, uint64_t* shares, size_t share_stride, 
     const size_t c = N - s0 < slab ? N - s0 : slab;
     rc = with_field(field, [&](auto f, auto ctx) -> int {
       using F = decltype(f);
-      AES4_LAUNCH((k_prg_coeff_rows<F>), c, S(stream), ctx, rows, slab, key, (u64)(counter0 + s0 * B), (int)t, c, lane);
+      AES4_LAUNCH((k_prg_coeff_rows<F>), c, S(stream), ctx, rows, rstride, key, (u64)(counter0 + s0 * B), (int)t, c, lane);
       LAUNCH_CHECK();
       return SCL_OK;
     });
     if (rc == SCL_OK)
-      rc = scl_hip_shamir_share(field, shares + s0 * L, share_stride, secrets + s0 * L, rows, slab, c, t, n, nullptr, stream);
+      rc = scl_hip_shamir_share(field, shares + s0 * L, share_stride, secrets + s0 * L, rows, rstride, c, t, n, nullptr, stream);
   }
   (void)temp_release(S(stream), 1);
   return rc;
