@@ -102,6 +102,19 @@ int main(int argc, char** argv) {
     if (d2) std::printf(" (first at party %zu secret %zu: %llx vs %llx)", firstbad / N, firstbad % N, (unsigned long long)a2[firstbad], (unsigned long long)a0[firstbad]);
     std::printf("\n");
   }
+  if (argc > 5) {  // where the p16 kernel's time goes on the memory side: share rows that alias (results are wrong by construction)
+    const size_t shmem = 2 * mf_b_bytes(KS, MT, 1);
+    auto kern = &k_share_mfma_m61_p16;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    const size_t nblocks = (N + 31) / 32;
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, 0, out2, N, c, c + N, N, tab, t, n, N); }, "p16: as shipped");
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, 0, out2, (size_t)0, c, c + N, N, tab, t, n, N); }, "p16: all share rows alias");
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, 0, out2, N, c, c, (size_t)0, tab, t, n, N); }, "p16: all coefficient rows alias");
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, 0, out2, (size_t)0, c, c, (size_t)0, tab, t, n, N); }, "p16: both alias");
+    time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, 0, out2 + 4, N, c, c + N, N, tab, t, n, N - 4); }, "p16: share rows 32 B into a line");
+    return 0;
+  }
   if (argc > 4) {  // ablations of the pipelined kernel (results are wrong by construction)
     const size_t shmem = mf_b_bytes(KS, MT, 1);
     const size_t nblocks = (N + 31) / 32;
