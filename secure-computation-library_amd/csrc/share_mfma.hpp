@@ -792,6 +792,10 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
   asm volatile("" : "+s"(mm.m0), "+s"(mm.m8), "+s"(mm.m16), "+s"(mm.m24));
   const bool rows_full = __builtin_amdgcn_readfirstlane(16 * w + 16 <= n);
   const bool aligned_rows = (reinterpret_cast<uintptr_t>(shares) & 15) == 0 && (stride & 1) == 0;
+  // streaming (non-temporal) stores only when a party's 16 secrets of a tile are exactly one 128-byte line: on rows that start
+  // inside a line every line is completed by two different trips, which costs 2.4x with streaming stores and 1.3x with
+  // cached ones (the L2 merges the halves; profiles/r2_mfma_store_side.txt)
+  const bool line_rows = (reinterpret_cast<uintptr_t>(shares) & 127) == 0 && (stride & 15) == 0;
 
   size_t blk = blockIdx.x;
   if (blk < nblocks) {
@@ -858,9 +862,12 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
       o0.y = v[1];
       o1.x = v[2];
       o1.y = v[3];
-      if (fast) {
+      if (fast && line_rows) {
         __builtin_nontemporal_store(o0, reinterpret_cast<u64x2*>(dst));
         __builtin_nontemporal_store(o1, reinterpret_cast<u64x2*>(dst) + 1);
+      } else if (fast) {
+        reinterpret_cast<u64x2*>(dst)[0] = o0;
+        reinterpret_cast<u64x2*>(dst)[1] = o1;
       } else if (party < n) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
