@@ -35,7 +35,8 @@
  *    thread's last diagnostic and scl_hip_status_message() the text of the
  *    exception the reference throws for that condition.
  *  - thread-safe: callable concurrently from several host threads on different streams / devices.  The only
- *    mutable state is per host thread (a scratch buffer, a temporary arena, the Mont128 modulus and the tuning
+ *    mutable state is per host thread (a scratch buffer, two temporary arenas -- kept and grown: at most 1 GiB for the
+ *    coefficient rows of PRG-driven sharing in two passes, otherwise what one call's tables and queues need --, the Mont128 modulus and the tuning
  *    knobs: each thread sets its own and starts from the defaults) or immutable once built (device tables of
  *    Vandermonde rows, behind a mutex, least-recently-used entries freed past 16).  A thread that exits calls
  *    scl_hip_thread_cleanup() to release its device buffers.
