@@ -111,7 +111,7 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the sto
  *   stream_block (default 64) workgroup size of the (m <= 16) reconstruct kernel: 64 or 256
  *   stream_waves (default -1) resident waves per CU that kernel is capped at; 0 = no cap, -1 = 10 for one-word
  *                elements and 12 for wider ones
- *   share_waves  (default 8) the same cap for the Mersenne61 small-node share kernel (threshold compiled in, stream_block
+ *   share_waves  (default 9) the same cap for the Mersenne61 small-node share kernel (threshold compiled in, stream_block
  *                workgroups); 0 = the 256-thread kernel with the threshold at run time, no cap
  *   mfma         1: force the matrix-core share / matmul / recover_detect path, -1: never use it
  *   prg_two_pass PRG-driven sharing: 1 = always draw the coefficient rows into a temporary and share from there, -1 = always the

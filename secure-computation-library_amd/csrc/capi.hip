@@ -73,7 +73,7 @@ thread_local Knob g_prg_two_pass{0};  // PRG-driven sharing: 0 auto, 1 always tw
 thread_local Knob g_stream_block{64};
 thread_local Knob g_stream_waves{-1};  // -1 = by element size: 10 for one-word elements, 12 for wider ones
                                         // (profiles/r2_probe_cap_rec.txt, r2_probe_c3_waves.txt)
-thread_local Knob g_share_waves{8};  // the same cap for the Mersenne61 small-node share kernel ("share_waves"; 0 = the
+thread_local Knob g_share_waves{9};  // the same cap for the Mersenne61 small-node share kernel ("share_waves"; 0 = the
                                      // 256-thread kernel without a cap)
 
 // dynamic LDS bytes that cap the residency of a kernel with `static_lds` bytes of its own at `waves` waves of

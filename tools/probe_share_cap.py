@@ -34,10 +34,11 @@ def timed(fn):
 
 caps = [int(v) for v in sys.argv[1:] if not v.startswith("-")] or [0, 8]
 share_fixed = "--share-8" in sys.argv      # sweep the reconstruct kernel's cap only
+rec_fixed = "--rec-10" in sys.argv         # sweep the share kernel's cap only
 for rnd in range(2):
     for sw in caps:
         scl.set_tuning("share_waves", 8 if share_fixed else sw)
-        scl.set_tuning("stream_waves", sw)
+        scl.set_tuning("stream_waves", 10 if rec_fixed else sw)
         row = []
         for secrets, coeffs, shares, out in sets:
             s_ms = timed(lambda: scl.shamir_share(f, secrets, coeffs, n, out=shares))
