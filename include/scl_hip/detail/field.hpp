@@ -343,6 +343,7 @@ struct M127 {
     const u128 f = (r & P()) + (r >> 127);
     return f >= P() ? f - P() : f;
   }
+  static SCL_HD u128 muladd_small_lazy(const Ctx&, u128 y, u32 x, u128 c) { return muladd_small_lazy(y, x, c); }
   static SCL_HD E muladd_small(const Ctx&, E y, u32 x, E c) { return canon(muladd_small_lazy(y, x, c)); }
 
   struct Acc {
@@ -500,7 +501,10 @@ struct Mont128 {
   }
   static SCL_HD E mul(const Ctx& c, E a, E b) { return redc(c, mulwide(a, b)); }
   static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
-  enum { SMALL_BITS = 0 };  // Montgomery residues are never small (the SMALLX Horner kernels do not apply)
+  // The Horner kernels' small-constant form (SMALLX): the node as a plain integer x < 2^32 (NOT its residue), y*x + c through
+  // muladd_small below -- one lazy limb product and one Barrett step instead of a Montgomery product; full-width moduli only
+  // (small_nodes_ok), the host hands those kernels the nodes' plain values
+  enum { SMALL_BITS = 32 };
 
   // Small-node sharing.  A node power v that is a small plain integer multiplies a residue without leaving
   // Montgomery form, (x R) v = (x v) R, so share_i = sum_k c_k v_ik needs no Montgomery product: four 32 x 32
@@ -564,7 +568,7 @@ struct Mont128 {
     return sacc_fold(c, s, a);
   }
   static SCL_HD E muladd_small_lazy(const Ctx& c, E y, u32 x, E a) { return muladd_small(c, y, x, a); }
-  static SCL_HD E muladd_small_lazy(E y, u32, E) { return y; }  // (SMALLX instantiations only; never run: SMALL_BITS = 0)
+  static SCL_HD E muladd_small_lazy(E y, u32, E) { return y; }  // (never run: every SMALLX caller passes the context)
   static SCL_HD E canon(E r) { return r; }
   static SCL_HD E to_mont(const Ctx& c, u128 x) { return mul(c, x, c.r2); }
   static SCL_HD u128 from_mont(const Ctx& c, E a) { return mul(c, a, 1); }
@@ -668,6 +672,7 @@ struct Gf128 {
   enum { SMALL_BITS = 16 };
   static SCL_HD E canon(E r) { return r; }
   static SCL_HD E muladd_small_lazy(E y, u32 x, E c) { return muladd_small(Ctx{}, y, x, c); }
+  static SCL_HD E muladd_small_lazy(const Ctx&, E y, u32 x, E c) { return muladd_small(Ctx{}, y, x, c); }
   static SCL_HD E muladd_small(const Ctx&, E y, u32 x, E c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // On the device x is WAVE-UNIFORM in every caller (a node read from LDS with a uniform index: the Horner kernels):
@@ -772,7 +777,7 @@ template <class PRM>
 struct Mont256 {
   typedef U256 E;
   struct Ctx {};
-  enum { LIMBS = 4, ACC_TERMS = 1 << 24, TAG = PRM::TAG, SMALL_BITS = 0 };
+  enum { LIMBS = 4, ACC_TERMS = 1 << 24, TAG = PRM::TAG, SMALL_BITS = 32 };  // SMALLX: nodes as plain integers < 2^32 (see Mont128)
 
   static SCL_HD u64 P(int i) { return PRM::P(i); }
   static constexpr u64 MC0 = PRM::MC0;
@@ -923,6 +928,7 @@ struct Mont256 {
     return v;
   }
   enum { SMALL_NODE_VALUE_BITS = 29 };
+  static SCL_HD bool small_nodes_ok(const Ctx&) { return true; }
   // y * x + c for a plain x < 2^32, canonical (the Horner step between the groups of k_share_blocked)
   static SCL_HD E muladd_small(const Ctx&, const E& y, u32 x, const E& c) {
     SAcc s;

@@ -444,16 +444,30 @@ int blocked_vandermonde(const typename F::Ctx& ctx, const BigTable<F>& al, size_
   return 0;
 }
 
-// every node below 2^SMALL_BITS as an integer / bit pattern -> the Horner kernels' small-constant form
+// every node below 2^SMALL_BITS as an integer / bit pattern -> the Horner kernels' small-constant form.  `plain` receives
+// what those kernels read the nodes from: the table itself for the Mersenne fields and GF(2^128), the nodes' plain integer
+// values (out of Montgomery form) for the Montgomery fields.
 template <class F>
-bool small_nodes(const BigTable<F>& al, size_t n) {
+bool small_nodes(const typename F::Ctx& ctx, const BigTable<F>& al, size_t n, BigTable<F>& plain) {
+  plain = al;
   if constexpr (F::SMALL_BITS == 0) {
     return false;
   } else {
     if (g_force_table.load() > 1) return false;
-    for (size_t i = 0; i < n; ++i)
-      if ((u128)al.v[i] >> F::SMALL_BITS) return false;
-    return true;
+    if constexpr (F::TAG == 2 || F::LIMBS == 4) {
+      if (!F::small_nodes_ok(ctx)) return false;
+      for (size_t i = 0; i < n; ++i) {
+        u128 a;
+        if (!node_value<F>(ctx, al.v[i], a) || (a >> F::SMALL_BITS)) return false;
+        u64 w[F::LIMBS] = {(u64)a};
+        plain.v[i] = F::ld(w);
+      }
+      return true;
+    } else {
+      for (size_t i = 0; i < n; ++i)
+        if ((u128)al.v[i] >> F::SMALL_BITS) return false;
+      return true;
+    }
   }
 }
 
@@ -810,11 +824,14 @@ static int share_chunked(int field, uint64_t* shares, size_t share_stride, const
     constexpr size_t TC = (size_t)share_chunk_t<F>(), C = TC + 1;
     std::vector<u64> nodes(n * F::LIMBS), tab(2 * n * F::LIMBS);
     SCL_TRY(nodes_to_host(field, alphas_host, n, first_party, nodes.data()));
+    BigTable<F> al, alx;
+    for (size_t i = 0; i < n; ++i) al.v[i] = F::ld(nodes.data() + i * F::LIMBS);
+    const bool smallx = small_nodes<F>(ctx, al, n, alx);  // nodes as small integers: the fields' small-constant Horner step
     for (size_t i = 0; i < n; ++i) {
-      const E a = F::ld(nodes.data() + i * F::LIMBS);
+      const E a = al.v[i];
       E pw = F::one(ctx);
       for (size_t k = 0; k < C; ++k) pw = F::mul(ctx, pw, a);
-      F::st(tab.data() + i * F::LIMBS, a);
+      F::st(tab.data() + i * F::LIMBS, smallx ? alx.v[i] : a);
       F::st(tab.data() + (n + i) * F::LIMBS, pw);
     }
     void* dev = nullptr;
@@ -827,8 +844,13 @@ static int share_chunked(int field, uint64_t* shares, size_t share_stride, const
         const size_t k_lo = j * C, k_hi = (k_lo + TC < t) ? k_lo + TC : t;
         const u64* c0 = k_lo == 0 ? secrets : coeffs + (k_lo - 1) * coeff_stride * F::LIMBS;
         const u64* crest = coeffs + k_lo * coeff_stride * F::LIMBS;
-        hipLaunchKernelGGL((k_share_chunk<F>), dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), ctx, shares, share_stride, c0, crest,
-                           coeff_stride, static_cast<const u64*>(dev), (int)(k_hi - k_lo), (int)n, N, j + 1 != nchunks ? 1 : 0);
+        if (smallx)
+          hipLaunchKernelGGL((k_share_chunk<F, true>), dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), ctx, shares, share_stride, c0,
+                             crest, coeff_stride, static_cast<const u64*>(dev), (int)(k_hi - k_lo), (int)n, N,
+                             j + 1 != nchunks ? 1 : 0);
+        else
+          hipLaunchKernelGGL((k_share_chunk<F>), dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), ctx, shares, share_stride, c0, crest,
+                             coeff_stride, static_cast<const u64*>(dev), (int)(k_hi - k_lo), (int)n, N, j + 1 != nchunks ? 1 : 0);
         LAUNCH_CHECK();
       }
       HIP_TRY(hipStreamSynchronize(S(stream)));  // the host tables die with this frame
@@ -1379,14 +1401,18 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
                                      t, n - b0 < cap ? n - b0 : cap, nodes.data() + b0 * (size_t)L, stream));
       return SCL_OK;
     }
-    if (t > 48) return share_chunked(field, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, alphas_host, 0, stream);
+    // (256-bit elements: 49 register-resident coefficients would be 392 registers -- the 48-coefficient Horner kernel spills --
+    // so past 16 they take the chunked kernel's 24 at a time)
+    if (t > 48 || (L == 4 && t > 16))
+      return share_chunked(field, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, alphas_host, 0, stream);
   }
   return with_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({shares, secrets, coeffs}));
     BigTable<F> al;
     SCL_TRY(alpha_table<F>(ctx, alphas_host, n, al));
-    const bool smallx = small_nodes<F>(al, n);
+    BigTable<F> alx;  // what the SMALLX kernels read the nodes from
+    const bool smallx = small_nodes<F>(ctx, al, n, alx);
     const int vec = vec_width<F>({shares, secrets, coeffs}, {share_stride, t ? coeff_stride : 0});
     if constexpr (F::TAG == 0) {
       // dense-contraction path on the matrix cores for large (n, t); "mfma" tuning: 1 forces, -1 disables
@@ -1486,7 +1512,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
   do {                                                                                                            \
     if (smallx)                                                                                                   \
       hipLaunchKernelGGL((k_share<F, VEC, TREG, true>), g, blk, 0, S(stream), ctx, sh, share_stride, se, co,      \
-                         coeff_stride, al, (int)t, (int)n, npacks);                                               \
+                         coeff_stride, alx, (int)t, (int)n, npacks);                                              \
     else                                                                                                          \
       hipLaunchKernelGGL((k_share<F, VEC, TREG, false>), g, blk, 0, S(stream), ctx, sh, share_stride, se, co,     \
                          coeff_stride, al, (int)t, (int)n, npacks);                                               \
@@ -1609,7 +1635,8 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
     SCL_TRY(check_align<F>({shares, secrets}));
     BigTable<F> al;
     SCL_TRY(alpha_table<F>(ctx, nullptr, n, al));
-    const bool smallx = small_nodes<F>(al, n);
+    BigTable<F> alx;  // what the SMALLX kernels read the nodes from
+    const bool smallx = small_nodes<F>(ctx, al, n, alx);
     AesKey key;
     make_aes_key(seed, seed_len, key);
     const int vec = vec_width<F>({shares, secrets}, {share_stride});
@@ -1665,12 +1692,13 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
       const u64* se = secrets + first * F::LIMBS;
 #define SHAREP_LAUNCH1(TREG, SX)                                                                                 \
   do {                                                                                                           \
+    const BigTable<F>& nodes_ = SX ? alx : al;                                                                   \
     if constexpr (share_prg_four_tables<F, TREG>())                                                              \
       AES4_LAUNCH((k_share_prg<F, VEC, TREG, SX>), npacks, S(stream), ctx, sh, share_stride, se, key,            \
-                  (u64)(counter0 + first * blocks_per_secret), al, (int)t, (int)n, npacks, lane);                \
+                  (u64)(counter0 + first * blocks_per_secret), nodes_, (int)t, (int)n, npacks, lane);            \
     else                                                                                                         \
       hipLaunchKernelGGL((k_share_prg<F, VEC, TREG, SX>), dim3(grid_aes(npacks)), dim3(BLOCK), 0, S(stream), ctx, \
-                         sh, share_stride, se, key, (u64)(counter0 + first * blocks_per_secret), al, (int)t,    \
+                         sh, share_stride, se, key, (u64)(counter0 + first * blocks_per_secret), nodes_, (int)t, \
                          (int)n, npacks, lane);                                                                  \
   } while (0)
 #define SHAREP_LAUNCH(TREG)                                                                                      \

@@ -562,7 +562,7 @@ __device__ __forceinline__ void horner_rows(const typename F::Ctx& ctx, const Pa
           y = c[k];
         } else if (k < t) {
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) y.v[v] = F::muladd_small_lazy(y.v[v], x, c[k].v[v]);  // canonical once, below
+          for (int v = 0; v < VEC; ++v) y.v[v] = F::muladd_small_lazy(ctx, y.v[v], x, c[k].v[v]);  // canonical once, below
         }
       }
 #pragma unroll
@@ -752,7 +752,7 @@ __device__ __forceinline__ void horner_pack_exact(const typename F::Ctx& ctx, u6
 #pragma unroll
       for (int k = T - 1; k >= 0; --k) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) y.v[v] = F::muladd_small_lazy(y.v[v], x, c[k].v[v]);
+        for (int v = 0; v < VEC; ++v) y.v[v] = F::muladd_small_lazy(ctx, y.v[v], x, c[k].v[v]);
       }
 #pragma unroll
       for (int v = 0; v < VEC; ++v) y.v[v] = F::canon(y.v[v]);
@@ -1601,7 +1601,8 @@ __global__ __launch_bounds__(ABLOCK) void k_share_prg_small(u64* shares, size_t 
 template <class F>
 constexpr int share_chunk_t() { return F::LIMBS >= 4 ? 23 : 47; }
 
-template <class F>
+// SMALLX: tables[0 .. n) hold the nodes as plain integers < 2^32 (the fields' small-constant Horner step)
+template <class F, bool SMALLX = false>
 __global__ __launch_bounds__(BLOCK) void k_share_chunk(typename F::Ctx ctx, u64* shares, size_t stride, const u64* c0,
                                                        const u64* crest, size_t cstride, const u64* tables, int tc, int n,
                                                        size_t N, int accumulate) {
@@ -1626,7 +1627,10 @@ __global__ __launch_bounds__(BLOCK) void k_share_chunk(typename F::Ctx ctx, u64*
 #pragma unroll
       for (int k = TC; k >= 0; --k) {
         if (k == tc) y = c[k].v[0];                                     // wave-uniform
-        else if (k < tc) y = F::add(ctx, F::mul(ctx, y, x), c[k].v[0]);
+        else if (k < tc) {
+          if constexpr (SMALLX) y = F::muladd_small(ctx, y, F::low32(x), c[k].v[0]);
+          else y = F::add(ctx, F::mul(ctx, y, x), c[k].v[0]);
+        }
       }
       u64* dst = shares + (size_t)i * stride * F::LIMBS + off;
       if (accumulate) y = F::add(ctx, F::mul(ctx, F::ld(dst), xpow[i]), y);
