@@ -1145,6 +1145,30 @@ def test_random_shapes_share_and_recover(scl, port, f):
             assert np.array_equal(host(scl, scl.shamir_recover(f, got, lam)), secrets), (n, t, N)
 
 
+def test_prg_share_two_pass_across_slabs(scl, port):
+    """PRG-driven sharing in two passes cuts a large batch into slabs of coefficient rows (at most 1 GiB each): at (128,42)
+    over Mersenne61 a slab is 3 145 728 secrets.  Seven million secrets = three slabs; windows around every slab boundary
+    and at both ends must equal what the same call gives for those secrets alone (first_secret = their index: no slabs
+    involved), the first window also the oracle's shares, and everything reconstructs."""
+    f, L, n, t, N = O.M61, 1, 128, 42, 7_000_003
+    torch = __import__("torch")
+    free = torch.cuda.mem_get_info()[0]
+    if free < (n * N * 8) * 1.3:
+        pytest.skip("not enough free device memory")
+    secrets = scl.vector_random(f, N, b"slab-secrets")
+    seed = b"slab-seed"
+    big = scl.shamir_share_prg(f, secrets, t, n, seed)
+    slab = 3_145_728
+    for a in (0, slab - 3, 2 * slab - 3, N - 6):
+        k = 6
+        part = scl.shamir_share_prg(f, secrets[a:a + k].clone(), t, n, seed, first_secret=a)
+        assert scl.equals(f, part.reshape(-1, L), big[:, a:a + k].reshape(-1, L).clone()), a
+    want = soa(port.shamir_share(f, seed, host(scl, secrets[:4].clone()), t, n))
+    assert np.array_equal(host(scl, big[:, :4].clone()), want)
+    lam = scl.lagrange_basis(f, n)
+    assert scl.equals(f, scl.shamir_recover(f, big, lam), secrets)
+
+
 # ---------------------------------------------------------------------------------------------- full size properties
 @pytest.mark.parametrize("f,n,t,N", [(O.M61, 10, 3, 100_000_000), (O.M127, 10, 3, 10_000_000), (O.MONT128, 10, 3, 10_000_000),
                                      (O.GF2_128, 40, 13, 12_500_000)])
