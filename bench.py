@@ -335,6 +335,15 @@ def main():
                 sd.open_and_reconstruct_local(f_, local, n, lam, chunk=chunk)
         t_pipe = timed_region(pipeline, steps, warmup) / steps
         ok = bool(scl.equals(f_, result["out"], secrets))
+        # the same open by partial sums (any field): each rank reduces its own parties, the ranks all-gather one element
+        # per secret and rank, every rank adds them -- 1/parties_per_rank of the volume, every rank still learns every secret
+        mine_rows = local[:cnt].contiguous() if cnt != per else local
+
+        def partial_pipeline(k):
+            result["pg"] = sd.open_by_partial_gather(f_, mine_rows, lam[first:first + cnt], chunk=chunk) if world > 1 else \
+                sd.open_and_reconstruct_local(f_, local, n, lam, chunk=chunk)
+        t_pg = timed_region(partial_pipeline, steps, warmup) / steps
+        ok_pg = bool(scl.equals(f_, result["pg"], secrets))
         gathered_bytes = world * per * c0 * E
         res = {"field": FIELD_NAMES[fkey], "n": n, "t": t, "secrets": N, "chunk": c0, "parties_per_rank": per,
                "collective": "all_gather_into_tensor" if world > 1 else "none (1 rank: local copy)",
@@ -343,7 +352,11 @@ def main():
                "rccl_busbw_GBps": gathered_bytes / t_gather / 1e9 * (world - 1) / world,
                "reconstruct_ms_per_chunk": rec_ms, "reconstruct_GBps": (n + 1) * E * c0 / rec_ms / 1e6,
                "reconstruct_hbm_frac": (n + 1) * E * c0 / rec_ms / 1e6 / HBM_PEAK_GBPS,
-               "pipeline_ms": 1e3 * t_pipe, "opened_secrets_per_s": N / t_pipe, "verified": ok}
+               "pipeline_ms": 1e3 * t_pipe, "opened_secrets_per_s": N / t_pipe, "verified": ok,
+               "partial_gather": {"collective": "all_gather_into_tensor of one partial sum per secret and rank" if world > 1
+                                  else "none (1 rank: the chunked reconstruct)",
+                                  "gathered_bytes_per_secret": world * E, "all_gather_bytes_per_secret": world * per * E,
+                                  "pipeline_ms": 1e3 * t_pg, "opened_secrets_per_s": N / t_pg, "verified": ok_pg}}
         del secrets, local, gathered, piece, out_c, result
         torch.cuda.empty_cache()
         return res

@@ -162,3 +162,50 @@ def test_open_on_one_rank_is_the_chunked_reconstruct():
 
     out = sd.open_and_reconstruct_local(f, torch.from_numpy(full.view(np.int64)), n, lam, chunk=chunk, recover=checker)
     assert np.array_equal(out.numpy().view(np.uint64), secrets) and calls == [20, 20, 20, 17]
+
+
+def _partial_gather_worker(rank, world, field, n, t, N, chunk):
+    """open_by_partial_gather over gloo, any field: the oracle computes each rank's partial sums and adds the gathered
+    partials, the collective is the real all-gather; EVERY rank must end with every secret, and with exactly what
+    the all-gather open gives"""
+    from scl_amd import dist as sd
+    port = O.Port()
+    L = O.LIMBS[field]
+    secrets = port.vector_random(field, b"pg-secrets", N)
+    secrets[0] = port.from_int(field, -1)
+    if field == O.GF2_128:      # the oracle's sharing walks x++ (meaningless in characteristic 2): explicit nodes 1..n as bit patterns
+        nodes = O.from_ints(list(range(1, n + 1)), L)
+        coeffs = port.vector_random(field, b"pg-coeffs", max(t, 1) * N).reshape(N, max(t, 1), L)[:, :t]
+        full = _soa(np.stack([port.poly_eval(field, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)]))
+    else:
+        nodes = np.stack([port.from_int(field, i + 1) for i in range(n)])
+        full = _soa(port.shamir_share(field, b"pg-seed", secrets, t, n))
+    lam = port.lagrange_basis(field, nodes, port.from_int(field, 0))
+    first, cnt = sd.party_slab(n, rank, world)
+    local = torch.from_numpy(np.ascontiguousarray(full[first:first + cnt]).view(np.int64))
+    calls = []
+
+    def partial(f, shares, lam_, out):
+        sh = np.ascontiguousarray(shares.numpy()).view(np.uint64)
+        rec = port.shamir_recover_lambda(f, np.ascontiguousarray(np.transpose(sh, (1, 0, 2))), lam_)
+        out.copy_(torch.from_numpy(rec.view(np.int64)))
+        calls.append(sh.shape[1])
+
+    def total(f, rows, out):
+        r = rows.numpy().view(np.uint64)
+        assert r.shape[0] == world
+        acc = r[0].copy()
+        for k in range(1, world):
+            acc = port.ew(f, O.ADD, acc, r[k])
+        out.copy_(torch.from_numpy(acc.view(np.int64)))
+
+    out = sd.open_by_partial_gather(field, local, lam[first:first + cnt], chunk=chunk, partial=partial, total=total)
+    assert np.array_equal(out.numpy().view(np.uint64), secrets)
+    assert (sum(calls) == N and len(calls) == -(-N // chunk)) if cnt else not calls
+
+
+@pytest.mark.parametrize("world,field,n,t,N,chunk", [(2, O.GF2_128, 40, 13, 50, 16), (3, O.M127, 7, 2, 33, 1 << 20),
+                                                     (2, O.M61, 10, 3, 200, 64), (3, O.MONT128, 2, 1, 9, 4),   # a rank with no party
+                                                     (2, O.SECP256K1_SCALAR, 5, 2, 12, 5)])
+def test_open_by_partial_gather(world, field, n, t, N, chunk):
+    _run(_partial_gather_worker, world, field, n, t, N, chunk)

@@ -1051,6 +1051,14 @@ def test_open_step_on_one_rank_rccl(scl, port):
         assert np.array_equal(host(scl, out), secrets)
         mine = sd.open_by_partial_sums(shares, lam)
         assert np.array_equal(host(scl, mine), secrets)
+        # the any-field partial-sum open (partial sums by the reconstruct kernel, all-gather of one element per secret and
+        # rank, Vector::sum per secret), C4's field and shape, with a ragged last chunk
+        f2, n2, t2, N2 = O.GF2_128, 40, 13, 3001
+        sec2 = scl.vector_random(f2, N2, b"open1-gf")
+        sh2 = scl.shamir_share(f2, sec2, scl.vector_random(f2, t2 * N2, b"open1-gfc").reshape(t2, N2, -1), n2)
+        lam2 = scl.lagrange_basis(f2, n2)
+        out2 = sd.open_by_partial_gather(f2, sh2, lam2, chunk=1024)
+        assert scl.equals(f2, out2, sec2) and scl.equals(f2, out2, sd.open_and_reconstruct(f2, sh2, n2, lam2, chunk=1024))
     finally:
         dist.destroy_process_group()
 
