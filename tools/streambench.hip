@@ -91,8 +91,8 @@ __global__ __launch_bounds__(BLK) void k_shr(u64* shares, size_t stride, const u
       acc[1].mac(c[k].v[1], w);
     }
     Pack<M61, 2> y;
-    y.v[0] = acc[0].fold(c[0].v[0]);
-    y.v[1] = acc[1].fold(c[0].v[1]);
+    y.v[0] = acc[0].fold(M61::Ctx{}, c[0].v[0]);
+    y.v[1] = acc[1].fold(M61::Ctx{}, c[0].v[1]);
     store_pack<M61, 2, true>(shares + (size_t)i * stride + off, y);
   }
 }
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(BLK) void k_shr2(u64* shares, size_t stride, const 
           acc[1].mac(c[p][k].v[1], w);
         }
         Pack<M61, 2> y;
-        y.v[0] = acc[0].fold(c[p][0].v[0]);
-        y.v[1] = acc[1].fold(c[p][0].v[1]);
+        y.v[0] = acc[0].fold(M61::Ctx{}, c[p][0].v[0]);
+        y.v[1] = acc[1].fold(M61::Ctx{}, c[p][0].v[1]);
         store_pack<M61, 2, NTS>(shares + (size_t)i * stride + q * 2, y);
       }
     }
