@@ -1436,13 +1436,13 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
       if (small) {
         return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
           constexpr int VEC = decltype(V)::value;
-          // Mersenne61: single-wave workgroups under the residency cap, threshold compiled in (k_share_small_t);
+          // The Mersenne fields: single-wave workgroups under the residency cap, threshold compiled in (k_share_small_t);
           // "share_waves" 0 or "stream_block" 256 give the 256-thread kernel with the threshold at run time
           const long sw = g_share_waves.load();
           bool launched = false;
-          if constexpr (F::TAG == 0) {
+          if constexpr (F::TAG <= 1) {  // (Mersenne127: 12 resident waves per CU, 0.39 -> 0.37 ms at C3's size and steadier)
             if (sw > 0 && g_stream_block.load() == 64) {
-              const size_t pad = residency_pad(sw, 64, sizeof(u32) * SmallVdm::CAP);
+              const size_t pad = residency_pad(F::LIMBS == 1 ? sw : 12, 64, sizeof(u32) * SmallVdm::CAP);
               const dim3 g(grid_for_block(npacks, 64));
 #define SST_CASE(TT)                                                                                                     \
   case TT:                                                                                                               \
