@@ -11,6 +11,10 @@ secrets per GPU.  Inputs are generated on the device before the timed region, in
                                           before this process has touched torch or the GPU) and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N     (what the driver does)
     python bench.py --mode open [--gpus N]   times only the cross-party "open" step (RCCL all-gather + reconstruct)
+    python bench.py --gpus 8 --config c4     BASELINE configs[3]: 10^8 GF(2^128) secrets (40,13) in all, the open step
+                                             (all-gather of the party slabs + reconstruct on every rank) is the timed step
+    python bench.py --gpus 8 --config c5     BASELINE configs[4]: 10^9 Mersenne61 secrets (128,42) in all, split over the
+                                             ranks; share (matrix cores) + reconstruct of the rank's shard per step
 
 Multi-GPU: the batch of independent secrets shards across ranks (rank r owns its own N secrets,
 weak scaling, no data-path collective); time = max over ranks.  The one exchange step of the path, the MPC
@@ -48,6 +52,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", default="path", choices=["path", "open"],
                     help="path: share + reconstruct per step (the headline); open: only the cross-party open step")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2 (default): BASELINE configs[1], weak scaling; c4 / c5: the configurations BASELINE quotes on 8 GPUs, "
+                         "their total split over the ranks (strong scaling)")
     ap.add_argument("--field", default="m61", choices=sorted(FIELD_TAGS))
     ap.add_argument("--n", type=int, default=10)
     ap.add_argument("--t", type=int, default=3)
@@ -64,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --dry-run: the launcher / rendezvous / timing skeleton on CPU (tests)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: steps are empty (launcher test)")
+    ap.add_argument("--total-secrets", type=int, default=0, help="--config c4 / c5: total over all ranks (default 10^8 / 10^9)")
     return ap.parse_args(argv)
 
 
@@ -75,6 +83,9 @@ def self_launch(args):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver supports only dmabuf IPC; without it RCCL's peer-buffer exchange
+    # fails with "hipIpcGetMemHandle: invalid argument".  The image exports it already (so a driver that starts torchrun
+    # itself has it too); it is set here only so that a bare environment behaves the same.  An explicit value wins.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
     lines = []
@@ -91,6 +102,38 @@ def self_launch(args):
     for ln in lines[-1:]:
         print(ln, flush=True)
     sys.exit(rc)
+
+
+C5_PER_GPU_CAP = 125_000_000   # (128,42) Mersenne61: 128 GB of shares + 42 GB of coefficients + 2 GB per GPU (of 288 GB)
+
+
+def plan(args, world, rank):
+    """What `--config` asks of this rank: field, shape, this rank's secrets, the total, and the strings of the result line.
+    c2 is weak scaling (--secrets per GPU); c4 and c5 split BASELINE's totals over the ranks (strong scaling)."""
+    from math import ceil
+    if args.config == "c4":
+        total = args.total_secrets or 100_000_000
+        per = ceil(40 / world)
+        return {"key": "c4", "field": "gf2_128", "n": 40, "t": 13, "total": total, "mine": total, "scaling": "strong",
+                "dtype": "u128", "parallelism": f"parties{world}",
+                "workload": f"open step of Shamir (n=40,t=13) over GF(2^128), {total} secrets in all: all-gather of the ranks' "
+                            f"party slabs ({per} parties per rank) + reconstruct on every rank (BASELINE configs[3])"}
+    if args.config == "c5":
+        full = args.total_secrets or 1_000_000_000
+        total = min(full, C5_PER_GPU_CAP * world)      # fewer than 8 GPUs cannot hold 10^9 x (128 + 42 + 2) x 8 bytes
+        base, rem = divmod(total, world)
+        mine = base + (1 if rank < rem else 0)
+        return {"key": "c5", "field": "m61", "n": 128, "t": 42, "total": total, "mine": mine,
+                "scaling": "strong" if total == full else "weak", "dtype": "u64", "parallelism": f"shard{world}",
+                "workload": f"shamir_share (Vandermonde x coefficient matrix on the matrix cores) + reconstruct n=128 t=42 "
+                            f"Mersenne61, {total} secrets in all split over {world} GPU(s) (BASELINE configs[4]"
+                            + ("" if total == full else f": {full} in all needs 8 GPUs; {C5_PER_GPU_CAP} per GPU here") + ")"}
+    n, t, N = args.n, args.t, args.secrets
+    headline = (n, t, args.field, N) == (10, 3, "m61", 100_000_000)
+    return {"key": "c2", "field": args.field, "n": n, "t": t, "total": N * world, "mine": N, "scaling": "weak",
+            "dtype": None, "parallelism": f"shard{world}",
+            "workload": f"shamir_share+reconstruct n={n} t={t} {FIELD_NAMES[args.field]} {N} secrets/GPU"
+                        + (" (BASELINE configs[1])" if headline else "")}
 
 
 def cpu_baseline(field_key, n, t, sample):
@@ -170,6 +213,21 @@ def pmc_traffic(dom, args):
         return None
 
 
+def pmc_config_traffic(key):
+    """{"share": bytes, "recover": bytes} per launch for a side configuration, from the same stamped PMC file (null when the
+    kernel sources have changed since, or the configuration was not in the PMC run)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("kernel_source_sha256_16") != kernel_source_hash():
+            return None
+        c = pmc["configs"][key]
+        return {"share": c["share"]["bytes"], "recover": c["recover"]["bytes"],
+                "share_kernel": c["share"]["kernel"], "recover_kernel": c["recover"]["kernel"]}
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -225,14 +283,21 @@ def main():
         sync()
         return max_over_ranks(time.perf_counter() - t0)
 
+    pl = plan(args, world, rank)
     if dry:
         elapsed = timed_region(lambda k: None, args.steps, args.warmup)
+        mine = torch.tensor([pl["mine"]], dtype=torch.int64)
+        if world > 1 and pl["key"] != "c4":
+            dist.all_reduce(mine)          # the shards add up to the total (c4: every rank opens every secret)
         if rank == 0:
             print(json.dumps({"metric": "shamir_reconstructions_per_sec", "value": 0.0, "unit": "reconstructions/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "none (dry run)",
-                              "config": {"workload": "dry run of the launcher", "parallelism": f"shard{world}"}}), flush=True)
+                              "scaling": pl["scaling"], "vs_baseline": None, "dtype": pl["dtype"] or "u64",
+                              "data": "none (dry run)",
+                              "config": {"workload": "dry run of the launcher: " + pl["workload"], "n": pl["n"], "t": pl["t"],
+                                         "field": FIELD_NAMES[pl["field"]], "total_secrets": pl["total"],
+                                         "secrets_over_ranks": int(mine.item()), "parallelism": pl["parallelism"]}}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -288,6 +353,98 @@ def main():
         del secrets, coeffs, shares, out
         torch.cuda.empty_cache()
         return res
+
+    def prg_mode_report():
+        """BASELINE configs[1] in the reference's OWN mode: scl::ss::shamirSecretShare(secret, t, n, prg) draws the
+        coefficients from the PRG (shamir.h:51-68, prg.cc:124-146); here that is scl_hip_shamir_share_prg, bit-identical to
+        the per-secret calls on one PRG.  After and outside the headline's timed region; AES rate of k_prg_blocks in the same
+        run beside it (the share draws 2 blocks per secret: Vector::random(4) of 8-byte elements)."""
+        f_, n_, t_, N_ = scl.M61, 10, 3, 100_000_000
+        sd_ = b"scl-bench-prg-mode"
+        secrets_ = scl.empty(f_, N_)
+        fill_random(secrets_, f_, sd_ + b"-secrets")
+        shares_ = scl.empty(f_, n_, N_)
+        out_ = scl.empty(f_, N_)
+        lam_ = scl.lagrange_basis(f_, n_)
+        reps = 5
+        ts, tr = [scl.Timer() for _ in range(reps)], [scl.Timer() for _ in range(reps)]
+        scl.shamir_share_prg(f_, secrets_, t_, n_, sd_, out=shares_)
+        for k in range(reps):
+            ts[k].start()
+            scl.shamir_share_prg(f_, secrets_, t_, n_, sd_, out=shares_)
+            ts[k].stop()
+            tr[k].start()
+            scl.shamir_recover(f_, shares_, lam_, out=out_)
+            tr[k].stop()
+        torch.cuda.synchronize()
+        sm = sum(x.elapsed_ms() for x in ts) / reps
+        rm = sum(x.elapsed_ms() for x in tr) / reps
+        ok = bool(scl.equals(f_, out_, secrets_))
+        del shares_, out_
+        torch.cuda.empty_cache()
+        bps = scl.blocks_per_secret(f_, t_)
+        nb = bps * N_
+        blocks = scl.prg_blocks(nb, sd_)
+        tb = scl.Timer()
+        tb.start()
+        for _ in range(3):
+            blocks = scl.prg_blocks(nb, sd_)
+        tb.stop()
+        bm = tb.elapsed_ms() / 3
+        del blocks, secrets_
+        torch.cuda.empty_cache()
+        sb = (1 + n_) * 8
+        return {"workload": f"scl_hip_shamir_share_prg n={n_} t={t_} Mersenne61 {N_} secrets (coefficients drawn from the "
+                            "AES-128-CTR PRG inside the call, the reference's mode) + reconstruct",
+                "share_ms": sm, "share_secrets_per_s": N_ / (sm * 1e-3), "aes_blocks_per_secret": bps,
+                "share_aes_blocks_per_s": nb / (sm * 1e-3), "share_GBps": sb * N_ / sm / 1e6,
+                "share_frac": sb * N_ / sm / 1e6 / HBM_PEAK_GBPS, "recover_ms": rm,
+                "round_trips_per_s": N_ / ((sm + rm) * 1e-3),
+                "k_prg_blocks": {"blocks": nb, "ms": bm, "blocks_per_s": nb / (bm * 1e-3)}, "verified": ok}
+
+    def c1_additive_report():
+        """BASELINE configs[0]: additive sharing over Mersenne61, n = 3, 10^6 secrets -- the reference's per-secret
+        additiveShare + Vector::sum on one host core (oracle/_ref), beside the GPU kernels at the SAME size (10^6 secrets is
+        24 MB: the kernels are launch-bound there) and at 10^8."""
+        import oracle_lib as O
+        f_, n_ = scl.M61, 3
+        rep = {"workload": "additive sharing Mersenne61 n=3 (BASELINE configs[0])"}
+        for N_, key in ((1_000_000, "gpu_1e6"), (100_000_000, "gpu_1e8")):
+            sd_ = b"scl-bench-c1"
+            secrets_ = scl.empty(f_, N_)
+            fill_random(secrets_, f_, sd_ + b"-secrets")
+            shares_ = scl.empty(f_, n_, N_)
+            out_ = scl.empty(f_, N_)
+            reps = 20 if N_ <= 1_000_000 else 5
+            scl.additive_share_prg(f_, secrets_, n_, sd_, out=shares_)
+            scl.additive_recover(f_, shares_, out=out_)
+            ts, tr = scl.Timer(), scl.Timer()
+            ts.start()
+            for _ in range(reps):
+                scl.additive_share_prg(f_, secrets_, n_, sd_, out=shares_)
+            ts.stop()
+            tr.start()
+            for _ in range(reps):
+                scl.additive_recover(f_, shares_, out=out_)
+            tr.stop()
+            sm, rm = ts.elapsed_ms() / reps, tr.elapsed_ms() / reps
+            rep[key] = {"secrets": N_, "share_ms": sm, "recover_ms": rm, "share_secrets_per_s": N_ / (sm * 1e-3),
+                        "reconstructions_per_s": N_ / (rm * 1e-3), "round_trips_per_s": N_ / ((sm + rm) * 1e-3),
+                        "recover_GBps": (n_ + 1) * 8 * N_ / rm / 1e6, "verified": bool(scl.equals(f_, out_, secrets_))}
+            del secrets_, shares_, out_
+            torch.cuda.empty_cache()
+        try:
+            lib, kind = O.Ref(), "reference"
+        except Exception:
+            lib, kind = O.Port(), "port"
+        r = lib.time_additive(O.M61, 1_000_000, n_)
+        if r["mismatches"]:
+            raise RuntimeError("CPU additive baseline failed its own round trip")
+        rep["cpu"] = {"kind": kind, "cores": 1, "secrets": 1_000_000, "share_s": r["share_s"], "recover_s": r["recover_s"],
+                      "share_secrets_per_s": 1e6 / r["share_s"], "reconstructions_per_s": 1e6 / r["recover_s"],
+                      "round_trips_per_s": 1e6 / (r["share_s"] + r["recover_s"])}
+        rep["verified"] = rep["gpu_1e6"]["verified"] and rep["gpu_1e8"]["verified"]
+        return rep
 
     def open_step(fkey, n, t, N, chunk, steps, warmup, seed):
         """The MPC open of N secrets: every rank holds ceil(n/G) parties' share vectors, one all-gather per chunk
@@ -395,6 +552,28 @@ def main():
                "m61_partial_sums": open_partial_sums(10, 3, N_ps, 3, 1, b"scl-bench-open")}
         return rep
 
+    if pl["key"] == "c4":
+        # BASELINE configs[3]: the exchange step is the timed step.  Every rank holds ceil(40 / G) parties' share vectors of
+        # ALL the secrets, one all-gather per chunk brings the 40 rows together, every rank reconstructs every secret.
+        c4 = open_step("gf2_128", 40, 13, pl["total"], args.open_chunk, args.steps, args.warmup, b"scl-bench-c4")
+        if rank == 0:
+            line = {"metric": "shamir_reconstructions_per_sec", "value": c4["opened_secrets_per_s"],
+                    "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": c4["pipeline_ms"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                    "dtype": "u128", "data": "synthetic",
+                    "config": {"workload": pl["workload"], "field": FIELD_NAMES["gf2_128"], "n": 40, "t": 13,
+                               "total_secrets": pl["total"], "chunk": c4["chunk"], "parallelism": pl["parallelism"]},
+                    "roofline": {"bound": "hbm", "kernel": "shamir_recover", "achieved": c4["reconstruct_GBps"],
+                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": c4["reconstruct_hbm_frac"], "traffic": None},
+                    "rccl_busbw_GBps": c4["rccl_busbw_GBps"], "verified": c4["verified"] and c4["partial_gather"]["verified"],
+                    "open": {"c4_all_gather": c4}}
+            if world == 1 and args.cpu_sample > 0:
+                line["cpu_baseline"] = cpu_baseline("gf2_128", 40, 13, min(args.cpu_sample, 20_000))
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     if args.mode == "open":
         rep = open_report()
         if rank == 0:
@@ -415,6 +594,12 @@ def main():
         return
 
     # =============================================== headline ===============================================
+    if pl["key"] == "c5":
+        args.field, args.n, args.t, args.secrets = pl["field"], pl["n"], pl["t"], pl["mine"]
+        args.configs = args.open = 0
+        if args.steps == 20 and args.warmup == 3:   # the defaults are the headline's: a (128,42) step is ~80 ms per 1.25e8
+            args.steps, args.warmup = 5, 1
+        args.cpu_sample = min(args.cpu_sample, 20_000)
     f, L = tag_limbs(args.field)
     E = 8 * L
     n, t, N = args.n, args.t, args.secrets
@@ -486,23 +671,32 @@ def main():
                 "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args),
                 "algorithmic_bytes": kernels[dom]["bytes_per_secret"] * N,
                 "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": ach / copy_gbps}
-    total = N * world * args.steps
-    headline = (n, t, args.field, N) == (10, 3, "m61", 100_000_000)
+    total = pl["total"] * args.steps       # c2: N per GPU x ranks; c5: BASELINE's total, split over the ranks
     line = {
         "metric": "shamir_reconstructions_per_sec", "value": total / elapsed, "unit": "reconstructions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": pl["scaling"], "vs_baseline": None,
         "dtype": {1: "u64", 2: "u128", 4: "u256"}[L], "data": "synthetic",
-        "config": {"workload": f"shamir_share+reconstruct n={n} t={t} {FIELD_NAMES[args.field]} {N} secrets/GPU"
-                               + (" (BASELINE configs[1])" if headline else ""),
-                   "field": FIELD_NAMES[args.field], "n": n, "t": t, "secrets_per_gpu": N,
+        "config": {"workload": pl["workload"],
+                   "field": FIELD_NAMES[args.field], "n": n, "t": t, "secrets_per_gpu": N, "total_secrets": pl["total"],
                    "share_mode": args.share_mode, "layout": "SoA [party][secret]", "allocation": "plain",
-                   "parallelism": f"shard{world}"},
+                   "parallelism": pl["parallelism"]},
         "roofline": roofline, "kernels": kernels, "verified": verified,
         "reconstruct_only_per_s": N * world / (rec_ms * 1e-3), "share_only_per_s": N * world / (share_ms * 1e-3),
     }
     if open_rep is not None:
         line["open"] = open_rep
+    if world == 1 and args.configs and pl["key"] == "c2":
+        try:
+            line["prg_mode"] = prg_mode_report()
+        except Exception as e:
+            line["prg_mode"] = {"error": str(e), "verified": False}
+            torch.cuda.empty_cache()
+        try:
+            line["c1_additive"] = c1_additive_report()
+        except Exception as e:
+            line["c1_additive"] = {"error": str(e), "verified": False}
+            torch.cuda.empty_cache()
     if world == 1 and args.configs:
         # the other BASELINE configurations at the size ONE GPU holds of them (C4, C5: an eighth), after the timed region
         cfgs = {}
@@ -514,6 +708,7 @@ def main():
         }.items():
             try:
                 cfgs[key] = share_recover_config(fk, n_, t_, N_, st, b"scl-bench-" + key.encode())
+                cfgs[key]["traffic"] = pmc_config_traffic(key)
             except Exception as e:  # a failed side configuration is reported, not hidden, and never fails the headline
                 cfgs[key] = {"error": str(e), "verified": False}
                 torch.cuda.empty_cache()

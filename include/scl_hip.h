@@ -36,10 +36,12 @@
  *    exception the reference throws for that condition.
  *  - thread-safe: callable concurrently from several host threads on different streams / devices.  The only
  *    mutable state is per host thread (a scratch buffer, two temporary arenas -- kept and grown: at most 1 GiB for the
- *    coefficient rows of PRG-driven sharing in two passes, otherwise what one call's tables and queues need --, the Mont128 modulus and the tuning
- *    knobs: each thread sets its own and starts from the defaults) or immutable once built (device tables of
- *    Vandermonde rows, behind a mutex, least-recently-used entries freed past 16).  A thread that exits calls
- *    scl_hip_thread_cleanup() to release its device buffers.
+ *    coefficient rows of PRG-driven sharing in two passes, otherwise what one call's tables and queues need --, the
+ *    tuning knobs: each thread sets its own and starts from the defaults), the Mont128 modulus (a process-wide default
+ *    behind a mutex that a thread's own scl_hip_mont128_set_prime overrides for that thread; see there) or immutable
+ *    once built (device tables of Vandermonde rows, behind a mutex; a caller holds a reference to the table it uses
+ *    until its kernel is enqueued, and past 16 entries the least recently used one is freed once nobody holds it).
+ *    A thread that exits calls scl_hip_thread_cleanup() to release its device buffers.
  */
 #ifndef SCL_HIP_H
 #define SCL_HIP_H
@@ -114,6 +116,8 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the sto
  *   share_waves  (default 9) the same cap for the Mersenne61 small-node share kernel (threshold compiled in, stream_block
  *                workgroups); 0 = the 256-thread kernel with the threshold at run time, no cap
  *   mfma         1: force the matrix-core share / matmul / recover_detect path, -1: never use it
+ *   gf_tiles     (default 1) GF(2^128) sharing at the default nodes, 5 <= t <= 16: eight nodes per Horner loop; 0 = one node
+ *                at a time (the kernel that serves any other small nodes)
  *   prg_two_pass PRG-driven sharing: 1 = always draw the coefficient rows into a temporary and share from there, -1 = always the
  *                fused kernels (where one exists), 0 (default) = by shape and field
  *   mfma_areg    (default 1) matrix-core kernel keeps V's digit fragments in registers for 97..128 parties
@@ -293,7 +297,44 @@ int scl_hip_frame_unpack(int field, uint64_t* dst_dev, size_t capacity, const un
 /* plain device copy kernel (16 B per lane) used to measure achievable HBM bandwidth */
 int scl_hip_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 
-/* MONT128: choose the modulus (odd, < 2^128) for the CALLING host thread; every thread starts at 2^128 - 159. */
+/* ---- the open step: every party sends its shares to every party, then reconstructs ----------------------------
+ * Replaces Network::send to each party + Network::recv from each party (include/scl/net/network.h:148-152,178-185; the
+ * pattern of test/scl/protocol/beaver.h:43-55) followed by shamirRecoverP per secret (shamir.h:81-104), for a whole
+ * batch: the n parties are dealt to the ranks of an RCCL communicator in contiguous blocks of ceil(n / world), one
+ * all-gather per chunk of secrets over xGMI brings the share rows together, the reconstruct kernel of chunk k runs
+ * beside the gather of chunk k + 1.  RCCL is opened with dlopen at the first of these calls (librccl.so.1; an instance
+ * the process already holds is reused), so the library has no link-time dependency on it.
+ *
+ * A communicator handle wraps an ncclComm_t with a stream for the collectives, events and two gather buffers:
+ *   scl_hip_comm_unique_id   ncclGetUniqueId on one rank; the caller distributes the 128 bytes (MPI, a file, gloo ..)
+ *   scl_hip_comm_init_rank   ncclCommInitRank on every rank (the current HIP device is the rank's device)
+ *   scl_hip_comm_adopt       wrap an ncclComm_t the caller created itself (not destroyed by scl_hip_comm_destroy)
+ *   scl_hip_comm_info / scl_hip_comm_destroy
+ * scl_hip_open_row_order (host only): row q = j * world + r of a gathered chunk holds party r * per + j (each of a
+ * rank's `per` rows is all-gathered on its own: no packing copy); order[q] = that party or -1 for padding. */
+int scl_hip_comm_unique_id(unsigned char id[128]);
+int scl_hip_comm_init_rank(void** comm, int world, int rank, const unsigned char id[128]);
+int scl_hip_comm_adopt(void** comm, void* nccl_comm);
+int scl_hip_comm_info(void* comm, int* world, int* rank);
+int scl_hip_comm_destroy(void* comm);
+int scl_hip_open_row_order(size_t n, size_t world, long* order);
+/* out_dev[s] = sum_p lambda[p] * share_p[s] for all N secrets on every rank.  local_dev: this rank's
+ * [ceil(n / world)][stride] share rows (device; rows past the rank's party count are padding); lambda_host: the n
+ * coefficients in party order (scl_hip_lagrange_basis).  chunk = secrets per all-gather (0: 2^24).  Asynchronous on
+ * `stream` like every batch call. */
+int scl_hip_open_all_gather(void* comm, int field, uint64_t* out_dev, const uint64_t* local_dev, size_t stride, size_t n,
+                            const uint64_t* lambda_host, size_t N, size_t chunk, void* stream);
+/* The same result from 1 / ceil(n / world) of the xGMI volume: each rank first reduces its own parties to one partial
+ * sum per secret, the ranks all-gather the partials and add them (Vector::sum per secret, vector.h:261-267).
+ * local_dev: the rank's OWN [parties_mine][stride] rows, lambda_local_host: their coefficients; parties_mine may be 0. */
+int scl_hip_open_partial_gather(void* comm, int field, uint64_t* out_dev, const uint64_t* local_dev, size_t stride,
+                                size_t parties_mine, const uint64_t* lambda_local_host, size_t N, size_t chunk,
+                                void* stream);
+
+/* MONT128: choose the modulus (odd, < 2^128).  The call sets it for the CALLING host thread and as the process-wide
+ * default: a thread that has called this keeps its own modulus whatever other threads choose later; a thread that never
+ * did (a pool worker started after the main thread chose the prime) works over the default = the modulus set last by any
+ * thread, 2^128 - 159 before any was. */
 int scl_hip_mont128_set_prime(const uint64_t p[2]);
 int scl_hip_mont128_get_prime(uint64_t p[2]);
 

@@ -7,8 +7,10 @@
 #ifndef SCL_HIP_HIP_DEVICE_H
 #define SCL_HIP_HIP_DEVICE_H
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -62,6 +64,35 @@ constexpr std::size_t limbsOf() {
   if constexpr (requires { T::kLimbs; }) return T::kLimbs;
   else return T::byteSize() / 8;
 }
+
+// ---- where a HOST-resident operand is worked on -----------------------------------------------------------------
+// The reference's containers (math::Vector, math::Matrix) and its per-secret scl::ss calls keep their values in host
+// memory.  Sending such an operand through a kernel costs two device allocations, two PCIe copies, a launch and a
+// synchronisation -- tens to hundreds of microseconds -- where the reference spends half a microsecond on a (10,3) sharing
+// (BASELINE.md section 3).  So a host-resident operand below a work threshold is computed on the host, by FF<FIELD>'s own
+// operators, i.e. by detail/field.hpp: the arithmetic source the kernels are compiled from (per-element arithmetic is
+// host work in the reference's plug-in boundary too, SURVEY.md section 8 b-i).  At and above the threshold, and for everything
+// that already lives in HBM (hip::DeviceVector, hip::ShareMatrix: the batch API), the kernels run and there is no host path.
+// The threshold counts 64-bit limb products: elements x limbs^2 (a 256-bit multiplication costs ~16 Mersenne61 ones).
+inline std::atomic<std::size_t>& hostThresholdRef() {
+  static std::atomic<std::size_t> v{16384};
+  return v;
+}
+/// 0 sends every host-resident operand of a field with kernels to the GPU (what tests of the kernels behind
+/// math::Vector / math::Matrix set)
+inline void setHostThreshold(std::size_t limb_products) { hostThresholdRef().store(limb_products); }
+inline std::size_t hostThreshold() { return hostThresholdRef().load(); }
+/// true: compute on the host.  Always for an element type without kernels (a user-defined field).
+template <typename T>
+bool onHost(std::size_t elems) {
+  if constexpr (!requires { T::Field::TAG; }) return true;
+  else return elems * limbsOf<T>() * limbsOf<T>() < hostThreshold();
+}
+/// PRG draws up to this many bytes are made by detail/aes_host.hpp instead of k_prg_blocks
+inline std::size_t prgHostBytes() { return 4 * hostThreshold(); }
+namespace detail {
+[[noreturn]] inline void unreachable() { std::abort(); }
+}  // namespace detail
 
 /// N elements in HBM.  T is an scl::math::FF<FIELD> or an scl::math::Z2k<K>.
 template <typename T>

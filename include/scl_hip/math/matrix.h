@@ -1,9 +1,9 @@
 // include/scl_hip/math/matrix.h -- scl::math::Matrix<T> (include/scl/math/matrix.h:52-968).
 //
 // Row-major host storage like the reference.  The data-parallel members -- multiply(Matrix),
-// multiply(Vector), the entry-wise family -- run on the GPU behind the C ABI (scl_hip_matmul,
-// scl_hip_ew); vandermonde / hyperInvertible build their O(n*m) tables through the library's host
-// table code.  invert() is a small dense Gauss-Jordan on scalars and stays host work, as in the
+// multiply(Vector), the entry-wise family, vandermonde -- run on the GPU behind the C ABI (scl_hip_matmul,
+// scl_hip_ew, scl_hip_vandermonde) from hip::hostThreshold() multiply-adds / entries on, and as the reference's
+// loops over FF's operators below it (hip/device.h); hyperInvertible builds its rows through computeLagrangeBasis.  invert() is a small dense Gauss-Jordan on scalars and stays host work, as in the
 // reference ("invert/solveLinearSystem host-side only").
 #ifndef SCL_HIP_MATH_MATRIX_H
 #define SCL_HIP_MATH_MATRIX_H
@@ -33,20 +33,23 @@ class Matrix {
   /// V(i, j) = xs[i]^j (matrix.h:444-460)
   static Matrix vandermonde(std::size_t n, std::size_t m, const Vector<ELEMENT>& xs) {
     if (xs.size() != n) hip::detail::raise(SCL_ERR_VANDERMONDE_XS);
-    if constexpr (!DEV) {  // V(i,0) = 1, V(i,j) = V(i,j-1) * xs[i]
+    if (hip::onHost<ELEMENT>(n * m)) {  // V(i,0) = 1, V(i,j) = V(i,j-1) * xs[i]
       Matrix v(n, m);
       for (std::size_t i = 0; i < n; ++i) {
         v(i, 0) = ELEMENT(1);
         for (std::size_t j = 1; j < m; ++j) v(i, j) = v(i, j - 1) * xs[i];
       }
       return v;
+    }
+    if constexpr (DEV) {
+      constexpr std::size_t L = hip::limbsOf<ELEMENT>();
+      hip::DeviceVector<ELEMENT> v(n * m);
+      std::vector<std::uint64_t> x(n * L + 1);
+      for (std::size_t i = 0; i < n; ++i) xs[i].toLimbs(x.data() + i * L);
+      hip::check(scl_hip_vandermonde(ELEMENT::Field::TAG, v.data(), n, m, x.data(), nullptr));
+      return Matrix(n, m, v.toHost());
     } else {
-    constexpr std::size_t L = hip::limbsOf<ELEMENT>();
-    hip::DeviceVector<ELEMENT> v(n * m);
-    std::vector<std::uint64_t> x(n * L + 1);
-    for (std::size_t i = 0; i < n; ++i) xs[i].toLimbs(x.data() + i * L);
-    hip::check(scl_hip_vandermonde(ELEMENT::Field::TAG, v.data(), n, m, x.data(), nullptr));
-    return Matrix(n, m, v.toHost());
+      hip::detail::unreachable();
     }
   }
   /// default nodes 1..n (matrix.h:102-104)
@@ -99,34 +102,40 @@ class Matrix {
   /// C = this * other on the GPU (matrix.h:477-495)
   Matrix multiply(const Matrix& o) const {
     if (cols() != o.rows()) hip::detail::raise(SCL_ERR_MATMUL_DIMS);
-    if constexpr (!DEV) {  // i-k-j triple loop
+    if (hip::onHost<ELEMENT>(rows() * cols() * o.cols())) {  // i-k-j triple loop
       Matrix r(rows(), o.cols());
       for (std::size_t i = 0; i < rows(); ++i)
         for (std::size_t k = 0; k < cols(); ++k)
           for (std::size_t j = 0; j < o.cols(); ++j) r(i, j) += (*this)(i, k) * o(k, j);
       return r;
+    }
+    if constexpr (DEV) {
+      hip::DeviceVector<ELEMENT> a(m_values), b(o.m_values), c(rows() * o.cols());
+      hip::check(scl_hip_matmul(ELEMENT::Field::TAG, c.data(), o.cols(), a.data(), cols(), b.data(), o.cols(), rows(), cols(),
+                                o.cols(), nullptr));
+      return Matrix(rows(), o.cols(), c.toHost());
     } else {
-    hip::DeviceVector<ELEMENT> a(m_values), b(o.m_values), c(rows() * o.cols());
-    hip::check(scl_hip_matmul(ELEMENT::Field::TAG, c.data(), o.cols(), a.data(), cols(), b.data(), o.cols(), rows(), cols(),
-                              o.cols(), nullptr));
-    return Matrix(rows(), o.cols(), c.toHost());
+      hip::detail::unreachable();
     }
   }
 
   /// matrix-vector product (matrix.h:497-513)
   Vector<ELEMENT> multiply(const Vector<ELEMENT>& v) const {
     if (cols() != v.size()) throw std::invalid_argument("matmul: this->cols() != vec.size()");
-    if constexpr (!DEV) {  // one innerProd per row
+    if (hip::onHost<ELEMENT>(rows() * cols())) {  // one innerProd per row
       std::vector<ELEMENT> r;
       r.reserve(rows());
       for (std::size_t i = 0; i < rows(); ++i)
         r.emplace_back(innerProd<ELEMENT>(m_values.begin() + static_cast<std::ptrdiff_t>(i * cols()),
                                           m_values.begin() + static_cast<std::ptrdiff_t>((i + 1) * cols()), v.begin()));
       return Vector<ELEMENT>(std::move(r));
+    }
+    if constexpr (DEV) {
+      hip::DeviceVector<ELEMENT> a(m_values), b(v.toStlVector()), c(rows());
+      hip::check(scl_hip_matmul(ELEMENT::Field::TAG, c.data(), 1, a.data(), cols(), b.data(), 1, rows(), cols(), 1, nullptr));
+      return Vector<ELEMENT>(c.toHost());
     } else {
-    hip::DeviceVector<ELEMENT> a(m_values), b(v.toStlVector()), c(rows());
-    hip::check(scl_hip_matmul(ELEMENT::Field::TAG, c.data(), 1, a.data(), cols(), b.data(), 1, rows(), cols(), 1, nullptr));
-    return Vector<ELEMENT>(c.toHost());
+      hip::detail::unreachable();
     }
   }
 

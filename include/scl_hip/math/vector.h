@@ -2,8 +2,9 @@
 //
 // Surface of include/scl/math/vector.h:45-586 (names, SizeType, error text).  Storage is a host
 // std::vector like the reference's; for element types with kernels (math::OnDevice: the built-in fields and rings)
-// every element-wise / reduction member uploads its operands, runs the HIP kernel behind the C ABI and downloads the
-// result -- a drop-in, PCIe-bound for large vectors.  Code that wants the data to stay in HBM uses
+// an element-wise / reduction member of a vector at or above hip::hostThreshold() uploads its operands, runs the HIP
+// kernel behind the C ABI and downloads the result -- a drop-in, PCIe-bound for large vectors; a shorter vector (the
+// reference's typical one: the n shares of a secret) is worked on where it lives, by FF's operators (hip/device.h).  Code that wants the data to stay in HBM uses
 // scl::hip::DeviceVector with the free functions of scl::hip (same kernels, no transfers).  An element type over a
 // user-defined field (fields/ff_ops.h) takes the reference's per-element loops on the host instead.
 #ifndef SCL_HIP_MATH_VECTOR_H
@@ -11,6 +12,7 @@
 
 #include <cstdint>
 #include <initializer_list>
+#include <iterator>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -51,18 +53,21 @@ std::vector<T> runEw(int op, const std::vector<T>& a, const std::vector<T>* b) {
 /// innerProd (vector.h:45-52): sum of x_k * y_k over [xb, xe)
 template <typename T, typename IT0, typename IT1>
 T innerProd(IT0 xb, IT0 xe, IT1 yb) {
-  if constexpr (!OnDevice<T>) {  // v = 0; v += x_k * y_k in order (vector.h:45-52)
+  const std::size_t n = static_cast<std::size_t>(std::distance(xb, xe));
+  if (hip::onHost<T>(n)) {  // v = 0; v += x_k * y_k in order (vector.h:45-52)
     T v{};
     for (; xb != xe; ++xb, ++yb) v += *xb * *yb;
     return v;
+  }
+  if constexpr (OnDevice<T>) {
+    std::vector<T> x(xb, xe);
+    std::vector<T> y(yb, yb + static_cast<std::ptrdiff_t>(x.size()));
+    hip::DeviceVector<T> dx(x), dy(y);
+    std::uint64_t limbs[hip::limbsOf<T>()];
+    hip::check(scl_hip_dot(vec_detail::tag<T>(), limbs, dx.data(), dy.data(), x.size(), nullptr));
+    return T::fromLimbs(limbs);
   } else {
-  std::vector<T> x(xb, xe);
-  std::vector<T> y(yb, yb + static_cast<std::ptrdiff_t>(x.size()));
-  if (x.empty()) return T{};
-  hip::DeviceVector<T> dx(x), dy(y);
-  std::uint64_t limbs[hip::limbsOf<T>()];
-  hip::check(scl_hip_dot(vec_detail::tag<T>(), limbs, dx.data(), dy.data(), x.size(), nullptr));
-  return T::fromLimbs(limbs);
+    hip::detail::unreachable();
   }
 }
 
@@ -80,20 +85,23 @@ class Vector final {
   /// as the device kernel on the PRG's counter; the PRG is advanced by ceil(n*byteSize/16) blocks.
   static Vector random(std::size_t n, util::PRG& prg) {
     if (n == 0) return Vector{};
-    if constexpr (!OnDevice<ELEMENT>) {  // one prg.next(n * byteSize), then ELEMENT::read per element
+    if (hip::onHost<ELEMENT>(n)) {  // one prg.next(n * byteSize), then ELEMENT::read per element
       std::vector<unsigned char> buf(n * ELEMENT::byteSize());
       prg.next(buf.data(), buf.size());
       std::vector<ELEMENT> v;
       v.reserve(n);
       for (std::size_t i = 0; i < n; ++i) v.emplace_back(ELEMENT::read(buf.data() + i * ELEMENT::byteSize()));
       return Vector(std::move(v));
+    }
+    if constexpr (OnDevice<ELEMENT>) {
+      hip::DeviceVector<ELEMENT> d(n);
+      const auto seed = prg.Seed();
+      hip::check(scl_hip_vector_random(vec_detail::tag<ELEMENT>(), d.data(), n, seed.data(), seed.size(), prg.counter(),
+                                       nullptr));
+      prg.advance((n * ELEMENT::byteSize() + 15) / 16);
+      return Vector(d.toHost());
     } else {
-    hip::DeviceVector<ELEMENT> d(n);
-    const auto seed = prg.Seed();
-    hip::check(scl_hip_vector_random(vec_detail::tag<ELEMENT>(), d.data(), n, seed.data(), seed.size(), prg.counter(),
-                                     nullptr));
-    prg.advance((n * ELEMENT::byteSize() + 15) / 16);
-    return Vector(d.toHost());
+      hip::detail::unreachable();
     }
   }
 
@@ -134,31 +142,37 @@ class Vector final {
 
   ELEMENT sum() const {
     if (empty()) return ELEMENT{};
-    if constexpr (!OnDevice<ELEMENT>) {
+    if (hip::onHost<ELEMENT>(size())) {
       ELEMENT v{};
       for (const auto& e : m_values) v += e;
       return v;
+    }
+    if constexpr (OnDevice<ELEMENT>) {
+      hip::DeviceVector<ELEMENT> d(m_values);
+      std::uint64_t limbs[hip::limbsOf<ELEMENT>()];
+      hip::check(scl_hip_sum(vec_detail::tag<ELEMENT>(), limbs, d.data(), m_values.size(), nullptr));
+      return ELEMENT::fromLimbs(limbs);
     } else {
-    hip::DeviceVector<ELEMENT> d(m_values);
-    std::uint64_t limbs[hip::limbsOf<ELEMENT>()];
-    hip::check(scl_hip_sum(vec_detail::tag<ELEMENT>(), limbs, d.data(), m_values.size(), nullptr));
-    return ELEMENT::fromLimbs(limbs);
+      hip::detail::unreachable();
     }
   }
 
   Vector scalarMultiply(const ELEMENT& scalar) const {
     if (empty()) return Vector{};
-    if constexpr (!OnDevice<ELEMENT>) {
+    if (hip::onHost<ELEMENT>(size())) {
       std::vector<ELEMENT> r;
       r.reserve(size());
       for (const auto& e : m_values) r.emplace_back(scalar * e);
       return Vector(std::move(r));
+    }
+    if constexpr (OnDevice<ELEMENT>) {
+      hip::DeviceVector<ELEMENT> d(m_values), out(m_values.size());
+      std::uint64_t limbs[hip::limbsOf<ELEMENT>()];
+      scalar.toLimbs(limbs);
+      hip::check(scl_hip_scalar_mul(vec_detail::tag<ELEMENT>(), out.data(), d.data(), limbs, m_values.size(), nullptr));
+      return Vector(out.toHost());
     } else {
-    hip::DeviceVector<ELEMENT> d(m_values), out(m_values.size());
-    std::uint64_t limbs[hip::limbsOf<ELEMENT>()];
-    scalar.toLimbs(limbs);
-    hip::check(scl_hip_scalar_mul(vec_detail::tag<ELEMENT>(), out.data(), d.data(), limbs, m_values.size(), nullptr));
-    return Vector(out.toHost());
+      hip::detail::unreachable();
     }
   }
   Vector& scalarMultiplyInPlace(const ELEMENT& scalar) { return *this = scalarMultiply(scalar); }
@@ -167,15 +181,18 @@ class Vector final {
   bool equals(const Vector& o) const {
     if (size() != o.size()) return false;
     if (empty()) return true;
-    if constexpr (!OnDevice<ELEMENT>) {
+    if (hip::onHost<ELEMENT>(size())) {
       bool eq = true;
       for (std::size_t i = 0; i < m_values.size(); ++i) eq &= m_values[i] == o.m_values[i];
       return eq;
+    }
+    if constexpr (OnDevice<ELEMENT>) {
+      hip::DeviceVector<ELEMENT> a(m_values), b(o.m_values);
+      int eq = 0;
+      hip::check(scl_hip_equals(vec_detail::tag<ELEMENT>(), &eq, a.data(), b.data(), m_values.size(), nullptr));
+      return eq != 0;
     } else {
-    hip::DeviceVector<ELEMENT> a(m_values), b(o.m_values);
-    int eq = 0;
-    hip::check(scl_hip_equals(vec_detail::tag<ELEMENT>(), &eq, a.data(), b.data(), m_values.size(), nullptr));
-    return eq != 0;
+      hip::detail::unreachable();
     }
   }
   friend bool operator==(const Vector& l, const Vector& r) { return l.equals(r); }
@@ -226,15 +243,18 @@ class Vector final {
   Vector binary(int op, const Vector& o) const {
     ensureCompatible(o);
     if (empty()) return Vector{};
-    if constexpr (!OnDevice<ELEMENT>) {
+    if (hip::onHost<ELEMENT>(size())) {
       std::vector<ELEMENT> r;
       r.reserve(size());
       for (std::size_t i = 0; i < m_values.size(); ++i)
         r.emplace_back(op == SCL_OP_ADD ? m_values[i] + o.m_values[i]
                                         : op == SCL_OP_SUB ? m_values[i] - o.m_values[i] : m_values[i] * o.m_values[i]);
       return Vector(std::move(r));
+    }
+    if constexpr (OnDevice<ELEMENT>) {
+      return Vector(vec_detail::runEw<ELEMENT>(op, m_values, &o.m_values));
     } else {
-    return Vector(vec_detail::runEw<ELEMENT>(op, m_values, &o.m_values));
+      hip::detail::unreachable();
     }
   }
 

@@ -36,21 +36,17 @@ hip::DeviceVector<T> additiveRecover(const hip::ShareMatrix<T>& shares) {
 /// additiveShare(secret, n, prg) (additive.h:41-53); reconstruct with shares.sum()
 template <typename T>
 math::Vector<T> additiveShare(const T& secret, std::size_t n, util::PRG& prg) {
-  if constexpr (!math::OnDevice<T>) {  // n - 1 random elements, the last = secret - their sum
-    if (n == 0) throw std::invalid_argument("cannot create shares for 0 people");
-    std::vector<T> shares;
-    shares.reserve(n);
-    T rest = secret;
-    for (std::size_t i = 0; i + 1 < n; ++i) {
-      shares.emplace_back(T::random(prg));
-      rest -= shares.back();
-    }
-    shares.emplace_back(rest);
-    return math::Vector<T>(std::move(shares));
-  } else {
-  hip::DeviceVector<T> one(std::vector<T>{secret});
-  return math::Vector<T>(additiveShare(one, n, prg).sharesOf(0));
+  // n - 1 random elements, the last = secret - their sum; on the host like every per-secret signature (ss/shamir.h)
+  if (n == 0) throw std::invalid_argument("cannot create shares for 0 people");
+  std::vector<T> shares;
+  shares.reserve(n);
+  T rest = secret;
+  for (std::size_t i = 0; i + 1 < n; ++i) {
+    shares.emplace_back(T::random(prg));
+    rest -= shares.back();
   }
+  shares.emplace_back(rest);
+  return math::Vector<T>(std::move(shares));
 }
 
 }  // namespace scl::ss

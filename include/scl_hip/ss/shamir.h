@@ -1,8 +1,8 @@
 // include/scl_hip/ss/shamir.h -- scl::ss Shamir sharing (include/scl/ss/shamir.h:51-155) on the GPU.
 //
 // The reference works one secret per call and returns a heap Vector of n shares; those signatures
-// are kept (they run the same kernels with N = 1, through the C ABI).  The batch forms in scl::ss
-// take many secrets at once and keep the shares in HBM as a ShareMatrix (SoA [party][secret]).
+// are kept and run on the host, over FF's operators (see "per-secret" below).  The batch forms in scl::ss
+// take many secrets at once, keep the shares in HBM as a ShareMatrix (SoA [party][secret]) and run the kernels.
 // Results are bit-identical to the per-secret reference calls driven by the same PRG.
 #ifndef SCL_HIP_SS_SHAMIR_H
 #define SCL_HIP_SS_SHAMIR_H
@@ -118,50 +118,46 @@ hip::DeviceVector<T> shamirRecoverD(const hip::ShareMatrix<T>& shares, std::size
 }
 
 // ------------------------------------------------------------------------------- per-secret (reference)
+// The reference's own signatures: ONE secret per call, values in host memory.  They run the reference's own steps on the
+// host through FF's operators (detail/field.hpp: the arithmetic the kernels compile) -- a device round trip per call
+// would cost two orders of magnitude more than the reference's 0.5 us (hip/device.h, "where a host-resident operand is
+// worked on").  Bit-identical to the batch kernels on the same PRG (every operation returns the canonical representative).
+namespace shamir_detail {
+/// the i-th evaluation point, i = 1, 2, ..: x++ on T::one() as in shamir.h:62-65 -- except over GF(2^128), where that walk
+/// cycles 1, 0, 1, .. and the nodes are the bit patterns of 1, 2, .. (T(int)), as in every batch path
+template <typename T>
+T nextNode(const T& x, std::size_t i) {
+  if constexpr (requires { T::Field::TAG; }) {
+    if constexpr (T::Field::TAG == SCL_GF2_128) return T(static_cast<int>(i + 1));
+  }
+  T y = x;
+  return ++y;
+}
+}  // namespace shamir_detail
+
 /// shamirSecretShare(secret, t, n, prg) (shamir.h:51-68)
 template <typename T>
 math::Vector<T> shamirSecretShare(const T& secret, std::size_t t, std::size_t n, util::PRG& prg) {
-  if constexpr (!math::OnDevice<T>) {
-    // the reference's own steps for an element type without kernels (a user-defined field, an Array of them): random
-    // coefficients, c_0 = secret, evaluate at 1, 2, .. produced by x++ on T::one()
-    auto c = math::Vector<T>::random(t + 1, prg);
-    c[0] = secret;
-    const auto p = math::Polynomial<T>::create(c);
-    std::vector<T> shares;
-    shares.reserve(n);
-    T x = T::one();
-    for (std::size_t i = 0; i < n; ++i) shares.emplace_back(p.evaluate(x++));
-    return math::Vector<T>(std::move(shares));
-  } else {
-  hip::DeviceVector<T> one(std::vector<T>{secret});
-  const auto m = shamirSecretShare(one, t, n, prg);
-  return math::Vector<T>(m.sharesOf(0));
+  // random coefficients, c_0 = secret, evaluate at 1, 2, .. produced by x++ on T::one()
+  auto c = math::Vector<T>::random(t + 1, prg);
+  c[0] = secret;
+  const auto p = math::Polynomial<T>::create(c);
+  std::vector<T> shares;
+  shares.reserve(n);
+  T x = T::one();
+  for (std::size_t i = 1; i <= n; ++i) {
+    shares.emplace_back(p.evaluate(x));
+    x = shamir_detail::nextNode(x, i);
   }
+  return math::Vector<T>(std::move(shares));
 }
-
-namespace shamir_detail {
-template <typename T>
-hip::ShareMatrix<T> upload(const math::Vector<T>& shares, std::size_t count) {
-  hip::ShareMatrix<T> m(count, 1);
-  std::vector<std::uint64_t> l(count * limbs<T>() + 1);
-  for (std::size_t i = 0; i < count; ++i) shares[i].toLimbs(l.data() + i * limbs<T>());
-  if (count) hip::check(scl_hip_memcpy_h2d(m.data(), l.data(), count * T::byteSize(), nullptr));
-  hip::check(scl_hip_stream_sync(nullptr));
-  return m;
-}
-}  // namespace shamir_detail
 
 /// shamirRecoverP(shares, alphas, x) (shamir.h:81-87): the basis is taken over ALL alphas and paired
 /// with the shares in order, as innerProd does there
 template <typename T>
 T shamirRecoverP(const math::Vector<T>& shares, const math::Vector<T>& alphas, const T& x) {
-  if constexpr (!math::OnDevice<T>) {
-    const auto lb = math::computeLagrangeBasis(alphas, x);
-    return math::innerProd<T>(shares.begin(), shares.end(), lb.begin());
-  } else {
-  const auto m = shamir_detail::upload(shares, shares.size());
-  return shamir_detail::recoverWithBasis(m, math::computeLagrangeBasis(alphas, x)).toHost()[0];
-  }
+  const auto lb = math::computeLagrangeBasis(alphas, x);
+  return math::innerProd<T>(shares.begin(), shares.end(), lb.begin());
 }
 
 /// shamirRecoverP(shares) (shamir.h:99-104): nodes 1..size, x = 0
@@ -176,29 +172,15 @@ T shamirRecoverD(const math::Vector<T>& shares, const math::Vector<T>& alphas, s
                  const T& x) {
   if (shares.size() < d + t || alphas.size() < d + t) hip::detail::raise(SCL_ERR_NOT_ENOUGH_SHARES);
   if (shares.size() < d + 1 || alphas.size() < d + 1) hip::detail::raise(SCL_ERR_INVALID_RANGE);  // t = 0 with d shares
-  if constexpr (!math::OnDevice<T>) {
-    const std::size_t m1 = d + 1;
-    const auto ns = alphas.subVector(m1);
-    for (std::size_t i = m1; i < d + t; ++i) {
-      const auto lb = math::computeLagrangeBasis(ns, alphas[i]);
-      if (math::innerProd<T>(shares.begin(), shares.begin() + static_cast<std::ptrdiff_t>(m1), lb.begin()) != shares[i])
-        hip::detail::raise(SCL_ERR_ERROR_DETECTED);
-    }
-    const auto lb = math::computeLagrangeBasis(ns, x);
-    return math::innerProd<T>(shares.begin(), shares.begin() + static_cast<std::ptrdiff_t>(m1), lb.begin());
-  } else {
-  const std::size_t m = d + t;  // shares d+t .. are never looked at
-  const auto sm = shamir_detail::upload(shares, m);
-  const auto al = shamir_detail::toLimbs(alphas.subVector(m));
-  std::uint64_t xl[shamir_detail::limbs<T>()];
-  x.toLimbs(xl);
-  hip::DeviceVector<T> out(1);
-  hip::DeviceBuffer status(1);
-  std::size_t nbad = 0;
-  hip::check(scl_hip_shamir_recover_detect(T::Field::TAG, out.data(), static_cast<unsigned char*>(status.get()),
-                                           sm.data(), 1, m, 1, t, d, al.data(), xl, &nbad, nullptr));
-  return out.toHost()[0];
+  const std::size_t m1 = d + 1;
+  const auto ns = alphas.subVector(m1);
+  for (std::size_t i = m1; i < d + t; ++i) {
+    const auto lb = math::computeLagrangeBasis(ns, alphas[i]);
+    if (math::innerProd<T>(shares.begin(), shares.begin() + static_cast<std::ptrdiff_t>(m1), lb.begin()) != shares[i])
+      hip::detail::raise(SCL_ERR_ERROR_DETECTED);
   }
+  const auto lb = math::computeLagrangeBasis(ns, x);
+  return math::innerProd<T>(shares.begin(), shares.begin() + static_cast<std::ptrdiff_t>(m1), lb.begin());
 }
 
 /// shamirRecoverD(shares, t) (shamir.h:150-155): n = 2t+1 nodes 1..n, d = t, x = 0
@@ -325,23 +307,13 @@ ErrorCorrectedSecret<T> recoverCHost(const math::Vector<T>& shares, const math::
 /// shamirRecoverC(shares, alphas) (shamir.h:202-250)
 template <typename T>
 ErrorCorrectedSecret<T> shamirRecoverC(const math::Vector<T>& shares, const math::Vector<T>& alphas) {
-  if constexpr (!math::OnDevice<T>) {
-    return shamir_detail::recoverCHost(shares, alphas);
-  } else {
-  const auto sm = shamir_detail::upload(shares, shares.size());
-  return shamirRecoverC(sm, &alphas).at(0);
-  }
+  return shamir_detail::recoverCHost(shares, alphas);
 }
 
 /// shamirRecoverC(shares) (shamir.h:255-259): nodes 1..size
 template <typename T>
 ErrorCorrectedSecret<T> shamirRecoverC(const math::Vector<T>& shares) {
-  if constexpr (!math::OnDevice<T>) {
-    return shamir_detail::recoverCHost(shares, math::Vector<T>::range(1, shares.size() + 1));
-  } else {
-  const auto sm = shamir_detail::upload(shares, shares.size());
-  return shamirRecoverC<T>(sm, nullptr).at(0);
-  }
+  return shamir_detail::recoverCHost(shares, math::Vector<T>::range(1, shares.size() + 1));
 }
 
 }  // namespace scl::ss

@@ -1,4 +1,5 @@
-// include/scl_hip/util/prg.h -- scl::util::PRG over the device AES-128-CTR kernel.
+// include/scl_hip/util/prg.h -- scl::util::PRG over the device AES-128-CTR kernel (draws of more than
+// hip::prgHostBytes() bytes) and the host AES of detail/aes_host.hpp (smaller ones).
 //
 // Mirrors include/scl/util/prg.h:64-173 / src/scl/util/prg.cc:88-146: key = seed zero-padded or
 // truncated to 16 bytes, block i = AES(LE64(counter) || LE64(0x0123456789ABCDEF)), next(buf, n)
@@ -15,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "../detail/aes_host.hpp"
 #include "../hip/device.h"
 
 namespace scl::util {
@@ -34,6 +36,18 @@ class PRG {
   void next(unsigned char* buffer, std::size_t n) {
     if (n == 0) return;
     const std::size_t nblocks = (n + 15) / 16;
+    if (n <= hip::prgHostBytes()) {  // a few blocks: AES on the host (detail/aes_host.hpp), no device round trip
+      const detail::Aes128Host& aes = m_aes;
+      if (n % 16 == 0) {
+        aes.prgBlocks(buffer, nblocks, m_counter);
+      } else {
+        std::vector<unsigned char> tmp(nblocks * 16);
+        aes.prgBlocks(tmp.data(), nblocks, m_counter);
+        std::copy(tmp.begin(), tmp.begin() + static_cast<std::ptrdiff_t>(n), buffer);
+      }
+      m_counter += nblocks;
+      return;
+    }
     hip::DeviceBuffer dev(nblocks * 16);
     hip::check(scl_hip_prg_blocks(static_cast<unsigned char*>(dev.get()), nblocks, m_seed.data(), m_seed.size(),
                                   m_counter, nullptr));
@@ -72,9 +86,11 @@ class PRG {
   PRG(const unsigned char* seed, std::size_t seed_len) {
     m_seed.fill(0);
     if (seed != nullptr) std::copy(seed, seed + std::min<std::size_t>(seed_len, 16), m_seed.begin());
+    m_aes = detail::Aes128Host(m_seed.data());
   }
 
   std::array<unsigned char, 16> m_seed;
+  detail::Aes128Host m_aes{std::array<unsigned char, 16>{}.data()};  // round keys of the seed, for the host-side draws
   std::uint64_t m_counter = 0;
 };
 

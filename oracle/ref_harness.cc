@@ -670,4 +670,42 @@ int sclref_time_shamir_hoisted(int field, std::size_t N, std::size_t t, std::siz
   return 0;
 }
 
+// BASELINE configs[0]: additive sharing, per secret additiveShare(secret, n, prg) (additive.h:41-53) then the
+// reconstruction shares.sum() (vector.h:261-267), exactly as a caller of the reference writes it.
+int sclref_time_additive(int field, std::size_t N, std::size_t n, const unsigned char* seed, std::size_t seed_len,
+                         double* share_s, double* recover_s, std::uint64_t* mismatches, std::uint64_t* checksum) {
+  using clk = std::chrono::steady_clock;
+  DISPATCH(field, {
+    auto prg = makePrg(seed, seed_len);
+    double ts = 0, tr = 0;
+    std::uint64_t bad = 0, acc = 0;
+    constexpr std::size_t CH = 4096;
+    std::vector<Vector<F>> held;
+    held.reserve(CH);
+    for (std::size_t s0 = 0; s0 < N; s0 += CH) {
+      const std::size_t cnt = std::min(CH, N - s0);
+      held.clear();
+      auto a = clk::now();
+      for (std::size_t i = 0; i < cnt; ++i)
+        held.emplace_back(scl::ss::additiveShare(F((int)((s0 + i) & 0x7fffffff)), n, prg));
+      auto b = clk::now();
+      for (std::size_t i = 0; i < cnt; ++i) {
+        const F r = held[i].sum();
+        std::uint64_t w[4] = {0, 0, 0, 0};
+        store<F>(w, r);
+        acc += w[0];
+        bad += !(r == F((int)((s0 + i) & 0x7fffffff)));
+      }
+      auto c = clk::now();
+      ts += std::chrono::duration<double>(b - a).count();
+      tr += std::chrono::duration<double>(c - b).count();
+    }
+    *share_s = ts;
+    *recover_s = tr;
+    *mismatches = bad;
+    *checksum = acc;
+  });
+  return 0;
+}
+
 }  // extern "C"

@@ -11,6 +11,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -67,6 +68,8 @@ thread_local Knob g_mfma_pipe{2};  // 4-row-tile shapes: 2 = two pipelined waves
                                    // rows; else as 1), 1 = one pipelined wave per SIMD, 0 = burst kernel ("mfma_pipe")
 thread_local Knob g_mfma_areg{1};  // register-resident V fragments for the 4-row-tile shapes ("mfma_areg" tuning key)
 thread_local Knob g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
+thread_local Knob g_gf_tiles{1};      // GF(2^128) sharing at the default nodes: 1 = eight nodes per Horner loop (k_share_gf_tiles),
+                                      // 0 = one node at a time (k_share_gf_nodes) ("gf_tiles")
 thread_local Knob g_prg_two_pass{0};  // PRG-driven sharing: 0 auto, 1 always two passes, -1 always the fused kernels
 // Headline streaming kernels (k_recover_fixed, k_share_small): workgroup size and resident waves per CU
 // (kernels.hpp, "Launch geometry"); "stream_block" 64 | 256, "stream_waves" 0 = no cap
@@ -77,15 +80,22 @@ thread_local Knob g_share_waves{9};  // the same cap for the Mersenne61 small-no
                                      // 256-thread kernel without a cap)
 
 // dynamic LDS bytes that cap the residency of a kernel with `static_lds` bytes of its own at `waves` waves of
-// `block` threads per CU (160 KiB of LDS per CU; allocation granularity 512 B assumed, one granule of slack)
+// `block` threads per CU.  A CU has 160 KiB of LDS and hands it out in granules; the granule of gfx950 is not documented
+// (512 B on earlier parts, 1280 B = 1/128 of the array is the other candidate), so the request is chosen to hold for BOTH:
+// `groups` allocations fit, `groups + 1` do not, whichever granule rounds it up.  No such size exists for every count
+// (24 and more groups per CU): then no cap is applied.
 size_t residency_pad(long waves, int block, size_t static_lds) {
   if (waves <= 0) return 0;
-  const long groups = waves * 64 / block;
+  const size_t groups = (size_t)(waves * 64 / block);
   if (groups < 1) return 0;
-  const size_t per = (size_t)(160 * 1024) / (size_t)groups;      // what each resident workgroup may take
-  const size_t want = per - 1024;                                // strictly more than 160 KiB / (groups + 1) for groups <= 12
-  if (want <= static_lds || want > 64 * 1024) return 0;
-  return (want - static_lds) & ~(size_t)511;
+  constexpr size_t LDS = 160 * 1024;
+  auto holds = [&](size_t total, size_t granule) {
+    const size_t alloc = (total + granule - 1) / granule * granule;
+    return groups * alloc <= LDS && (groups + 1) * alloc > LDS;
+  };
+  for (size_t total = LDS / groups / 128 * 128; total > static_lds && total >= 1024; total -= 128)
+    if (holds(total, 512) && holds(total, 1280)) return total <= 64 * 1024 ? total - static_lds : 0;
+  return 0;
 }
 
 unsigned grid_for(size_t work_items) {
@@ -138,19 +148,29 @@ unsigned grid_aes4(size_t work_items) {
     hipLaunchKernelGGL(kern_, dim3(grid_aes4(WORK)), dim3(ABLOCK), AES4_LDS_BYTES, ST, __VA_ARGS__);                \
   } while (0)
 
-// ---- Mont128 modulus: per host thread ---------------------------------------------------------------
-// (two threads working over different primes must not see each other's; every thread starts at 2^128 - 159)
-thread_local Mont128::Ctx g_mont = {0, 0, 0, 0};
+// ---- Mont128 modulus: a process-wide default, overridden per host thread ------------------------------
+// scl_hip_mont128_set_prime sets the CALLING thread's modulus and the process-wide default.  A thread that has set its
+// own keeps it whatever other threads do (two threads working over different primes do not see each other's); a thread
+// that never set one -- a pool worker, a Python thread started after the main thread chose the prime -- works over the
+// default, i.e. the modulus set last by any thread, and over 2^128 - 159 before any was.
+thread_local Mont128::Ctx g_mont = {0, 0, 0, 0};  // p == 0: this thread follows the default
+std::mutex g_mont_default_mu;
+Mont128::Ctx g_mont_default = {0, 0, 0, 0};
 
 int mont_set(u128 p) {
   if (!(p & 1) || p < 3) return fail(SCL_ERR_BAD_ARG, "mont128: modulus must be odd and >= 3");
   g_mont = Mont128::make_ctx(p);
+  std::lock_guard<std::mutex> lk(g_mont_default_mu);
+  g_mont_default = g_mont;
   return SCL_OK;
 }
 
 Mont128::Ctx mont_ctx() {
-  if (!g_mont.p) mont_set((((u128)0xFFFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFF61ull);  // 2^128 - 159
-  return g_mont;
+  if (g_mont.p) return g_mont;
+  std::lock_guard<std::mutex> lk(g_mont_default_mu);
+  if (!g_mont_default.p)
+    g_mont_default = Mont128::make_ctx((((u128)0xFFFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFF61ull);  // 2^128 - 159
+  return g_mont_default;
 }
 
 template <class Fn>
@@ -486,30 +506,35 @@ int alpha_table(const typename F::Ctx& ctx, const u64* alphas_host, size_t n, Bi
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
 // ---- MFMA share path (Mersenne61): limb planes of the Vandermonde matrix, cached per device ----------
+// A cached device table is owned through a shared pointer: the cache holds one reference, every caller holds another (its
+// "pin") from the lookup until its kernel is enqueued.  An entry evicted in between -- by another host thread that misses
+// while 16 entries are cached -- is therefore freed only when the last pin drops, i.e. after the launch; hipFree then waits
+// for the kernels already enqueued, the pinning one included.
+using DevPin = std::shared_ptr<void>;
+inline DevPin make_dev_pin(void* dev) {
+  return DevPin(dev, [](void* p) { (void)hipFree(p); });
+}
 struct MfmaTable {
   int device, n, t, KS, MT;
   std::vector<u64> alphas;
-  void* dev;
+  DevPin dev;
 };
 std::mutex g_mfma_mu;
 std::vector<MfmaTable> g_mfma_tables;  // immutable once built; most recently used last, at most TABLE_CACHE_CAP entries
 constexpr size_t TABLE_CACHE_CAP = 16;
 
-// Keeps a table cache bounded: a hit moves its entry to the back, a miss past the cap frees the front (least recently
-// used) entry.  hipFree waits for the device, so a kernel still reading the evicted table has finished by then.
+// Keeps a table cache bounded: a hit moves its entry to the back, a miss past the cap drops the cache's reference to the
+// front (least recently used) entry; the table itself goes when no caller pins it any more (DevPin above).
 template <class Entry>
 void cache_touch(std::vector<Entry>& cache, size_t hit) {
   if (hit + 1 != cache.size()) std::rotate(cache.begin() + hit, cache.begin() + hit + 1, cache.end());
 }
 template <class Entry>
 void cache_make_room(std::vector<Entry>& cache) {
-  while (cache.size() >= TABLE_CACHE_CAP) {
-    (void)hipFree(cache.front().dev);
-    cache.erase(cache.begin());
-  }
+  while (cache.size() >= TABLE_CACHE_CAP) cache.erase(cache.begin());
 }
 
-int mfma_table(const BigTable<M61>& al, size_t n, size_t t, int KS, int MT, const unsigned char** out) {
+int mfma_table(const BigTable<M61>& al, size_t n, size_t t, int KS, int MT, DevPin* pin, const unsigned char** out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_mfma_mu);
@@ -517,7 +542,8 @@ int mfma_table(const BigTable<M61>& al, size_t n, size_t t, int KS, int MT, cons
     const MfmaTable& e = g_mfma_tables[k];
     if (e.device == dev && e.n == (int)n && e.t == (int)t && e.KS == KS && e.MT == MT &&
         std::equal(e.alphas.begin(), e.alphas.end(), al.v)) {
-      *out = static_cast<const unsigned char*>(e.dev);
+      *pin = e.dev;
+      *out = static_cast<const unsigned char*>(e.dev.get());
       cache_touch(g_mfma_tables, k);
       return SCL_OK;
     }
@@ -535,11 +561,13 @@ int mfma_table(const BigTable<M61>& al, size_t n, size_t t, int KS, int MT, cons
         host[((size_t)(l * MT + (int)(i / 32)) * 32 + (i % 32)) * ROWB + k] = (unsigned char)(digits >> (8 * l));
     }
   }
-  MfmaTable e{dev, (int)n, (int)t, KS, MT, std::vector<u64>(al.v, al.v + n), nullptr};
-  HIP_TRY(hipMalloc(&e.dev, host.size()));
-  HIP_TRY(hipMemcpy(e.dev, host.data(), host.size(), hipMemcpyHostToDevice));
+  void* raw = nullptr;
+  HIP_TRY(hipMalloc(&raw, host.size()));
+  MfmaTable e{dev, (int)n, (int)t, KS, MT, std::vector<u64>(al.v, al.v + n), make_dev_pin(raw)};
+  HIP_TRY(hipMemcpy(raw, host.data(), host.size(), hipMemcpyHostToDevice));
   g_mfma_tables.push_back(e);
-  *out = static_cast<const unsigned char*>(e.dev);
+  *pin = e.dev;
+  *out = static_cast<const unsigned char*>(raw);
   return SCL_OK;
 }
 
@@ -693,7 +721,8 @@ int share_mfma(const BigTable<M61>& al, u64* shares, size_t stride, const u64* s
   const int KS = t + 1 <= 32 ? 1 : 2;
   const int MT = (n <= 32 && KS == 1) ? 1 : n <= 64 ? 2 : 4;  // (as matmul_mfma: no one-row-tile form with two k-steps)
   const unsigned char* tab = nullptr;
-  SCL_TRY(mfma_table(al, n, t, KS, MT, &tab));
+  DevPin pin;  // held until the launch below is enqueued
+  SCL_TRY(mfma_table(al, n, t, KS, MT, &pin, &tab));
 #define MF_CASE(ks, mt) \
   if (KS == ks && MT == mt) return launch_share_mfma<ks, mt>(shares, stride, secrets, coeffs, cstride, tab, (int)t, (int)n, N, st);
   MF_CASE(1, 1) MF_CASE(1, 2) MF_CASE(1, 4) MF_CASE(2, 2) MF_CASE(2, 4)
@@ -706,7 +735,7 @@ int share_mfma(const BigTable<M61>& al, u64* shares, size_t stride, const u64* s
 struct VdmTable {
   int device, tag, n, t;
   std::vector<u64> key;  // raw_coeffs flag, field parameters (Mont128: the prime), then the nodes
-  void* dev;
+  DevPin dev;
 };
 std::mutex g_vdm_mu;
 std::vector<VdmTable> g_vdm_tables;  // immutable once built; bounded like g_mfma_tables
@@ -717,7 +746,7 @@ bool vdm_eligible(size_t n, size_t t) {
 }
 
 template <class F>
-int vdm_table(const typename F::Ctx& ctx, const BigTable<F>& al, size_t n, size_t t, bool raw_coeffs, const u64** out) {
+int vdm_table(const typename F::Ctx& ctx, const BigTable<F>& al, size_t n, size_t t, bool raw_coeffs, DevPin* pin, const u64** out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::vector<u64> key{raw_coeffs ? 1u : 0u};
@@ -734,7 +763,8 @@ int vdm_table(const typename F::Ctx& ctx, const BigTable<F>& al, size_t n, size_
   for (size_t k = 0; k < g_vdm_tables.size(); ++k) {
     const VdmTable& e = g_vdm_tables[k];
     if (e.device == dev && e.tag == (int)F::TAG && e.n == (int)n && e.t == (int)t && e.key == key) {
-      *out = static_cast<const u64*>(e.dev);
+      *pin = e.dev;
+      *out = static_cast<const u64*>(e.dev.get());
       cache_touch(g_vdm_tables, k);
       return SCL_OK;
     }
@@ -750,11 +780,13 @@ int vdm_table(const typename F::Ctx& ctx, const BigTable<F>& al, size_t n, size_
       v = F::mul(ctx, v, al.v[i]);
     }
   }
-  VdmTable e{dev, (int)F::TAG, (int)n, (int)t, key, nullptr};
-  HIP_TRY(hipMalloc(&e.dev, host.size() * sizeof(u64)));
-  HIP_TRY(hipMemcpy(e.dev, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
+  void* raw = nullptr;
+  HIP_TRY(hipMalloc(&raw, host.size() * sizeof(u64)));
+  VdmTable e{dev, (int)F::TAG, (int)n, (int)t, key, make_dev_pin(raw)};
+  HIP_TRY(hipMemcpy(raw, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
   g_vdm_tables.push_back(e);
-  *out = static_cast<const u64*>(e.dev);
+  *pin = e.dev;
+  *out = static_cast<const u64*>(raw);
   return SCL_OK;
 }
 
@@ -1029,6 +1061,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "stream_waves") g_stream_waves = value;
   else if (k == "share_waves") g_share_waves = value;
   else if (k == "mfma") g_mfma = value;
+  else if (k == "gf_tiles") g_gf_tiles = value;
   else return fail(SCL_ERR_BAD_ARG, "unknown tuning key " + k);
   return SCL_OK;
 }
@@ -1490,7 +1523,8 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
     if constexpr (F::TAG == 2 || F::LIMBS == 4) {
       if (vdm_eligible<F>(n, t) && !g_force_table.load()) {
         const u64* vdm = nullptr;
-        SCL_TRY((vdm_table<F>(ctx, al, n, t, false, &vdm)));
+        DevPin pin;  // held until the launch below is enqueued
+        SCL_TRY((vdm_table<F>(ctx, al, n, t, false, &pin, &vdm)));
         const dim3 g(grid_for(N)), blk(BLOCK);
         if (t <= 4)
           hipLaunchKernelGGL((k_share_vdm<F, 4>), g, blk, 0, S(stream), ctx, shares, share_stride, secrets, coeffs,
@@ -1523,8 +1557,23 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
           // a few persistent workgroups per CU keep the waves of a CU on the same few nodes' code (4.91 against 5.06 ms at
           // C4's shard size with one pack per thread; profiles/r2_gf128_node_horner.txt)
           const dim3 gg(g_max_blocks.load() > 0 ? g.x : std::min<unsigned>(g.x, 4096u));
-          hipLaunchKernelGGL(k_share_gf_nodes, gg, blk, 0, S(stream), sh, share_stride, se, co, coeff_stride, al, (int)t, (int)n,
-                             npacks);
+          bool default_nodes_in_order = n <= 64 && g_gf_tiles.load() != 0;
+          for (size_t i = 0; i < n && default_nodes_in_order; ++i) default_nodes_in_order = (u128)al.v[i] == (u128)(i + 1);
+          if (default_nodes_in_order) {  // party i at the bit pattern of i + 1: eight nodes per Horner loop
+#define GFT_CASE(TT)                                                                                                          \
+  case TT:                                                                                                                    \
+    hipLaunchKernelGGL(k_share_gf_tiles<TT>, gg, blk, 0, S(stream), sh, share_stride, se, co, coeff_stride, (int)n, npacks); \
+    break;
+            switch (t) {
+              GFT_CASE(5) GFT_CASE(6) GFT_CASE(7) GFT_CASE(8) GFT_CASE(9) GFT_CASE(10) GFT_CASE(11) GFT_CASE(12) GFT_CASE(13)
+              GFT_CASE(14) GFT_CASE(15) GFT_CASE(16)
+              default: break;
+            }
+#undef GFT_CASE
+          } else {
+            hipLaunchKernelGGL(k_share_gf_nodes, gg, blk, 0, S(stream), sh, share_stride, se, co, coeff_stride, al, (int)t, (int)n,
+                               npacks);
+          }
           launched = true;
         }
       }
@@ -1674,7 +1723,8 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
     if constexpr (F::TAG == 2 || F::LIMBS == 4) {
       if (vdm_eligible<F>(n, t) && !g_force_table.load()) {
         const u64* vdm = nullptr;
-        SCL_TRY((vdm_table<F>(ctx, al, n, t, true, &vdm)));
+        DevPin pin;  // held until the launch below is enqueued
+        SCL_TRY((vdm_table<F>(ctx, al, n, t, true, &pin, &vdm)));
         const dim3 g(grid_aes(N)), blk(BLOCK);
         if (t <= 4)
           hipLaunchKernelGGL((k_share_prg_vdm<F, 4>), g, blk, 0, S(stream), ctx, shares, share_stride, secrets, key,
@@ -2248,5 +2298,8 @@ int scl_hip_stream_copy(void* dst, const void* src, size_t bytes, void* stream) 
   LAUNCH_CHECK();
   return SCL_OK;
 }
+
+// ---- the open step: RCCL all-gather + reconstruct ----------------------------------------------------------------------
+#include "open_rccl.inc"
 
 }  // extern "C"

@@ -623,7 +623,7 @@ __device__ __forceinline__ void gf_node_step(u32 (&y)[5], u128 c) {
     r3 ^= __builtin_amdgcn_alignbit(y[3], y[2], 32 - B);      \
     r4 ^= __builtin_amdgcn_alignbit(y[4], y[3], 32 - B);      \
   }
-  SCL_GFN_BIT(1) SCL_GFN_BIT(2) SCL_GFN_BIT(3) SCL_GFN_BIT(4) SCL_GFN_BIT(5)
+  SCL_GFN_BIT(1) SCL_GFN_BIT(2) SCL_GFN_BIT(3) SCL_GFN_BIT(4) SCL_GFN_BIT(5) SCL_GFN_BIT(6)
 #undef SCL_GFN_BIT
   y[0] = r0;
   y[1] = r1;
@@ -787,6 +787,247 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) v
       default: break;
     }
 #undef SCL_GFX_CASE
+  }
+}
+
+// shamirSecretShare over GF(2^128) at the DEFAULT nodes (party i at the bit pattern of i + 1, n <= 64), 5 <= t <= 16.
+//
+// k_share_gf_nodes above runs one node's Horner steps, then the next node's: per step it pays the four register-indexed
+// moves that fetch c_k, the loop's scalar bookkeeping and a switch per node -- 18.4 scalar + 4 branch instructions beside
+// 31.8 vector ones per step, 121 SIMD-cycles against ~99 of vector work (profiles/r2_pmc_round_end.txt).  Three changes here:
+//
+// 1. EIGHT nodes advance together: the nodes 8H .. 8H+7 of a tile are compile-time constants, a loop iteration fetches
+//    its coefficients once and applies them to eight accumulators -- eight independent straight-line steps, the fetch and
+//    the loop control amortised over them.  A tile's code is a few KB; all tiles of a threshold stay in the instruction cache.
+// 2. Horner in a^2 over coefficient PAIRS:  y <- y * a^2 + (c_2B + a * c_2B+1).  Squaring is linear in characteristic 2,
+//    a^2 = sum_b a_b x^(2b) has as few terms as a, so the outer product costs what a plain Horner step costs (one shifted
+//    copy of y per set bit: 1 v_lshlrev + 4 v_alignbit at 4.5 cycles each + 5 v_xor at 2.6) -- but there are half as
+//    many of them: at (40,13) 6 outer products per node instead of 13.
+// 3. The inner term g(a) = c_2B + a * c_2B+1 is LINEAR in the bits of a, and the tile's nodes are 8H + l, l = 0 .. 7: with
+//    base = c_2B + (H x^3) * c_2B+1 (built once per tile and pair) the eight values are base + {0, d0, d1, d0+d1, ..}
+//    over d_e = c_2B+1 << e, e = 0, 1, 2 -- walked in Gray-code order, ONE five-word xor per node, no shifts.
+// The fifth accumulator word takes the bits pushed past x^127 (2 deg a per outer step) and comes down through
+// x^128 = x^7 + x^2 + x + 1 once per (32 - deg) / (2 deg) steps, for the tile as a whole.
+template <u32 A>
+__device__ __forceinline__ void gf_outer_step(u32 (&y)[5], const u32 (&g)[5]) {  // y <- y * A^2 + g  (A^2: bit b of A at 2b)
+  u32 r4 = g[4], r3 = g[3], r2 = g[2], r1 = g[1], r0 = g[0];
+  if constexpr (A & 1u) {
+    r4 ^= y[4];
+    r3 ^= y[3];
+    r2 ^= y[2];
+    r1 ^= y[1];
+    r0 ^= y[0];
+  }
+#define SCL_GFN_OUT(B)                                            \
+  if constexpr ((A >> B) & 1u) {                                  \
+    r4 ^= __builtin_amdgcn_alignbit(y[4], y[3], 32 - 2 * B);      \
+    r3 ^= __builtin_amdgcn_alignbit(y[3], y[2], 32 - 2 * B);      \
+    r2 ^= __builtin_amdgcn_alignbit(y[2], y[1], 32 - 2 * B);      \
+    r1 ^= __builtin_amdgcn_alignbit(y[1], y[0], 32 - 2 * B);      \
+    r0 ^= y[0] << (2 * B);                                        \
+  }
+  SCL_GFN_OUT(1) SCL_GFN_OUT(2) SCL_GFN_OUT(3) SCL_GFN_OUT(4) SCL_GFN_OUT(5) SCL_GFN_OUT(6)
+#undef SCL_GFN_OUT
+  y[4] = r4;
+  y[3] = r3;
+  y[2] = r2;
+  y[1] = r1;
+  y[0] = r0;
+}
+__device__ __forceinline__ void gf_words(u32 (&w)[4], u128 c) {
+  w[0] = (u32)c;
+  w[1] = (u32)(c >> 32);
+  w[2] = (u32)(c >> 64);
+  w[3] = (u32)(c >> 96);
+}
+// g <- c0 + (H x^3) * c1: the part of the inner term every node of tile H shares
+template <int H>
+__device__ __forceinline__ void gf_tile_base(u32 (&g)[5], const u32 (&c0)[4], const u32 (&c1)[4]) {
+  g[0] = c0[0];
+  g[1] = c0[1];
+  g[2] = c0[2];
+  g[3] = c0[3];
+  g[4] = 0;
+#define SCL_GFN_HB(B)                                               \
+  if constexpr ((H >> B) & 1) {                                      \
+    g[0] ^= c1[0] << (B + 3);                                        \
+    g[1] ^= __builtin_amdgcn_alignbit(c1[1], c1[0], 32 - (B + 3));   \
+    g[2] ^= __builtin_amdgcn_alignbit(c1[2], c1[1], 32 - (B + 3));   \
+    g[3] ^= __builtin_amdgcn_alignbit(c1[3], c1[2], 32 - (B + 3));   \
+    g[4] ^= c1[3] >> (32 - (B + 3));                                 \
+  }
+  SCL_GFN_HB(0) SCL_GFN_HB(1) SCL_GFN_HB(2) SCL_GFN_HB(3)
+#undef SCL_GFN_HB
+}
+// one pair of coefficients into the eight accumulators of tile H.  OUTER = false: the start value y = g(a) (top pair).
+// `nv` (RAGGED tiles only, wave-uniform): the nodes 8H + l with l < nv exist; the others are skipped.
+template <int H, bool OUTER, bool RAGGED>
+__device__ __forceinline__ void gf_tile_pair(u32 (&y)[8][5], u128 c0v, u128 c1v, int nv) {
+  u32 c0[4], c1[4], g[5], d1[5], d2[5];
+  gf_words(c0, c0v);
+  gf_words(c1, c1v);
+  gf_tile_base<H>(g, c0, c1);
+  d1[0] = c1[0] << 1;
+  d1[1] = __builtin_amdgcn_alignbit(c1[1], c1[0], 31);
+  d1[2] = __builtin_amdgcn_alignbit(c1[2], c1[1], 31);
+  d1[3] = __builtin_amdgcn_alignbit(c1[3], c1[2], 31);
+  d1[4] = c1[3] >> 31;
+  d2[0] = c1[0] << 2;
+  d2[1] = __builtin_amdgcn_alignbit(c1[1], c1[0], 30);
+  d2[2] = __builtin_amdgcn_alignbit(c1[2], c1[1], 30);
+  d2[3] = __builtin_amdgcn_alignbit(c1[3], c1[2], 30);
+  d2[4] = c1[3] >> 30;
+  auto node = [&](auto L) {  // g holds g(8H + l)
+    constexpr int l = decltype(L)::value;
+    if constexpr (H == 0 && l == 0) {
+      return;  // node 0 is nobody's
+    } else {
+      if (RAGGED && l >= nv) return;
+      if constexpr (OUTER) {
+        gf_outer_step<(u32)(8 * H + l)>(y[l], g);
+      } else {
+#pragma unroll
+        for (int w = 0; w < 5; ++w) y[l][w] = g[w];
+      }
+    }
+  };
+  auto add0 = [&]() {
+    g[0] ^= c1[0];
+    g[1] ^= c1[1];
+    g[2] ^= c1[2];
+    g[3] ^= c1[3];
+  };
+  auto add = [&](const u32(&d)[5]) {
+#pragma unroll
+    for (int w = 0; w < 5; ++w) g[w] ^= d[w];
+  };
+  // Gray-code walk over l: 0, 1, 3, 2, 6, 7, 5, 4
+  node(std::integral_constant<int, 0>{});
+  add0();
+  node(std::integral_constant<int, 1>{});
+  add(d1);
+  node(std::integral_constant<int, 3>{});
+  add0();
+  node(std::integral_constant<int, 2>{});
+  add(d2);
+  node(std::integral_constant<int, 6>{});
+  add0();
+  node(std::integral_constant<int, 7>{});
+  add(d1);
+  node(std::integral_constant<int, 5>{});
+  add0();
+  node(std::integral_constant<int, 4>{});
+}
+__device__ __forceinline__ void gf_tile_fold(u32 (&y)[8][5]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gf_fold5(y[j]);
+}
+// Coefficients 0 .. 7 of a lane's secret wait in LDS (a 16-byte slot per lane and coefficient that only the lane itself
+// touches: 32 KiB per 256-thread workgroup, four workgroups = four waves per SIMD per CU), those above in a 32-word
+// register vector read through the register-index mode: with all sixteen in registers beside 40 accumulator words the
+// kernel spills (98 registers at a budget of 128).
+template <int T, int H, bool RAGGED>
+__device__ __forceinline__ void gf_tile(u64* shares, size_t stride, size_t off, int n, u128 top, const v32u& hi, const uint4* lo) {
+  constexpr int TOPNODE = 8 * H + 7;
+  constexpr int DEG = TOPNODE >= 64 ? 6 : TOPNODE >= 32 ? 5 : TOPNODE >= 16 ? 4 : TOPNODE >= 8 ? 3 : 2;
+  constexpr int EVERY = (32 - DEG) / (2 * DEG);  // outer products the fifth word can take before it must come down
+  // coefficients c_0 .. c_T; pairs (c_2B, c_2B+1); with T even the top coefficient starts the recurrence alone
+  constexpr int BTOP = (T % 2 == 0 ? T / 2 : (T - 1) / 2) - 1;  // the highest pair below the start value
+  const int nv = n - 8 * H + 1;                                 // nodes 8H + l <= n  <=>  l < nv
+  u32 y[8][5];
+  auto hi_coeff = [&](int k) {  // 8 <= k < 16, wave-uniform
+    const int b = 4 * (k - 8);
+    return (u128)hi[b] | ((u128)hi[b + 1] << 32) | ((u128)hi[b + 2] << 64) | ((u128)hi[b + 3] << 96);
+  };
+  auto lo_coeff = [&](int k) {  // k < 8
+    const uint4 w = lo[k * BLOCK];
+    return (u128)w.x | ((u128)w.y << 32) | ((u128)w.z << 64) | ((u128)w.w << 96);
+  };
+  if constexpr (T % 2 == 0) {  // y = c_T
+    u32 c[4];
+    gf_words(c, top);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      y[j][0] = c[0];
+      y[j][1] = c[1];
+      y[j][2] = c[2];
+      y[j][3] = c[3];
+      y[j][4] = 0;
+    }
+  } else {  // y = c_(T-1) + a * c_T: the top pair, no outer product
+    constexpr int k = T - 1;
+    u128 ck;
+    if constexpr (k >= 8) ck = hi_coeff(k);
+    else ck = lo_coeff(k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j][0] = y[j][1] = y[j][2] = y[j][3] = y[j][4] = 0;
+    gf_tile_pair<H, false, RAGGED>(y, ck, top, nv);
+  }
+  int since = 0;
+  if constexpr (BTOP >= 4) {
+#pragma unroll 1
+    for (int B = BTOP; B >= 4; --B) {
+      gf_tile_pair<H, true, RAGGED>(y, hi_coeff(2 * B), hi_coeff(2 * B + 1), nv);
+      if (++since == EVERY) {
+        gf_tile_fold(y);
+        since = 0;
+      }
+    }
+  }
+#pragma unroll 1
+  for (int B = (BTOP < 3 ? BTOP : 3); B >= 0; --B) {
+    gf_tile_pair<H, true, RAGGED>(y, lo_coeff(2 * B), lo_coeff(2 * B + 1), nv);
+    if (++since == EVERY) {
+      gf_tile_fold(y);
+      since = 0;
+    }
+  }
+  gf_tile_fold(y);
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    if (8 * H + l >= 1 && (!RAGGED || l < nv)) {  // wave-uniform
+      Pack<Gf128, 1> r;
+      r.v[0] = (u128)y[l][0] | ((u128)y[l][1] << 32) | ((u128)y[l][2] << 64) | ((u128)y[l][3] << 96);
+      store_pack<Gf128, 1, true>(shares + (size_t)(8 * H + l - 1) * stride * Gf128::LIMBS + off, r);
+    }
+  }
+}
+template <int T, int H>
+__device__ __forceinline__ void gf_tile_any(u64* shares, size_t stride, size_t off, int n, u128 top, const v32u& hi, const uint4* lo) {
+  if (n >= 8 * H + 7) gf_tile<T, H, false>(shares, stride, off, n, top, hi, lo);
+  else if (n >= 8 * H && (H > 0 || n >= 1)) gf_tile<T, H, true>(shares, stride, off, n, top, hi, lo);
+}
+template <int T>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_share_gf_tiles(
+    u64* shares, size_t stride, const u64* secrets, const u64* coeffs, size_t cstride, int n, size_t npacks) {
+  __shared__ uint4 gft_lo[8 * BLOCK];
+  uint4* const lo = gft_lo + threadIdx.x;
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * Gf128::LIMBS;
+#pragma unroll
+    for (int k = 0; k < (T < 8 ? T : 8); ++k) {
+      const u128 v = gf_load_coeff(secrets, coeffs, cstride, off, k);
+      lo[k * BLOCK] = make_uint4((u32)v, (u32)(v >> 32), (u32)(v >> 64), (u32)(v >> 96));
+    }
+    v32u hi = {};
+#pragma unroll
+    for (int k = 8; k < T; ++k) {
+      const u128 v = gf_load_coeff(secrets, coeffs, cstride, off, k);
+      hi[4 * (k - 8)] = (u32)v;
+      hi[4 * (k - 8) + 1] = (u32)(v >> 32);
+      hi[4 * (k - 8) + 2] = (u32)(v >> 64);
+      hi[4 * (k - 8) + 3] = (u32)(v >> 96);
+    }
+    const u128 top = gf_load_coeff(secrets, coeffs, cstride, off, T);
+    gf_tile_any<T, 0>(shares, stride, off, n, top, hi, lo);
+    gf_tile_any<T, 1>(shares, stride, off, n, top, hi, lo);
+    gf_tile_any<T, 2>(shares, stride, off, n, top, hi, lo);
+    gf_tile_any<T, 3>(shares, stride, off, n, top, hi, lo);
+    gf_tile_any<T, 4>(shares, stride, off, n, top, hi, lo);
+    gf_tile_any<T, 5>(shares, stride, off, n, top, hi, lo);
+    gf_tile_any<T, 6>(shares, stride, off, n, top, hi, lo);
+    gf_tile_any<T, 7>(shares, stride, off, n, top, hi, lo);
+    gf_tile_any<T, 8>(shares, stride, off, n, top, hi, lo);
   }
 }
 

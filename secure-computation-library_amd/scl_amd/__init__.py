@@ -50,7 +50,19 @@ def _declare_prototypes():
     source of truth): a forgotten c_size_t wrap or a swapped argument is then a ctypes.ArgumentError, not a wild
     pointer.  Every pointer parameter is c_void_p (accepts ints, data_ptr() wrappers, bytes, byref() and None)."""
     import re
-    hdr = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "scl_hip.h")
+    import warnings
+    # the repository's header, or the copy the csrc Makefile leaves next to the .so (a package moved without the tree)
+    candidates = [os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "scl_hip.h"), os.path.join(_HERE, "scl_hip.h")]
+    hdr = next((c for c in candidates if os.path.exists(c)), None)
+    if hdr is None:
+        # no header to read: result types only (status ints, the two size_t / string getters); arguments unchecked
+        warnings.warn("scl_amd: include/scl_hip.h not found beside the package; ctypes argument checking is off")
+        for name, ret in (("scl_hip_last_error", C.c_char_p), ("scl_hip_status_message", C.c_char_p),
+                          ("scl_hip_field_name", C.c_char_p), ("scl_hip_wire_size", C.c_size_t),
+                          ("scl_hip_wire_size_matrix", C.c_size_t), ("scl_hip_frame_size", C.c_size_t)):
+            if hasattr(lib, name):
+                getattr(lib, name).restype = ret
+        return 0
     src = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
     scalars = {"int": C.c_int, "long": C.c_long, "size_t": C.c_size_t, "uint64_t": C.c_uint64, "unsigned": C.c_uint,
                "float": C.c_float}
@@ -68,6 +80,8 @@ def _declare_prototypes():
                 argt.append(C.c_void_p)
             else:
                 base = re.sub(r"\bconst\b", "", prm).split()
+                if base[0] not in scalars:
+                    raise ImportError(f"scl_amd: {name}: parameter type {base[0]!r} in {hdr} has no ctypes mapping here")
                 argt.append(scalars[base[0]])
         fn.argtypes = argt
         n += 1
@@ -165,6 +179,9 @@ def set_tuning(key: str, value: int):
 
 
 def set_mont128_prime(p: int):
+    """Modulus of the MONT128 field for the calling thread AND the process-wide default (scl_hip.h): threads that never
+    call this -- ThreadPoolExecutor workers, say -- compute over the modulus set last by any thread; a thread that has
+    called it keeps its own."""
     a = np.array([p & (2 ** 64 - 1), p >> 64], dtype=np.uint64)
     _chk(lib.scl_hip_mont128_set_prime(_hp(a)))
 

@@ -45,9 +45,14 @@ static int g_fail = 0, g_checks = 0;
     }                                                                        \
   } while (0)
 
+// where a case runs: HOST = scalars and host containers only (no device call at any threshold); GPU = uses the batch
+// API (hip::DeviceVector / hip::ShareMatrix): kernels, always; BOTH = host containers of a field with kernels: runs on the
+// host below hip::hostThreshold() -- so also without a GPU -- and is run a second time with the threshold at 0, when
+// every Vector / Matrix / PRG member goes through its kernel
+enum Where { HOST = 0, GPU = 1, BOTH = 2 };
 struct Case {
   const char* name;
-  bool needs_gpu;
+  int where;
   std::function<void()> fn;
 };
 static std::vector<Case>& cases() {
@@ -55,7 +60,7 @@ static std::vector<Case>& cases() {
   return c;
 }
 struct Reg {
-  Reg(const char* n, bool g, std::function<void()> f) { cases().push_back({n, g, std::move(f)}); }
+  Reg(const char* n, int g, std::function<void()> f) { cases().push_back({n, g, std::move(f)}); }
 };
 #define TEST_CASE(id, name, gpu) \
   static void id();              \
@@ -112,7 +117,7 @@ static void field_identities(const char* seed_tag) {
   REQUIRE(FF(-5) == zero - FF(5));
 }
 
-TEST_CASE(ff_mersenne61, "FF<Mersenne61> identities + metadata", false) {
+TEST_CASE(ff_mersenne61, "FF<Mersenne61> identities + metadata", HOST) {
   field_identities<F61>("a");
   REQUIRE(std::string(F61::name()) == "Mersenne61");  // test_mersenne61.cc:28-33
   REQUIRE(F61::bitSize() == 61);
@@ -127,7 +132,7 @@ TEST_CASE(ff_mersenne61, "FF<Mersenne61> identities + metadata", false) {
   REQUIRE(ss.str() == "ff");
 }
 
-TEST_CASE(ff_mersenne127, "FF<Mersenne127> identities + metadata", false) {
+TEST_CASE(ff_mersenne127, "FF<Mersenne127> identities + metadata", HOST) {
   field_identities<F127>("b");
   REQUIRE(std::string(F127::name()) == "Mersenne127");  // test_mersenne127.cc:28-33
   REQUIRE(F127::bitSize() == 127);
@@ -139,7 +144,7 @@ TEST_CASE(ff_mersenne127, "FF<Mersenne127> identities + metadata", false) {
   REQUIRE((std::is_same_v<math::Fp<1>, F61>));
 }
 
-TEST_CASE(ff_secp256k1_scalar, "FF<Secp256k1Scalar> identities + metadata", false) {
+TEST_CASE(ff_secp256k1_scalar, "FF<Secp256k1Scalar> identities + metadata", HOST) {
   using FS = math::FF<math::ff::Secp256k1Scalar>;
   field_identities<FS>("s");
   REQUIRE(std::string(FS::name()) == "secp256k1_order");
@@ -152,7 +157,7 @@ TEST_CASE(ff_secp256k1_scalar, "FF<Secp256k1Scalar> identities + metadata", fals
   REQUIRE_THROWS_MSG(FS::fromString(std::string(66, 'f')), std::invalid_argument, "hex string too large to parse");
 }
 
-TEST_CASE(ff_secp256k1_field, "FF<Secp256k1Field> identities + metadata", false) {
+TEST_CASE(ff_secp256k1_field, "FF<Secp256k1Field> identities + metadata", HOST) {
   // the prime the curve is defined over, 2^256 - 2^32 - 977 (src/scl/math/fields/secp256k1_field.cc:43-135)
   using FP = math::FF<math::ff::Secp256k1Field>;
   field_identities<FP>("p");
@@ -169,7 +174,7 @@ TEST_CASE(ff_secp256k1_field, "FF<Secp256k1Field> identities + metadata", false)
   REQUIRE(buf[0] == 0xff && buf[27] == 0xfe && buf[31] == 0x2d && FP::read(buf) == FP(-2));  // value, big-endian
 }
 
-TEST_CASE(ff_plugins, "plug-in fields: Mont128, GF(2^128) identities", false) {
+TEST_CASE(ff_plugins, "plug-in fields: Mont128, GF(2^128) identities", HOST) {
   field_identities<math::FF<math::ff::Mont128>>("c");
   using G = math::FF<math::ff::GF2_128>;
   G a = G::fromString("0123456789abcdeffedcba9876543210"), b = G::fromString("ffeeddccbbaa99887766554433221100");
@@ -181,7 +186,7 @@ TEST_CASE(ff_plugins, "plug-in fields: Mont128, GF(2^128) identities", false) {
   REQUIRE(G::fromString("80000000000000000000000000000000") * G(2) == G(0x87));
 }
 
-TEST_CASE(small_forms, "detail/field.hpp: small-constant and lazy forms == generic mul/add", false) {
+TEST_CASE(small_forms, "detail/field.hpp: small-constant and lazy forms == generic mul/add", HOST) {
   // the device kernels' shortcuts (muladd_small, lazy accumulators) against plain mul/add on the host
   std::uint64_t st = 88172645463325252ull;
   auto rnd = [&]() {
@@ -247,7 +252,7 @@ TEST_CASE(small_forms, "detail/field.hpp: small-constant and lazy forms == gener
   }
 }
 
-TEST_CASE(prepared_constants, "detail/field.hpp: kc_make / kmac / kacc_fold == mul/add, K_TERMS worst case", false) {
+TEST_CASE(prepared_constants, "detail/field.hpp: kc_make / kmac / kacc_fold == mul/add, K_TERMS worst case", HOST) {
   // the table-driven kernels' multiply-accumulate against a prepared constant, on the host
   std::uint64_t st = 0x9E3779B97F4A7C15ull;
   auto rnd = [&]() {
@@ -303,7 +308,7 @@ TEST_CASE(prepared_constants, "detail/field.hpp: kc_make / kmac / kacc_fold == m
   }
 }
 
-TEST_CASE(poly_host, "Polynomial: create / evaluate / arithmetic", false) {
+TEST_CASE(poly_host, "Polynomial: create / evaluate / arithmetic", HOST) {
   using P = math::Polynomial<F61>;
   // test/scl/math/test_poly.cc:64-71: 4 + 5x + x^2 at 5 = 54
   const auto p = P::create({F61(4), F61(5), F61(1)});
@@ -325,7 +330,7 @@ TEST_CASE(poly_host, "Polynomial: create / evaluate / arithmetic", false) {
   REQUIRE(p.subtract(p).isZero());
 }
 
-TEST_CASE(lagrange_host, "computeLagrangeBasis (host table code)", false) {
+TEST_CASE(lagrange_host, "computeLagrangeBasis (host table code)", HOST) {
   // closed form for nodes 1..n at 0: (-1)^(i-1) C(n,i)   
   const auto lb = math::computeLagrangeBasis(math::Vector<F61>::range(1, 11), 0);
   const int want[10] = {10, -45, 120, -210, 252, -210, 120, -45, 10, -1};
@@ -336,7 +341,7 @@ TEST_CASE(lagrange_host, "computeLagrangeBasis (host table code)", false) {
   REQUIRE(math::Vector<F61>::range(2, 2).empty());
 }
 
-TEST_CASE(matrix_host, "Matrix: identity / transpose / invert on scalars", false) {
+TEST_CASE(matrix_host, "Matrix: identity / transpose / invert on scalars", HOST) {
   using M = math::Matrix<F61>;
   auto m = M::fromVector(2, 2, {F61(1), F61(2), F61(3), F61(4)});
   REQUIRE(m.transpose()(0, 1) == F61(3));
@@ -359,7 +364,7 @@ TEST_CASE(matrix_host, "Matrix: identity / transpose / invert on scalars", false
 using G7 = math::FF<usr::Gf7>;
 static_assert(!math::OnDevice<G7> && math::OnDevice<F61>, "GF(7) has no kernels; the built-in fields do");
 
-TEST_CASE(gf7_scalars, "user-defined field GF(7): FF<Gf7> over the eleven ff:: specialisations", false) {
+TEST_CASE(gf7_scalars, "user-defined field GF(7): FF<Gf7> over the eleven ff:: specialisations", HOST) {
   REQUIRE(std::string(G7::name()) == "GF(7)" && G7::byteSize() == 1 && G7::bitSize() == 8);
   for (int a = 0; a < 7; ++a)
     for (int b = 0; b < 7; ++b) {
@@ -383,7 +388,7 @@ TEST_CASE(gf7_scalars, "user-defined field GF(7): FF<Gf7> over the eleven ff:: s
   REQUIRE(x == G7::zero());  // the x++ walk of shamirSecretShare wraps in a 7-element field
 }
 
-TEST_CASE(gf7_containers, "user-defined field GF(7): Vector / Matrix / Polynomial / Lagrange on the host", false) {
+TEST_CASE(gf7_containers, "user-defined field GF(7): Vector / Matrix / Polynomial / Lagrange on the host", HOST) {
   using V = math::Vector<G7>;
   const V a = {G7(1), G7(2), G7(3)}, b = {G7(6), G7(5), G7(4)};
   REQUIRE(a.add(b) == V({G7(0), G7(0), G7(0)}) && a.subtract(b) == V({G7(2), G7(4), G7(6)}));
@@ -422,7 +427,7 @@ TEST_CASE(gf7_containers, "user-defined field GF(7): Vector / Matrix / Polynomia
   REQUIRE(math::Matrix<G7>::vandermonde(3, 3).multiply(math::Matrix<G7>::vandermonde(3, 3).invert()).isIdentity());
 }
 
-TEST_CASE(gf7_berlekamp_welch, "user-defined field GF(7): the Wikipedia Berlekamp-Welch case (test_shamir.cc:144-160)", false) {
+TEST_CASE(gf7_berlekamp_welch, "user-defined field GF(7): the Wikipedia Berlekamp-Welch case (test_shamir.cc:144-160)", HOST) {
   // https://en.wikipedia.org/wiki/Berlekamp%E2%80%93Welch_algorithm#Example: seven shares of a degree-2 sharing,
   // the ones at nodes 2 and 5 wrong
   const math::Vector<G7> received = {G7(1), G7(5), G7(3), G7(6), G7(3), G7(2), G7(2)};
@@ -444,7 +449,7 @@ TEST_CASE(gf7_berlekamp_welch, "user-defined field GF(7): the Wikipedia Berlekam
   REQUIRE(s2.f.constantTerm() == s.f.constantTerm());
 }
 
-TEST_CASE(prg_gpu, "util::PRG stream", true) {
+TEST_CASE(prg_gpu, "util::PRG stream", BOTH) {
   // test/scl/util/test_prg.cc:49-125 (determinism, reset, seed truncation) + known answers
   auto prg = util::PRG::create("shamir passive");
   const auto b = prg.next(32);
@@ -469,7 +474,7 @@ TEST_CASE(prg_gpu, "util::PRG stream", true) {
   REQUIRE_THROWS_MSG(prg.next(small, 5), std::invalid_argument, "n exceeds buffer.size()");
 }
 
-TEST_CASE(vector_gpu, "Vector<FF> members", true) {
+TEST_CASE(vector_gpu, "Vector<FF> members", BOTH) {
   using Vec = math::Vector<F61>;
   // test/scl/math/test_vector.cc:39-203
   const Vec v0{F61(1), F61(2), F61(3)}, v1{F61(2), F61(123), F61(5)};
@@ -512,7 +517,7 @@ TEST_CASE(vector_gpu, "Vector<FF> members", true) {
   REQUIRE((math::innerProd<F61>(a.begin(), a.end(), b.begin())) == d);
 }
 
-TEST_CASE(matrix_gpu, "Matrix multiply / vandermonde", true) {
+TEST_CASE(matrix_gpu, "Matrix multiply / vandermonde", BOTH) {
   using M = math::Matrix<F61>;
   // test/scl/math/test_matrix.cc:367-395
   const auto v = M::vandermonde(3, 3);
@@ -542,7 +547,7 @@ TEST_CASE(matrix_gpu, "Matrix multiply / vandermonde", true) {
   REQUIRE(him.multiply(him.invert()).isIdentity());
 }
 
-TEST_CASE(shamir_gpu, "ss::shamir*", true) {
+TEST_CASE(shamir_mirror, "ss::shamir* per secret (reference signatures)", BOTH) {
   // test/scl/ss/test_shamir.cc:34-40
   {
     auto prg = util::PRG::create("shamir passive");
@@ -608,6 +613,9 @@ TEST_CASE(shamir_gpu, "ss::shamir*", true) {
     REQUIRE(ss::shamirRecoverD(shares, alphas, 3, 3, F61(0)) == F61(123));
     REQUIRE(ss::shamirRecoverD(shares, alphas, 3, 3, alphas[0]) == shares[0]);
   }
+}
+
+TEST_CASE(shamir_gpu, "ss::shamir*", GPU) {
   // batch == the per-secret calls on one PRG, in order
   {
     const std::size_t N = 1000, n = 10, t = 3;
@@ -636,7 +644,7 @@ TEST_CASE(shamir_gpu, "ss::shamir*", true) {
   }
 }
 
-TEST_CASE(recover_c_gpu, "ss::shamirRecoverC (Berlekamp-Welch)", true) {
+TEST_CASE(recover_c_mirror, "ss::shamirRecoverC per secret (Berlekamp-Welch, reference signatures)", BOTH) {
   // test/scl/ss/test_shamir.cc:111-126
   {
     auto prg = util::PRG::create("shamir correct");
@@ -668,6 +676,9 @@ TEST_CASE(recover_c_gpu, "ss::shamirRecoverC (Berlekamp-Welch)", true) {
     REQUIRE(r.f.constantTerm() == F61(123));
     REQUIRE(r.err.evaluate(alphas[4]) == F61(0));
   }
+}
+
+TEST_CASE(recover_c_gpu, "ss::shamirRecoverC (Berlekamp-Welch)", GPU) {
   // batch: 500 secrets, every third one with up to t corrupted shares
   {
     std::vector<F61> secrets;
@@ -714,7 +725,7 @@ TEST_CASE(recover_c_gpu, "ss::shamirRecoverC (Berlekamp-Welch)", true) {
   }
 }
 
-TEST_CASE(additive_gpu, "ss::additiveShare", true) {
+TEST_CASE(additive_mirror, "ss::additiveShare per secret (reference signature)", BOTH) {
   // test/scl/ss/test_additive.cc:26-41
   auto prg = util::PRG::create();
   const auto shares = ss::additiveShare(F61(12345), 3, prg);
@@ -729,6 +740,9 @@ TEST_CASE(additive_gpu, "ss::additiveShare", true) {
   REQUIRE(x.sum() == F61(55));
   REQUIRE(x.add(y).sum() == F61(66));  // additive homomorphism
   REQUIRE(ss::additiveShare(F61(9), 1, prg2) == math::Vector<F61>{F61(9)});
+}
+
+TEST_CASE(additive_gpu, "ss::additiveShare", GPU) {
   // batch
   std::vector<F61> secrets;
   for (int s = 0; s < 300; ++s) secrets.emplace_back(s * 31 + 5);
@@ -769,7 +783,7 @@ static void ring_identities() {
   REQUIRE(Z::fromString(a.toString().size() % 2 ? "0" + a.toString() : a.toString()) == a || Z::bitSize() > 64);
 }
 
-TEST_CASE(z2k_host, "Z2k<62> / Z2k<123> / Z2k<32> identities (host scalars)", false) {
+TEST_CASE(z2k_host, "Z2k<62> / Z2k<123> / Z2k<32> identities (host scalars)", HOST) {
   ring_identities<math::Z2k<62>>();
   ring_identities<math::Z2k<123>>();
   ring_identities<math::Z2k<32>>();
@@ -782,7 +796,7 @@ TEST_CASE(z2k_host, "Z2k<62> / Z2k<123> / Z2k<32> identities (host scalars)", fa
   REQUIRE(Z(0x1234567890ull).toString() == "34567890");
 }
 
-TEST_CASE(z2k_gpu, "Vector<Z2k>, additive sharing over a ring", true) {
+TEST_CASE(z2k_mirror, "Vector<Z2k>, additive sharing over a ring per secret", BOTH) {
   using Z = math::Z2k<62>;
   using Zb = math::Z2k<123>;
   {
@@ -814,6 +828,10 @@ TEST_CASE(z2k_gpu, "Vector<Z2k>, additive sharing over a ring", true) {
   const auto shares = ss::additiveShare(Z(12345), 3, prg3);
   REQUIRE(shares.size() == 3 && prg3.counter() == 2);
   REQUIRE(shares.sum() == Z(12345));
+}
+
+TEST_CASE(z2k_gpu, "additive sharing over a ring, batch", GPU) {
+  using Zb = math::Z2k<123>;
   std::vector<Zb> secrets;
   for (int i = 0; i < 257; ++i) secrets.emplace_back(Zb((__uint128_t)i * 0x9E3779B97F4A7C15ull));
   auto prg4 = util::PRG::create("ring-batch");
@@ -828,8 +846,7 @@ TEST_CASE(z2k_gpu, "Vector<Z2k>, additive sharing over a ring", true) {
 int main(int argc, char** argv) {
   const bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
   int ran = 0;
-  for (const auto& c : cases()) {
-    if (host_only && c.needs_gpu) continue;
+  auto run = [&](const Case& c, const char* suffix) {
     const int before = g_fail;
     try {
       c.fn();
@@ -837,8 +854,19 @@ int main(int argc, char** argv) {
       ++g_fail;
       std::printf("  EXCEPTION in '%s': %s\n", c.name, e.what());
     }
-    std::printf("[%s] %s\n", g_fail == before ? " ok " : "FAIL", c.name);
+    std::printf("[%s] %s%s\n", g_fail == before ? " ok " : "FAIL", c.name, suffix);
     ++ran;
+  };
+  for (const auto& c : cases()) {
+    if (host_only && c.where == GPU) continue;
+    run(c, "");
+  }
+  if (!host_only) {  // the same host-container cases with every Vector / Matrix / PRG member on its kernel
+    const std::size_t keep = hip::hostThreshold();
+    hip::setHostThreshold(0);
+    for (const auto& c : cases())
+      if (c.where == BOTH) run(c, " [host threshold 0: through the kernels]");
+    hip::setHostThreshold(keep);
   }
   std::printf("%d cases, %d checks, %d failures\n", ran, g_checks, g_fail);
   return g_fail ? 1 : 0;

@@ -69,3 +69,35 @@ def test_pmc_traffic_is_stamped_and_only_quoted_for_its_own_kernels():
         assert bench.pmc_traffic("shamir_share", args) is None
     finally:
         bench.kernel_source_hash = real
+
+
+def test_configs_quoted_on_eight_gpus_dry_run():
+    """`--gpus 8 --config c4 / c5`: BASELINE configs[3] and [4] as the multi-rank headline -- strong scaling, the totals
+    split over the ranks (c5: 8 x 1.25e8 = 10^9 shards adding up; c4: every rank opens all 10^8 secrets from its 5 parties'
+    slabs).  gloo + --dry-run checks the launch, the plan and the strings of the result line; the arithmetic needs the GPUs."""
+    r = _run(["--gpus", "8", "--config", "c4", "--backend", "gloo", "--dry-run", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["dtype"] == "u128"
+    c = line["config"]
+    assert c["total_secrets"] == 100_000_000 and c["n"] == 40 and c["t"] == 13 and c["parallelism"] == "parties8"
+    assert "GF(2^128)" in c["workload"] and "5 parties per rank" in c["workload"] and "BASELINE configs[3]" in c["workload"]
+    r = _run(["--gpus", "8", "--config", "c5", "--backend", "gloo", "--dry-run", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = line["config"]
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["dtype"] == "u64"
+    assert c["total_secrets"] == 1_000_000_000 == c["secrets_over_ranks"] and c["n"] == 128 and c["t"] == 42
+    assert "BASELINE configs[4]" in c["workload"] and c["parallelism"] == "shard8"
+
+
+def test_c5_on_fewer_gpus_is_capacity_bound_and_says_so():
+    sys.path.insert(0, ROOT)
+    import bench
+    pl = bench.plan(bench.parse_args(["--config", "c5", "--gpus", "2"]), 2, 1)
+    assert pl["total"] == 250_000_000 and pl["mine"] == 125_000_000 and pl["scaling"] == "weak"
+    assert "needs 8 GPUs" in pl["workload"]
+    # ragged totals: the first total % world ranks take one more
+    a = bench.parse_args(["--config", "c5", "--gpus", "8", "--total-secrets", "1000003"])
+    assert sum(bench.plan(a, 8, r)["mine"] for r in range(8)) == 1000003
+    assert bench.plan(bench.parse_args([]), 4, 0)["total"] == 400_000_000

@@ -37,18 +37,40 @@ def pick(table, needle):
 fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
 copy_bytes = float(sys.argv[3])
 out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py "
-                   "--configs 0 --open 0 --cpu-sample 0` (BASELINE configs[1]: n=10, t=3, Mersenne61, 1e8 secrets); counters are "
-                   "in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section), calibrated on k_copy16 below",
+                   "--open 0 --cpu-sample 0 --steps 5` (headline = BASELINE configs[1]: n=10, t=3, Mersenne61, 1e8 secrets; "
+                   "`configs` = the side configurations of the same run); counters are in KiB; FETCH_SIZE doubled per "
+                   "MI355X_MICROARCH.md (HBM section), calibrated on k_copy16 below (16-byte-per-lane streaming loads, which is "
+                   "what every kernel listed here issues)",
        "config": {"field": "m61", "n": 10, "t": 3, "secrets_per_gpu": 100000000, "share_mode": "coeffs"},
        "kernel_source_sha256_16": bench.kernel_source_hash(), "kernel_sources": list(bench.KERNEL_SOURCES)}
 ck, (cf, cn) = pick(fetch, "k_copy16")
 _, (cw, _) = pick(write, "k_copy16")
 out["calibration_k_copy16"] = {"bytes_read_per_launch": copy_bytes, "fetch_kib_reported": cf, "write_kib": cw,
                                "fetch_correction": copy_bytes / (cf * 1024.0), "launches": cn}
-for key, needle in (("shamir_share", "k_share_small"), ("shamir_recover", "k_recover_fixed")):
+def entry(needle):
     name, (f_kib, nl) = pick(fetch, needle)
     _, (w_kib, _) = pick(write, needle)
-    out[key] = {"kernel": name.split("(")[0].replace("void ", ""), "launches": nl, "fetch_kib_reported": f_kib, "write_kib": w_kib,
-                "bytes": int(round(2 * f_kib * 1024 + w_kib * 1024))}
+    return {"kernel": name.split("(")[0].replace("void ", ""), "launches": nl, "fetch_kib_reported": f_kib, "write_kib": w_kib,
+            "bytes": int(round(2 * f_kib * 1024 + w_kib * 1024))}
+
+
+for key, needle in (("shamir_share", "k_share_small_t<sclhip::M61"), ("shamir_recover", "k_recover_fixed<sclhip::M61")):
+    out[key] = entry(needle)
+# the side configurations of the same bench run (`configs` in the result line), by the kernel each one launches; a
+# configuration whose kernels are not in the passes (bench.py run with --configs 0) is left out
+out["configs"] = {}
+for cfg, (share_needle, rec_needle, algo) in {
+    "C3_mersenne127_10_3": ("k_share_small_t<sclhip::M127", "k_recover_fixed<sclhip::M127", (224 * 10**7, 176 * 10**7)),
+    "C3_mont128_10_3": ("k_share_small<sclhip::Mont128", "k_recover_table<sclhip::Mont128", (224 * 10**7, 176 * 10**7)),
+    "C4_shard_gf2_128_40_13": ("k_share_gf_tiles<13>", "k_recover_gf128", (864 * 125 * 10**5, 656 * 125 * 10**5)),
+    "C5_shard_mersenne61_128_42": ("k_share_mfma_m61", "k_recover_table<sclhip::M61", (1368 * 125 * 10**6, 1032 * 125 * 10**6)),
+}.items():
+    try:
+        sh, rc = entry(share_needle), entry(rec_needle)
+    except AssertionError:
+        continue
+    sh["algorithmic_bytes"], rc["algorithmic_bytes"] = algo
+    sh["traffic_over_algorithmic"], rc["traffic_over_algorithmic"] = sh["bytes"] / algo[0], rc["bytes"] / algo[1]
+    out["configs"][cfg] = {"share": sh, "recover": rc}
 json.dump(out, sys.stdout, indent=2)
 print()
