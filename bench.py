@@ -233,6 +233,16 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)          # never returns
 
+    # The contract is ONE line on stdout.  Libraries write there too (RCCL prints a version banner from ncclCommInitRank
+    # when NCCL_DEBUG asks for it): from here on file descriptor 1 goes to stderr, and the result line alone is written to
+    # the descriptor stdout had.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -290,14 +300,14 @@ def main():
         if world > 1 and pl["key"] != "c4":
             dist.all_reduce(mine)          # the shards add up to the total (c4: every rank opens every secret)
         if rank == 0:
-            print(json.dumps({"metric": "shamir_reconstructions_per_sec", "value": 0.0, "unit": "reconstructions/s",
+            emit({"metric": "shamir_reconstructions_per_sec", "value": 0.0, "unit": "reconstructions/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True,
                               "scaling": pl["scaling"], "vs_baseline": None, "dtype": pl["dtype"] or "u64",
                               "data": "none (dry run)",
                               "config": {"workload": "dry run of the launcher: " + pl["workload"], "n": pl["n"], "t": pl["t"],
                                          "field": FIELD_NAMES[pl["field"]], "total_secrets": pl["total"],
-                                         "secrets_over_ranks": int(mine.item()), "parallelism": pl["parallelism"]}}), flush=True)
+                                         "secrets_over_ranks": int(mine.item()), "parallelism": pl["parallelism"]}})
         if world > 1:
             dist.destroy_process_group()
         return
@@ -501,8 +511,28 @@ def main():
                 sd.open_and_reconstruct_local(f_, local, n, lam, chunk=chunk)
         t_pg = timed_region(partial_pipeline, steps, warmup) / steps
         ok_pg = bool(scl.equals(f_, result["pg"], secrets))
+        # the same two opens behind the C ABI: RCCL called by the library itself (scl_hip_open_all_gather /
+        # scl_hip_open_partial_gather; per-row grouped all-gathers, no packing copy), what a C++ caller of include/scl_hip/ gets
+        c_abi = None
+        try:
+            comm = sd.Communicator()
+            try:
+                def c_pipeline(k):
+                    result["c"] = sd.open_all_gather_c(comm, f_, local, n, lam, chunk=chunk)
+                t_c = timed_region(c_pipeline, steps, warmup) / steps
+
+                def c_partial(k):
+                    result["cp"] = sd.open_partial_gather_c(comm, f_, mine_rows, lam[first:first + cnt], chunk=chunk)
+                t_cp = timed_region(c_partial, steps, warmup) / steps
+                c_abi = {"pipeline_ms": 1e3 * t_c, "opened_secrets_per_s": N / t_c,
+                         "partial_gather_pipeline_ms": 1e3 * t_cp, "partial_gather_opened_secrets_per_s": N / t_cp,
+                         "verified": bool(scl.equals(f_, result["c"], secrets)) and bool(scl.equals(f_, result["cp"], secrets))}
+            finally:
+                comm.close()
+        except Exception as e:   # reported, never fatal to the line
+            c_abi = {"error": str(e), "verified": False}
         gathered_bytes = world * per * c0 * E
-        res = {"field": FIELD_NAMES[fkey], "n": n, "t": t, "secrets": N, "chunk": c0, "parties_per_rank": per,
+        res = {"field": FIELD_NAMES[fkey], "n": n, "t": t, "secrets": N, "chunk": c0, "parties_per_rank": per, "c_abi": c_abi,
                "collective": "all_gather_into_tensor" if world > 1 else "none (1 rank: local copy)",
                "gather_ms_per_chunk": 1e3 * t_gather, "gathered_bytes_per_chunk": gathered_bytes,
                "rccl_algbw_GBps": gathered_bytes / t_gather / 1e9,
@@ -569,7 +599,7 @@ def main():
                     "open": {"c4_all_gather": c4}}
             if world == 1 and args.cpu_sample > 0:
                 line["cpu_baseline"] = cpu_baseline("gf2_128", 40, 13, min(args.cpu_sample, 20_000))
-            print(json.dumps(line), flush=True)
+            emit(line)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -588,7 +618,7 @@ def main():
                     "roofline": {"bound": "hbm", "kernel": "shamir_recover", "achieved": c4["reconstruct_GBps"],
                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": c4["reconstruct_hbm_frac"], "traffic": None},
                     "open": rep}
-            print(json.dumps(line), flush=True)
+            emit(line)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -715,7 +745,7 @@ def main():
         line["configs"] = cfgs
     if world == 1 and args.cpu_sample > 0:
         line["cpu_baseline"] = cpu_baseline(args.field, n, t, args.cpu_sample)
-    print(json.dumps(line), flush=True)
+    emit(line)
     if world > 1:
         dist.destroy_process_group()
 

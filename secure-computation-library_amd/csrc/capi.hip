@@ -2299,7 +2299,7 @@ int scl_hip_stream_copy(void* dst, const void* src, size_t bytes, void* stream) 
   return SCL_OK;
 }
 
+}  // extern "C"
+
 // ---- the open step: RCCL all-gather + reconstruct ----------------------------------------------------------------------
 #include "open_rccl.inc"
-
-}  // extern "C"

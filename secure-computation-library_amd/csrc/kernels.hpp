@@ -930,7 +930,9 @@ template <int T, int H, bool RAGGED>
 __device__ __forceinline__ void gf_tile(u64* shares, size_t stride, size_t off, int n, u128 top, const v32u& hi, const uint4* lo) {
   constexpr int TOPNODE = 8 * H + 7;
   constexpr int DEG = TOPNODE >= 64 ? 6 : TOPNODE >= 32 ? 5 : TOPNODE >= 16 ? 4 : TOPNODE >= 8 ? 3 : 2;
-  constexpr int EVERY = (32 - DEG) / (2 * DEG);  // outer products the fifth word can take before it must come down
+  // outer products the fifth word can take before it must come down: from the start value (degree <= 127 + DEG) and from a
+  // folded one (degree <= 127); each adds 2 DEG bits and the word holds 32
+  constexpr int EVERY0 = (32 - DEG) / (2 * DEG), EVERY1 = 32 / (2 * DEG);
   // coefficients c_0 .. c_T; pairs (c_2B, c_2B+1); with T even the top coefficient starts the recurrence alone
   constexpr int BTOP = (T % 2 == 0 ? T / 2 : (T - 1) / 2) - 1;  // the highest pair below the start value
   const int nv = n - 8 * H + 1;                                 // nodes 8H + l <= n  <=>  l < nv
@@ -963,23 +965,23 @@ __device__ __forceinline__ void gf_tile(u64* shares, size_t stride, size_t off, 
     for (int j = 0; j < 8; ++j) y[j][0] = y[j][1] = y[j][2] = y[j][3] = y[j][4] = 0;
     gf_tile_pair<H, false, RAGGED>(y, ck, top, nv);
   }
-  int since = 0;
+  int left = EVERY0;  // outer products until the next fold
   if constexpr (BTOP >= 4) {
 #pragma unroll 1
     for (int B = BTOP; B >= 4; --B) {
       gf_tile_pair<H, true, RAGGED>(y, hi_coeff(2 * B), hi_coeff(2 * B + 1), nv);
-      if (++since == EVERY) {
+      if (--left == 0) {
         gf_tile_fold(y);
-        since = 0;
+        left = EVERY1;
       }
     }
   }
 #pragma unroll 1
   for (int B = (BTOP < 3 ? BTOP : 3); B >= 0; --B) {
     gf_tile_pair<H, true, RAGGED>(y, lo_coeff(2 * B), lo_coeff(2 * B + 1), nv);
-    if (++since == EVERY) {
+    if (--left == 0 && B > 0) {  // (the last pair is followed by the final fold)
       gf_tile_fold(y);
-      since = 0;
+      left = EVERY1;
     }
   }
   gf_tile_fold(y);
@@ -1004,6 +1006,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) v
   uint4* const lo = gft_lo + threadIdx.x;
   SCL_GRID_STRIDE(q, npacks) {
     const size_t off = q * Gf128::LIMBS;
+    // the row offsets i * stride of the 40+ stores are loop invariants; hoisted out of this loop they take two scalar
+    // registers each and spill (278 scalar spills, ~600 v_readlane / v_writelane per secret).  An opaque copy of the
+    // stride per iteration keeps them where they are used: a scalar multiply per row.
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(stride), "+s"(cstride), "+s"(n));  // (n: the "node exists" tests of the ragged tiles, likewise)
+#endif
 #pragma unroll
     for (int k = 0; k < (T < 8 ? T : 8); ++k) {
       const u128 v = gf_load_coeff(secrets, coeffs, cstride, off, k);

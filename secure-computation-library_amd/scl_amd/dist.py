@@ -173,3 +173,80 @@ def open_by_partial_gather(field: int, local: torch.Tensor, lam_local, chunk: in
         pwork.wait()
         total(field, pbuf, out[ps0:ps0 + pc])
     return out
+
+
+# ---- the same open step behind the C ABI (scl_hip_comm_*, scl_hip_open_*: RCCL called from the library itself) -------------
+class Communicator:
+    """The C ABI's communicator handle: an RCCL communicator made by the library (ncclCommInitRank) plus the stream, events and
+    gather buffers of the open step.  With torch.distributed initialised the 128-byte unique id travels from rank 0 by a
+    broadcast on that process group (any backend); a single process needs no process group at all."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+
+        from . import _chk, lib
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            _chk(lib.scl_hip_comm_unique_id(ident))
+        if self.world > 1:
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = (C.c_ubyte * 128)(*t.cpu().tolist())
+        self._h = C.c_void_p()
+        _chk(lib.scl_hip_comm_init_rank(C.byref(self._h), self.world, self.rank, ident))
+
+    def close(self):
+        from . import lib
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.scl_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def open_row_order(n: int, world: int) -> list[int]:
+    """party held by each row of a gathered chunk (scl_hip_open_row_order; -1 = padding): host only"""
+    import ctypes as C
+
+    from . import _chk, lib
+    per = parties_per_rank(n, world)
+    order = (C.c_long * (per * world))()
+    _chk(lib.scl_hip_open_row_order(n, world, order))
+    return list(order)
+
+
+def open_all_gather_c(comm: Communicator, field: int, local: torch.Tensor, n: int, lam, chunk: int = 1 << 24,
+                      out: torch.Tensor | None = None) -> torch.Tensor:
+    """scl_hip_open_all_gather: `local` is this rank's [parties_per_rank(n)][N][L] slab; every rank returns all N secrets"""
+    from . import _chk, _dev, _host, _hp, _stream, lib
+    per, N, L = local.shape
+    if per != parties_per_rank(n, comm.world):
+        raise ValueError(f"local slab must have {parties_per_rank(n, comm.world)} party rows (pad the last rank)")
+    if out is None:
+        out = torch.empty((N, L), dtype=local.dtype, device=local.device)
+    lam_h = _host(lam)
+    _chk(lib.scl_hip_open_all_gather(comm._h, field, _dev(out), _dev(local), N, n, _hp(lam_h), N, chunk, _stream()))
+    return out
+
+
+def open_partial_gather_c(comm: Communicator, field: int, mine: torch.Tensor, lam_local, chunk: int = 1 << 24,
+                          out: torch.Tensor | None = None) -> torch.Tensor:
+    """scl_hip_open_partial_gather: `mine` is the rank's OWN [parties][N][L] rows (may have zero rows), lam_local their
+    Lagrange coefficients"""
+    from . import _chk, _dev, _host, _hp, _stream, lib
+    cnt, N, L = mine.shape
+    if out is None:
+        out = torch.empty((N, L), dtype=mine.dtype, device=mine.device)
+    lam_h = _host(lam_local) if cnt else None
+    _chk(lib.scl_hip_open_partial_gather(comm._h, field, _dev(out), _dev(mine) if cnt else None, N, cnt,
+                                         _hp(lam_h) if cnt else None, N, chunk, _stream()))
+    return out

@@ -843,6 +843,42 @@ TEST_CASE(z2k_gpu, "additive sharing over a ring, batch", GPU) {
   REQUIRE(math::Vector<Zb>(m.sharesOf(9)) == ss::additiveShare(secrets[9], 5, prg5));
 }
 
+// ---------------------------------------------------------------------------- the open step (RCCL)
+template <typename F>
+static void open_one_rank(std::size_t N, std::size_t n, std::size_t t, std::size_t chunk, const char* seed) {
+  // one rank holds every party: the all-gather is RCCL's one-rank copy, everything else (row order, chunking, the two
+  // streams and their events, the partial-sum form) is the code that runs on eight ranks
+  hip::Communicator comm(1, 0, hip::Communicator::uniqueId());
+  REQUIRE(comm.world() == 1 && comm.rank() == 0 && comm.partiesPerRank(n) == n);
+  std::vector<F> secrets;
+  for (std::size_t s = 0; s < N; ++s) secrets.emplace_back((int)(s * 2654435761u >> 1));
+  auto prg = util::PRG::create(seed);
+  const hip::DeviceVector<F> dsec(secrets);
+  const auto shares = ss::shamirSecretShare(dsec, t, n, prg);
+  const auto want = ss::shamirRecoverP(shares).toHost();
+  REQUIRE(math::Vector<F>(want) == math::Vector<F>(secrets));
+  const auto opened = hip::open(comm, shares, n, chunk).toHost();
+  REQUIRE(math::Vector<F>(opened) == math::Vector<F>(secrets));
+  const auto lambda = math::computeLagrangeBasis(math::Vector<F>::range(1, n + 1), F{});
+  const auto partial = hip::openByPartialSums(comm, shares, n, lambda, chunk).toHost();
+  REQUIRE(math::Vector<F>(partial) == math::Vector<F>(secrets));
+}
+
+TEST_CASE(open_rccl, "hip::open / openByPartialSums over a one-rank RCCL communicator", GPU) {
+  // test/scl/protocol/beaver.h:43-55 opens by send-to-all / recv-from-all; the batch form over RCCL
+  open_one_rank<F61>(5001, 10, 3, 2048, "open61");          // three chunks, the last one ragged and odd
+  open_one_rank<F61>(1000, 10, 3, 0, "open61b");            // one chunk
+  open_one_rank<F127>(3000, 7, 2, 1024, "open127");
+  open_one_rank<math::FF<math::ff::GF2_128>>(4097, 40, 13, 2048, "opengf");
+  // the row order of a gathered chunk on 8 ranks, 40 parties: row j * 8 + r is party 5 r + j
+  long order[40];
+  hip::check(scl_hip_open_row_order(40, 8, order));
+  REQUIRE(order[0] == 0 && order[1] == 5 && order[8] == 1 && order[39] == 39);
+  long ragged[12];  // 10 parties on 4 ranks: 3 per rank, the last rank holds one party and two padding rows
+  hip::check(scl_hip_open_row_order(10, 4, ragged));
+  REQUIRE(ragged[3] == 9 && ragged[7] == -1 && ragged[11] == -1 && ragged[4] == 1);
+}
+
 int main(int argc, char** argv) {
   const bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
   int ran = 0;

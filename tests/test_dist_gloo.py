@@ -209,3 +209,33 @@ def _partial_gather_worker(rank, world, field, n, t, N, chunk):
                                                      (2, O.SECP256K1_SCALAR, 5, 2, 12, 5)])
 def test_open_by_partial_gather(world, field, n, t, N, chunk):
     _run(_partial_gather_worker, world, field, n, t, N, chunk)
+
+
+@pytest.mark.parametrize("world,n", [(8, 40), (4, 10), (2, 7), (1, 10), (8, 3)])
+def test_c_abi_open_row_order_matches_the_grouped_gather_layout(world, n):
+    """scl_hip_open_all_gather moves a chunk by one all-gather PER PARTY ROW of the slab (no packing copy), so row
+    j * world + r of the gathered buffer holds party r * per + j, and the reconstruct kernel is handed lambda in that order
+    (zero for padding rows).  Host-only entry point: the layout is rebuilt here in numpy and reconstructed by the oracle."""
+    import scl_amd  # noqa: F401  (loads the library; no GPU call below)
+    from scl_amd import dist as sd
+    port = O.Port()
+    f, t, N = O.M61, min(3, n - 1), 50
+    per = sd.parties_per_rank(n, world)
+    order = sd.open_row_order(n, world)
+    assert len(order) == per * world and sorted(p for p in order if p >= 0) == list(range(n))
+    secrets = port.vector_random(f, b"ro-secrets", N)
+    full = _soa(port.shamir_share(f, b"ro-seed", secrets, t, n))            # [n][N][1]
+    slabs = []
+    for r in range(world):
+        first, cnt = sd.party_slab(n, r, world)
+        slab = np.full((per, N, 1), 0xDEADBEEF, dtype=np.uint64)            # padding rows hold junk
+        slab[:cnt] = full[first:first + cnt]
+        slabs.append(slab)
+    # what `per` grouped all-gathers leave in the buffer: for each row j, the ranks' rows j one after the other
+    buf = np.stack([slabs[r][j] for j in range(per) for r in range(world)])
+    nodes = np.stack([port.from_int(f, i + 1) for i in range(n)])
+    lam = port.lagrange_basis(f, nodes, port.from_int(f, 0))
+    lam_rows = np.stack([lam[p] if p >= 0 else np.zeros_like(lam[0]) for p in order])
+    buf = np.where(np.array(order)[:, None, None] >= 0, buf, 0)             # lambda = 0 kills the padding rows
+    rec = port.shamir_recover_lambda(f, np.ascontiguousarray(np.transpose(buf, (1, 0, 2))), lam_rows)
+    assert np.array_equal(rec, secrets)
