@@ -70,6 +70,7 @@ thread_local Knob g_mfma_areg{1};  // register-resident V fragments for the 4-ro
 thread_local Knob g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
 thread_local Knob g_gf_tiles{1};      // GF(2^128) sharing at the default nodes: 1 = eight nodes per Horner loop (k_share_gf_tiles),
                                       // 0 = one node at a time (k_share_gf_nodes) ("gf_tiles")
+thread_local Knob g_prg_t3{1};        // PRG-driven sharing at t = 3 over the Mersenne fields: 1 = threshold compiled in ("prg_t3")
 thread_local Knob g_prg_two_pass{0};  // PRG-driven sharing: 0 auto, 1 always two passes, -1 always the fused kernels
 // Headline streaming kernels (k_recover_fixed, k_share_small): workgroup size and resident waves per CU
 // (kernels.hpp, "Launch geometry"); "stream_block" 64 | 256, "stream_waves" 0 = no cap
@@ -284,21 +285,35 @@ void load_host(const u64* src, size_t n, std::vector<typename F::E>& out) {
   for (size_t i = 0; i < n; ++i) out[i] = F::ld(src + i * F::LIMBS);
 }
 
-// computeLagrangeBasis (lagrange.h:54-71)
+// computeLagrangeBasis (lagrange.h:54-71): ell_i = prod_{j != i} (x - x_j) / (x_i - x_j).  The reference divides factor by
+// factor (n (n - 1) inversions); here each ell_i is one numerator times the inverse of one denominator, and the n
+// denominators are inverted together (prefix products, ONE field inversion, back-substitution): the per-secret
+// shamirRecoverP of the C++ mirror spends its time here (tests/cxx/bench_per_secret.cc).  Same canonical values.
 template <class F>
 int lagrange(const typename F::Ctx& ctx, const std::vector<typename F::E>& nodes, typename F::E x,
              typename F::E* out) {
+  using E = typename F::E;
   const size_t m = nodes.size();
+  if (m == 0) return SCL_OK;
+  std::vector<E> num(m), den(m), pre(m);
   for (size_t i = 0; i < m; ++i) {
-    typename F::E num = F::one(ctx), den = F::one(ctx);
+    E nu = F::one(ctx), de = F::one(ctx);
     for (size_t j = 0; j < m; ++j) {
       if (i == j) continue;
-      const typename F::E d = F::sub(ctx, nodes[i], nodes[j]);
+      const E d = F::sub(ctx, nodes[i], nodes[j]);
       if (F::is_zero(d)) return fail(SCL_ERR_ZERO_INVERSE, scl_hip_status_message(SCL_ERR_ZERO_INVERSE));
-      num = F::mul(ctx, num, F::sub(ctx, x, nodes[j]));
-      den = F::mul(ctx, den, d);
+      nu = F::mul(ctx, nu, F::sub(ctx, x, nodes[j]));
+      de = F::mul(ctx, de, d);
     }
-    out[i] = F::mul(ctx, num, F::inv(ctx, den));
+    num[i] = nu;
+    den[i] = de;
+    pre[i] = i ? F::mul(ctx, pre[i - 1], de) : de;  // den_0 * .. * den_i (no factor is zero)
+  }
+  E inv = F::inv(ctx, pre[m - 1]);  // 1 / (den_0 * .. * den_(m-1))
+  for (size_t i = m; i-- > 0;) {
+    const E inv_i = i ? F::mul(ctx, inv, pre[i - 1]) : inv;  // 1 / den_i
+    out[i] = F::mul(ctx, num[i], inv_i);
+    inv = F::mul(ctx, inv, den[i]);
   }
   return SCL_OK;
 }
@@ -1062,6 +1077,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "share_waves") g_share_waves = value;
   else if (k == "mfma") g_mfma = value;
   else if (k == "gf_tiles") g_gf_tiles = value;
+  else if (k == "prg_t3") g_prg_t3 = value;
   else return fail(SCL_ERR_BAD_ARG, "unknown tuning key " + k);
   return SCL_OK;
 }
@@ -1349,6 +1365,73 @@ int scl_hip_shamir_recover(int field, uint64_t* out, const uint64_t* shares, siz
   return SCL_OK;
 }
 
+// k_recover_gf128_pos issues its LDS reads from inline assembly one batch ahead of the `s_waitcnt lgkmcnt` that covers them
+// (kernels.hpp): between the two the compiler believes the destination registers hold data.  The generated code of this
+// toolchain leaves them alone, which is a property of its register allocation, not a guarantee.  So the first GF(2^128)
+// reconstruct of a process runs both launch shapes of that kernel once against k_recover_gf128 (compiler-scheduled reads)
+// on 4096 pseudo-random secrets; if a result differs, the position-table kernel is never used by this process
+// (scl_hip_last_error says so) -- a toolchain change then costs speed, not correctness.  -1 unknown, 1 good, 0 bad.
+std::atomic<int> g_gfpos_state{-1};
+std::mutex g_gfpos_mu;
+
+static int launch_gfpos(bool big_block, u64* out, const u64* shares, size_t stride, const BigTable<Gf128>& big, size_t m, size_t N,
+                        hipStream_t st) {
+  const size_t lds = gfpos_lds_bytes(m);
+  if (!big_block) {  // two 512-thread workgroups per CU
+    auto kern = &k_recover_gf128_pos<512, 2>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t blocks = (N + 511) / 512;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(512), lds, st, out, shares, stride, big, (int)m, N);
+  } else {           // one 1024-thread workgroup per CU
+    auto kern = &k_recover_gf128_pos<1024, 1>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t blocks = (N + 1023) / 1024;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(1024), lds, st, out, shares, stride, big, (int)m, N);
+  }
+  LAUNCH_CHECK();
+  return SCL_OK;
+}
+
+static int gfpos_usable(bool* usable) {
+  int stt = g_gfpos_state.load();
+  if (stt < 0) {
+    std::lock_guard<std::mutex> lk(g_gfpos_mu);
+    stt = g_gfpos_state.load();
+    if (stt < 0) {
+      constexpr size_t N = 4096, M = 7;  // 7 parties: two groups of five, the second one padded
+      u64 *sh = nullptr, *o = nullptr;
+      HIP_TRY(hipMalloc(&sh, M * N * 16));
+      HIP_TRY(hipMalloc(&o, 3 * N * 16));
+      auto body = [&]() -> int {
+        const unsigned char seed[] = "gfpos self-check";
+        SCL_TRY(scl_hip_prg_blocks(reinterpret_cast<unsigned char*>(sh), M * N, seed, sizeof seed - 1, 0, nullptr));
+        BigTable<Gf128> big;
+        for (size_t i = 0; i < M; ++i) big.v[i] = ((u128)(0x9E3779B97F4A7C15ull * (i + 1)) << 64) | (0xD1B54A32D192ED03ull * (i + 7));
+        hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, nullptr, o, sh, N, big, (int)M, N, (const u64*)nullptr);
+        LAUNCH_CHECK();
+        SCL_TRY(launch_gfpos(false, o + 2 * N, sh, N, big, M, N, nullptr));
+        SCL_TRY(launch_gfpos(true, o + 4 * N, sh, N, big, M, N, nullptr));
+        std::vector<u64> h(6 * N);
+        HIP_TRY(hipMemcpy(h.data(), o, h.size() * 8, hipMemcpyDeviceToHost));
+        const bool same = std::equal(h.begin(), h.begin() + 2 * N, h.begin() + 2 * N) &&
+                          std::equal(h.begin(), h.begin() + 2 * N, h.begin() + 4 * N);
+        g_gfpos_state.store(same ? 1 : 0);
+        if (!same)
+          std::fprintf(stderr, "libscl_hip: k_recover_gf128_pos failed its self-check against k_recover_gf128 on this toolchain; "
+                               "GF(2^128) reconstruction uses the shared-shift table kernel instead\n");
+        return SCL_OK;
+      };
+      const int rc = body();
+      (void)hipFree(sh);
+      (void)hipFree(o);
+      if (rc != SCL_OK) return rc;
+      stt = g_gfpos_state.load();
+    }
+  }
+  *usable = stt == 1;
+  return SCL_OK;
+}
+
 static int recover_block(int field, uint64_t* out, const uint64_t* shares, size_t stride, const uint64_t* lambda_host,
                          size_t m, size_t N, const uint64_t* prev, void* stream) {
   return with_field(field, [&](auto f, auto ctx) -> int {
@@ -1369,21 +1452,15 @@ static int recover_block(int field, uint64_t* out, const uint64_t* shares, size_
       const long ft = g_force_table.load();
       if (!ft || ft == 3) {  // GF(2^128): nibble-table kernels ("force_table" 3: the shared-shift form at any m)
         const size_t lds = gfpos_lds_bytes(m);
+        bool pos_ok = false;  // the position-table kernel passed its first-use self-check (see gfpos_usable)
+        if (!prev && ft != 3 && lds <= 160 * 1024) SCL_TRY(gfpos_usable(&pos_ok));
         if (prev) {
           hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
                              (int)m, N, prev);
-        } else if (ft != 3 && lds <= 80 * 1024) {  // position tables, two 512-thread workgroups per CU
-          auto kern = &k_recover_gf128_pos<512, 2>;
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          const size_t blocks = (N + 511) / 512;
-          hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(512), lds, S(stream), out, shares, stride,
-                             big, (int)m, N);
-        } else if (ft != 3 && lds <= 160 * 1024) {  // one 1024-thread workgroup per CU
-          auto kern = &k_recover_gf128_pos<1024, 1>;
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          const size_t blocks = (N + 1023) / 1024;
-          hipLaunchKernelGGL(kern, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(1024), lds, S(stream), out, shares, stride,
-                             big, (int)m, N);
+        } else if (pos_ok && lds <= 80 * 1024) {  // position tables, two 512-thread workgroups per CU
+          SCL_TRY(launch_gfpos(false, out, shares, stride, big, m, N, S(stream)));
+        } else if (pos_ok) {  // one 1024-thread workgroup per CU
+          SCL_TRY(launch_gfpos(true, out, shares, stride, big, m, N, S(stream)));
         } else {
           hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
                              (int)m, N, (const u64*)nullptr);
@@ -1696,6 +1773,13 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
         return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
           constexpr int VEC = decltype(V)::value;
           const int nblk = F::LIMBS == 1 ? (int)(t / 2 + 1) : (int)t;
+          if (t == 3 && g_prg_t3.load() != 0) {  // BASELINE's threshold: the term loop compiled in ("prg_t3" 0: the generic kernel)
+            AES4_LAUNCH((k_share_prg_small_t<F, VEC, (F::LIMBS == 1 ? 2 : 3), 3>), npacks, S(stream), shares + first * F::LIMBS,
+                        share_stride, secrets + first * F::LIMBS, key, (u64)(counter0 + first * blocks_per_secret), sv, (int)n,
+                        npacks);
+            LAUNCH_CHECK();
+            return SCL_OK;
+          }
 #define SPS_CASE(NB)                                                                                          \
   case NB:                                                                                                    \
     AES4_LAUNCH((k_share_prg_small<F, VEC, NB>), npacks, S(stream), shares + first * F::LIMBS, share_stride,   \

@@ -1842,6 +1842,58 @@ __global__ __launch_bounds__(ABLOCK) void k_share_prg_small(u64* shares, size_t 
   }
 }
 
+// The same with the threshold T compiled in (the shape BASELINE quotes: T = 3).  k_share_prg_small walks a party's row of
+// the Vandermonde table in LDS under a run-time "k <= t" test per term: seven scalar compare-and-branch pairs and up to
+// seven LDS reads per share, in a kernel whose LDS array is already the AES's bottleneck.  Here the term loop is straight
+// line and the small powers come from the kernel argument by scalar loads (wave-uniform, no LDS traffic).
+template <class F, int VEC, int NBLK, int T>
+__global__ __launch_bounds__(ABLOCK) void k_share_prg_small_t(u64* shares, size_t stride, const u64* secrets, AesKey key,
+                                                              u64 counter0, SmallVdm tab, int n, size_t npacks) {
+  static_assert(T >= 1 && T <= SmallVdm::TMAX && NBLK == (F::LIMBS == 1 ? T / 2 + 1 : T), "blocks that carry a used coefficient");
+  SCL_AES4_PROLOGUE(key)
+  const typename F::Ctx ctx{};
+  constexpr u64 B = F::LIMBS == 1 ? (u64)(T + 2) / 2 : (u64)(T + 1);
+  SCL_AES4_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> c[T + 2];
+    c[0] = load_pack<F, VEC, true>(secrets + off);
+    u64 ctr[VEC * NBLK], lo[VEC * NBLK], hi[VEC * NBLK];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j)
+        ctr[v * NBLK + j] = counter0 + (q * VEC + v) * B + j + (F::LIMBS == 1 ? 0 : 1);
+    aes4_blocks<VEC * NBLK>(aes, key, ctr, lo, hi);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) {
+        if constexpr (F::LIMBS == 1) {
+          if (j > 0) c[2 * j].v[v] = F::from_le_word(ctx, lo[v * NBLK + j]);
+          if (2 * j + 1 <= T) c[2 * j + 1].v[v] = F::from_le_word(ctx, hi[v * NBLK + j]);
+        } else {
+          c[j + 1].v[v] = F::from_le_word(ctx, ((u128)hi[v * NBLK + j] << 64) | lo[v * NBLK + j]);
+        }
+      }
+    for (int i = 0; i < n; ++i) {
+      const u32* row = tab.v + i * (T + 1);  // kernel argument: scalar loads
+      SmallAcc<F> acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v].init();
+#pragma unroll
+      for (int k = 1; k <= T; ++k) {
+        const u32 w = row[k];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v].mac(c[k].v[v], w);
+      }
+      Pack<F, VEC> y;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) y.v[v] = acc[v].fold(ctx, c[0].v[v]);  // V[i][0] = 1
+      store_pack<F, VEC, true>(shares + (size_t)i * stride * F::LIMBS + off, y);
+    }
+  }
+}
+
 // ---- any threshold: the polynomial in chunks of at most SHARE_CHUNK_T + 1 coefficients, one launch per chunk -------
 // shamirSecretShare has no bound on t (shamir.h:51-68); the register-resident kernels above hold 49 coefficients.  A longer
 // polynomial f(x) = sum_j x^(C j) g_j(x), C = SHARE_CHUNK_T + 1, is evaluated by Horner over its chunks from the top: the
