@@ -787,7 +787,14 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
       asm volatile("" : "=a"(vfrag[l]) : "0"(vfrag[l]));
     }
   }
-  const u32 crow_lds = (u32)reinterpret_cast<uintptr_t>(Bs + (size_t)r16 * ROWB + 16 * kb);  // secret lane & 15 of tile 0
+  // Which secret a ROW of the 16 x 16 tile is: row 4 q + i (the lane group q = lane >> 4 ends up with rows 4 q .. 4 q + 3 of
+  // its party's column) is secret 2 q + (i & 1) + 8 (i >> 1) of the tile.  A lane's four results are then two PAIRS of
+  // consecutive secrets, and each of its two 16-byte stores lines up with the other three lane groups' into 64 contiguous
+  // bytes of the party's row; with row = secret every store instruction wrote four separate 16-byte pieces of the 128-byte
+  // line, half of each 32-byte sector, and the kernel's WRITE_SIZE was 1.25 x its algorithmic bytes
+  // (profiles/pmc_traffic.json of round 3's first PMC pass: 160 GB written for 128 GB of shares).
+  const int srow = 2 * (r16 >> 2) + (r16 & 1) + 8 * ((r16 >> 1) & 1);
+  const u32 crow_lds = (u32)reinterpret_cast<uintptr_t>(Bs + (size_t)srow * ROWB + 16 * kb);  // that secret's digits of tile 0
   MfMul mm{1, 256, 65536, 16777216};
   asm volatile("" : "+s"(mm.m0), "+s"(mm.m8), "+s"(mm.m16), "+s"(mm.m24));
   const bool rows_full = __builtin_amdgcn_readfirstlane(16 * w + 16 <= n);
@@ -797,14 +804,21 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
   // cached ones (the L2 merges the halves; profiles/r2_mfma_store_side.txt)
   const bool line_rows = (reinterpret_cast<uintptr_t>(shares) & 127) == 0 && (stride & 15) == 0;
 
-  size_t blk = blockIdx.x;
+  // the order in which a workgroup takes its blocks: MF16_CHUNK consecutive blocks, then on by gridDim.x chunks (1: block
+  // b, b + gridDim.x, ..: every workgroup of the grid writes into the same 64 KiB window of a share row at about the same time)
+#ifndef MF16_CHUNK
+#define MF16_CHUNK 1
+#endif
+  auto block_of = [&](size_t it) { return ((it / MF16_CHUNK) * gridDim.x + blockIdx.x) * MF16_CHUNK + it % MF16_CHUNK; };
+  size_t it = 0;
+  size_t blk = block_of(0);
   if (blk < nblocks) {
     fetch(blk);
     recode(0);
   }
-  if (blk + gridDim.x < nblocks) fetch(blk + gridDim.x);
+  if (block_of(1) < nblocks) fetch(block_of(1));
 
-  for (int img = 0; blk < nblocks; blk += gridDim.x, img ^= 1) {
+  for (int img = 0; blk < nblocks; ++it, blk = block_of(it), img ^= 1) {
     const size_t s_base = blk * COLS;
     mf_lds_barrier();  // this block's digits are complete in image img; everyone is done reading the other image
     const u32 crow = crow_lds + (u32)img * IMG;
@@ -825,14 +839,14 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
     MF16_LD(0);
     MF16_LD(1);
 #undef MF16_LD
-    const bool have_next = blk + gridDim.x < nblocks, have_next2 = blk + 2 * (size_t)gridDim.x < nblocks;
+    const bool have_next = block_of(it + 1) < nblocks, have_next2 = block_of(it + 2) < nblocks;
     auto side = [&](auto Ac, auto Ic, auto NMc) {
       constexpr int A_ = decltype(Ac)::value, I_ = decltype(Ic)::value, NM_ = decltype(NMc)::value;
       if constexpr (A_ == 2 && I_ == NM_ / 2) {
         if (have_next) recode(img ^ 1);
       }
       if constexpr (A_ == 1 && I_ == NM_ / 4) {
-        if (have_next2) fetch(blk + 2 * (size_t)gridDim.x);
+        if (have_next2) fetch(block_of(it + 2));
       }
     };
     u64 S[8], T[8];
@@ -843,9 +857,10 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
     mf16_pipe_word<0, true>(vfrag, cfrag, accY, accX, mm, T, S, side, std::make_integer_sequence<int, mf16_word_nops<0>()>{});
     mf16_recombine_units<0, 0, MF16_UNITS>(accY, mm, T, S);
 
-    // ---- fold and store: element e = 4 ct + i is secret s_base + 16 ct + 4 (lane >> 4) + i of party 16 w + (lane & 15)
+    // ---- fold and store: element e = 4 ct + i is secret s_base + 16 ct + 2 (lane >> 4) + (i & 1) + 8 (i >> 1) of party
+    // 16 w + (lane & 15) (the row permutation above)
     const bool fast = rows_full && aligned_rows && s_base + COLS <= N;  // wave-uniform
-    u64* rowp = shares + (size_t)party * stride + s_base + 4 * kb;
+    u64* rowp = shares + (size_t)party * stride + s_base + 2 * kb;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       u64 v[4];
@@ -856,22 +871,27 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
         v[i] = f >= P ? f - P : f;
       }
       u64* dst = rowp + 16 * ct;
-      const size_t s0 = s_base + 16 * ct + 4 * kb;
+      const size_t s0 = s_base + 16 * ct + 2 * kb;
       u64x2 o0, o1;
       o0.x = v[0];
       o0.y = v[1];
       o1.x = v[2];
       o1.y = v[3];
-      if (fast && line_rows) {
+#ifndef MF16_PLAIN_STORES
+#define MF16_PLAIN_STORES 0
+#endif
+      if (fast && line_rows && !MF16_PLAIN_STORES) {
         __builtin_nontemporal_store(o0, reinterpret_cast<u64x2*>(dst));
-        __builtin_nontemporal_store(o1, reinterpret_cast<u64x2*>(dst) + 1);
+        __builtin_nontemporal_store(o1, reinterpret_cast<u64x2*>(dst + 8));
       } else if (fast) {
-        reinterpret_cast<u64x2*>(dst)[0] = o0;
-        reinterpret_cast<u64x2*>(dst)[1] = o1;
+        *reinterpret_cast<u64x2*>(dst) = o0;
+        *reinterpret_cast<u64x2*>(dst + 8) = o1;
       } else if (party < n) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (s0 + i < N) dst[i] = v[i];
+        for (int i = 0; i < 4; ++i) {
+          const int o = (i & 1) + 8 * (i >> 1);
+          if (s0 + o < N) dst[o] = v[i];
+        }
       }
     }
   }

@@ -25,7 +25,14 @@ def means(d, counter):
             for row in csv.DictReader(fh):
                 if row["Counter_Name"] == counter:
                     acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+    # one kernel may run at several sizes in the bench run (the first-use self-check of the GF(2^128) reconstruct kernel is
+    # a 4096-secret launch of the kernel C4 then runs at 1.25e7): the figure is the mean over the launches of the LARGEST
+    # size, told apart by their counter value (within a factor of two of the maximum)
+    out = {}
+    for k, v in acc.items():
+        big = [x for x in v if x >= 0.5 * max(v)]
+        out[k] = (sum(big) / len(big), len(big))
+    return out
 
 
 def pick(table, needle):
@@ -62,7 +69,7 @@ out["configs"] = {}
 for cfg, (share_needle, rec_needle, algo) in {
     "C3_mersenne127_10_3": ("k_share_small_t<sclhip::M127", "k_recover_fixed<sclhip::M127", (224 * 10**7, 176 * 10**7)),
     "C3_mont128_10_3": ("k_share_small<sclhip::Mont128", "k_recover_table<sclhip::Mont128", (224 * 10**7, 176 * 10**7)),
-    "C4_shard_gf2_128_40_13": ("k_share_gf_tiles<13>", "k_recover_gf128", (864 * 125 * 10**5, 656 * 125 * 10**5)),
+    "C4_shard_gf2_128_40_13": ("k_share_gf_tiles<13>", "k_recover_gf128_pos<512", (864 * 125 * 10**5, 656 * 125 * 10**5)),
     "C5_shard_mersenne61_128_42": ("k_share_mfma_m61", "k_recover_table<sclhip::M61", (1368 * 125 * 10**6, 1032 * 125 * 10**6)),
 }.items():
     try:
