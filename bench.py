@@ -515,6 +515,8 @@ def main():
         # scl_hip_open_partial_gather; per-row grouped all-gathers, no packing copy), what a C++ caller of include/scl_hip/ gets
         c_abi = None
         try:
+            if one_device and world > 1:
+                raise RuntimeError("skipped in the one-device rehearsal: RCCL does not take two ranks on one GPU")
             comm = sd.Communicator()
             try:
                 def c_pipeline(k):

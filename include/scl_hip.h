@@ -116,6 +116,8 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the sto
  *   share_waves  (default 9) the same cap for the Mersenne61 small-node share kernel (threshold compiled in, stream_block
  *                workgroups); 0 = the 256-thread kernel with the threshold at run time, no cap
  *   mfma         1: force the matrix-core share / matmul / recover_detect path, -1: never use it
+ *   open_gather_always (default 0) scl_hip_open_all_gather on a ONE-rank communicator: 1 = through the collective path all the
+ *                same (tests); 0 = reconstruct straight from the slab
  *   prg_t3       (default 1) PRG-driven sharing at t = 3 over the Mersenne fields: the fused kernel with the threshold
  *                compiled in; 0 = the fused kernel that takes any t <= 7
  *   gf_tiles     (default 1) GF(2^128) sharing at the default nodes, 5 <= t <= 16: eight nodes per Horner loop; 0 = one node

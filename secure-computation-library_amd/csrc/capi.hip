@@ -70,6 +70,7 @@ thread_local Knob g_mfma_areg{1};  // register-resident V fragments for the 4-ro
 thread_local Knob g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
 thread_local Knob g_gf_tiles{1};      // GF(2^128) sharing at the default nodes: 1 = eight nodes per Horner loop (k_share_gf_tiles),
                                       // 0 = one node at a time (k_share_gf_nodes) ("gf_tiles")
+thread_local Knob g_open_gather_always{0};  // the open step on ONE rank: 1 = still through RCCL's all-gather ("open_gather_always")
 thread_local Knob g_prg_t3{1};        // PRG-driven sharing at t = 3 over the Mersenne fields: 1 = threshold compiled in ("prg_t3")
 thread_local Knob g_prg_two_pass{0};  // PRG-driven sharing: 0 auto, 1 always two passes, -1 always the fused kernels
 // Headline streaming kernels (k_recover_fixed, k_share_small): workgroup size and resident waves per CU
@@ -1078,6 +1079,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "mfma") g_mfma = value;
   else if (k == "gf_tiles") g_gf_tiles = value;
   else if (k == "prg_t3") g_prg_t3 = value;
+  else if (k == "open_gather_always") g_open_gather_always = value;
   else return fail(SCL_ERR_BAD_ARG, "unknown tuning key " + k);
   return SCL_OK;
 }

@@ -437,6 +437,9 @@ __global__ __launch_bounds__(BLOCK) void k_recover_gf128(u64* out, const u64* sh
 // Counters at (40,13), profiles/r2_pmc_gf128.txt: LDS array 68 % busy (4 cycles per ds_read_b128, no bank conflicts),
 // vector ALU 60 % (5.8 instructions per lookup); the two overlap only partly, so neither saturates:
 // 2.12 -> 2.44 TB/s.  At 100 % of the LDS array the form would reach 4.4 TB/s.
+// The hand-issued reads below are covered by their s_waitcnt only as far as the compiler leaves the destination registers
+// alone in between; capi.hip therefore checks this kernel against k_recover_gf128 once per process before it is used
+// (gfpos_usable) and falls back to that kernel if the two ever disagree.
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 template <int B>

@@ -799,10 +799,9 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
   asm volatile("" : "+s"(mm.m0), "+s"(mm.m8), "+s"(mm.m16), "+s"(mm.m24));
   const bool rows_full = __builtin_amdgcn_readfirstlane(16 * w + 16 <= n);
   const bool aligned_rows = (reinterpret_cast<uintptr_t>(shares) & 15) == 0 && (stride & 1) == 0;
-  // streaming (non-temporal) stores only when a party's 16 secrets of a tile are exactly one 128-byte line: on rows that start
-  // inside a line every line is completed by two different trips, which costs 2.4x with streaming stores and 1.3x with
-  // cached ones (the L2 merges the halves; profiles/r2_mfma_store_side.txt)
+  // (rows on which a party's 16 secrets of a tile are exactly one 128-byte line: the only ones streaming stores were ever used on)
   const bool line_rows = (reinterpret_cast<uintptr_t>(shares) & 127) == 0 && (stride & 15) == 0;
+  (void)line_rows;
 
   // the order in which a workgroup takes its blocks: MF16_CHUNK consecutive blocks, then on by gridDim.x chunks (1: block
   // b, b + gridDim.x, ..: every workgroup of the grid writes into the same 64 KiB window of a share row at about the same time)
@@ -877,10 +876,13 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
       o0.y = v[1];
       o1.x = v[2];
       o1.y = v[3];
-#ifndef MF16_PLAIN_STORES
-#define MF16_PLAIN_STORES 0
+      // cached stores (MF16_STREAMING_STORES 1: non-temporal ones on line-aligned rows, as until round 3).  An instruction
+      // writes 64 contiguous bytes of each of 16 rows; streamed, those half lines cost 24.35 GB of WRITE_SIZE for 20.48 GB
+      // of shares and 2 % of time; cached, the L2 completes the lines: 20.48 GB (profiles/r3_mfma_write_size.txt)
+#ifndef MF16_STREAMING_STORES
+#define MF16_STREAMING_STORES 0
 #endif
-      if (fast && line_rows && !MF16_PLAIN_STORES) {
+      if (fast && line_rows && MF16_STREAMING_STORES) {
         __builtin_nontemporal_store(o0, reinterpret_cast<u64x2*>(dst));
         __builtin_nontemporal_store(o1, reinterpret_cast<u64x2*>(dst + 8));
       } else if (fast) {

@@ -850,6 +850,7 @@ static void open_one_rank(std::size_t N, std::size_t n, std::size_t t, std::size
   // streams and their events, the partial-sum form) is the code that runs on eight ranks
   hip::Communicator comm(1, 0, hip::Communicator::uniqueId());
   REQUIRE(comm.world() == 1 && comm.rank() == 0 && comm.partiesPerRank(n) == n);
+  hip::check(scl_hip_set_tuning("open_gather_always", 1));  // (one rank would otherwise reconstruct straight from its slab)
   std::vector<F> secrets;
   for (std::size_t s = 0; s < N; ++s) secrets.emplace_back((int)(s * 2654435761u >> 1));
   auto prg = util::PRG::create(seed);

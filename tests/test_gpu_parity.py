@@ -1106,6 +1106,7 @@ def test_open_step_behind_the_c_abi_one_rank_rccl(scl, port):
     their events, the permuted lambda and the partial-sum form are the code that runs on eight ranks."""
     from scl_amd import dist as sd
     comm = sd.Communicator()
+    scl.set_tuning("open_gather_always", 1)     # one rank would otherwise reconstruct straight from its slab
     try:
         assert (comm.world, comm.rank) == (1, 0)
         f, n, t, N = O.M61, 10, 3, 5001
@@ -1129,7 +1130,10 @@ def test_open_step_behind_the_c_abi_one_rank_rccl(scl, port):
         assert not torch.any(z).item()
         with pytest.raises(ValueError):
             sd.open_all_gather_c(comm, f2, sh2[:5], n2, lam2)
+        scl.set_tuning("open_gather_always", 0)  # and the one-rank shortcut gives the same secrets
+        assert scl.equals(f2, sd.open_all_gather_c(comm, f2, sh2, n2, lam2, chunk=2500), sec2)
     finally:
+        scl.set_tuning("open_gather_always", 0)
         comm.close()
 
 
@@ -1396,6 +1400,35 @@ def test_bench_two_ranks_rehearsal_on_one_device(scl):
     assert c4["verified"] and c4["parties_per_rank"] == 20 and c4["collective"] == "all_gather_into_tensor"
     assert c4["rccl_busbw_GBps"] > 0 and ps["verified"] and ps["collective"].startswith("reduce_scatter_tensor")
     assert "cpu_baseline" not in line and "configs" not in line
+    assert "skipped in the one-device rehearsal" in c4["c_abi"]["error"]
+
+
+@pytest.mark.parametrize("config,extra,check", [
+    ("c4", ["--total-secrets", "100000", "--open-chunk", "32768"],
+     lambda ln: ln["scaling"] == "strong" and ln["config"]["total_secrets"] == 100000 and ln["config"]["parallelism"] == "parties2"
+     and ln["open"]["c4_all_gather"]["parties_per_rank"] == 20 and ln["rccl_busbw_GBps"] > 0),
+    ("c5", ["--total-secrets", "200003"],
+     lambda ln: ln["scaling"] == "strong" and ln["config"]["total_secrets"] == 200003 and ln["config"]["n"] == 128
+     and ln["config"]["secrets_per_gpu"] == 100002 and ln["dtype"] == "u64")])
+def test_bench_configs_quoted_on_eight_gpus_rehearsal_on_one_device(scl, config, extra, check):
+    """`bench.py --gpus 2 --config c4 / c5` with the HIP kernels, both ranks on this box's one GPU over gloo (a rehearsal of
+    the code the driver runs on eight GPUs over RCCL, never a measurement): BASELINE configs[3] as the open step over the
+    total, configs[4] as share + reconstruct of ragged shards of the total; every round trip must verify."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCL_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", config,
+                        "--cpu-sample", "0", "--steps", "2", "--warmup", "1"] + extra, capture_output=True, text=True, timeout=900,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified"] is True and check(line), line
 
 
 @pytest.mark.parametrize("n,t,N", [(128, 42, 3 * 256 * 32 + 17), (97, 5, 2 * 256 * 32 + 31), (128, 48, 256 * 32 + 1), (100, 33, 4 * 256 * 32)])
