@@ -73,9 +73,14 @@ constexpr std::size_t limbsOf() {
 // operators, i.e. by detail/field.hpp: the arithmetic source the kernels are compiled from (per-element arithmetic is
 // host work in the reference's plug-in boundary too, SURVEY.md section 8 b-i).  At and above the threshold, and for everything
 // that already lives in HBM (hip::DeviceVector, hip::ShareMatrix: the batch API), the kernels run and there is no host path.
-// The threshold counts 64-bit limb products: elements x limbs^2 (a 256-bit multiplication costs ~16 Mersenne61 ones).
+// The threshold counts 64-bit limb products: elements x limbs^2 (a 256-bit multiplication costs ~16 Mersenne61 ones).  Its
+// default, 2^20, is read off tests/cxx/bench_threshold.cc on the GPU box (profiles/r3_host_threshold.txt): a round trip costs
+// ~55 us plus the per-element limb conversions on both sides, so an element-wise member of a HOST vector is faster on the host
+// at every size measured (Mersenne61: 20 us against 91 us at 16 384 elements, 1.1 ms against 3.6 ms at 2^20), and dot only
+// pays off on the device for the wide fields (secp256k1 from ~4 096 elements, Mersenne127 from ~65 536).  Code that wants the
+// GPU for its vectors keeps them there (hip::DeviceVector); a host container is the reference's convenience type.
 inline std::atomic<std::size_t>& hostThresholdRef() {
-  static std::atomic<std::size_t> v{16384};
+  static std::atomic<std::size_t> v{std::size_t(1) << 20};
   return v;
 }
 /// 0 sends every host-resident operand of a field with kernels to the GPU (what tests of the kernels behind
@@ -88,8 +93,8 @@ bool onHost(std::size_t elems) {
   if constexpr (!requires { T::Field::TAG; }) return true;
   else return elems * limbsOf<T>() * limbsOf<T>() < hostThreshold();
 }
-/// PRG draws up to this many bytes are made by detail/aes_host.hpp instead of k_prg_blocks
-inline std::size_t prgHostBytes() { return 4 * hostThreshold(); }
+/// PRG draws up to this many bytes are made by detail/aes_host.hpp instead of k_prg_blocks (64 KiB; none with the threshold at 0)
+inline std::size_t prgHostBytes() { return hostThreshold() ? std::size_t(64) << 10 : 0; }
 namespace detail {
 [[noreturn]] inline void unreachable() { std::abort(); }
 }  // namespace detail
