@@ -477,6 +477,35 @@ __device__ __forceinline__ void gfpos_pipe(u32x4 (&A)[4], u32x4 (&B)[4], u32x4 (
     gfpos_pipe<G, IDX + 1>(A, B, acc, gbase, w);
   }
 }
+// the same pipeline NBUF - 1 batches deep: batch IDX + NBUF - 1 is issued before batch IDX is waited for (all but the
+// 4 (NBUF - 1) newest reads: LDS returns in order)
+template <int I>
+__device__ __forceinline__ void gfpos_wait(u32x4 (&cur)[4]) {
+  static_assert(I >= 0 && I <= 12 && I % 4 == 0, "lgkmcnt is a 4-bit counter");
+  if constexpr (I == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+  if constexpr (I == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+  if constexpr (I == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+  if constexpr (I == 12) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+}
+template <int G, int IDX, int NBUF>
+__device__ __forceinline__ void gfpos_pipe_n(u32x4 (&buf)[NBUF][4], u32x4 (&acc)[4], u32 gbase, const u32 (&w)[G][4]) {
+  constexpr int NB = 8 * G;
+  if constexpr (IDX < NB) {
+    if constexpr (IDX + NBUF - 1 < NB) gfpos_issue4<G, IDX + NBUF - 1>(buf[(IDX + NBUF - 1) % NBUF], gbase, w);
+    constexpr int younger = (NB - 1 - IDX) < (NBUF - 1) ? (NB - 1 - IDX) : (NBUF - 1);
+    u32x4(&cur)[4] = buf[IDX % NBUF];
+    gfpos_wait<4 * younger>(cur);
+    acc[IDX / (2 * G)] ^= (cur[0] ^ cur[1]) ^ (cur[2] ^ cur[3]);
+    gfpos_pipe_n<G, IDX + 1, NBUF>(buf, acc, gbase, w);
+  }
+}
+template <int G, int IDX, int NBUF>
+__device__ __forceinline__ void gfpos_prologue_n(u32x4 (&buf)[NBUF][4], u32 gbase, const u32 (&w)[G][4]) {
+  if constexpr (IDX < NBUF - 1) {
+    gfpos_issue4<G, IDX>(buf[IDX], gbase, w);
+    gfpos_prologue_n<G, IDX + 1, NBUF>(buf, gbase, w);
+  }
+}
 __device__ __forceinline__ void gf_mulx32(u32 (&r)[4]) {  // r * x^32: the word that leaves the top times x^7 + x^2 + x + 1
   const u32 t = r[3];
   r[3] = r[2];
@@ -488,7 +517,7 @@ __device__ __forceinline__ void gf_mulx32(u32 (&r)[4]) {  // r * x^32: the word 
 constexpr int GFPOS_G = 5;  // parties per group: 8 G batches of 4 lookups, 20 share words + 20 prefetched
 inline size_t gfpos_lds_bytes(size_t m) { return (m + GFPOS_G - 1) / GFPOS_G * GFPOS_G * 2048; }
 
-template <int BLK, int WPS>
+template <int BLK, int WPS, int NBUF = 2>
 __global__ __launch_bounds__(BLK, WPS) void k_recover_gf128_pos(u64* out, const u64* shares, size_t stride,
                                                                 BigTable<Gf128> tab, int m, size_t N) {
   constexpr int G = GFPOS_G;
@@ -523,9 +552,15 @@ __global__ __launch_bounds__(BLK, WPS) void k_recover_gf128_pos(u64* out, const 
     for (int i0 = 0; i0 < m; i0 += G) {
       if (i0 + G < m) load_group(wn, i0 + G, s);
       const u32 gbase = tbase + (u32)i0 * 2048u;
-      u32x4 A[4], B[4];
-      gfpos_issue4<G, 0>(A, gbase, w);
-      gfpos_pipe<G, 0>(A, B, acc, gbase, w);
+      if constexpr (NBUF == 2) {
+        u32x4 A[4], B[4];
+        gfpos_issue4<G, 0>(A, gbase, w);
+        gfpos_pipe<G, 0>(A, B, acc, gbase, w);
+      } else {
+        u32x4 buf[NBUF][4];
+        gfpos_prologue_n<G, 0, NBUF>(buf, gbase, w);
+        gfpos_pipe_n<G, 0, NBUF>(buf, acc, gbase, w);
+      }
 #pragma unroll
       for (int j = 0; j < G; ++j)
 #pragma unroll

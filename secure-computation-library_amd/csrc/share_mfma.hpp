@@ -643,10 +643,24 @@ __global__ __launch_bounds__(256, 1) void k_share_mfma_m61_pipe(u64* shares, siz
 // does that: the same multiply-accumulate rate, all 64 k-slots in one instruction, and a 16x16 tile is 4 accumulator
 // registers instead of 16.  Eight waves per workgroup; wave w owns parties 16w .. 16w+15 for the block's 32 secrets
 // (two tiles): accumulators 2 sets x 4 diagonals x 2 tiles x 4 = 64 VGPRs, V's digit fragments 32 and the block's
-// coefficient fragments 64 accumulation registers.  The product is taken transposed -- rows of the tile are secrets
-// (A operand: coefficient digits), columns are parties (B operand: V's digits) -- so that a lane ends up with four
-// consecutive secrets of one party: two 16-byte stores, no cross-lane exchange.  Same digit tables, same LDS image of
-// the recoded coefficients ([digit][32 columns][row of 64 k-bytes + pad]) as the kernels above.
+// coefficient fragments 64 accumulation registers.  Rows of a tile are parties (A operand: V's digits), columns are secrets
+// (B operand: the coefficient digits), so a lane ends up with one secret of four parties and sixteen adjacent lanes write
+// sixteen adjacent secrets of one party: every store instruction writes whole 128-byte lines.  (Until round 3 the product was
+// taken transposed -- a lane then held four consecutive secrets of one party, two 16-byte stores that covered 64 bytes of
+// each of 16 rows per instruction -- at the same speed within 2 %, but with a fast path that needed 16-byte-aligned rows.)
+// Same digit tables, same LDS image of the recoded coefficients ([digit][32 columns][row of 64 k-bytes + pad]) as the kernels
+// above.
+//
+// What bounds it (profiles/r3_p16_ablation.txt, r3_p16_sq.txt; 128 parties, t = 42, 2 10^7 secrets, 9.2 ms): per trip and
+// wave 128 matrix instructions, 294 other vector instructions, 71 scalar, 20 LDS, 11 vector-memory; a wave's 7 250 cycles
+// per trip are 2 230 issuing, 2 960 stalled at issue (the SIMD's matrix pipe busy with the other wave's instruction; the
+// pipe is busy 56 % of the time) and 2 060 parked at a wait (fragment loads, barriers).  Taking things OUT of the kernel
+// shortens it by: the stores 2.0 ms (by cycles only 1.0: without them the chip holds 2.23 GHz instead of 2.0), the matrix
+// instructions 2.4, the recombination 1.1, recode + fetch 1.1, the fragment loads 0.5, the barriers 0 -- the parts add, and
+// the clock gives back about half of every saving (the in-step and the staggered schedule differ by 6 % in cycles and 2-3 %
+// in time).  Tried on top and measured equal within +-2 % (tools/mfma_bench.hip switches, not kept): stores deferred into
+// the next trip's matrix instructions one at a time; recode + fetch at the end of the trip instead of word 2; a wave tile of
+// 32 parties x 16 secrets (half the LDS fragment traffic); the transposed product.
 typedef int v4acc __attribute__((ext_vector_type(4)));
 struct MfOp16 {
   int l, m, j, ct;
@@ -674,49 +688,67 @@ __host__ __device__ constexpr bool mf16_word_first(int i) {
     if (mf16_word_op<A>(k).j == mf16_word_op<A>(i).j && mf16_word_op<A>(k).ct == mf16_word_op<A>(i).ct) return false;
   return true;
 }
-// recombination of word A as 40 unit operations: stage k = 0..3 adds diagonal 4A+k of the lane's eight elements
-// (tile ct = e / 4, register e % 4) into T, stage 4 rotates the finished words into S
-constexpr int MF16_UNITS = 40;
+// Recombination with TWO running 64-bit sums instead of one word per four diagonals: 2^64 = 2^3 mod p, so word 2's diagonals
+// enter the SAME sum as word 0's with multipliers 2^3 times as large (2^3 .. 2^27, still int32), and word 3's the same sum as
+// word 1's:   T = sum_j E_j 2^(8j) + E_(8+j) 2^(8j+3),   S = sum_j E_(4+j) 2^(8j) + E_(12+j) 2^(8j+3),   result = T + 2^32 S.
+// |T|, |S| < 9 * 2^24 * 2^24.01 < 2^52; each starts from the bias 2^53, removed at the end as 2^53 (1 + 2^32) = 2^53 + 2^24.
+// One rotation per element instead of three and no per-word placement step: 32 unit operations per word (stage k = 0..3 adds
+// diagonal 4A+k of the lane's eight elements, tile ct = e / 4, register e % 4), 15 v_mad_i64_i32 + one rotation per element
+// where the four-word form of the kernels above spends 15 + three rotations + three 64-bit adds.
+constexpr int MF16_UNITS = 32;
+constexpr u64 MF16_BIAS = 1ull << 53;
+constexpr u64 MF16_TOTAL_BIAS = (1ull << 53) + (1ull << 24);
+struct MfMul16 {  // scalar registers, opaque (see mf_word)
+  int m0, m8, m16, m24, h0, h8, h16, h24;
+};
 template <int A, int U>
-__device__ __forceinline__ void mf16_recombine_unit(const v4acc (&acc)[4][2], const MfMul& mm, u64 (&T)[8], u64 (&S)[8]) {
+__device__ __forceinline__ void mf16_recombine_unit(const v4acc (&acc)[4][2], const MfMul16& mm, u64 (&T)[8], u64 (&S)[8]) {
   constexpr int k = U / 8, e = U % 8, ct = e / 4, i = e % 4;
-  if constexpr (k == 0) T[e] = (u64)((long long)acc[0][ct][i] * mm.m0 + (long long)MF_WORD_BIAS);
-  if constexpr (k == 1) T[e] = (u64)((long long)acc[1][ct][i] * mm.m8 + (long long)T[e]);
-  if constexpr (k == 2) T[e] = (u64)((long long)acc[2][ct][i] * mm.m16 + (long long)T[e]);
-  if constexpr (k == 3 && 4 * A + 3 <= 2 * (MF_LIMBS - 1)) T[e] = (u64)((long long)acc[3][ct][i] * mm.m24 + (long long)T[e]);
-  if constexpr (k == 4) {
-    const u64 w = T[e];  // 0 < w < 2^51
-    if constexpr (A == 3) S[e] = rotl61(w, 35);   // 2^96
-    if constexpr (A == 2) S[e] += w << 3;         // 2^64
-    if constexpr (A == 1) S[e] += rotl61(w, 32);  // 2^32
-    if constexpr (A == 0) S[e] += w;
-    asm volatile("" : "+v"(S[e]));
+  u64& sum = (A & 1) ? S[e] : T[e];
+  if constexpr (4 * A + k <= 2 * (MF_LIMBS - 1)) {
+    const int mult = A >= 2 ? (k == 0 ? mm.h0 : k == 1 ? mm.h8 : k == 2 ? mm.h16 : mm.h24)
+                            : (k == 0 ? mm.m0 : k == 1 ? mm.m8 : k == 2 ? mm.m16 : mm.m24);
+    // words 3 and 2 come first and start their sums from the bias
+    const long long add = (A >= 2 && k == 0) ? (long long)MF16_BIAS : (long long)sum;
+    sum = (u64)((long long)acc[k][ct][i] * mult + add);
   }
-  asm volatile("" : "+v"(T[e]));  // pinned in place (see mf_recombine_unit)
+  asm volatile("" : "+v"(sum));  // pinned in place (see mf_recombine_unit)
 }
 template <int A, int U0, int U1>
-__device__ __forceinline__ void mf16_recombine_units(const v4acc (&acc)[4][2], const MfMul& mm, u64 (&T)[8], u64 (&S)[8]) {
+__device__ __forceinline__ void mf16_recombine_units(const v4acc (&acc)[4][2], const MfMul16& mm, u64 (&T)[8], u64 (&S)[8]) {
   if constexpr (U0 < U1) {
     mf16_recombine_unit<A, U0>(acc, mm, T, S);
     mf16_recombine_units<A, U0 + 1, U1>(acc, mm, T, S);
   }
 }
+// MF16_ABL: ablation switches for tools/mfma_bench.hip (1 no matrix instructions, 2 no recombination, 4 no stores, 8 no recode /
+// fetch, 16 no fragment loads, 32 no barriers; results are then wrong by construction); the library builds with 0
+#ifndef MF16_ABL
+#define MF16_ABL 0
+#endif
 template <int A, int I, int NM, bool PREV, class Side>
 __device__ __forceinline__ void mf16_pipe_op(const v4i (&vfrag)[MF_LIMBS], const v4i (&cfrag)[2][MF_LIMBS], v4acc (&accN)[4][2],
-                                             const v4acc (&accP)[4][2], const MfMul& mm, u64 (&T)[8], u64 (&S)[8], Side& side) {
+                                             const v4acc (&accP)[4][2], const MfMul16& mm, u64 (&T)[8], u64 (&S)[8], Side& side) {
   constexpr MfOp16 op = mf16_word_op<A>(I);
   constexpr bool first = mf16_word_first<A>(I);
   const v4acc zero = {0, 0, 0, 0};
-  accN[op.j][op.ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cfrag[op.ct][op.m], vfrag[op.l], first ? zero : accN[op.j][op.ct], 0, 0, 0);
-  if constexpr (PREV) mf16_recombine_units<A + 1, MF16_UNITS * I / NM, MF16_UNITS * (I + 1) / NM>(accP, mm, T, S);
+  if constexpr (!(MF16_ABL & 1))
+    accN[op.j][op.ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vfrag[op.l], cfrag[op.ct][op.m], first ? zero : accN[op.j][op.ct], 0, 0, 0);
+  else if constexpr (first)
+    accN[op.j][op.ct] = cfrag[op.ct][op.m] ^ vfrag[op.l];
+  if constexpr (PREV && !(MF16_ABL & 2)) mf16_recombine_units<A + 1, MF16_UNITS * I / NM, MF16_UNITS * (I + 1) / NM>(accP, mm, T, S);
   side(std::integral_constant<int, A>{}, std::integral_constant<int, I>{}, std::integral_constant<int, NM>{});
   __builtin_amdgcn_sched_barrier(0);
 }
 template <int A, bool PREV, class Side, int... Is>
 __device__ __forceinline__ void mf16_pipe_word(const v4i (&vfrag)[MF_LIMBS], const v4i (&cfrag)[2][MF_LIMBS], v4acc (&accN)[4][2],
-                                               const v4acc (&accP)[4][2], const MfMul& mm, u64 (&T)[8], u64 (&S)[8], Side& side,
+                                               const v4acc (&accP)[4][2], const MfMul16& mm, u64 (&T)[8], u64 (&S)[8], Side& side,
                                                std::integer_sequence<int, Is...>) {
   (mf16_pipe_op<A, Is, (int)sizeof...(Is), PREV>(vfrag, cfrag, accN, accP, mm, T, S, side), ...);
+  if constexpr ((MF16_ABL & 2) != 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(accN[j][0]), "v"(accN[j][1]));
+  }
 }
 
 // Atab: the KS = 2, MT = 4 table of mfma_table (rows = parties, 64 k-bytes + pad per row)
@@ -734,7 +766,7 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
   const int wu = __builtin_amdgcn_readfirstlane(w);
   const size_t nblocks = (N + COLS - 1) / COLS;
   const u64 P = M61::P;
-  const int party = 16 * w + r16;
+  const int pbase = 16 * wu;  // the wave's first party
 
   // one (column, k-group) item per thread: column lane & 31 of k-group 2 wave + (lane >> 5)
   u64 creg[4];
@@ -777,31 +809,23 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
     }
   };
 
-  // V's digit fragments of this wave's sixteen parties (B operand: k-block lane >> 4 of party lane & 15), kernel lifetime
+  // V's digit fragments of this wave's parties (A operand: k-block lane >> 4 of party lane & 15 of the tile), kernel lifetime
   v4i vfrag[MF_LIMBS], cfrag[2][MF_LIMBS];
   {
-    const unsigned char* vrow = Atab + ((size_t)(party >> 5) * 32 + (party & 31)) * ROWB + 16 * kb;
+    const unsigned char* vrow = Atab + (size_t)(pbase + r16) * ROWB + 16 * kb;
 #pragma unroll
     for (int l = 0; l < MF_LIMBS; ++l) {
       vfrag[l] = *reinterpret_cast<const v4i*>(vrow + (size_t)l * MT * 32 * ROWB);
       asm volatile("" : "=a"(vfrag[l]) : "0"(vfrag[l]));
     }
   }
-  // Which secret a ROW of the 16 x 16 tile is: row 4 q + i (the lane group q = lane >> 4 ends up with rows 4 q .. 4 q + 3 of
-  // its party's column) is secret 2 q + (i & 1) + 8 (i >> 1) of the tile.  A lane's four results are then two PAIRS of
-  // consecutive secrets, and each of its two 16-byte stores lines up with the other three lane groups' into 64 contiguous
-  // bytes of the party's row; with row = secret every store instruction wrote four separate 16-byte pieces of the 128-byte
-  // line, half of each 32-byte sector, and the kernel's WRITE_SIZE was 1.25 x its algorithmic bytes
-  // (profiles/pmc_traffic.json of round 3's first PMC pass: 160 GB written for 128 GB of shares).
-  const int srow = 2 * (r16 >> 2) + (r16 & 1) + 8 * ((r16 >> 1) & 1);
-  const u32 crow_lds = (u32)reinterpret_cast<uintptr_t>(Bs + (size_t)srow * ROWB + 16 * kb);  // that secret's digits of tile 0
-  MfMul mm{1, 256, 65536, 16777216};
-  asm volatile("" : "+s"(mm.m0), "+s"(mm.m8), "+s"(mm.m16), "+s"(mm.m24));
-  const bool rows_full = __builtin_amdgcn_readfirstlane(16 * w + 16 <= n);
-  const bool aligned_rows = (reinterpret_cast<uintptr_t>(shares) & 15) == 0 && (stride & 1) == 0;
-  // (rows on which a party's 16 secrets of a tile are exactly one 128-byte line: the only ones streaming stores were ever used on)
-  const bool line_rows = (reinterpret_cast<uintptr_t>(shares) & 127) == 0 && (stride & 15) == 0;
-  (void)line_rows;
+  // rows of a tile are parties (A operand: V's digits), columns are secrets (B operand: the coefficients' digits of secret
+  // lane & 15 of the tile): a lane ends up with ONE secret (lane & 15) of four parties (4 (lane >> 4) + i), and a store
+  // instruction writes whole 128-byte lines -- 16 adjacent lanes, 16 adjacent secrets of one party
+  const u32 crow_lds = (u32)reinterpret_cast<uintptr_t>(Bs + (size_t)r16 * ROWB + 16 * kb);  // that secret's digits, tile 0
+  MfMul16 mm{1, 1 << 8, 1 << 16, 1 << 24, 1 << 3, 1 << 11, 1 << 19, 1 << 27};
+  asm volatile("" : "+s"(mm.m0), "+s"(mm.m8), "+s"(mm.m16), "+s"(mm.m24), "+s"(mm.h0), "+s"(mm.h8), "+s"(mm.h16), "+s"(mm.h24));
+  const bool rows_full = __builtin_amdgcn_readfirstlane(pbase + 16 <= n);
 
   // the order in which a workgroup takes its blocks: MF16_CHUNK consecutive blocks, then on by gridDim.x chunks (1: block
   // b, b + gridDim.x, ..: every workgroup of the grid writes into the same 64 KiB window of a share row at about the same time)
@@ -816,10 +840,24 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
     recode(0);
   }
   if (block_of(1) < nblocks) fetch(block_of(1));
+  // Two barriers per trip, at its start and after the last matrix instruction of word 2, and waves 4-7 (the second wave of
+  // each SIMD) run HALF A TRIP BEHIND waves 0-3: a late wave takes one extra barrier here, an early one after the loop, so a
+  // late wave's trip start is an early wave's mid-trip.  On every SIMD one wave is then in its first half (fragment loads from
+  // the LDS, words 3 and 2, the recode) while the other is in its second (words 1 and 0, most of the recombination, the fold
+  // and the stores), instead of both waiting on the LDS and both folding at the same time.  Image protocol: every wave
+  // recodes block i+1 in the FIRST half of its trip i (before its mid-trip barrier), so the image is complete at the barrier
+  // that starts the early waves' trip i+1; the buffer it goes to was last read by the late waves at the start of their trip
+  // i-1, one barrier before the early waves' trip i begins.  (MF16_STAGGER 0: all eight in step, one barrier per trip; 3 %
+  // slower, tools/mfma_bench.hip.)
+#ifndef MF16_STAGGER
+#define MF16_STAGGER 1
+#endif
+  const bool late = MF16_STAGGER && (wu >> 2);  // wave-uniform
+  if (late) mf_lds_barrier();
 
   for (int img = 0; blk < nblocks; ++it, blk = block_of(it), img ^= 1) {
     const size_t s_base = blk * COLS;
-    mf_lds_barrier();  // this block's digits are complete in image img; everyone is done reading the other image
+    if constexpr (!(MF16_ABL & 32)) mf_lds_barrier();  // this block's digits are complete in image img; everyone is done reading the other image
     const u32 crow = crow_lds + (u32)img * IMG;
     // the sixteen loads and their wait are ONE asm statement: nothing the compiler might insert (a copy, a spill)
     // can touch a fragment register before its data has arrived
@@ -835,18 +873,25 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
                  "n"(4 * COLS * ROWB + ct * 16 * ROWB), "n"(5 * COLS * ROWB + ct * 16 * ROWB),                               \
                  "n"(6 * COLS * ROWB + ct * 16 * ROWB), "n"(7 * COLS * ROWB + ct * 16 * ROWB)                                \
                : "memory")
-    MF16_LD(0);
-    MF16_LD(1);
+    if constexpr (!(MF16_ABL & 16)) {
+      MF16_LD(0);
+      MF16_LD(1);
+    } else {
+#pragma unroll
+      for (int m = 0; m < MF_LIMBS; ++m) asm volatile("" : "=a"(cfrag[0][m]), "=a"(cfrag[1][m]) : "v"(crow));
+    }
 #undef MF16_LD
     const bool have_next = block_of(it + 1) < nblocks, have_next2 = block_of(it + 2) < nblocks;
     auto side = [&](auto Ac, auto Ic, auto NMc) {
       constexpr int A_ = decltype(Ac)::value, I_ = decltype(Ic)::value, NM_ = decltype(NMc)::value;
-      if constexpr (A_ == 2 && I_ == NM_ / 2) {
+      // the next block's recode (first half of the trip: see the barriers above) and the fetch of the block after it
+      if constexpr (A_ == 2 && I_ == NM_ / 4 && !(MF16_ABL & 8)) {
         if (have_next) recode(img ^ 1);
       }
-      if constexpr (A_ == 1 && I_ == NM_ / 4) {
+      if constexpr (A_ == 2 && I_ == NM_ / 2 && !(MF16_ABL & 8)) {
         if (have_next2) fetch(block_of(it + 2));
       }
+      if constexpr (MF16_STAGGER && A_ == 1 && I_ == 0 && !(MF16_ABL & 32)) mf_lds_barrier();  // mid-trip
     };
     u64 S[8], T[8];
     v4acc accX[4][2], accY[4][2];
@@ -854,49 +899,45 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
     mf16_pipe_word<2, true>(vfrag, cfrag, accY, accX, mm, T, S, side, std::make_integer_sequence<int, mf16_word_nops<2>()>{});
     mf16_pipe_word<1, true>(vfrag, cfrag, accX, accY, mm, T, S, side, std::make_integer_sequence<int, mf16_word_nops<1>()>{});
     mf16_pipe_word<0, true>(vfrag, cfrag, accY, accX, mm, T, S, side, std::make_integer_sequence<int, mf16_word_nops<0>()>{});
-    mf16_recombine_units<0, 0, MF16_UNITS>(accY, mm, T, S);
-
-    // ---- fold and store: element e = 4 ct + i is secret s_base + 16 ct + 2 (lane >> 4) + (i & 1) + 8 (i >> 1) of party
-    // 16 w + (lane & 15) (the row permutation above)
-    const bool fast = rows_full && aligned_rows && s_base + COLS <= N;  // wave-uniform
-    u64* rowp = shares + (size_t)party * stride + s_base + 2 * kb;
+    if constexpr (!(MF16_ABL & 2)) {
+      mf16_recombine_units<0, 0, MF16_UNITS>(accY, mm, T, S);
+    } else {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      u64 v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const u64 sum = S[4 * ct + i] + (P - MF_TOTAL_BIAS);  // < 2^63
-        const u64 f = (sum & P) + (sum >> 61);
-        v[i] = f >= P ? f - P : f;
+      for (int e = 0; e < 8; ++e) {
+        T[e] = (u64)(u32)accY[e & 3][e >> 2][0];
+        S[e] = (u64)(u32)accX[e & 3][e >> 2][1];
       }
-      u64* dst = rowp + 16 * ct;
-      const size_t s0 = s_base + 16 * ct + 2 * kb;
-      u64x2 o0, o1;
-      o0.x = v[0];
-      o0.y = v[1];
-      o1.x = v[2];
-      o1.y = v[3];
-      // cached stores (MF16_STREAMING_STORES 1: non-temporal ones on line-aligned rows, as until round 3).  An instruction
-      // writes 64 contiguous bytes of each of 16 rows; streamed, those half lines cost 24.35 GB of WRITE_SIZE for 20.48 GB
-      // of shares and 2 % of time; cached, the L2 completes the lines: 20.48 GB (profiles/r3_mfma_write_size.txt)
-#ifndef MF16_STREAMING_STORES
-#define MF16_STREAMING_STORES 0
-#endif
-      if (fast && line_rows && MF16_STREAMING_STORES) {
-        __builtin_nontemporal_store(o0, reinterpret_cast<u64x2*>(dst));
-        __builtin_nontemporal_store(o1, reinterpret_cast<u64x2*>(dst + 8));
-      } else if (fast) {
-        *reinterpret_cast<u64x2*>(dst) = o0;
-        *reinterpret_cast<u64x2*>(dst + 8) = o1;
-      } else if (party < n) {
+    }
+
+    // ---- fold and store: element e = 4 ct + i is party pbase + 4 (lane >> 4) + i, secret s_base + 16 ct + (lane & 15)
+    const bool fast = rows_full && s_base + COLS <= N;  // wave-uniform
+    const int p0 = pbase + 4 * kb;
+    const size_t s0 = s_base + r16;
+    u64* rowp = shares + (size_t)p0 * stride + s0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int o = (i & 1) + 8 * (i >> 1);
-          if (s0 + o < N) dst[o] = v[i];
-        }
+    for (int i = 0; i < 4; ++i) {
+      u64 v[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const u64 sum = T[4 * ct + i] + rotl61(S[4 * ct + i], 32) + (P - MF16_TOTAL_BIAS);  // < 2^54 + 2^61 + 2^61
+        const u64 f = (sum & P) + (sum >> 61);
+        v[ct] = f >= P ? f - P : f;
+      }
+      u64* dst = rowp + (size_t)i * stride;
+      // cached stores: each instruction writes one whole 128-byte line of each of four parties' rows (rows that start on a
+      // line; otherwise two part lines that the L2 completes)
+      if constexpr ((MF16_ABL & 4) != 0) {
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(dst));
+      } else if (fast) {
+        dst[0] = v[0];
+        dst[16] = v[1];
+      } else if (p0 + i < n) {
+        if (s0 < N) dst[0] = v[0];
+        if (s0 + 16 < N) dst[16] = v[1];
       }
     }
   }
+  if (MF16_STAGGER && !late) mf_lds_barrier();  // (the late waves' extra barrier before the loop)
 }
 
 // Digit planes of an arbitrary row-major matrix A[M x K] (device memory) in the A-table layout above, so

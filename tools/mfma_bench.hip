@@ -1,7 +1,10 @@
 // tools/mfma_bench.hip -- the Mersenne61 matrix-core share kernels side by side, outside the library:
 // k_share_mfma_m61 (two waves per SIMD, word bursts) against k_share_mfma_m61_pipe (one wave per SIMD, matrix
 // and VALU instructions interleaved).  Checks that the two agree bit for bit and a sample against a host Horner.
-// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/_build/mfma_bench tools/mfma_bench.hip
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -o tools/_build/mfma_bench tools/mfma_bench.hip
+//   k_share_mfma_m61_p16's experiment switches (csrc/share_mfma.hpp): -DMF16_STAGGER=0 (all eight waves in step),
+//   -DMF16_ABL=<bits> (1 no matrix instructions, 2 no recombination, 4 no stores, 8 no recode / fetch, 16 no fragment loads,
+//   32 no barriers; results then wrong by construction) -- profiles/r3_p16_ablation.txt; counters: tools/p16_sq.sh
 // usage: mfma_bench [n=128] [t=42] [N=10000000]
 #include <hip/hip_runtime.h>
 
