@@ -136,6 +136,9 @@ def plan(args, world, rank):
                         + (" (BASELINE configs[1])" if headline else "")}
 
 
+CPU_BASELINE_SECONDS = 8.0   # per leg of cpu_baseline (single thread, all cores, hoisted basis): the default run stays in minutes
+
+
 def cpu_baseline(field_key, n, t, sample):
     """The reference CPU path on this box's host cores (single thread, like SCL itself): per secret
     shamirSecretShare + shamirRecoverP(shares).  oracle/_ref (the real reference, prebuilt) when it
@@ -147,14 +150,24 @@ def cpu_baseline(field_key, n, t, sample):
     except Exception:
         lib, kind = O.Port(), "port"
     f = FIELD_TAGS[field_key]
+    # A pilot of a few secrets bounds the sample to about CPU_BASELINE_SECONDS of work per leg whatever the shape costs (the
+    # per-secret Lagrange basis is n(n-1) field inversions: 40 parties over GF(2^128) in the oracle port take milliseconds per
+    # secret, where (10,3) over Mersenne61 takes two microseconds).
+    pilot_n = min(sample, 16)
     try:
-        r = lib.time_shamir(f, sample, t, n)
+        pilot = lib.time_shamir(f, pilot_n, t, n)
     except O.OracleError:
         if kind != "reference":
             raise
         # a field the reference library does not have (GF(2^128)): the oracle port is the CPU baseline for it
         lib, kind = O.Port(), "port"
-        r = lib.time_shamir(f, sample, t, n)
+        pilot = lib.time_shamir(f, pilot_n, t, n)
+    while pilot["share_s"] + pilot["recover_s"] < 0.25 and pilot_n < sample:   # (the first calls also pay for cold caches)
+        pilot_n = min(sample, pilot_n * 8)
+        pilot = lib.time_shamir(f, pilot_n, t, n)
+    per_secret = max((pilot["share_s"] + pilot["recover_s"]) / pilot_n, 1e-9)
+    sample = max(16, min(sample, int(CPU_BASELINE_SECONDS / per_secret)))
+    r = lib.time_shamir(f, sample, t, n)
     if r["mismatches"]:
         raise RuntimeError("CPU baseline failed its own round trip")
     total = r["share_s"] + r["recover_s"]

@@ -1137,6 +1137,39 @@ def test_open_step_behind_the_c_abi_one_rank_rccl(scl, port):
         comm.close()
 
 
+@pytest.mark.parametrize("n,t,N,off,pad", [(128, 42, 1001, 1, 3), (100, 40, 777, 3, 0), (128, 63, 96, 0, 1)])
+def test_matrix_core_share_on_unaligned_rows_through_the_raw_abi(scl, port, n, t, N, off, pad):
+    """k_share_mfma_m61_p16 (n > 96, 32 <= t <= 63) stores one secret per lane, whole lines when the rows start on one; rows
+    that start 8 or 24 bytes into a line, odd row strides and ragged party / secret counts go through the same kernel: the C
+    ABI called directly with offset pointers, the whole share matrix against the oracle, the gaps between rows untouched."""
+    import ctypes as C
+    f = O.M61
+    stride, cstride = N + pad, N + 5
+    secrets = rand_elems(port, f, N, b"p16-s")
+    coeffs = rand_elems(port, f, t * N, b"p16-c").reshape(N, t, 1)
+    want = soa(port.shamir_share_coeffs(f, secrets, coeffs, n))            # [n][N][1]
+    sec_buf = torch.zeros(N + off, dtype=torch.int64, device="cuda")
+    sec_buf[off:] = torch.from_numpy(secrets.view(np.int64).reshape(N)).cuda()
+    co_buf = torch.zeros(t * cstride + off, dtype=torch.int64, device="cuda")
+    co_buf[off:].view(t, cstride)[:, :N] = torch.from_numpy(
+        np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2))).view(np.int64).reshape(t, N)).cuda()
+    sh_buf = torch.full((n * stride + off + 64,), -1, dtype=torch.int64, device="cuda")
+    p = lambda tns: C.c_void_p(tns.data_ptr() + 8 * off)
+    scl.set_tuning("mfma", 1)
+    try:
+        st = scl.lib.scl_hip_shamir_share(f, p(sh_buf), C.c_size_t(stride), p(sec_buf), p(co_buf), C.c_size_t(cstride),
+                                          C.c_size_t(N), C.c_size_t(t), C.c_size_t(n), None, None)
+        assert st == 0, scl.lib.scl_hip_last_error()
+    finally:
+        scl.set_tuning("mfma", 0)
+    torch.cuda.synchronize()
+    flat = sh_buf.cpu().numpy().view(np.uint64)
+    got = flat[off:off + n * stride].reshape(n, stride)
+    assert np.array_equal(got[:, :N], want[:, :, 0])
+    untouched = np.uint64(2 ** 64 - 1)
+    assert (got[:, N:] == untouched).all() and (flat[:off] == untouched).all() and (flat[off + n * stride:] == untouched).all()
+
+
 @pytest.mark.parametrize("t,mode", [(3, {}), (9, {}), (9, {"force_table": 1}), (20, {"mfma": 1}), (3, {"force_scalar": 1})])
 def test_odd_strides_and_8_byte_alignment_through_the_raw_abi(scl, port, t, mode):
     """Mersenne61 rows that are only 8-byte aligned and row strides that are odd (so the 16-byte packs cannot be
