@@ -41,6 +41,25 @@ FIELD_TAGS = {"m61": 0, "m127": 1, "mont128": 2, "gf2_128": 3, "secp256k1": 4, "
 FIELD_NAMES = {"m61": "Mersenne61", "m127": "Mersenne127", "mont128": "Mont128", "gf2_128": "GF(2^128)",
                "secp256k1": "secp256k1_order", "secp256k1_field": "secp256k1_field"}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
+I8_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md, matrix cores: I8 runs at 2x the BF16 rate per clock; BF16 dense ~2.5 PFLOP/s
+
+
+def mfma_share_roofline(n, t, N, ms):
+    """The matrix-core share kernel (k_share_mfma_m61_*, Mersenne61 at n > 96 / t >= 32) is bound by the matrix pipe, not by
+    HBM.  Algorithmic work of its formulation: V (n x (t+1)) times C ((t+1) x N) in 8 signed base-256
+    digits each = 64 digit-pair products, 2 int8 operations per multiply-accumulate.  `executed` counts what the instructions
+    do: K padded to 64 coefficient slots and the party tile to 16 rows."""
+    ops = 2.0 * 64 * (t + 1) * n * N
+    executed = 2.0 * 64 * 64 * ((n + 15) // 16 * 16) * N
+    ach = ops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "shamir_share", "achieved": ach, "peak": I8_PEAK_TOPS, "unit": "TOP/s (int8)",
+            "frac": ach / I8_PEAK_TOPS, "algorithmic_ops": ops, "executed_TOPs": executed / (ms * 1e-3) / 1e12,
+            "executed_frac": executed / (ms * 1e-3) / 1e12 / I8_PEAK_TOPS}
+
+
+def on_matrix_cores(fkey, n, t):
+    """the shapes scl_hip_shamir_share sends to k_share_mfma_m61_p16 (capi.hip: Mersenne61, n > 96, 32 <= t <= 63)"""
+    return fkey == "m61" and n > 96 and 32 <= t <= 63
 KERNEL_SOURCES = ("secure-computation-library_amd/csrc/kernels.hpp", "secure-computation-library_amd/csrc/capi.hip",
                   "secure-computation-library_amd/csrc/share_mfma.hpp", "include/scl_hip/detail/field.hpp")
 
@@ -380,6 +399,8 @@ def main():
                "share_GBps": sb * N / sm / 1e6, "recover_GBps": rb * N / rm / 1e6,
                "share_frac": sb * N / sm / 1e6 / HBM_PEAK_GBPS, "recover_frac": rb * N / rm / 1e6 / HBM_PEAK_GBPS,
                "round_trips_per_s": N / ((sm + rm) * 1e-3), "reconstructions_per_s": N / (rm * 1e-3), "verified": ok}
+        if on_matrix_cores(fkey, n, t):
+            res["share_roofline"] = mfma_share_roofline(n, t, N, sm)   # share_frac above is its HBM-equivalent rate only
         del secrets, coeffs, shares, out
         torch.cuda.empty_cache()
         return res
@@ -723,6 +744,16 @@ def main():
                 "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args),
                 "algorithmic_bytes": kernels[dom]["bytes_per_secret"] * N,
                 "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": ach / copy_gbps}
+    if dom == "shamir_share" and args.share_mode == "coeffs" and on_matrix_cores(args.field, n, t):
+        # --config c5: the dominant kernel runs on the matrix cores; its HBM-equivalent figures stay beside the matrix roofline
+        hbm = roofline
+        roofline = mfma_share_roofline(n, t, N, share_ms)
+        roofline["traffic"] = hbm["traffic"]
+        if roofline["traffic"] is None and (n, t, N) == (128, 42, 125_000_000):
+            # the stamped PMC run measured this very launch as its side configuration C5 (same kernel, same shard size)
+            side = pmc_config_traffic("C5_shard_mersenne61_128_42")
+            roofline["traffic"] = side["share"] if side else None
+        roofline["hbm_equivalent"] = {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes")}
     total = pl["total"] * args.steps       # c2: N per GPU x ranks; c5: BASELINE's total, split over the ranks
     line = {
         "metric": "shamir_reconstructions_per_sec", "value": total / elapsed, "unit": "reconstructions/s",

@@ -759,7 +759,7 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
   constexpr int ROWB = mf_rowb(KS);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // two images [digit][32 cols][ROWB] of recoded coefficients: block i is read from image i & 1 while block i + 1 is
-  // recoded into the other one, so one barrier per block suffices
+  // recoded into the other one (the barriers that order the two: below, at the loop)
   constexpr int IMG = MF_LIMBS * COLS * ROWB;
   unsigned char* Bs = smem;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, kb = lane >> 4, r32 = lane & 31, h = lane >> 5;

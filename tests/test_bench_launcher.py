@@ -113,3 +113,18 @@ def test_c5_on_fewer_gpus_is_capacity_bound_and_says_so():
     a = bench.parse_args(["--config", "c5", "--gpus", "8", "--total-secrets", "1000003"])
     assert sum(bench.plan(a, 8, r)["mine"] for r in range(8)) == 1000003
     assert bench.plan(bench.parse_args([]), 4, 0)["total"] == 400_000_000
+
+
+def test_matrix_core_share_is_priced_against_the_matrix_pipe():
+    """C5's share kernel runs on the matrix cores: bench.py quotes it against the int8 matrix peak (its HBM-equivalent rate
+    stays beside it), only for the shapes capi.hip sends there, with the formulation's own operation count."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.on_matrix_cores("m61", 128, 42) and bench.on_matrix_cores("m61", 97, 32)
+    assert not bench.on_matrix_cores("m61", 10, 3) and not bench.on_matrix_cores("m61", 96, 42)
+    assert not bench.on_matrix_cores("m127", 128, 42) and not bench.on_matrix_cores("m61", 128, 64)
+    r = bench.mfma_share_roofline(128, 42, 1_000_000, 1.0)
+    assert r["bound"] == "mfma" and r["peak"] == bench.I8_PEAK_TOPS
+    assert r["algorithmic_ops"] == 2 * 64 * 43 * 128 * 1_000_000           # 64 digit pairs, 43 coefficients, 128 parties
+    assert abs(r["achieved"] - r["algorithmic_ops"] / 1e-3 / 1e12) < 1e-9 and abs(r["frac"] - r["achieved"] / 5000.0) < 1e-12
+    assert abs(r["executed_frac"] / r["frac"] - 64 / 43) < 1e-9             # K padded from 43 to 64 slots
