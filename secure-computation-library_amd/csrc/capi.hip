@@ -383,6 +383,7 @@ void make_aes_key(const unsigned char* seed, size_t seed_len, AesKey& k) {
     const unsigned s3 = s2 ^ s;
     k.te0[x] = s2 | (s << 8) | (s << 16) | (s3 << 24);
   }
+  aes_key_round1(k);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

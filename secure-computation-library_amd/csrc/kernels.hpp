@@ -1391,7 +1391,26 @@ __global__ __launch_bounds__(BLOCK) void k_share_blocked(typename F::Ctx ctx, u6
 struct AesKey {
   u32 rk[44];    // 11 round keys, little-endian column words (wave-uniform: scalar loads)
   u32 te0[256];  // te0[x] = (2S, S, S, 3S) as bytes 0..3, S = sbox[x]
+  u32 r1[4];     // the key-only half of round 1 (aes_key_round1 below)
 };
+
+// The PRG's input block is LE64(counter) || LE64(0x0123456789ABCDEF) (prg.h:34-43): its upper two columns do not depend on the
+// counter, so the eight table terms of round 1 that read them, and round key 1, are one constant per key and column:
+//   r1[0] = T2[s2.b2] ^ T3[s3.b3] ^ rk[4]     r1[1] = T1[s2.b1] ^ T2[s3.b2] ^ rk[5]
+//   r1[2] = T0[s2.b0] ^ T1[s3.b1] ^ rk[6]     r1[3] = T0[s3.b0] ^ T3[s2.b3] ^ rk[7]
+// with s2 = 0x89ABCDEF ^ rk[2], s3 = 0x01234567 ^ rk[3], T_r[x] = te0[x] rotated left by 8 r.  Round 1 of a block is then
+// eight lookups instead of sixteen (152 per block instead of 160).  Call after rk and te0 are filled.
+inline void aes_key_round1(AesKey& k) {
+  auto T = [&](int r, u32 word, int byte) {
+    const u32 v = k.te0[(word >> (8 * byte)) & 255u];
+    return r ? (v << (8 * r)) | (v >> (32 - 8 * r)) : v;
+  };
+  const u32 s2 = 0x89ABCDEFu ^ k.rk[2], s3 = 0x01234567u ^ k.rk[3];
+  k.r1[0] = T(2, s2, 2) ^ T(3, s3, 3) ^ k.rk[4];
+  k.r1[1] = T(1, s2, 1) ^ T(2, s3, 2) ^ k.rk[5];
+  k.r1[2] = T(0, s2, 0) ^ T(1, s3, 1) ^ k.rk[6];
+  k.r1[3] = T(0, s3, 0) ^ T(3, s2, 3) ^ k.rk[7];
+}
 
 constexpr int AES_LDS_WORDS = 256 * 32;
 constexpr int AES_GRID_CAP = 256 * 4;  // 4 x 34 KiB blocks per CU; the PRG kernels grid-stride
@@ -1402,10 +1421,16 @@ __device__ __forceinline__ u32 rotl32(u32 x, int r) { return (x << r) | (x >> (3
 // tl = te0 + (lane & 31): the lane's private copy, entries 32 words apart
 __device__ __forceinline__ void aes_ctr_block(const u32* tl, const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) {
 #define SCL_T(x) tl[(x) << 5]
-  u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2 = 0x89ABCDEFu ^ key.rk[2],
-      s3 = 0x01234567u ^ key.rk[3];
+  u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2, s3;
+  {  // round 1: the counter's two columns only (aes_key_round1)
+    const u32 t0 = SCL_T(s0 & 255) ^ rotl32(SCL_T((s1 >> 8) & 255), 8) ^ key.r1[0];
+    const u32 t1 = SCL_T(s1 & 255) ^ rotl32(SCL_T(s0 >> 24), 24) ^ key.r1[1];
+    const u32 t2 = rotl32(SCL_T((s0 >> 16) & 255), 16) ^ rotl32(SCL_T(s1 >> 24), 24) ^ key.r1[2];
+    const u32 t3 = rotl32(SCL_T((s0 >> 8) & 255), 8) ^ rotl32(SCL_T((s1 >> 16) & 255), 16) ^ key.r1[3];
+    s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+  }
 #pragma unroll
-  for (int r = 1; r < 10; ++r) {
+  for (int r = 2; r < 10; ++r) {
     const u32 t0 = SCL_T(s0 & 255) ^ rotl32(SCL_T((s1 >> 8) & 255), 8) ^ rotl32(SCL_T((s2 >> 16) & 255), 16) ^
                    rotl32(SCL_T(s3 >> 24), 24) ^ key.rk[4 * r + 0];
     const u32 t1 = SCL_T(s1 & 255) ^ rotl32(SCL_T((s2 >> 8) & 255), 8) ^ rotl32(SCL_T((s3 >> 16) & 255), 16) ^
@@ -1539,10 +1564,16 @@ struct Aes1 {  // the single-table form above behind the same interface
 // scheduler.  Four address registers (one per table), each a chain of byte-1 replacements.
 __device__ __forceinline__ void Aes4::block(const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) const {
   u32 a0 = lane, a1 = lane, a2 = lane + 65536u, a3 = lane + 65536u;
-  u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2 = 0x89ABCDEFu ^ key.rk[2],
-      s3 = 0x01234567u ^ key.rk[3];
+  u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2, s3;
+  {  // round 1: the counter's two columns only (aes_key_round1)
+    const u32 u0 = look<0, 0>(a0, s0) ^ look<1, 128>(a1, s1) ^ key.r1[0];
+    const u32 u1 = look<0, 0>(a0, s1) ^ look<3, 128>(a3, s0) ^ key.r1[1];
+    const u32 u2 = look<2, 0>(a2, s0) ^ look<3, 128>(a3, s1) ^ key.r1[2];
+    const u32 u3 = look<1, 128>(a1, s0) ^ look<2, 0>(a2, s1) ^ key.r1[3];
+    s0 = u0; s1 = u1; s2 = u2; s3 = u3;
+  }
 #pragma unroll
-  for (int r = 1; r < 10; ++r) {
+  for (int r = 2; r < 10; ++r) {
     const u32 u0 = look<0, 0>(a0, s0) ^ look<1, 128>(a1, s1) ^ look<2, 0>(a2, s2) ^ look<3, 128>(a3, s3) ^ key.rk[4 * r + 0];
     const u32 u1 = look<0, 0>(a0, s1) ^ look<1, 128>(a1, s2) ^ look<2, 0>(a2, s3) ^ look<3, 128>(a3, s0) ^ key.rk[4 * r + 1];
     const u32 u2 = look<0, 0>(a0, s2) ^ look<1, 128>(a1, s3) ^ look<2, 0>(a2, s0) ^ look<3, 128>(a3, s1) ^ key.rk[4 * r + 2];

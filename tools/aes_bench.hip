@@ -181,6 +181,7 @@ int main() {
   AesKey key;
   for (int i = 0; i < 44; ++i) key.rk[i] = 0x9E3779B9u * (i + 1);
   for (int i = 0; i < 256; ++i) key.te0[i] = 0x85EBCA6Bu * (i + 7) ^ (i << 13);
+  aes_key_round1(key);
   u64 *a, *b;
   CK(hipMalloc(&a, nblocks * 16));
   CK(hipMalloc(&b, nblocks * 16));

@@ -202,6 +202,7 @@ int main(int argc, char** argv) {
     AesKey key;
     for (int i = 0; i < 44; ++i) key.rk[i] = 0x9E3779B9u * (i + 1);
     for (int i = 0; i < 256; ++i) key.te0[i] = 0x85EBCA6Bu * (i + 7) ^ (i << 13);
+    aes_key_round1(key);
     auto kern = &k_vector_random<M61>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AES4_LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, M61::Ctx{}, secrets[0], key, 1ull, N);
