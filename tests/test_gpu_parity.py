@@ -165,7 +165,9 @@ def test_prg_golden_and_oracle(scl, port):
         if case["sizes"] == [4096]:
             got = bytes(scl.prg_blocks(256, bytes.fromhex(case["seed"])).cpu().numpy())
             assert got.hex() == case["out"]
-    for seed, c0, nb in ((b"shamir passive", 0, 2), (b"", 5, 1000), (b"x" * 40, 2 ** 40, 4097), (b"k", 2 ** 63, 3)):
+    # (the last two launches cross a 2^32 / 2^48 boundary of the counter: the upper word of the input block changes inside them)
+    for seed, c0, nb in ((b"shamir passive", 0, 2), (b"", 5, 1000), (b"x" * 40, 2 ** 40, 4097), (b"k", 2 ** 63, 3),
+                         (b"wrap", 2 ** 32 - 777, 5000), (b"wrap48", 2 ** 48 - 3, 64)):
         got = bytes(scl.prg_blocks(nb, seed, c0).cpu().numpy())
         assert got == port.prg_blocks(seed, c0 % 2 ** 64, nb)
     assert scl.prg_blocks(0, b"s").numel() == 0
@@ -1333,6 +1335,25 @@ def test_full_size_round_trip(scl, port, f, n, t, N):
     # additive at size
     ad = scl.additive_share_prg(f, secrets, 3, b"big-add")
     assert scl.equals(f, scl.additive_recover(f, ad), secrets)
+
+
+@pytest.mark.parametrize("f", [O.M61, O.M127])
+def test_prg_share_across_a_2_32_counter_boundary(scl, port, f):
+    """shamirSecretShare(secret, t, n, prg) on a PRG whose block counter passes 2^32 in the middle of the batch (prg.h:167-169:
+    the counter is a 64-bit `long`; the upper word of the AES input block changes inside the launch): every share against the
+    oracle's per-secret evaluation of the coefficients the oracle's PRG blocks spell, and additive sharing the same way."""
+    L, n, t, N = O.LIMBS[f], 10, 3, 1500
+    B = (t + 2) // 2 if L == 1 else t + 1
+    c0 = 2 ** 32 - 700 * B - (1 if B > 1 else 0)      # the boundary falls inside secret 700's blocks
+    secrets = rand_elems(port, f, N, b"wrap-secrets")
+    sh = scl.shamir_share_prg(f, dev(scl, secrets), t, n, b"wrap-seed", counter0=c0)
+    elems = port.from_bytes(f, port.prg_blocks(b"wrap-seed", c0, N * B)).reshape(N, -1, L)
+    want = soa(port.shamir_share_coeffs(f, secrets, np.ascontiguousarray(elems[:, 1:t + 1]), n))
+    assert np.array_equal(host(scl, sh), want)
+    assert scl.equals(f, scl.shamir_recover(f, sh), dev(scl, secrets))
+    v = scl.vector_random(f, 4000, b"wrap-vr", counter0=2 ** 32 - 1000)
+    bs = 8 * L
+    assert np.array_equal(host(scl, v), port.from_bytes(f, port.prg_blocks(b"wrap-vr", 2 ** 32 - 1000, (4000 * bs + 15) // 16)[: 4000 * bs]))
 
 
 def test_c5_shard_size(scl, port):
