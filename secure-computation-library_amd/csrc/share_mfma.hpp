@@ -644,23 +644,30 @@ __global__ __launch_bounds__(256, 1) void k_share_mfma_m61_pipe(u64* shares, siz
 // registers instead of 16.  Eight waves per workgroup; wave w owns parties 16w .. 16w+15 for the block's 32 secrets
 // (two tiles): accumulators 2 sets x 4 diagonals x 2 tiles x 4 = 64 VGPRs, V's digit fragments 32 and the block's
 // coefficient fragments 64 accumulation registers.  Rows of a tile are parties (A operand: V's digits), columns are secrets
-// (B operand: the coefficient digits), so a lane ends up with one secret of four parties and sixteen adjacent lanes write
-// sixteen adjacent secrets of one party: every store instruction writes whole 128-byte lines.  (Until round 3 the product was
-// taken transposed -- a lane then held four consecutive secrets of one party, two 16-byte stores that covered 64 bytes of
-// each of 16 rows per instruction -- at the same speed within 2 %, but with a fast path that needed 16-byte-aligned rows.)
-// Same digit tables, same LDS image of the recoded coefficients ([digit][32 columns][row of 64 k-bytes + pad]) as the kernels
-// above.
+// (B operand: the coefficient digits), and column c of tile ct is secret 2 c + ct of the block (the recode writes secret s to
+// image row 16 (s & 1) + (s >> 1)): a lane ends up with two CONSECUTIVE secrets of each of four parties, one 16-byte store
+// per party, and sixteen adjacent lanes write 256 contiguous bytes of a party's row -- four store instructions per trip and
+// wave, each two whole 128-byte lines of four rows.  (Round 2: the product transposed, a lane held four consecutive secrets
+// of one party, four stores that each touched 64 bytes of 16 rows.  First half of round 3: one secret per lane, eight 8-byte
+// stores of whole lines.  Per store instruction the kernel pays about 80 cycles of issue whatever it carries: 8 -> 4
+// instructions was 4.8 % of the kernel, profiles/r3_p16_stamps.txt.)  Same digit tables, same LDS image of the recoded
+// coefficients ([digit][32 columns][row of 64 k-bytes + pad]) as the kernels above.
 //
-// What bounds it (profiles/r3_p16_ablation.txt, r3_p16_sq.txt; 128 parties, t = 42, 2 10^7 secrets, 9.2 ms): per trip and
-// wave 128 matrix instructions, 294 other vector instructions, 71 scalar, 20 LDS, 11 vector-memory; a wave's 7 250 cycles
-// per trip are 2 230 issuing, 2 960 stalled at issue (the SIMD's matrix pipe busy with the other wave's instruction; the
-// pipe is busy 56 % of the time) and 2 060 parked at a wait (fragment loads, barriers).  Taking things OUT of the kernel
-// shortens it by: the stores 2.0 ms (by cycles only 1.0: without them the chip holds 2.23 GHz instead of 2.0), the matrix
-// instructions 2.4, the recombination 1.1, recode + fetch 1.1, the fragment loads 0.5, the barriers 0 -- the parts add, and
-// the clock gives back about half of every saving (the in-step and the staggered schedule differ by 6 % in cycles and 2-3 %
-// in time).  Tried on top and measured equal within +-2 % (tools/mfma_bench.hip switches, not kept): stores deferred into
-// the next trip's matrix instructions one at a time; recode + fetch at the end of the trip instead of word 2; a wave tile of
-// 32 parties x 16 secrets (half the LDS fragment traffic); the transposed product.
+// What bounds it (profiles/r3_p16_ablation.txt, r3_p16_sq.txt, r3_p16_stamps.txt; 128 parties, t = 42, 2 10^7 secrets):
+// per trip and wave 128 matrix instructions, ~290 other vector instructions, 71 scalar, 20 LDS, 8 vector-memory.  The two
+// waves of a SIMD are WORK-CONSERVING: in-kernel stamps show a wave parked at a barrier for 10-25 % of its trip, yet moving
+// that wait around -- waves in step (the older wave of the SIMD wins every arbitration and waits 1 900 cycles per trip for
+// the younger), staggered (1 650), staggered with s_setprio by half-trip (both wait 700), the mid-trip barrier 14 to 26
+// instructions earlier -- leaves the trip at 7 200-7 500 cycles: while one wave waits the other has the SIMD to itself.
+// What the trip costs is the SUM of what both waves issue: 256 matrix instructions of 16 cycles, ~580 vector instructions of
+// 4.5, and every vector-memory instruction at ~80 -- so the levers are instruction COUNTS (stores 8 -> 4: -4.8 %; eight
+// stores issued back to back at the trip's end instead of between the folds: +8 %; a branch per stored value: +1 %), not
+// schedules.  Taking things OUT of the kernel shortens it by: the stores 2.0 ms of 9.2 (by cycles only 1.0: without them the
+// chip holds 2.23 GHz instead of 2.0), the matrix instructions 2.4, the recombination 1.1, recode + fetch 1.1, the fragment
+// loads 0.5, the barriers 0 -- the parts add, and the clock gives back about half of every saving.  Tried and measured
+// equal within +-2 % (tools/mfma_bench.hip switches, not kept): stores deferred into the next trip's matrix instructions one
+// at a time; recode + fetch at the end of the trip instead of word 2; a wave tile of 32 parties x 16 secrets (half the LDS
+// fragment traffic); s_setprio by half-trip; the mid-trip barrier at other places.
 typedef int v4acc __attribute__((ext_vector_type(4)));
 struct MfOp16 {
   int l, m, j, ct;
@@ -708,8 +715,11 @@ __device__ __forceinline__ void mf16_recombine_unit(const v4acc (&acc)[4][2], co
   if constexpr (4 * A + k <= 2 * (MF_LIMBS - 1)) {
     const int mult = A >= 2 ? (k == 0 ? mm.h0 : k == 1 ? mm.h8 : k == 2 ? mm.h16 : mm.h24)
                             : (k == 0 ? mm.m0 : k == 1 ? mm.m8 : k == 2 ? mm.m16 : mm.m24);
-    // words 3 and 2 come first and start their sums from the bias
-    const long long add = (A >= 2 && k == 0) ? (long long)MF16_BIAS : (long long)sum;
+    // words 3 and 2 come first and start their sums from the bias; T's also carries the constant of the final fold,
+    // P - MF16_TOTAL_BIAS (T stays below 2^62)
+    const long long add = (A == 3 && k == 0)   ? (long long)MF16_BIAS
+                          : (A == 2 && k == 0) ? (long long)(MF16_BIAS + (M61::P - MF16_TOTAL_BIAS))
+                                               : (long long)sum;
     sum = (u64)((long long)acc[k][ct][i] * mult + add);
   }
   asm volatile("" : "+v"(sum));  // pinned in place (see mf_recombine_unit)
@@ -725,6 +735,14 @@ __device__ __forceinline__ void mf16_recombine_units(const v4acc (&acc)[4][2], c
 // fetch, 16 no fragment loads, 32 no barriers; results are then wrong by construction); the library builds with 0
 #ifndef MF16_ABL
 #define MF16_ABL 0
+#endif
+// MF16_HOOK(p): empty in the library.  tools/mfma_bench.hip -DMF16_STAMP defines the three hooks to accumulate s_memtime deltas
+// between the points of a trip: 0 before / 1 after the trip-start barrier, 2 fragments loaded, 3 before / 4 after the recode,
+// 5 fetch issued, 6 before / 7 after the mid-trip barrier, 8 matrix instructions and recombination done, 9 stores issued
+#ifndef MF16_HOOK
+#define MF16_HOOK(p)
+#define MF16_HOOK_DECL
+#define MF16_HOOK_END
 #endif
 template <int A, int I, int NM, bool PREV, class Side>
 __device__ __forceinline__ void mf16_pipe_op(const v4i (&vfrag)[MF_LIMBS], const v4i (&cfrag)[2][MF_LIMBS], v4acc (&accN)[4][2],
@@ -790,7 +808,9 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
   };
   auto recode = [&](int img) {
     const int kg = 2 * w + h;
-    unsigned char* dst = Bs + (size_t)img * IMG + (size_t)r32 * ROWB + 4 * kg;
+    // secret r32 of the block goes to row 16 (r32 & 1) + (r32 >> 1) of the image: column c of tile ct is then secret 2 c + ct,
+    // so a lane's two tiles hold two CONSECUTIVE secrets of each of its four parties -- one 16-byte store per party
+    unsigned char* dst = Bs + (size_t)img * IMG + (size_t)(16 * (r32 & 1) + (r32 >> 1)) * ROWB + 4 * kg;
     u32 lo[4], hi[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -826,6 +846,7 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
   MfMul16 mm{1, 1 << 8, 1 << 16, 1 << 24, 1 << 3, 1 << 11, 1 << 19, 1 << 27};
   asm volatile("" : "+s"(mm.m0), "+s"(mm.m8), "+s"(mm.m16), "+s"(mm.m24), "+s"(mm.h0), "+s"(mm.h8), "+s"(mm.h16), "+s"(mm.h24));
   const bool rows_full = __builtin_amdgcn_readfirstlane(pbase + 16 <= n);
+  const bool aligned_rows = (reinterpret_cast<uintptr_t>(shares) & 15) == 0 && (stride & 1) == 0;  // 16-byte stores allowed
 
   // the order in which a workgroup takes its blocks: MF16_CHUNK consecutive blocks, then on by gridDim.x chunks (1: block
   // b, b + gridDim.x, ..: every workgroup of the grid writes into the same 64 KiB window of a share row at about the same time)
@@ -854,10 +875,13 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
 #endif
   const bool late = MF16_STAGGER && (wu >> 2);  // wave-uniform
   if (late) mf_lds_barrier();
+  MF16_HOOK_DECL
 
   for (int img = 0; blk < nblocks; ++it, blk = block_of(it), img ^= 1) {
     const size_t s_base = blk * COLS;
+    MF16_HOOK(0);
     if constexpr (!(MF16_ABL & 32)) mf_lds_barrier();  // this block's digits are complete in image img; everyone is done reading the other image
+    MF16_HOOK(1);
     const u32 crow = crow_lds + (u32)img * IMG;
     // the sixteen loads and their wait are ONE asm statement: nothing the compiler might insert (a copy, a spill)
     // can touch a fragment register before its data has arrived
@@ -881,17 +905,25 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
       for (int m = 0; m < MF_LIMBS; ++m) asm volatile("" : "=a"(cfrag[0][m]), "=a"(cfrag[1][m]) : "v"(crow));
     }
 #undef MF16_LD
+    MF16_HOOK(2);
     const bool have_next = block_of(it + 1) < nblocks, have_next2 = block_of(it + 2) < nblocks;
     auto side = [&](auto Ac, auto Ic, auto NMc) {
       constexpr int A_ = decltype(Ac)::value, I_ = decltype(Ic)::value, NM_ = decltype(NMc)::value;
       // the next block's recode (first half of the trip: see the barriers above) and the fetch of the block after it
       if constexpr (A_ == 2 && I_ == NM_ / 4 && !(MF16_ABL & 8)) {
+        MF16_HOOK(3);
         if (have_next) recode(img ^ 1);
+        MF16_HOOK(4);
       }
       if constexpr (A_ == 2 && I_ == NM_ / 2 && !(MF16_ABL & 8)) {
         if (have_next2) fetch(block_of(it + 2));
+        MF16_HOOK(5);
       }
-      if constexpr (MF16_STAGGER && A_ == 1 && I_ == 0 && !(MF16_ABL & 32)) mf_lds_barrier();  // mid-trip
+      if constexpr (MF16_STAGGER && A_ == 1 && I_ == 0 && !(MF16_ABL & 32)) {
+        MF16_HOOK(6);
+        mf_lds_barrier();  // mid-trip
+        MF16_HOOK(7);
+      }
     };
     u64 S[8], T[8];
     v4acc accX[4][2], accY[4][2];
@@ -909,34 +941,60 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
       }
     }
 
-    // ---- fold and store: element e = 4 ct + i is party pbase + 4 (lane >> 4) + i, secret s_base + 16 ct + (lane & 15)
+    MF16_HOOK(8);
+    // ---- fold and store: element e = 4 ct + i is party pbase + 4 (lane >> 4) + i, secret s_base + 16 ct + (lane & 15).
+    // ONE wave-uniform branch around the whole part, and inside it a party's two values are folded and stored before the next
+    // party's are touched: eight stores issued back to back at the end cost 8 % of the kernel (they queue at the memory pipe and
+    // the next trip's wait for its coefficients then waits for all of them), a branch per value as much again in scalar work.
+    // T already carries P - MF16_TOTAL_BIAS (mf16_recombine_unit).
+    auto finish = [&](int e) -> u64 {
+      const u32 slo = (u32)S[e], shi = (u32)(S[e] >> 32);                                       // S < 2^55
+      const u64 x = ((u64)(slo & 0x1FFFFFFFu) << 32) | __builtin_amdgcn_alignbit(shi, slo, 29);  // 2^32 S mod p: rotl61(S, 32)
+      const u64 sum = T[e] + x;                                                                 // < 2^62 + 2^61
+      const u64 f = (sum & P) + (sum >> 61);                                                    // <= P + 2
+      return (f + ((f + 1) >> 61)) & P;                                                         // canonical, no compare / select
+    };
     const bool fast = rows_full && s_base + COLS <= N;  // wave-uniform
     const int p0 = pbase + 4 * kb;
-    const size_t s0 = s_base + r16;
+    const size_t s0 = s_base + 2 * r16;  // element e = 4 ct + i: party p0 + i, secret s0 + ct
     u64* rowp = shares + (size_t)p0 * stride + s0;
+    // cached stores: an instruction writes 256 contiguous bytes (two whole lines on rows that start on a line) of each of four
+    // parties' rows; rows that are only 8-byte aligned take two 8-byte stores per party
+    if constexpr ((MF16_ABL & 4) != 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      u64 v[2];
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const u64 sum = T[4 * ct + i] + rotl61(S[4 * ct + i], 32) + (P - MF16_TOTAL_BIAS);  // < 2^54 + 2^61 + 2^61
-        const u64 f = (sum & P) + (sum >> 61);
-        v[ct] = f >= P ? f - P : f;
+      for (int e = 0; e < 8; ++e) {
+        const u64 v = finish(e);
+        asm volatile("" ::"v"(v), "v"(rowp));
       }
-      u64* dst = rowp + (size_t)i * stride;
-      // cached stores: each instruction writes one whole 128-byte line of each of four parties' rows (rows that start on a
-      // line; otherwise two part lines that the L2 completes)
-      if constexpr ((MF16_ABL & 4) != 0) {
-        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(dst));
-      } else if (fast) {
-        dst[0] = v[0];
-        dst[16] = v[1];
-      } else if (p0 + i < n) {
-        if (s0 < N) dst[0] = v[0];
-        if (s0 + 16 < N) dst[16] = v[1];
+    } else if (fast && aligned_rows) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u64x2 o;
+        o.x = finish(i);
+        o.y = finish(4 + i);
+        *reinterpret_cast<u64x2*>(rowp + (size_t)i * stride) = o;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if (fast) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u64* dst = rowp + (size_t)i * stride;
+        dst[0] = finish(i);
+        dst[1] = finish(4 + i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u64* dst = rowp + (size_t)i * stride;
+        const u64 v0 = finish(i), v1 = finish(4 + i);
+        if (p0 + i < n && s0 < N) dst[0] = v0;
+        if (p0 + i < n && s0 + 1 < N) dst[1] = v1;
       }
     }
+    MF16_HOOK(9);
   }
+  MF16_HOOK_END
   if (MF16_STAGGER && !late) mf_lds_barrier();  // (the late waves' extra barrier before the loop)
 }
 

@@ -12,6 +12,35 @@
 #include <cstdlib>
 #include <vector>
 
+#ifdef MF16_STAMP
+// diagnostic build (-DMF16_STAMP): waves 0 (early) and 4 (late) of every workgroup accumulate s_memtime deltas between the hook
+// points of k_share_mfma_m61_p16's trip (csrc/share_mfma.hpp, MF16_HOOK) and write them out at the end; printed below as mean
+// cycles per trip and phase, with the in-kernel clock (s_memtime ticks per s_memrealtime tick x 100 MHz).  The stamps cost
+// cycles of their own (each waits for outstanding LDS / scalar-memory operations): read the split, not the total.
+__device__ unsigned long long* mf16_stamp_buf;
+#define MF16_HOOK_DECL                                                                                     \
+  const bool stamp_on = (wu & 3) == 0;                                                                     \
+  unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_trips = 0;                      \
+  unsigned long long stamp_last = __builtin_amdgcn_s_memtime();                                            \
+  const unsigned long long stamp_t0 = stamp_last, stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#define MF16_HOOK(p)                                                                                       \
+  do {                                                                                                     \
+    if (stamp_on) {                                                                                        \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
+      stamp_acc[p] += t_ - stamp_last;                                                                     \
+      stamp_last = t_;                                                                                     \
+      if ((p) == 9) ++stamp_trips;                                                                         \
+    }                                                                                                      \
+  } while (0)
+#define MF16_HOOK_END                                                                                      \
+  if (stamp_on && lane == 0) {                                                                             \
+    unsigned long long* o_ = mf16_stamp_buf + ((size_t)blockIdx.x * 2 + (wu >> 2)) * 16;                   \
+    for (int p_ = 0; p_ < 10; ++p_) o_[p_] = stamp_acc[p_];                                                \
+    o_[10] = stamp_trips;                                                                                  \
+    o_[11] = __builtin_amdgcn_s_memtime() - stamp_t0;                                                      \
+    o_[12] = __builtin_amdgcn_s_memrealtime() - stamp_r0;                                                  \
+  }
+#endif
 #include "../secure-computation-library_amd/csrc/share_mfma.hpp"
 using namespace sclhip;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1);} } while (0)
@@ -94,7 +123,34 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     const size_t nblocks = (N + 31) / 32;
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
+#ifdef MF16_STAMP
+    unsigned long long* stamps;
+    CK(hipMalloc(&stamps, (size_t)grid * 2 * 16 * 8));
+    CK(hipMemset(stamps, 0, (size_t)grid * 2 * 16 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(mf16_stamp_buf), &stamps, sizeof(stamps)));
+#endif
     time_it([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shmem, 0, out2, N, c, c + N, N, tab, t, n, N); }, "k_share_mfma_m61_p16");
+#ifdef MF16_STAMP
+    {
+      std::vector<unsigned long long> h((size_t)grid * 2 * 16);
+      CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+      static const char* names[10] = {"loop edge -> trip start", "trip-start barrier", "fragment loads (16 ds_read_b128 + wait)",
+                                      "word 3 + first quarter of word 2", "recode (with its wait for the coefficients)",
+                                      "second quarter of word 2 + fetch issue", "rest of word 2", "mid-trip barrier",
+                                      "words 1 and 0 + last recombination", "fold + stores"};
+      for (int g = 0; g < 2; ++g) {
+        double acc[13] = {0};
+        for (unsigned b = 0; b < grid; ++b)
+          for (int p = 0; p < 13; ++p) acc[p] += (double)h[((size_t)b * 2 + g) * 16 + p];
+        const double trips = acc[10];
+        double sum = 0;
+        for (int p = 0; p < 10; ++p) sum += acc[p];
+        std::printf("  %s waves (wave %d of each workgroup): %.0f trips each, in-kernel clock %.2f GHz, %.0f cycles per trip\n",
+                    g ? "late" : "early", 4 * g, trips / grid, acc[11] / acc[12] * 0.1, sum / trips);
+        for (int p = 0; p < 10; ++p) std::printf("    %-46s %7.0f cycles  %5.1f %%\n", names[p], acc[p] / trips, 100 * acc[p] / sum);
+      }
+    }
+#endif
     std::vector<u64> a0((size_t)n * N), a2((size_t)n * N);
     CK(hipMemcpy(a0.data(), out0, a0.size() * 8, hipMemcpyDeviceToHost));
     CK(hipMemcpy(a2.data(), out2, a2.size() * 8, hipMemcpyDeviceToHost));
