@@ -22,6 +22,26 @@ constexpr int FIXED_M_MAX = 16;  // recover kernels with lambda in kernel argume
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
+// gfx950's three-input bitwise instruction (v_bitop3_b32, truth table in the immediate): a ^ b ^ c and the bit select
+// (a & m) | (b & ~m) in one instruction each.  Measured at 3.0 cycles per wave-instruction with four or more waves per SIMD
+// (v_xor_b32 2.7, so a three-way xor costs 3.0 instead of 5.5; profiles/r3_oprate_bitop3.txt); the compiler does not form it
+// from two xors by itself.
+__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+__device__ __forceinline__ u32 bitsel(u32 a, u32 b, u32 m) {  // bits of a where m is set, of b elsewhere
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, m, 0xE4);  // table bit 4a + 2b + c (tools/bitop3_probe.hip)
+#else
+  return (a & m) | (b & ~m);
+#endif
+}
+
+
 // ---- 16-byte (or 8-byte) pack loads/stores ---------------------------------------------------
 template <class F, int VEC>
 struct Pack {
@@ -465,6 +485,17 @@ __device__ __forceinline__ void gfpos_issue4(u32x4 (&buf)[4], u32 gbase, const u
   lds_read128<j * 2048 + (4 + (1 - half)) * 256>(buf[2], add_byte<2>(gbase, m));
   lds_read128<j * 2048 + (6 + (1 - half)) * 256>(buf[3], add_byte<3>(gbase, m));
 }
+// acc ^= the four table entries of a batch: two three-way xors per word (v_bitop3_b32, 3.0 cycles each) where four two-way
+// ones stood (2.7 each) -- the xors were two thirds of the kernel's vector instructions
+__device__ __forceinline__ void gfpos_fold(u32x4& acc, const u32x4 (&cur)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    acc[c] = xor3(xor3(cur[0][c], cur[1][c], cur[2][c]), cur[3][c], acc[c]);
+#else
+  acc ^= (cur[0] ^ cur[1]) ^ (cur[2] ^ cur[3]);
+#endif
+}
 template <int G, int IDX>
 __device__ __forceinline__ void gfpos_pipe(u32x4 (&A)[4], u32x4 (&B)[4], u32x4 (&acc)[4], u32 gbase, const u32 (&w)[G][4]) {
   constexpr int NB = 8 * G;
@@ -473,7 +504,7 @@ __device__ __forceinline__ void gfpos_pipe(u32x4 (&A)[4], u32x4 (&B)[4], u32x4 (
     u32x4(&cur)[4] = (IDX & 1) ? B : A;
     if constexpr (IDX + 1 < NB) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
-    acc[IDX / (2 * G)] ^= (cur[0] ^ cur[1]) ^ (cur[2] ^ cur[3]);
+    gfpos_fold(acc[IDX / (2 * G)], cur);
     gfpos_pipe<G, IDX + 1>(A, B, acc, gbase, w);
   }
 }
@@ -495,7 +526,7 @@ __device__ __forceinline__ void gfpos_pipe_n(u32x4 (&buf)[NBUF][4], u32x4 (&acc)
     constexpr int younger = (NB - 1 - IDX) < (NBUF - 1) ? (NB - 1 - IDX) : (NBUF - 1);
     u32x4(&cur)[4] = buf[IDX % NBUF];
     gfpos_wait<4 * younger>(cur);
-    acc[IDX / (2 * G)] ^= (cur[0] ^ cur[1]) ^ (cur[2] ^ cur[3]);
+    gfpos_fold(acc[IDX / (2 * G)], cur);
     gfpos_pipe_n<G, IDX + 1, NBUF>(buf, acc, gbase, w);
   }
 }
@@ -639,8 +670,8 @@ __device__ __forceinline__ void stage_nodes(const BigTable<F>& tab, int n, typen
 // step) and come back down through x^128 = x^7 + x^2 + x + 1 once per 32 / deg A steps instead of every step.
 __device__ __forceinline__ void gf_fold5(u32 (&y)[5]) {
   const u32 t = y[4];
-  y[0] ^= t ^ (t << 1) ^ (t << 2) ^ (t << 7);
-  y[1] ^= (t >> 31) ^ (t >> 30) ^ (t >> 25);
+  y[0] = xor3(xor3(y[0], t, t << 1), t << 2, t << 7);
+  y[1] = xor3(y[1], t >> 31, t >> 30) ^ (t >> 25);
   y[4] = 0;
 }
 template <u32 A>
@@ -848,29 +879,36 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) v
 // x^128 = x^7 + x^2 + x + 1 once per (32 - deg) / (2 deg) steps, for the tile as a whole.
 template <u32 A>
 __device__ __forceinline__ void gf_outer_step(u32 (&y)[5], const u32 (&g)[5]) {  // y <- y * A^2 + g  (A^2: bit b of A at 2b)
-  u32 r4 = g[4], r3 = g[3], r2 = g[2], r1 = g[1], r0 = g[0];
-  if constexpr (A & 1u) {
-    r4 ^= y[4];
-    r3 ^= y[3];
-    r2 ^= y[2];
-    r1 ^= y[1];
-    r0 ^= y[0];
+  // g and one copy of y per set bit of A, added up with THREE-way xors (v_bitop3_b32): copy number idx (counting the set bits of
+  // A from bit 0) waits in p when idx is even and goes in together with the next one; an odd copy out is added at the end
+  u32 r[5] = {g[0], g[1], g[2], g[3], g[4]}, p[5] = {0, 0, 0, 0, 0};
+#define SCL_GFN_TERM(B, E0, E1, E2, E3, E4)                              \
+  if constexpr ((A >> B) & 1u) {                                         \
+    constexpr int idx = __builtin_popcount(A & ((1u << B) - 1u));        \
+    if constexpr (idx % 2 == 0) {                                        \
+      p[0] = E0, p[1] = E1, p[2] = E2, p[3] = E3, p[4] = E4;             \
+    } else {                                                             \
+      r[0] = xor3(r[0], p[0], E0);                                       \
+      r[1] = xor3(r[1], p[1], E1);                                       \
+      r[2] = xor3(r[2], p[2], E2);                                       \
+      r[3] = xor3(r[3], p[3], E3);                                       \
+      r[4] = xor3(r[4], p[4], E4);                                       \
+    }                                                                    \
   }
-#define SCL_GFN_OUT(B)                                            \
-  if constexpr ((A >> B) & 1u) {                                  \
-    r4 ^= __builtin_amdgcn_alignbit(y[4], y[3], 32 - 2 * B);      \
-    r3 ^= __builtin_amdgcn_alignbit(y[3], y[2], 32 - 2 * B);      \
-    r2 ^= __builtin_amdgcn_alignbit(y[2], y[1], 32 - 2 * B);      \
-    r1 ^= __builtin_amdgcn_alignbit(y[1], y[0], 32 - 2 * B);      \
-    r0 ^= y[0] << (2 * B);                                        \
-  }
+#define SCL_GFN_OUT(B)                                                                                            \
+  SCL_GFN_TERM(B, y[0] << (2 * B), __builtin_amdgcn_alignbit(y[1], y[0], 32 - 2 * B),                             \
+               __builtin_amdgcn_alignbit(y[2], y[1], 32 - 2 * B), __builtin_amdgcn_alignbit(y[3], y[2], 32 - 2 * B), \
+               __builtin_amdgcn_alignbit(y[4], y[3], 32 - 2 * B))
+  SCL_GFN_TERM(0, y[0], y[1], y[2], y[3], y[4])
   SCL_GFN_OUT(1) SCL_GFN_OUT(2) SCL_GFN_OUT(3) SCL_GFN_OUT(4) SCL_GFN_OUT(5) SCL_GFN_OUT(6)
 #undef SCL_GFN_OUT
-  y[4] = r4;
-  y[3] = r3;
-  y[2] = r2;
-  y[1] = r1;
-  y[0] = r0;
+#undef SCL_GFN_TERM
+  if constexpr (__builtin_popcount(A & 0x7Fu) % 2 == 1) {
+#pragma unroll
+    for (int w = 0; w < 5; ++w) r[w] ^= p[w];
+  }
+#pragma unroll
+  for (int w = 0; w < 5; ++w) y[w] = r[w];
 }
 __device__ __forceinline__ void gf_words(u32 (&w)[4], u128 c) {
   w[0] = (u32)c;
@@ -1423,22 +1461,22 @@ __device__ __forceinline__ void aes_ctr_block(const u32* tl, const AesKey& key, 
 #define SCL_T(x) tl[(x) << 5]
   u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2, s3;
   {  // round 1: the counter's two columns only (aes_key_round1)
-    const u32 t0 = SCL_T(s0 & 255) ^ rotl32(SCL_T((s1 >> 8) & 255), 8) ^ key.r1[0];
-    const u32 t1 = SCL_T(s1 & 255) ^ rotl32(SCL_T(s0 >> 24), 24) ^ key.r1[1];
-    const u32 t2 = rotl32(SCL_T((s0 >> 16) & 255), 16) ^ rotl32(SCL_T(s1 >> 24), 24) ^ key.r1[2];
-    const u32 t3 = rotl32(SCL_T((s0 >> 8) & 255), 8) ^ rotl32(SCL_T((s1 >> 16) & 255), 16) ^ key.r1[3];
+    const u32 t0 = xor3(SCL_T(s0 & 255), rotl32(SCL_T((s1 >> 8) & 255), 8), key.r1[0]);
+    const u32 t1 = xor3(SCL_T(s1 & 255), rotl32(SCL_T(s0 >> 24), 24), key.r1[1]);
+    const u32 t2 = xor3(rotl32(SCL_T((s0 >> 16) & 255), 16), rotl32(SCL_T(s1 >> 24), 24), key.r1[2]);
+    const u32 t3 = xor3(rotl32(SCL_T((s0 >> 8) & 255), 8), rotl32(SCL_T((s1 >> 16) & 255), 16), key.r1[3]);
     s0 = t0; s1 = t1; s2 = t2; s3 = t3;
   }
 #pragma unroll
   for (int r = 2; r < 10; ++r) {
-    const u32 t0 = SCL_T(s0 & 255) ^ rotl32(SCL_T((s1 >> 8) & 255), 8) ^ rotl32(SCL_T((s2 >> 16) & 255), 16) ^
-                   rotl32(SCL_T(s3 >> 24), 24) ^ key.rk[4 * r + 0];
-    const u32 t1 = SCL_T(s1 & 255) ^ rotl32(SCL_T((s2 >> 8) & 255), 8) ^ rotl32(SCL_T((s3 >> 16) & 255), 16) ^
-                   rotl32(SCL_T(s0 >> 24), 24) ^ key.rk[4 * r + 1];
-    const u32 t2 = SCL_T(s2 & 255) ^ rotl32(SCL_T((s3 >> 8) & 255), 8) ^ rotl32(SCL_T((s0 >> 16) & 255), 16) ^
-                   rotl32(SCL_T(s1 >> 24), 24) ^ key.rk[4 * r + 2];
-    const u32 t3 = SCL_T(s3 & 255) ^ rotl32(SCL_T((s0 >> 8) & 255), 8) ^ rotl32(SCL_T((s1 >> 16) & 255), 16) ^
-                   rotl32(SCL_T(s2 >> 24), 24) ^ key.rk[4 * r + 3];
+    const u32 t0 = xor3(xor3(SCL_T(s0 & 255), rotl32(SCL_T((s1 >> 8) & 255), 8), rotl32(SCL_T((s2 >> 16) & 255), 16)),
+                        rotl32(SCL_T(s3 >> 24), 24), key.rk[4 * r + 0]);
+    const u32 t1 = xor3(xor3(SCL_T(s1 & 255), rotl32(SCL_T((s2 >> 8) & 255), 8), rotl32(SCL_T((s3 >> 16) & 255), 16)),
+                        rotl32(SCL_T(s0 >> 24), 24), key.rk[4 * r + 1]);
+    const u32 t2 = xor3(xor3(SCL_T(s2 & 255), rotl32(SCL_T((s3 >> 8) & 255), 8), rotl32(SCL_T((s0 >> 16) & 255), 16)),
+                        rotl32(SCL_T(s1 >> 24), 24), key.rk[4 * r + 2]);
+    const u32 t3 = xor3(xor3(SCL_T(s3 & 255), rotl32(SCL_T((s0 >> 8) & 255), 8), rotl32(SCL_T((s1 >> 16) & 255), 16)),
+                        rotl32(SCL_T(s2 >> 24), 24), key.rk[4 * r + 3]);
     s0 = t0; s1 = t1; s2 = t2; s3 = t3;
   }
   // last round: SubBytes + ShiftRows only; S = byte 1 of te0
@@ -1566,30 +1604,32 @@ __device__ __forceinline__ void Aes4::block(const AesKey& key, u64 counter, u64&
   u32 a0 = lane, a1 = lane, a2 = lane + 65536u, a3 = lane + 65536u;
   u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2, s3;
   {  // round 1: the counter's two columns only (aes_key_round1)
-    const u32 u0 = look<0, 0>(a0, s0) ^ look<1, 128>(a1, s1) ^ key.r1[0];
-    const u32 u1 = look<0, 0>(a0, s1) ^ look<3, 128>(a3, s0) ^ key.r1[1];
-    const u32 u2 = look<2, 0>(a2, s0) ^ look<3, 128>(a3, s1) ^ key.r1[2];
-    const u32 u3 = look<1, 128>(a1, s0) ^ look<2, 0>(a2, s1) ^ key.r1[3];
+    const u32 u0 = xor3(look<0, 0>(a0, s0), look<1, 128>(a1, s1), key.r1[0]);
+    const u32 u1 = xor3(look<0, 0>(a0, s1), look<3, 128>(a3, s0), key.r1[1]);
+    const u32 u2 = xor3(look<2, 0>(a2, s0), look<3, 128>(a3, s1), key.r1[2]);
+    const u32 u3 = xor3(look<1, 128>(a1, s0), look<2, 0>(a2, s1), key.r1[3]);
     s0 = u0; s1 = u1; s2 = u2; s3 = u3;
   }
 #pragma unroll
   for (int r = 2; r < 10; ++r) {
-    const u32 u0 = look<0, 0>(a0, s0) ^ look<1, 128>(a1, s1) ^ look<2, 0>(a2, s2) ^ look<3, 128>(a3, s3) ^ key.rk[4 * r + 0];
-    const u32 u1 = look<0, 0>(a0, s1) ^ look<1, 128>(a1, s2) ^ look<2, 0>(a2, s3) ^ look<3, 128>(a3, s0) ^ key.rk[4 * r + 1];
-    const u32 u2 = look<0, 0>(a0, s2) ^ look<1, 128>(a1, s3) ^ look<2, 0>(a2, s0) ^ look<3, 128>(a3, s1) ^ key.rk[4 * r + 2];
-    const u32 u3 = look<0, 0>(a0, s3) ^ look<1, 128>(a1, s0) ^ look<2, 0>(a2, s1) ^ look<3, 128>(a3, s2) ^ key.rk[4 * r + 3];
+    // two three-way xors per column (v_bitop3_b32) where four two-way ones stood
+    const u32 u0 = xor3(xor3(look<0, 0>(a0, s0), look<1, 128>(a1, s1), look<2, 0>(a2, s2)), look<3, 128>(a3, s3), key.rk[4 * r + 0]);
+    const u32 u1 = xor3(xor3(look<0, 0>(a0, s1), look<1, 128>(a1, s2), look<2, 0>(a2, s3)), look<3, 128>(a3, s0), key.rk[4 * r + 1]);
+    const u32 u2 = xor3(xor3(look<0, 0>(a0, s2), look<1, 128>(a1, s3), look<2, 0>(a2, s0)), look<3, 128>(a3, s1), key.rk[4 * r + 2]);
+    const u32 u3 = xor3(xor3(look<0, 0>(a0, s3), look<1, 128>(a1, s0), look<2, 0>(a2, s1)), look<3, 128>(a3, s2), key.rk[4 * r + 3]);
     s0 = u0; s1 = u1; s2 = u2; s3 = u3;
   }
   // last round (SubBytes + ShiftRows only): te0[x] = (2s, s, s, 3s) from the top byte down, so the S-box byte already sits in
   // byte 0 of table 3, byte 1 of table 0, byte 2 of table 1 and byte 3 of table 2
-  const u32 o0 = ((look<0, 128>(a3, s0) & 0xFFu) | (look<1, 0>(a0, s1) & 0xFF00u) | (look<2, 128>(a1, s2) & 0xFF0000u) |
-                  (look<3, 0>(a2, s3) & 0xFF000000u)) ^ key.rk[40];
-  const u32 o1 = ((look<0, 128>(a3, s1) & 0xFFu) | (look<1, 0>(a0, s2) & 0xFF00u) | (look<2, 128>(a1, s3) & 0xFF0000u) |
-                  (look<3, 0>(a2, s0) & 0xFF000000u)) ^ key.rk[41];
-  const u32 o2 = ((look<0, 128>(a3, s2) & 0xFFu) | (look<1, 0>(a0, s3) & 0xFF00u) | (look<2, 128>(a1, s0) & 0xFF0000u) |
-                  (look<3, 0>(a2, s1) & 0xFF000000u)) ^ key.rk[42];
-  const u32 o3 = ((look<0, 128>(a3, s3) & 0xFFu) | (look<1, 0>(a0, s0) & 0xFF00u) | (look<2, 128>(a1, s1) & 0xFF0000u) |
-                  (look<3, 0>(a2, s2) & 0xFF000000u)) ^ key.rk[43];
+  // (three bit selects per word -- byte 0 of the first, byte 1 of the second, .. -- where four masks and three ors stood)
+  const u32 o0 = bitsel(bitsel(bitsel(look<0, 128>(a3, s0), look<1, 0>(a0, s1), 0xFFu), look<2, 128>(a1, s2), 0xFFFFu),
+                        look<3, 0>(a2, s3), 0xFFFFFFu) ^ key.rk[40];
+  const u32 o1 = bitsel(bitsel(bitsel(look<0, 128>(a3, s1), look<1, 0>(a0, s2), 0xFFu), look<2, 128>(a1, s3), 0xFFFFu),
+                        look<3, 0>(a2, s0), 0xFFFFFFu) ^ key.rk[41];
+  const u32 o2 = bitsel(bitsel(bitsel(look<0, 128>(a3, s2), look<1, 0>(a0, s3), 0xFFu), look<2, 128>(a1, s0), 0xFFFFu),
+                        look<3, 0>(a2, s1), 0xFFFFFFu) ^ key.rk[42];
+  const u32 o3 = bitsel(bitsel(bitsel(look<0, 128>(a3, s3), look<1, 0>(a0, s0), 0xFFu), look<2, 128>(a1, s1), 0xFFFFu),
+                        look<3, 0>(a2, s2), 0xFFFFFFu) ^ key.rk[43];
   out_lo = (u64)o0 | ((u64)o1 << 32);
   out_hi = (u64)o2 | ((u64)o3 << 32);
 }

@@ -232,8 +232,12 @@ def equals(field, a, b) -> bool:
 
 
 # ---- randomness: scl::util::PRG ------------------------------------------------------------------------
-def prg_blocks(nblocks: int, seed: bytes, counter0: int = 0, device="cuda") -> torch.Tensor:
-    out = torch.empty(max(nblocks, 1) * 16, dtype=torch.uint8, device=device)
+def prg_blocks(nblocks: int, seed: bytes, counter0: int = 0, device="cuda", out=None) -> torch.Tensor:
+    """PRG::next: blocks counter0 .. counter0 + nblocks - 1 of the stream as bytes; `out` (uint8, >= 16 nblocks bytes) is reused"""
+    if out is None:
+        out = torch.empty(max(nblocks, 1) * 16, dtype=torch.uint8, device=device)
+    elif out.dtype != torch.uint8 or out.numel() < nblocks * 16:
+        raise SclError(ERR_BAD_ARG, "prg_blocks out: uint8 tensor of at least 16 * nblocks bytes")
     _chk(lib.scl_hip_prg_blocks(_dev(out), C.c_size_t(nblocks), seed, C.c_size_t(len(seed)), C.c_uint64(counter0),
                                 _stream()))
     return out[: nblocks * 16]

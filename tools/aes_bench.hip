@@ -176,6 +176,18 @@ __global__ __launch_bounds__(ABLOCK) void k_prg_blocks4p(u64* dst, AesKey key, u
   run_blocks<NB>(aes, dst, key, counter0, nblocks);
 }
 
+// the same kernel with a clock reading: s_memtime ticks per s_memrealtime tick (100 MHz) around the block loop, one per workgroup
+__global__ __launch_bounds__(ABLOCK) void k_prg_blocks4p_clock(u64* dst, AesKey key, u64 counter0, size_t nblocks, u64* stamps) {
+  SCL_AES4_PROLOGUE(key)
+  const u64 t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  run_blocks<4>(aes, dst, key, counter0, nblocks);
+  const u64 t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = t1 - t0;
+    stamps[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
+
 int main() {
   const size_t nblocks = (size_t)1 << 28;
   AesKey key;
@@ -240,5 +252,19 @@ int main() {
   size_t diff = 0;
   for (size_t i = 0; i < ha.size(); ++i) diff += ha[i] != hb[i];
   std::printf("last 2^19 blocks: %zu differing words\n", diff);
+  {  // in-kernel clock of the library's form under full load
+    u64* st;
+    CK(hipMalloc(&st, AES4_GRID_CAP * 16));
+    auto kern = &k_prg_blocks4p_clock;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AES4_LDS_BYTES));
+    for (int r = 0; r < 6; ++r) hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, a, key, 1ull, nblocks, st);
+    CK(hipDeviceSynchronize());
+    std::vector<u64> h(AES4_GRID_CAP * 2);
+    CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+    double tt = 0, rr = 0;
+    for (int bq = 0; bq < AES4_GRID_CAP; ++bq) tt += (double)h[2 * bq], rr += (double)h[2 * bq + 1];
+    std::printf("in-kernel clock of k_prg_blocks (4 blocks per lane), sixth launch in a row: %.2f GHz; %.3g shader cycles per workgroup loop\n",
+                tt / rr * 0.1, tt / AES4_GRID_CAP);
+  }
   return diff != 0;
 }
