@@ -26,15 +26,16 @@ typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 // (a & m) | (b & ~m) in one instruction each.  Measured at 3.0 cycles per wave-instruction with four or more waves per SIMD
 // (v_xor_b32 2.7, so a three-way xor costs 3.0 instead of 5.5; profiles/r3_oprate_bitop3.txt); the compiler does not form it
 // from two xors by itself.
+// (-DSCL_NO_BITOP3: the two-input forms, for A/B runs of the tools)
 __device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SCL_NO_BITOP3)
   return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 #else
   return a ^ b ^ c;
 #endif
 }
 __device__ __forceinline__ u32 bitsel(u32 a, u32 b, u32 m) {  // bits of a where m is set, of b elsewhere
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SCL_NO_BITOP3)
   return __builtin_amdgcn_bitop3_b32(a, b, m, 0xE4);  // table bit 4a + 2b + c (tools/bitop3_probe.hip)
 #else
   return (a & m) | (b & ~m);
