@@ -1265,6 +1265,7 @@ int scl_hip_prg_blocks(unsigned char* dst, size_t nblocks, const unsigned char* 
   if (!aligned16(dst)) return fail(SCL_ERR_BAD_ARG, "dst not 16-byte aligned");
   AesKey key;
   make_aes_key(seed, seed_len, key);
+  aes_key_range(key, (u64)counter0, (u64)nblocks);
   AES4_LAUNCH(k_prg_blocks, (nblocks + 3) / 4, S(stream), reinterpret_cast<u64*>(dst), key, (u64)counter0, nblocks);
   LAUNCH_CHECK();
   return SCL_OK;
@@ -1319,6 +1320,7 @@ int scl_hip_vector_random(int field, uint64_t* dst, size_t n, const unsigned cha
     SCL_TRY(check_align<F>({dst}));
     AesKey key;
     make_aes_key(seed, seed_len, key);
+    aes_key_range(key, (u64)counter0, ((u64)n * F::LIMBS * 8 + 15) / 16);
     const size_t work = F::LIMBS == 4 ? (n + 1) / 2 : ((F::LIMBS == 1 ? (n + 1) / 2 : n) + 3) / 4;
     if (F::LIMBS == 1 && !aligned16(dst))  // an 8-byte aligned window of a larger vector: element-wise stores
       AES4_LAUNCH((k_vector_random<F, false>), work, S(stream), ctx, dst, key, (u64)counter0, n);
@@ -1697,6 +1699,7 @@ static int share_prg_two_pass(int field, uint64_t* shares, size_t share_stride, 
   u64* rows = static_cast<u64*>(rows_v);
   AesKey key;
   make_aes_key(seed, seed_len, key);
+  aes_key_range(key, (u64)counter0, (u64)N * B);
   int rc = SCL_OK;
   for (size_t s0 = 0; s0 < N && rc == SCL_OK; s0 += slab) {
     const size_t c = N - s0 < slab ? N - s0 : slab;
@@ -1770,6 +1773,7 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
     make_aes_key(seed, seed_len, key);
     const int vec = vec_width<F>({shares, secrets}, {share_stride});
     const u64 blocks_per_secret = ((u64)(t + 1) * lane.W * F::LIMBS * 8 + 15) / 16;  // ceil((t+1)*W*byteSize/16)
+    aes_key_range(key, (u64)counter0, (u64)N * blocks_per_secret);
     if constexpr (F::TAG <= 1) {
       SmallVdm sv;
       if (lane.W == 1 && t >= 1 && small_vandermonde<F>(ctx, al, n, t, sv)) {
@@ -2101,6 +2105,7 @@ int scl_hip_additive_share_prg(int field, uint64_t* shares, size_t share_stride,
     SCL_TRY(check_align<F>({shares, secrets}));
     AesKey key;
     make_aes_key(seed, seed_len, key);
+    aes_key_range(key, (u64)counter0, (u64)N * (n - 1) * ((F::LIMBS * 8 + 15) / 16));
     const int vec = vec_width<F>({shares, secrets}, {share_stride});
     return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;

@@ -1431,6 +1431,8 @@ struct AesKey {
   u32 rk[44];    // 11 round keys, little-endian column words (wave-uniform: scalar loads)
   u32 te0[256];  // te0[x] = (2S, S, S, 3S) as bytes 0..3, S = sbox[x]
   u32 r1[4];     // the key-only half of round 1 (aes_key_round1 below)
+  u32 hi_same;   // every counter of the launch has the same upper word (aes_key_range below): round 1 reads r1h and
+  u32 r1h[4];    // only the lower word's four table entries
 };
 
 // The PRG's input block is LE64(counter) || LE64(0x0123456789ABCDEF) (prg.h:34-43): its upper two columns do not depend on the
@@ -1449,6 +1451,29 @@ inline void aes_key_round1(AesKey& k) {
   k.r1[1] = T(1, s2, 1) ^ T(2, s3, 2) ^ k.rk[5];
   k.r1[2] = T(0, s2, 0) ^ T(1, s3, 1) ^ k.rk[6];
   k.r1[3] = T(0, s3, 0) ^ T(3, s2, 3) ^ k.rk[7];
+  k.hi_same = 0;
+  for (int c = 0; c < 4; ++c) k.r1h[c] = k.r1[c];
+}
+
+// A launch that draws blocks first .. first + count - 1: when all of them (and the few a kernel rounds its work up by) share
+// the upper 32 bits of the counter -- every launch that does not straddle a multiple of 2^32 blocks = 64 GiB of stream -- the
+// four table terms of round 1 that read the upper word are constants too:
+//   r1h[0] = r1[0] ^ T1[s1.b1]   r1h[1] = r1[1] ^ T0[s1.b0]   r1h[2] = r1[2] ^ T3[s1.b3]   r1h[3] = r1[3] ^ T2[s1.b2]
+// with s1 = (first >> 32) ^ rk[1]; round 1 is then four lookups (146 per block).  Otherwise hi_same = 0 and the kernels take
+// the eight-lookup round.  Call after aes_key_round1.
+inline void aes_key_range(AesKey& k, u64 first, u64 count) {
+  const u64 last = first + count + 64;  // slack for rounded-up work; on wrap-around of the 64-bit counter: no folding
+  k.hi_same = last >= first && (first >> 32) == (last >> 32);
+  if (!k.hi_same) return;
+  auto T = [&](int r, u32 word, int byte) {
+    const u32 v = k.te0[(word >> (8 * byte)) & 255u];
+    return r ? (v << (8 * r)) | (v >> (32 - 8 * r)) : v;
+  };
+  const u32 s1 = (u32)(first >> 32) ^ k.rk[1];
+  k.r1h[0] = k.r1[0] ^ T(1, s1, 1);
+  k.r1h[1] = k.r1[1] ^ T(0, s1, 0);
+  k.r1h[2] = k.r1[2] ^ T(3, s1, 3);
+  k.r1h[3] = k.r1[3] ^ T(2, s1, 2);
 }
 
 constexpr int AES_LDS_WORDS = 256 * 32;
@@ -1461,7 +1486,13 @@ __device__ __forceinline__ u32 rotl32(u32 x, int r) { return (x << r) | (x >> (3
 __device__ __forceinline__ void aes_ctr_block(const u32* tl, const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) {
 #define SCL_T(x) tl[(x) << 5]
   u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2, s3;
-  {  // round 1: the counter's two columns only (aes_key_round1)
+  if (key.hi_same) {  // round 1 from the counter's lower word only (aes_key_range; wave-uniform)
+    const u32 t0 = SCL_T(s0 & 255) ^ key.r1h[0];
+    const u32 t1 = rotl32(SCL_T(s0 >> 24), 24) ^ key.r1h[1];
+    const u32 t2 = rotl32(SCL_T((s0 >> 16) & 255), 16) ^ key.r1h[2];
+    const u32 t3 = rotl32(SCL_T((s0 >> 8) & 255), 8) ^ key.r1h[3];
+    s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+  } else {  // round 1: the counter's two columns only (aes_key_round1)
     const u32 t0 = xor3(SCL_T(s0 & 255), rotl32(SCL_T((s1 >> 8) & 255), 8), key.r1[0]);
     const u32 t1 = xor3(SCL_T(s1 & 255), rotl32(SCL_T(s0 >> 24), 24), key.r1[1]);
     const u32 t2 = xor3(rotl32(SCL_T((s0 >> 16) & 255), 16), rotl32(SCL_T(s1 >> 24), 24), key.r1[2]);
@@ -1604,7 +1635,13 @@ struct Aes1 {  // the single-table form above behind the same interface
 __device__ __forceinline__ void Aes4::block(const AesKey& key, u64 counter, u64& out_lo, u64& out_hi) const {
   u32 a0 = lane, a1 = lane, a2 = lane + 65536u, a3 = lane + 65536u;
   u32 s0 = (u32)counter ^ key.rk[0], s1 = (u32)(counter >> 32) ^ key.rk[1], s2, s3;
-  {  // round 1: the counter's two columns only (aes_key_round1)
+  if (key.hi_same) {  // round 1 from the counter's lower word only (aes_key_range; wave-uniform)
+    const u32 u0 = look<0, 0>(a0, s0) ^ key.r1h[0];
+    const u32 u1 = look<3, 128>(a3, s0) ^ key.r1h[1];
+    const u32 u2 = look<2, 0>(a2, s0) ^ key.r1h[2];
+    const u32 u3 = look<1, 128>(a1, s0) ^ key.r1h[3];
+    s0 = u0; s1 = u1; s2 = u2; s3 = u3;
+  } else {  // round 1: the counter's two columns only (aes_key_round1)
     const u32 u0 = xor3(look<0, 0>(a0, s0), look<1, 128>(a1, s1), key.r1[0]);
     const u32 u1 = xor3(look<0, 0>(a0, s1), look<3, 128>(a3, s0), key.r1[1]);
     const u32 u2 = xor3(look<2, 0>(a2, s0), look<3, 128>(a3, s1), key.r1[2]);

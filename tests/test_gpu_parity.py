@@ -1354,6 +1354,26 @@ def test_prg_share_across_a_2_32_counter_boundary(scl, port, f):
     v = scl.vector_random(f, 4000, b"wrap-vr", counter0=2 ** 32 - 1000)
     bs = 8 * L
     assert np.array_equal(host(scl, v), port.from_bytes(f, port.prg_blocks(b"wrap-vr", 2 ** 32 - 1000, (4000 * bs + 15) // 16)[: 4000 * bs]))
+    # the two-pass form (coefficient rows first; forced) across the boundary, and a threshold that takes it by itself
+    scl.set_tuning("prg_two_pass", 1)
+    try:
+        sh2 = scl.shamir_share_prg(f, dev(scl, secrets), t, n, b"wrap-seed", counter0=c0)
+    finally:
+        scl.set_tuning("prg_two_pass", 0)
+    assert np.array_equal(host(scl, sh2), want)
+    t9, B9 = 9, (9 + 2) // 2 if L == 1 else 10
+    c9 = 2 ** 32 - 300 * B9 - 1
+    sh9 = scl.shamir_share_prg(f, dev(scl, secrets), t9, n, b"wrap-seed9", counter0=c9)
+    el9 = port.from_bytes(f, port.prg_blocks(b"wrap-seed9", c9, N * B9)).reshape(N, -1, L)
+    assert np.array_equal(host(scl, sh9), soa(port.shamir_share_coeffs(f, secrets, np.ascontiguousarray(el9[:, 1:t9 + 1]), n)))
+    # additive sharing: share i < n - 1 of secret s is the element drawn from block s (n - 1) + i (one block per FF::random)
+    na, ca = 3, 2 ** 32 - 900
+    ad = scl.additive_share_prg(f, dev(scl, secrets), na, b"wrap-add", counter0=ca)
+    blk = np.frombuffer(port.prg_blocks(b"wrap-add", ca, N * (na - 1)), dtype=np.uint8).reshape(N * (na - 1), 16)
+    rnd = port.from_bytes(f, blk[:, :bs].tobytes()).reshape(N, na - 1, L)
+    had = host(scl, ad)
+    assert np.array_equal(had[: na - 1], np.ascontiguousarray(np.transpose(rnd, (1, 0, 2))))
+    assert scl.equals(f, scl.additive_recover(f, ad), dev(scl, secrets))
 
 
 def test_c5_shard_size(scl, port):

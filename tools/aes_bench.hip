@@ -194,6 +194,7 @@ int main() {
   for (int i = 0; i < 44; ++i) key.rk[i] = 0x9E3779B9u * (i + 1);
   for (int i = 0; i < 256; ++i) key.te0[i] = 0x85EBCA6Bu * (i + 7) ^ (i << 13);
   aes_key_round1(key);
+  aes_key_range(key, 0, nblocks + (1u << 20));  // every counter below stays under 2^32: round 1 from the lower word only
   u64 *a, *b;
   CK(hipMalloc(&a, nblocks * 16));
   CK(hipMalloc(&b, nblocks * 16));
