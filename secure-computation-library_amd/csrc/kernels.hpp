@@ -880,33 +880,36 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) v
 // x^128 = x^7 + x^2 + x + 1 once per (32 - deg) / (2 deg) steps, for the tile as a whole.
 template <u32 A>
 __device__ __forceinline__ void gf_outer_step(u32 (&y)[5], const u32 (&g)[5]) {  // y <- y * A^2 + g  (A^2: bit b of A at 2b)
-  // g and one copy of y per set bit of A, added up with THREE-way xors (v_bitop3_b32): copy number idx (counting the set bits of
-  // A from bit 0) waits in p when idx is even and goes in together with the next one; an odd copy out is added at the end
+  // g and one copy of y per set bit of A, added up with THREE-way xors (v_bitop3_b32): the shifted copies (bits 1 .. 6) first,
+  // copy number idx among them waits in p when idx is even and goes in together with the next one; the unshifted copy (bit 0)
+  // comes last and pairs with a waiting shifted one or goes in alone -- y itself is never copied
   u32 r[5] = {g[0], g[1], g[2], g[3], g[4]}, p[5] = {0, 0, 0, 0, 0};
-#define SCL_GFN_TERM(B, E0, E1, E2, E3, E4)                              \
-  if constexpr ((A >> B) & 1u) {                                         \
-    constexpr int idx = __builtin_popcount(A & ((1u << B) - 1u));        \
-    if constexpr (idx % 2 == 0) {                                        \
-      p[0] = E0, p[1] = E1, p[2] = E2, p[3] = E3, p[4] = E4;             \
-    } else {                                                             \
-      r[0] = xor3(r[0], p[0], E0);                                       \
-      r[1] = xor3(r[1], p[1], E1);                                       \
-      r[2] = xor3(r[2], p[2], E2);                                       \
-      r[3] = xor3(r[3], p[3], E3);                                       \
-      r[4] = xor3(r[4], p[4], E4);                                       \
-    }                                                                    \
+#define SCL_GFN_OUT(B)                                                       \
+  if constexpr ((A >> B) & 1u) {                                             \
+    constexpr int idx = __builtin_popcount(A & ((1u << B) - 2u));            \
+    const u32 e0 = y[0] << (2 * B);                                          \
+    const u32 e1 = __builtin_amdgcn_alignbit(y[1], y[0], 32 - 2 * B);        \
+    const u32 e2 = __builtin_amdgcn_alignbit(y[2], y[1], 32 - 2 * B);        \
+    const u32 e3 = __builtin_amdgcn_alignbit(y[3], y[2], 32 - 2 * B);        \
+    const u32 e4 = __builtin_amdgcn_alignbit(y[4], y[3], 32 - 2 * B);        \
+    if constexpr (idx % 2 == 0) {                                            \
+      p[0] = e0, p[1] = e1, p[2] = e2, p[3] = e3, p[4] = e4;                 \
+    } else {                                                                 \
+      r[0] = xor3(r[0], p[0], e0);                                           \
+      r[1] = xor3(r[1], p[1], e1);                                           \
+      r[2] = xor3(r[2], p[2], e2);                                           \
+      r[3] = xor3(r[3], p[3], e3);                                           \
+      r[4] = xor3(r[4], p[4], e4);                                           \
+    }                                                                        \
   }
-#define SCL_GFN_OUT(B)                                                                                            \
-  SCL_GFN_TERM(B, y[0] << (2 * B), __builtin_amdgcn_alignbit(y[1], y[0], 32 - 2 * B),                             \
-               __builtin_amdgcn_alignbit(y[2], y[1], 32 - 2 * B), __builtin_amdgcn_alignbit(y[3], y[2], 32 - 2 * B), \
-               __builtin_amdgcn_alignbit(y[4], y[3], 32 - 2 * B))
-  SCL_GFN_TERM(0, y[0], y[1], y[2], y[3], y[4])
   SCL_GFN_OUT(1) SCL_GFN_OUT(2) SCL_GFN_OUT(3) SCL_GFN_OUT(4) SCL_GFN_OUT(5) SCL_GFN_OUT(6)
 #undef SCL_GFN_OUT
-#undef SCL_GFN_TERM
-  if constexpr (__builtin_popcount(A & 0x7Fu) % 2 == 1) {
+  constexpr bool waiting = __builtin_popcount(A & 0x7Eu) % 2 == 1;  // a shifted copy still sits in p
 #pragma unroll
-    for (int w = 0; w < 5; ++w) r[w] ^= p[w];
+  for (int w = 0; w < 5; ++w) {
+    if constexpr ((A & 1u) && waiting) r[w] = xor3(r[w], p[w], y[w]);
+    else if constexpr ((A & 1u) != 0) r[w] ^= y[w];
+    else if constexpr (waiting) r[w] ^= p[w];
   }
 #pragma unroll
   for (int w = 0; w < 5; ++w) y[w] = r[w];
