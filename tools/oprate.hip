@@ -43,11 +43,13 @@ constexpr int ITERS = 2048, CH = 8;
   X(27, "v_mad_u64_u32", "v_mad_u64_u32 %0, s[6:7], %1, %2, %0", 2)                                   \
   X(28, "v_mov_b32 dpp row_shr", "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf", 1)                   \
   X(29, "v_bitop3_b32 (a^b^c)", "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96", 1)                          \
-  X(30, "v_lshl_add_u64", "v_lshl_add_u64 %0, %0, 3, %0", 2)
+  X(30, "v_lshl_add_u64", "v_lshl_add_u64 %0, %0, 3, %0", 2)                                         \
+  X(31, "v_lshlrev_b64", "v_lshlrev_b64 %0, 3, %0", 2)                                               \
+  X(32, "v_lshrrev_b64", "v_lshrrev_b64 %0, 3, %0", 2)
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(u32* out, u32 seed) {
-  typename std::conditional<OP == 27 || OP == 30, u64, u32>::type a[CH];
+  typename std::conditional<OP == 27 || OP >= 30, u64, u32>::type a[CH];
   u32 b = seed | 1, c = threadIdx.x * 2654435761u + seed;
   for (int j = 0; j < CH; ++j) a[j] = threadIdx.x * 0x9E3779B9u + j;
   for (int i = 0; i < ITERS; ++i) {
