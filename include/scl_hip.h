@@ -38,7 +38,7 @@
  *    mutable state is per host thread (a scratch buffer, two temporary arenas -- kept and grown: at most 1 GiB for the
  *    coefficient rows of PRG-driven sharing in two passes, otherwise what one call's tables and queues need --, the
  *    tuning knobs: each thread sets its own and starts from the defaults), the Mont128 modulus (a process-wide default
- *    behind a mutex that a thread's own scl_hip_mont128_set_prime overrides for that thread; see there) or immutable
+ *    behind a mutex that a thread latches at its first use or replaces with scl_hip_mont128_set_prime; see there) or immutable
  *    once built (device tables of Vandermonde rows, behind a mutex; a caller holds a reference to the table it uses
  *    until its kernel is enqueued, and past 16 entries the least recently used one is freed once nobody holds it).
  *    A thread that exits calls scl_hip_thread_cleanup() to release its device buffers.
@@ -315,7 +315,13 @@ int scl_hip_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* 
  *   scl_hip_comm_adopt       wrap an ncclComm_t the caller created itself (not destroyed by scl_hip_comm_destroy)
  *   scl_hip_comm_info / scl_hip_comm_destroy
  * scl_hip_open_row_order (host only): row q = j * world + r of a gathered chunk holds party r * per + j (each of a
- * rank's `per` rows is all-gathered on its own: no packing copy); order[q] = that party or -1 for padding. */
+ * rank's `per` rows is all-gathered on its own: no packing copy); order[q] = that party or -1 for padding.
+ *
+ * One host thread at a time per handle (different handles -- the ranks of an in-process world -- run concurrently); calls on
+ * one handle may come from different streams: a call waits for the previous call's readers of the handle's buffers.  The
+ * padding rows of a slab (party >= n) are never read: zeros are sent in their place.  The calling thread's current device
+ * must be the one the handle was made on (SCL_ERR_BAD_ARG otherwise).  SCL_HIP_RCCL_LIBRARY (environment, read at the first
+ * of these calls) names the library to bind instead of librccl.so.1. */
 int scl_hip_comm_unique_id(unsigned char id[128]);
 int scl_hip_comm_init_rank(void** comm, int world, int rank, const unsigned char id[128]);
 int scl_hip_comm_adopt(void** comm, void* nccl_comm);
@@ -337,8 +343,9 @@ int scl_hip_open_partial_gather(void* comm, int field, uint64_t* out_dev, const 
 
 /* MONT128: choose the modulus (odd, < 2^128).  The call sets it for the CALLING host thread and as the process-wide
  * default: a thread that has called this keeps its own modulus whatever other threads choose later; a thread that never
- * did (a pool worker started after the main thread chose the prime) works over the default = the modulus set last by any
- * thread, 2^128 - 159 before any was. */
+ * did (a pool worker started after the main thread chose the prime) LATCHES the default at its first Mont128 call -- the
+ * modulus set last by any thread before that, 2^128 - 159 if none was -- and keeps it from then on: a worker between a
+ * share and its recover does not change field because another thread picked a different prime. */
 int scl_hip_mont128_set_prime(const uint64_t p[2]);
 int scl_hip_mont128_get_prime(uint64_t p[2]);
 

@@ -16,6 +16,10 @@
 #include <string>
 #include <vector>
 
+#include "tu_config.hpp"
+#if SCL_TU_FIELDS != 0xff
+#include "capi_names.inc"  // this unit's names for the field-taking entry points
+#endif
 #include "../../include/scl_hip.h"
 #include "../../include/scl_hip/detail/field.hpp"
 #include "kernels.hpp"
@@ -23,9 +27,77 @@
 
 using namespace sclhip;
 
-namespace {
+// ---- state shared by the translation units of the library ------------------------------------------------
+// The library is this file compiled once per field family (tu_config.hpp, Makefile); the unit built with SCL_TU_COMMON
+// defines the state below, the others see it as extern.  Everything mutable is per host thread except the Mont128 default
+// (behind its mutex).
+struct Knob {
+  long v;
+  long load() const { return v; }
+  Knob& operator=(long x) {
+    v = x;
+    return *this;
+  }
+};
+struct Scratch {
+  int device = -1;
+  void* dev = nullptr;
+  size_t bytes = 0;
+};
+struct TempArena {
+  int device = -1;
+  void* dev = nullptr;
+  size_t bytes = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+namespace sclhip_state {
+#if SCL_TU_COMMON
+#define SCL_STATE(decl, ...) decl __VA_ARGS__
+#else
+#define SCL_STATE(decl, ...) extern decl
+#endif
+SCL_STATE(thread_local std::string g_err);
+// Experiment knobs (scl_hip_set_tuning).  Per host thread, like the Mont128 modulus below: the library keeps no mutable
+// state that two host threads share, so concurrent callers with different settings cannot race (scl_hip.h, Conventions).
+SCL_STATE(thread_local Knob g_max_blocks, {0});
+SCL_STATE(thread_local Knob g_nontemporal, {1});
+SCL_STATE(thread_local Knob g_force_scalar, {0});
+SCL_STATE(thread_local Knob g_force_table, {0});
+SCL_STATE(thread_local Knob g_mfma_tpb, {0});
+// 4-row-tile shapes: 2 = two pipelined waves per SIMD on 16x16x64 tiles (33..64 coefficient rows; else as 1), 1 = one
+// pipelined wave per SIMD, 0 = burst kernel ("mfma_pipe")
+SCL_STATE(thread_local Knob g_mfma_pipe, {2});
+SCL_STATE(thread_local Knob g_mfma_areg, {1});  // register-resident V fragments for the 4-row-tile shapes ("mfma_areg")
+SCL_STATE(thread_local Knob g_mfma, {0});       // 0 auto, 1 always (where applicable), -1 never
+// GF(2^128) sharing at the default nodes: 1 = eight nodes per Horner loop (k_share_gf_tiles), 0 = one node at a time
+// (k_share_gf_nodes) ("gf_tiles")
+SCL_STATE(thread_local Knob g_gf_tiles, {1});
+SCL_STATE(thread_local Knob g_open_gather_always, {0});  // the open step on ONE rank: 1 = still through RCCL's all-gather
+SCL_STATE(thread_local Knob g_prg_t3, {1});  // PRG-driven sharing at t = 3 over the Mersenne fields: 1 = threshold compiled in
+SCL_STATE(thread_local Knob g_prg_two_pass, {0});  // PRG-driven sharing: 0 auto, 1 always two passes, -1 always fused
+// Headline streaming kernels (k_recover_fixed, k_share_small): workgroup size and resident waves per CU
+// (kernels.hpp, "Launch geometry"); "stream_block" 64 | 256, "stream_waves" 0 = no cap
+SCL_STATE(thread_local Knob g_stream_block, {64});
+// -1 = by element size: 10 for one-word elements, 12 for wider ones (profiles/r2_probe_cap_rec.txt, r2_probe_c3_waves.txt)
+SCL_STATE(thread_local Knob g_stream_waves, {-1});
+// the same cap for the Mersenne61 small-node share kernel ("share_waves"; 0 = the 256-thread kernel without a cap)
+SCL_STATE(thread_local Knob g_share_waves, {9});
+SCL_STATE(thread_local Knob g_aes_blocks, {0});
+// Mont128 modulus: a process-wide default, latched per host thread at its first use (mont_ctx below)
+SCL_STATE(thread_local Mont128::Ctx g_mont, = {0, 0, 0, 0});  // p == 0: this thread has not latched a modulus yet
+SCL_STATE(std::mutex g_mont_default_mu);
+SCL_STATE(Mont128::Ctx g_mont_default, = {0, 0, 0, 0});
+// per-thread device scratch (only used by calls that synchronise before returning)
+SCL_STATE(thread_local Scratch g_scratch);
+// arena 0: tables, queues and products of one call; arena 1: the coefficient rows of a two-pass PRG sharing (whose second
+// pass may take arena 0 itself)
+SCL_STATE(thread_local TempArena g_temps[2]);
+#undef SCL_STATE
+}  // namespace sclhip_state
+using namespace sclhip_state;
 
-thread_local std::string g_err;
+namespace {
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -47,39 +119,6 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
-
-// ---- tuning --------------------------------------------------------------------------------------
-// Experiment knobs (scl_hip_set_tuning).  Per host thread, like the Mont128 modulus below: the library keeps no mutable
-// state that two host threads share, so concurrent callers with different settings cannot race (scl_hip.h, Conventions).
-struct Knob {
-  long v;
-  long load() const { return v; }
-  Knob& operator=(long x) {
-    v = x;
-    return *this;
-  }
-};
-thread_local Knob g_max_blocks{0};
-thread_local Knob g_nontemporal{1};
-thread_local Knob g_force_scalar{0};
-thread_local Knob g_force_table{0};
-thread_local Knob g_mfma_tpb{0};
-thread_local Knob g_mfma_pipe{2};  // 4-row-tile shapes: 2 = two pipelined waves per SIMD on 16x16x64 tiles (33..64 coefficient
-                                   // rows; else as 1), 1 = one pipelined wave per SIMD, 0 = burst kernel ("mfma_pipe")
-thread_local Knob g_mfma_areg{1};  // register-resident V fragments for the 4-row-tile shapes ("mfma_areg" tuning key)
-thread_local Knob g_mfma{0};  // 0 auto, 1 always (where applicable), -1 never
-thread_local Knob g_gf_tiles{1};      // GF(2^128) sharing at the default nodes: 1 = eight nodes per Horner loop (k_share_gf_tiles),
-                                      // 0 = one node at a time (k_share_gf_nodes) ("gf_tiles")
-thread_local Knob g_open_gather_always{0};  // the open step on ONE rank: 1 = still through RCCL's all-gather ("open_gather_always")
-thread_local Knob g_prg_t3{1};        // PRG-driven sharing at t = 3 over the Mersenne fields: 1 = threshold compiled in ("prg_t3")
-thread_local Knob g_prg_two_pass{0};  // PRG-driven sharing: 0 auto, 1 always two passes, -1 always the fused kernels
-// Headline streaming kernels (k_recover_fixed, k_share_small): workgroup size and resident waves per CU
-// (kernels.hpp, "Launch geometry"); "stream_block" 64 | 256, "stream_waves" 0 = no cap
-thread_local Knob g_stream_block{64};
-thread_local Knob g_stream_waves{-1};  // -1 = by element size: 10 for one-word elements, 12 for wider ones
-                                        // (profiles/r2_probe_cap_rec.txt, r2_probe_c3_waves.txt)
-thread_local Knob g_share_waves{9};  // the same cap for the Mersenne61 small-node share kernel ("share_waves"; 0 = the
-                                     // 256-thread kernel without a cap)
 
 // dynamic LDS bytes that cap the residency of a kernel with `static_lds` bytes of its own at `waves` waves of
 // `block` threads per CU.  A CU has 160 KiB of LDS and hands it out in granules; the granule of gfx950 is not documented
@@ -122,7 +161,6 @@ unsigned grid_for_block(size_t work_items, int block) {
 
 // PRG kernels carry a 32 KiB replicated AES table per block: a fixed grid of resident blocks that
 // grid-strides amortises filling it.
-thread_local Knob g_aes_blocks{0};
 unsigned grid_aes(size_t work_items) {
   size_t blocks = (work_items + BLOCK - 1) / BLOCK;
   long cap = g_aes_blocks.load();
@@ -150,15 +188,11 @@ unsigned grid_aes4(size_t work_items) {
     hipLaunchKernelGGL(kern_, dim3(grid_aes4(WORK)), dim3(ABLOCK), AES4_LDS_BYTES, ST, __VA_ARGS__);                \
   } while (0)
 
-// ---- Mont128 modulus: a process-wide default, overridden per host thread ------------------------------
-// scl_hip_mont128_set_prime sets the CALLING thread's modulus and the process-wide default.  A thread that has set its
-// own keeps it whatever other threads do (two threads working over different primes do not see each other's); a thread
-// that never set one -- a pool worker, a Python thread started after the main thread chose the prime -- works over the
-// default, i.e. the modulus set last by any thread, and over 2^128 - 159 before any was.
-thread_local Mont128::Ctx g_mont = {0, 0, 0, 0};  // p == 0: this thread follows the default
-std::mutex g_mont_default_mu;
-Mont128::Ctx g_mont_default = {0, 0, 0, 0};
-
+// ---- Mont128 modulus: a process-wide default, latched per host thread ---------------------------------------
+// scl_hip_mont128_set_prime sets the CALLING thread's modulus and the process-wide default.  A thread that has set its own
+// keeps it whatever other threads do; a thread that never set one LATCHES the default at its first use (the modulus set last
+// by any thread before that, 2^128 - 159 if none was) and keeps that value for the rest of its life: a worker in the middle
+// of a share-then-recover sequence does not switch modulus because some other thread set a different prime.
 int mont_set(u128 p) {
   if (!(p & 1) || p < 3) return fail(SCL_ERR_BAD_ARG, "mont128: modulus must be odd and >= 3");
   g_mont = Mont128::make_ctx(p);
@@ -172,18 +206,34 @@ Mont128::Ctx mont_ctx() {
   std::lock_guard<std::mutex> lk(g_mont_default_mu);
   if (!g_mont_default.p)
     g_mont_default = Mont128::make_ctx((((u128)0xFFFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFF61ull);  // 2^128 - 159
-  return g_mont_default;
+  g_mont = g_mont_default;
+  return g_mont;
 }
+
+// (tu_config.hpp: the fields THIS translation unit instantiates kernels for)
+int not_in_this_unit() { return fail(SCL_ERR_BAD_ARG, "field family not built into this translation unit"); }
 
 template <class Fn>
 int with_field(int field, Fn&& fn) {
   switch (field) {
-    case SCL_M61: return fn(M61{}, M61::Ctx{});
-    case SCL_M127: return fn(M127{}, M127::Ctx{});
-    case SCL_MONT128: return fn(Mont128{}, mont_ctx());
-    case SCL_GF2_128: return fn(Gf128{}, Gf128::Ctx{});
-    case SCL_SECP256K1_SCALAR: return fn(Secp256k1Scalar{}, Secp256k1Scalar::Ctx{});
-    case SCL_SECP256K1_FIELD: return fn(Secp256k1Field{}, Secp256k1Field::Ctx{});
+    case SCL_M61:
+      if constexpr (SCL_TU_HAS(0)) return fn(M61{}, M61::Ctx{});
+      else return not_in_this_unit();
+    case SCL_M127:
+      if constexpr (SCL_TU_HAS(1)) return fn(M127{}, M127::Ctx{});
+      else return not_in_this_unit();
+    case SCL_MONT128:
+      if constexpr (SCL_TU_HAS(2)) return fn(Mont128{}, mont_ctx());
+      else return not_in_this_unit();
+    case SCL_GF2_128:
+      if constexpr (SCL_TU_HAS(3)) return fn(Gf128{}, Gf128::Ctx{});
+      else return not_in_this_unit();
+    case SCL_SECP256K1_SCALAR:
+      if constexpr (SCL_TU_HAS(4)) return fn(Secp256k1Scalar{}, Secp256k1Scalar::Ctx{});
+      else return not_in_this_unit();
+    case SCL_SECP256K1_FIELD:
+      if constexpr (SCL_TU_HAS(5)) return fn(Secp256k1Field{}, Secp256k1Field::Ctx{});
+      else return not_in_this_unit();
     default: return fail(SCL_ERR_BAD_ARG, "unknown field tag");
   }
 }
@@ -197,19 +247,17 @@ template <class Fn>
 int with_ring_or_field(int field, Fn&& fn) {
   if (is_ring(field)) {
     const int K = field - 0x100;
-    if (K <= 64) return fn(Z2k64{}, Z2k64::make_ctx(K));
-    return fn(Z2k128{}, Z2k128::make_ctx(K));
+    if constexpr (SCL_TU_HAS(6)) {
+      if (K <= 64) return fn(Z2k64{}, Z2k64::make_ctx(K));
+      return fn(Z2k128{}, Z2k128::make_ctx(K));
+    } else {
+      return not_in_this_unit();
+    }
   }
   return with_field(field, fn);
 }
 
 // ---- per-thread device scratch (only used by calls that synchronise before returning) -------------
-struct Scratch {
-  int device = -1;
-  void* dev = nullptr;
-  size_t bytes = 0;
-};
-thread_local Scratch g_scratch;
 
 int scratch(size_t bytes, void** out) {
   int dev = 0;
@@ -233,16 +281,6 @@ int scratch(size_t bytes, void** out) {
 // host thread, kept and grown; an event recorded after the last use makes the next user -- possibly on another
 // stream -- wait for it.  (hipMallocAsync / hipFreeAsync on the null stream proved unreliable under the ROCm 7.2
 // runtime: a queue allocated that way lost writes between two kernels of one call.)
-struct TempArena {
-  int device = -1;
-  void* dev = nullptr;
-  size_t bytes = 0;
-  hipEvent_t done = nullptr;
-  bool pending = false;
-};
-// arena 0: tables, queues and products of one call; arena 1: the coefficient rows of a two-pass PRG sharing (whose second
-// pass may take arena 0 itself)
-thread_local TempArena g_temps[2];
 
 int temp_acquire(size_t bytes, hipStream_t st, void** out, int which = 0) {
   int dev = 0;
@@ -551,6 +589,7 @@ void cache_make_room(std::vector<Entry>& cache) {
   while (cache.size() >= TABLE_CACHE_CAP) cache.erase(cache.begin());
 }
 
+template <class FieldG>
 int mfma_table(const BigTable<M61>& al, size_t n, size_t t, int KS, int MT, DevPin* pin, const unsigned char** out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
@@ -597,11 +636,11 @@ int launch_share_mfma(u64* shares, size_t stride, const u64* secrets, const u64*
     if (g_mfma_pipe.load() >= 2) {
       // k_share_mfma_m61_p16: one 8-wave workgroup per CU, 32 secrets per trip, two LDS images of the recoded block
       const size_t shmem = 2 * mf_b_bytes(KS, MT, 1);
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_mfma_m61_p16),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_mfma_m61_p16<>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
       const size_t nblocks = (N + 31) / 32;
       const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
-      hipLaunchKernelGGL(k_share_mfma_m61_p16, dim3(grid), dim3(512), shmem, st, shares, stride, secrets, coeffs, cstride, tab,
+      hipLaunchKernelGGL(k_share_mfma_m61_p16<>, dim3(grid), dim3(512), shmem, st, shares, stride, secrets, coeffs, cstride, tab,
                          t, n, N);
       HIP_TRY(hipGetLastError());
       return SCL_OK;
@@ -679,6 +718,7 @@ int matmul_mfma_impl(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B,
   return rc;
 }
 
+template <class FieldG>
 int matmul_mfma(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M, size_t K, size_t N,
                 hipStream_t st) {
   const int KS = K <= 32 ? 1 : 2;
@@ -722,6 +762,7 @@ int detect_mfma_impl(u64* out, unsigned char* status, const u64* shares, size_t 
   return rc;
 }
 
+template <class FieldG>
 int detect_mfma(u64* out, unsigned char* status, const u64* shares, size_t stride, const std::vector<u64>& L, size_t rows,
                 size_t d1, size_t N, unsigned long long* cnt, hipStream_t st) {
   const int KS = d1 <= 32 ? 1 : 2;
@@ -733,13 +774,14 @@ int detect_mfma(u64* out, unsigned char* status, const u64* shares, size_t strid
   return fail(SCL_ERR_BAD_ARG, "detect_mfma: unsupported shape");
 }
 
+template <class FieldG>
 int share_mfma(const BigTable<M61>& al, u64* shares, size_t stride, const u64* secrets, const u64* coeffs,
                size_t cstride, size_t N, size_t t, size_t n, hipStream_t st) {
   const int KS = t + 1 <= 32 ? 1 : 2;
   const int MT = (n <= 32 && KS == 1) ? 1 : n <= 64 ? 2 : 4;  // (as matmul_mfma: no one-row-tile form with two k-steps)
   const unsigned char* tab = nullptr;
   DevPin pin;  // held until the launch below is enqueued
-  SCL_TRY(mfma_table(al, n, t, KS, MT, &pin, &tab));
+  SCL_TRY(mfma_table<FieldG>(al, n, t, KS, MT, &pin, &tab));
 #define MF_CASE(ks, mt) \
   if (KS == ks && MT == mt) return launch_share_mfma<ks, mt>(shares, stride, secrets, coeffs, cstride, tab, (int)t, (int)n, N, st);
   MF_CASE(1, 1) MF_CASE(1, 2) MF_CASE(1, 4) MF_CASE(2, 2) MF_CASE(2, 4)
@@ -916,6 +958,7 @@ static int share_chunked(int field, uint64_t* shares, size_t share_stride, const
 // =====================================================================================================
 extern "C" {
 
+#if SCL_TU_COMMON
 int scl_hip_abi_version(void) { return 1; }
 
 const char* scl_hip_last_error(void) { return g_err.c_str(); }
@@ -1092,6 +1135,7 @@ int scl_hip_mont128_get_prime(uint64_t p[2]) {
   p[1] = (u64)(c.p >> 64);
   return SCL_OK;
 }
+#endif  // SCL_TU_COMMON
 
 // ---- element-wise ---------------------------------------------------------------------------------------
 int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
@@ -1228,6 +1272,7 @@ int scl_hip_dot(int field, uint64_t* out_host, const uint64_t* a, const uint64_t
   return reduce_impl(field, out_host, a, b, n, stream, true);
 }
 
+#if SCL_TU_COMMON
 int scl_hip_equals(int field, int* equal_host, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
   const int L = scl_hip_limbs(field);
   if (L < 0) return fail(SCL_ERR_BAD_ARG, "unknown field tag");
@@ -1245,9 +1290,9 @@ int scl_hip_equals(int field, int* equal_host, const uint64_t* a, const uint64_t
   if (is_ring(field)) {
     const int K = field - 0x100;
     const u64 lo = K >= 64 ? ~0ull : ((1ull << K) - 1), hi = K >= 128 ? ~0ull : K > 64 ? ((1ull << (K - 64)) - 1) : 0;
-    hipLaunchKernelGGL(k_count_diff_masked, dim3(grid_for(words)), dim3(BLOCK), 0, S(stream), cnt, a, b, words, lo, hi, L);
+    hipLaunchKernelGGL(k_count_diff_masked<>, dim3(grid_for(words)), dim3(BLOCK), 0, S(stream), cnt, a, b, words, lo, hi, L);
   } else {
-    hipLaunchKernelGGL(k_count_diff, dim3(grid_for(words)), dim3(BLOCK), 0, S(stream), cnt, a, b, words);
+    hipLaunchKernelGGL(k_count_diff<>, dim3(grid_for(words)), dim3(BLOCK), 0, S(stream), cnt, a, b, words);
   }
   LAUNCH_CHECK();
   unsigned long long h = 0;
@@ -1256,8 +1301,10 @@ int scl_hip_equals(int field, int* equal_host, const uint64_t* a, const uint64_t
   *equal_host = (h == 0);
   return SCL_OK;
 }
+#endif  // SCL_TU_COMMON
 
 // ---- randomness ----------------------------------------------------------------------------------------------
+#if SCL_TU_COMMON
 int scl_hip_prg_blocks(unsigned char* dst, size_t nblocks, const unsigned char* seed, size_t seed_len,
                        uint64_t counter0, void* stream) {
   if (nblocks == 0) return SCL_OK;
@@ -1266,10 +1313,11 @@ int scl_hip_prg_blocks(unsigned char* dst, size_t nblocks, const unsigned char* 
   AesKey key;
   make_aes_key(seed, seed_len, key);
   aes_key_range(key, (u64)counter0, (u64)nblocks);
-  AES4_LAUNCH(k_prg_blocks, (nblocks + 3) / 4, S(stream), reinterpret_cast<u64*>(dst), key, (u64)counter0, nblocks);
+  AES4_LAUNCH(k_prg_blocks<>, (nblocks + 3) / 4, S(stream), reinterpret_cast<u64*>(dst), key, (u64)counter0, nblocks);
   LAUNCH_CHECK();
   return SCL_OK;
 }
+#endif  // SCL_TU_COMMON
 
 // Z2k::read per element at a stride of byteSize (z2k.h:50-52,71-75)
 static int ring_from_bytes(int field, uint64_t* dst, const unsigned char* src, size_t n, hipStream_t st) {
@@ -1376,9 +1424,11 @@ int scl_hip_shamir_recover(int field, uint64_t* out, const uint64_t* shares, siz
 // reconstruct of a process runs both launch shapes of that kernel once against k_recover_gf128 (compiler-scheduled reads)
 // on 4096 pseudo-random secrets; if a result differs, the position-table kernel is never used by this process
 // (scl_hip_last_error says so) -- a toolchain change then costs speed, not correctness.  -1 unknown, 1 good, 0 bad.
-std::atomic<int> g_gfpos_state{-1};
-std::mutex g_gfpos_mu;
+static std::atomic<int> g_gfpos_state{-1};
+static std::mutex g_gfpos_mu;
 
+extern "C++" {
+template <class FieldG>
 static int launch_gfpos(bool big_block, u64* out, const u64* shares, size_t stride, const BigTable<Gf128>& big, size_t m, size_t N,
                         hipStream_t st) {
   const size_t lds = gfpos_lds_bytes(m);
@@ -1397,6 +1447,7 @@ static int launch_gfpos(bool big_block, u64* out, const u64* shares, size_t stri
   return SCL_OK;
 }
 
+template <class FieldG>
 static int gfpos_usable(bool* usable) {
   int stt = g_gfpos_state.load();
   if (stt < 0) {
@@ -1412,10 +1463,10 @@ static int gfpos_usable(bool* usable) {
         SCL_TRY(scl_hip_prg_blocks(reinterpret_cast<unsigned char*>(sh), M * N, seed, sizeof seed - 1, 0, nullptr));
         BigTable<Gf128> big;
         for (size_t i = 0; i < M; ++i) big.v[i] = ((u128)(0x9E3779B97F4A7C15ull * (i + 1)) << 64) | (0xD1B54A32D192ED03ull * (i + 7));
-        hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, nullptr, o, sh, N, big, (int)M, N, (const u64*)nullptr);
+        hipLaunchKernelGGL(k_recover_gf128<FieldG>, dim3(grid_for(N)), dim3(BLOCK), 0, nullptr, o, sh, N, big, (int)M, N, (const u64*)nullptr);
         LAUNCH_CHECK();
-        SCL_TRY(launch_gfpos(false, o + 2 * N, sh, N, big, M, N, nullptr));
-        SCL_TRY(launch_gfpos(true, o + 4 * N, sh, N, big, M, N, nullptr));
+        SCL_TRY(launch_gfpos<FieldG>(false, o + 2 * N, sh, N, big, M, N, nullptr));
+        SCL_TRY(launch_gfpos<FieldG>(true, o + 4 * N, sh, N, big, M, N, nullptr));
         std::vector<u64> h(6 * N);
         HIP_TRY(hipMemcpy(h.data(), o, h.size() * 8, hipMemcpyDeviceToHost));
         const bool same = std::equal(h.begin(), h.begin() + 2 * N, h.begin() + 2 * N) &&
@@ -1436,6 +1487,8 @@ static int gfpos_usable(bool* usable) {
   *usable = stt == 1;
   return SCL_OK;
 }
+
+}  // extern "C++"
 
 static int recover_block(int field, uint64_t* out, const uint64_t* shares, size_t stride, const uint64_t* lambda_host,
                          size_t m, size_t N, const uint64_t* prev, void* stream) {
@@ -1458,16 +1511,16 @@ static int recover_block(int field, uint64_t* out, const uint64_t* shares, size_
       if (!ft || ft == 3) {  // GF(2^128): nibble-table kernels ("force_table" 3: the shared-shift form at any m)
         const size_t lds = gfpos_lds_bytes(m);
         bool pos_ok = false;  // the position-table kernel passed its first-use self-check (see gfpos_usable)
-        if (!prev && ft != 3 && lds <= 160 * 1024) SCL_TRY(gfpos_usable(&pos_ok));
+        if (!prev && ft != 3 && lds <= 160 * 1024) SCL_TRY(gfpos_usable<F>(&pos_ok));
         if (prev) {
-          hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
+          hipLaunchKernelGGL(k_recover_gf128<F>, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
                              (int)m, N, prev);
         } else if (pos_ok && lds <= 80 * 1024) {  // position tables, two 512-thread workgroups per CU
-          SCL_TRY(launch_gfpos(false, out, shares, stride, big, m, N, S(stream)));
+          SCL_TRY(launch_gfpos<F>(false, out, shares, stride, big, m, N, S(stream)));
         } else if (pos_ok) {  // one 1024-thread workgroup per CU
-          SCL_TRY(launch_gfpos(true, out, shares, stride, big, m, N, S(stream)));
+          SCL_TRY(launch_gfpos<F>(true, out, shares, stride, big, m, N, S(stream)));
         } else {
-          hipLaunchKernelGGL(k_recover_gf128, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
+          hipLaunchKernelGGL(k_recover_gf128<F>, dim3(grid_for(N)), dim3(BLOCK), 0, S(stream), out, shares, stride, big,
                              (int)m, N, (const u64*)nullptr);
         }
         LAUNCH_CHECK();
@@ -1543,7 +1596,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
       const size_t work_min = blocked ? 1024 : 512;
       if (eligible && (mode > 0 || (mode == 0 && n * (t + 1) >= work_min && !small_vandermonde<F>(ctx, al, n, t, probe) &&
                                     !g_force_table.load())))
-        return share_mfma(al, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, S(stream));
+        return share_mfma<F>(al, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, S(stream));
     }
     if constexpr (F::TAG <= 2 || F::LIMBS == 4) {  // the Mersenne fields and the Montgomery primes (Mont128: of full width)
       SmallVdm sv;
@@ -1653,7 +1706,7 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
             }
 #undef GFT_CASE
           } else {
-            hipLaunchKernelGGL(k_share_gf_nodes, gg, blk, 0, S(stream), sh, share_stride, se, co, coeff_stride, al, (int)t, (int)n,
+            hipLaunchKernelGGL(k_share_gf_nodes<F>, gg, blk, 0, S(stream), sh, share_stride, se, co, coeff_stride, al, (int)t, (int)n,
                                npacks);
           }
           launched = true;
@@ -1893,7 +1946,7 @@ int scl_hip_shamir_recover_detect(int field, uint64_t* out, unsigned char* statu
         unsigned long long* cnt = static_cast<unsigned long long*>(sc);
         HIP_TRY(hipMemsetAsync(cnt, 0, 8, S(stream)));
         std::vector<u64> Lw(L.begin(), L.end());
-        SCL_TRY(detect_mfma(out, status, shares, stride, Lw, rows, d1, N, cnt, S(stream)));
+        SCL_TRY(detect_mfma<F>(out, status, shares, stride, Lw, rows, d1, N, cnt, S(stream)));
         unsigned long long h = 0;
         HIP_TRY(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, S(stream)));
         HIP_TRY(hipStreamSynchronize(S(stream)));
@@ -2180,7 +2233,7 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
       // small left factor, long right factor (Vandermonde evaluation, share generation): matrix cores
       const long mode = g_mfma.load();
       if (M <= 128 && K >= 1 && K <= 64 && (mode > 0 || (mode == 0 && M * K >= 512 && N >= 4096)))
-        return matmul_mfma(C, ldc, A, lda, B, ldb, M, K, N, S(stream));
+        return matmul_mfma<F>(C, ldc, A, lda, B, ldb, M, K, N, S(stream));
     }
     const size_t esz = F::LIMBS * 8;
     const size_t kk = K ? K : 1;
@@ -2237,16 +2290,20 @@ int scl_hip_soa_to_aos(int field, uint64_t* aos, const uint64_t* soa, size_t str
 }
 
 // ---- wire image ------------------------------------------------------------------------------------------------------------
+#if SCL_TU_COMMON
 size_t scl_hip_wire_size(int field, size_t n) {
   const int L = scl_hip_limbs(field);
   return L < 0 ? 0 : 4 + n * (size_t)L * 8;
 }
+#endif  // SCL_TU_COMMON
 
 static int wire_pack_impl(int field, unsigned char* dst, const uint64_t* src, size_t n, bool framed, void* stream);
 int scl_hip_wire_pack(int field, unsigned char* dst, const uint64_t* src, size_t n, void* stream) {
   return wire_pack_impl(field, dst, src, n, false, stream);
 }
+#if SCL_TU_COMMON
 size_t scl_hip_frame_size(size_t image_bytes) { return 4 + image_bytes; }
+#endif  // SCL_TU_COMMON
 int scl_hip_frame_pack(int field, unsigned char* dst, const uint64_t* src, size_t n, void* stream) {
   return wire_pack_impl(field, dst, src, n, true, stream);
 }
@@ -2268,10 +2325,12 @@ static int wire_pack_impl(int field, unsigned char* dst, const uint64_t* src, si
   });
 }
 
+#if SCL_TU_COMMON
 size_t scl_hip_wire_size_matrix(int field, size_t rows, size_t cols) {
   const int L = scl_hip_limbs(field);
   return L < 0 ? 0 : 12 + rows * cols * (size_t)L * 8;
 }
+#endif  // SCL_TU_COMMON
 
 static int wire_pack_matrix_impl(int field, unsigned char* dst, const uint64_t* src, size_t ld, size_t rows, size_t cols,
                                  bool framed, void* stream);
@@ -2380,18 +2439,25 @@ static int wire_unpack_impl(int field, uint64_t* dst, size_t capacity, const uns
 }
 
 // ---- roofline probe -------------------------------------------------------------------------------------------------------
+#if SCL_TU_COMMON
 int scl_hip_stream_copy(void* dst, const void* src, size_t bytes, void* stream) {
   if (bytes == 0) return SCL_OK;
   if (!dst || !src || !aligned16(dst) || !aligned16(src) || (bytes & 15))
     return fail(SCL_ERR_BAD_ARG, "stream_copy: 16-byte aligned buffers and sizes only");
   const size_t n16 = bytes / 16;
-  hipLaunchKernelGGL(k_copy16, dim3(grid_for(n16)), dim3(BLOCK), 0, S(stream), static_cast<u64x2*>(dst),
+  hipLaunchKernelGGL(k_copy16<>, dim3(grid_for(n16)), dim3(BLOCK), 0, S(stream), static_cast<u64x2*>(dst),
                      static_cast<const u64x2*>(src), n16);
   LAUNCH_CHECK();
   return SCL_OK;
 }
+#endif  // SCL_TU_COMMON
 
 }  // extern "C"
 
 // ---- the open step: RCCL all-gather + reconstruct ----------------------------------------------------------------------
+#if SCL_TU_COMMON
+#if SCL_TU_FIELDS != 0xff
+#include "capi_names_undef.inc"  // the open step calls the PUBLIC scl_hip_shamir_recover / scl_hip_additive_recover (any field)
+#endif
 #include "open_rccl.inc"
+#endif  // SCL_TU_COMMON

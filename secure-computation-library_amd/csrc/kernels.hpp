@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/scl_hip/detail/field.hpp"
+#include "tu_config.hpp"
 
 namespace sclhip {
 
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(BLOCK) void k_dot(typename F::Ctx ctx, u64* partial
 }
 
 // Vector::equals (vector.h:558-570): counts mismatching limbs
+template <int = 0>  // (a template so that only the unit that launches it compiles it)
 __global__ __launch_bounds__(BLOCK) void k_count_diff(unsigned long long* count, const u64* a, const u64* b,
                                                       size_t nwords) {
   unsigned long long local = 0;
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(BLOCK) void k_count_diff(unsigned long long* count,
 }
 
 // Z2k equality compares modulo 2^K (z2k_ops.h:97-103): mask = 2^K - 1 as (lo, hi) words, L limbs per element
+template <int = 0>  // (a template so that only the unit that launches it compiles it)
 __global__ __launch_bounds__(BLOCK) void k_count_diff_masked(unsigned long long* count, const u64* a, const u64* b,
                                                              size_t nwords, u64 mask_lo, u64 mask_hi, int L) {
   unsigned long long local = 0;
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(BLOCK) void k_recover_table(typename F::Ctx ctx, u6
 // walk: T_i[j] = j(x) * lambda_i for the 16 nibble values (256 B per party = one LDS bank row, so a
 // ds_read_b128 with data-dependent nibbles is conflict-free).  The x^4 shifts are shared across
 // parties: for nibble position k (high to low)  r = r * x^4  ^  XOR_i T_i[nib_k(s_i)].
+template <class FieldG = Gf128>  // (a template so that only the unit that launches it compiles it)
 __global__ __launch_bounds__(BLOCK) void k_recover_gf128(u64* out, const u64* shares, size_t stride,
                                                          BigTable<Gf128> tab, int m, size_t N, const u64* prev = nullptr) {
   __shared__ u128 T[BigTable<Gf128>::CAP * 16];
@@ -841,6 +845,7 @@ __device__ __forceinline__ void horner_pack_exact(const typename F::Ctx& ctx, u6
 // shamirSecretShare over GF(2^128) at small nodes (every node < 2^16 as a bit pattern), 5 <= t <= 16: per-node Horner code
 // over register-indexed coefficients (gf_horner_at).  Four waves per SIMD asked of the register allocator: the two
 // 32-word coefficient vectors and a dozen temporaries need no more.
+template <class FieldG = Gf128>  // (a template so that only the unit that launches it compiles it)
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_share_gf_nodes(
     u64* shares, size_t stride, const u64* secrets, const u64* coeffs, size_t cstride, BigTable<Gf128> tab, int t, int n,
     size_t npacks) {
@@ -1728,6 +1733,7 @@ __device__ __forceinline__ typename F::E elem_from_blocks(const typename F::Ctx&
 
 // PRG::next as raw counter-addressed blocks (prg.cc:124-146); each lane computes 4 blocks a grid
 // stride apart so that every store instruction is a contiguous 1 KiB per wave.
+template <int = 0>  // (a template so that only the unit that launches it compiles it)
 __global__ __launch_bounds__(ABLOCK) void k_prg_blocks(u64* dst, AesKey key, u64 counter0, size_t nblocks) {
   SCL_AES4_PROLOGUE(key)
   const size_t G = (size_t)gridDim.x * ABLOCK;
@@ -2701,6 +2707,7 @@ __global__ __launch_bounds__(BLOCK) void k_wire_unpack(typename F::Ctx ctx, u64*
 }
 
 // ---- roofline probe ------------------------------------------------------------------------------------
+template <int = 0>  // (a template so that only the unit that launches it compiles it)
 __global__ __launch_bounds__(BLOCK) void k_copy16(u64x2* dst, const u64x2* src, size_t n16) {
   SCL_GRID_STRIDE(q, n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + q), dst + q);
 }

@@ -770,6 +770,7 @@ __device__ __forceinline__ void mf16_pipe_word(const v4i (&vfrag)[MF_LIMBS], con
 }
 
 // Atab: the KS = 2, MT = 4 table of mfma_table (rows = parties, 64 k-bytes + pad per row)
+template <class FieldG = M61>  // (a template so that only the unit that launches it compiles it)
 __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size_t stride, const u64* secrets,
                                                                const u64* coeffs, size_t cstride, const unsigned char* Atab,
                                                                int t, int n, size_t N) {

@@ -128,3 +128,13 @@ def test_prototypes_come_from_the_header(scl):
         scl.lib.scl_hip_limbs()                      # too few arguments
     with pytest.raises((C.ArgumentError, TypeError)):
         scl.lib.scl_hip_limbs("m61")                 # not an int
+
+
+def test_route_tables_are_current():
+    """csrc/capi_names.inc and csrc/capi_route.cc (the per-family unit names and the forwarding entry points) are what
+    tools/gen_capi_route.py writes from include/scl_hip.h today"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_capi_route.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 with open(os.path.join(HERE, "golden", "golden_v1.json")) as fh:
     GOLD = json.load(fh)
 with open(os.path.join(HERE, "golden", "golden_secp256k1_field.json")) as fh:   # FF<Secp256k1Field>, same generator
@@ -1078,6 +1079,36 @@ def test_open_step_on_one_rank_rccl(scl, port):
         assert scl.equals(f2, out2, sec2) and scl.equals(f2, out2, sd.open_and_reconstruct(f2, sh2, n2, lam2, chunk=1024))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,f,n,t,N,chunk", [
+    (2, O.M61, 10, 3, 5001, 1000),      # BASELINE configs[1]'s shape: 6 chunks, the last one a single (odd) secret
+    (4, O.M61, 7, 2, 3001, 700),        # 7 parties on 4 ranks: two rows per rank, one padding row on the last
+    (4, O.M61, 5, 2, 2001, 512),        # 5 parties on 4 ranks: a rank with a padding row AND a rank without parties
+    (8, O.M61, 10, 3, 2501, 600),       # ranks 5..7 hold nothing
+    (3, O.M127, 10, 3, 1001, 300),      # 16-byte elements, a world that does not divide n
+    (2, O.GF2_128, 40, 13, 1201, 256),  # BASELINE configs[3]'s shape (the position-table reconstruct kernel)
+    (8, O.GF2_128, 40, 13, 1001, 300),  # .. on the world BASELINE quotes it on: five parties per rank
+])
+def test_c_abi_open_with_a_world_of_threads(scl, world, f, n, t, N, chunk):
+    """scl_hip_open_all_gather / scl_hip_open_partial_gather with world = 2, 3, 4, 8 on this one GPU: the ranks are host threads
+    of a child process and the library binds tests/cxx/_build/libfake_rccl.so (SCL_HIP_RCCL_LIBRARY), whose all-gather is a
+    rendezvous + device-to-device copies.  The permuted lambda (row q = j * world + r), the grouped per-row gathers, the two
+    streams and their events across >= 3 chunks and across calls from different streams, padding rows (sent as zeros, filled
+    with ones here), ranks without parties and the partial-sum form all run as they would on eight GPUs; every rank's four
+    outputs must equal the secrets the oracle shared (tests/open_world_check.py)."""
+    import subprocess
+    import sys
+    fake = os.path.join(ROOT, "tests", "cxx", "_build", "libfake_rccl.so")
+    assert os.path.exists(fake), "tests/cxx/_build/libfake_rccl.so is built by make -C tests/cxx (__graft_entry__.build)"
+    env = dict(os.environ, SCL_HIP_RCCL_LIBRARY=fake)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "open_world_check.py")] + [str(x) for x in (world, f, n, t, N, chunk)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:] + r.stderr[-4000:]
+    rep = json.loads(lines[-1])
+    assert r.returncode == 0 and rep["ok"], (rep, r.stderr[-2000:])
+    assert rep["chunks"] >= 3 and rep["padding_rows"] == -(-n // world) * world - n
 
 
 @pytest.mark.parametrize("n,counter0", [(1003, 0), (1004, 5), (1, 0), (2, 7)])

@@ -215,7 +215,7 @@ int main() {
   };
   time_it([&] { hipLaunchKernelGGL(k_prg_blocks1, dim3(1024), dim3(256), 0, 0, a, key, 12345ull, nblocks); }, "one table + rotations, 4 x 256 threads per CU");
   {
-    auto kern = &k_prg_blocks;  // the library's kernel: four tables, one 1024-thread workgroup per CU
+    auto kern = &k_prg_blocks<>;  // the library's kernel: four tables, one 1024-thread workgroup per CU
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AES4_LDS_BYTES));
     time_it([&] { hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, b, key, 12345ull, nblocks); },
             "library: k_prg_blocks (four tables, SDWA addresses)");

@@ -581,7 +581,7 @@ int main(int argc, char** argv) {
   std::printf("-- reconstruct, n = %d, N = %zu (%.0f B per secret)\n", M, N, rec_bytes / N);
   {
     const unsigned g = (unsigned)((N + 255) / 256);
-    const float ms = time_it([&] { hipLaunchKernelGGL(k_recover_gf128, dim3(g), dim3(256), 0, 0, o0, sh, N, big, M, N); }, 5);
+    const float ms = time_it([&] { hipLaunchKernelGGL(k_recover_gf128<>, dim3(g), dim3(256), 0, 0, o0, sh, N, big, M, N); }, 5);
     std::printf("%-44s %8.3f ms  %6.2f TB/s  %6.2f G secrets/s\n", "library k_recover_gf128", ms, rec_bytes / ms / 1e9, N / ms / 1e6);
   }
 #define REC(G, BLK, WPS)                                                                                             \

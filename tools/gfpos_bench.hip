@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&ref, N * 16));
   CK(hipMalloc(&out, N * 16));
   hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, sh, (size_t)m * N * 2, 777ull);
-  hipLaunchKernelGGL(k_recover_gf128, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, ref, sh, N, big, m, N, (const u64*)nullptr);
+  hipLaunchKernelGGL(k_recover_gf128<>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, ref, sh, N, big, m, N, (const u64*)nullptr);
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));

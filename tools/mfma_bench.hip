@@ -119,7 +119,7 @@ int main(int argc, char** argv) {
   CK(hipMemset(out2, 0x33, (size_t)n * N * 8));
   {
     const size_t shmem = 2 * mf_b_bytes(KS, MT, 1);
-    auto kern = &k_share_mfma_m61_p16;
+    auto kern = &k_share_mfma_m61_p16<>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     const size_t nblocks = (N + 31) / 32;
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
@@ -163,7 +163,7 @@ int main(int argc, char** argv) {
   }
   if (argc > 5) {  // where the p16 kernel's time goes on the memory side: share rows that alias (results are wrong by construction)
     const size_t shmem = 2 * mf_b_bytes(KS, MT, 1);
-    auto kern = &k_share_mfma_m61_p16;
+    auto kern = &k_share_mfma_m61_p16<>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     const size_t nblocks = (N + 31) / 32;
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);
