@@ -91,6 +91,10 @@ def parse_args(argv=None):
                     help="gloo + --dry-run: the launcher / rendezvous / timing skeleton on CPU (tests)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: steps are empty (launcher test)")
     ap.add_argument("--total-secrets", type=int, default=0, help="--config c4 / c5: total over all ranks (default 10^8 / 10^9)")
+    ap.add_argument("--c4-rank-secrets", type=int, default=100_000_000,
+                    help="open.c4_rank_shape: secrets of the one-rank-of-eight shape of BASELINE configs[3] (0 = skip)")
+    ap.add_argument("--inject-error", default="", choices=["", "c_abi"],
+                    help="tests only: make the named side leg fail, to see the line report it and the exit code follow")
     return ap.parse_args(argv)
 
 
@@ -191,7 +195,8 @@ def cpu_baseline(field_key, n, t, sample):
         raise RuntimeError("CPU baseline failed its own round trip")
     total = r["share_s"] + r["recover_s"]
     out = {
-        "value": sample / total, "unit": "reconstructions/s", "cores": 1, "kind": kind,
+        "value": sample / total, "unit": "reconstructions/s", "cores": 1, "kind": kind, "cpu_model": cpu_model(),
+        "host_cores_available": len(os.sched_getaffinity(0)),
         "sample": f"{sample} secrets, per-secret shamirSecretShare + shamirRecoverP (n={n}, t={t}), "
                   f"share {r['share_s']:.2f}s + recover {r['recover_s']:.2f}s",
         "recover_only_per_s": sample / r["recover_s"], "share_only_per_s": sample / r["share_s"],
@@ -366,9 +371,12 @@ def main():
         for k in range(rows.shape[0]):
             scl.vector_random(f_, N_, seed, counter0=counter0 + k * per_row, out=rows[k])
 
-    def share_recover_config(fkey, n, t, N, steps, seed):
+    def share_recover_config(fkey, n, t, N, steps, seed, warmup=1):
         """one configuration end to end on this GPU: plain allocations, share + reconstruct timed with HIP events on the
-        launch stream, round trip verified.  Returns the per-kernel figures."""
+        launch stream, round trip verified.  Returns the per-kernel figures.  `warmup` untimed rounds first: the first tens of
+        milliseconds after an idle gap (allocation, fill) run under a clock transient -- five launches of a 0.3 ms kernel
+        right after it read 0.33-0.40 ms where fifty read 0.28-0.29 (profiles/r4_probe_c3_bench.txt) -- so the
+        sub-millisecond configurations take 10 + 50 rounds."""
         f_, L = tag_limbs(fkey)
         E = 8 * L
         secrets = scl.empty(f_, N)
@@ -379,7 +387,7 @@ def main():
         out = scl.empty(f_, N)
         lam = scl.lagrange_basis(f_, n)
         tms = [(scl.Timer(), scl.Timer()) for _ in range(steps)]
-        for k in range(-1, steps):
+        for k in range(-warmup, steps):
             if k >= 0:
                 tms[k][0].start()
             scl.shamir_share(f_, secrets, coeffs, n, out=shares)
@@ -398,7 +406,10 @@ def main():
                "share_ms": sm, "recover_ms": rm, "bytes_per_secret": {"share": sb, "recover": rb},
                "share_GBps": sb * N / sm / 1e6, "recover_GBps": rb * N / rm / 1e6,
                "share_frac": sb * N / sm / 1e6 / HBM_PEAK_GBPS, "recover_frac": rb * N / rm / 1e6 / HBM_PEAK_GBPS,
-               "round_trips_per_s": N / ((sm + rm) * 1e-3), "reconstructions_per_s": N / (rm * 1e-3), "verified": ok}
+               "round_trips_per_s": N / ((sm + rm) * 1e-3), "reconstructions_per_s": N / (rm * 1e-3), "verified": ok,
+               "steps": steps, "warmup": warmup,
+               "share_ms_min_max": [min(tm[0].elapsed_ms() for tm in tms), max(tm[0].elapsed_ms() for tm in tms)],
+               "recover_ms_min_max": [min(tm[1].elapsed_ms() for tm in tms), max(tm[1].elapsed_ms() for tm in tms)]}
         if on_matrix_cores(fkey, n, t):
             res["share_roofline"] = mfma_share_roofline(n, t, N, sm)   # share_frac above is its HBM-equivalent rate only
         del secrets, coeffs, shares, out
@@ -556,8 +567,10 @@ def main():
         # scl_hip_open_partial_gather; per-row grouped all-gathers, no packing copy), what a C++ caller of include/scl_hip/ gets
         c_abi = None
         try:
-            if one_device and world > 1:
-                raise RuntimeError("skipped in the one-device rehearsal: RCCL does not take two ranks on one GPU")
+            if one_device and world > 1:   # a leg that did not run is not a leg that failed
+                raise InterruptedError("skipped in the one-device rehearsal: RCCL does not take two ranks on one GPU")
+            if args.inject_error == "c_abi":
+                raise RuntimeError("injected by --inject-error c_abi")
             comm = sd.Communicator()
             try:
                 def c_pipeline(k):
@@ -572,7 +585,9 @@ def main():
                          "verified": bool(scl.equals(f_, result["c"], secrets)) and bool(scl.equals(f_, result["cp"], secrets))}
             finally:
                 comm.close()
-        except Exception as e:   # reported, never fatal to the line
+        except InterruptedError as e:
+            c_abi = {"skipped": str(e)}
+        except Exception as e:   # reported in the line (and in its `errors`, with a non-zero exit code after the line is out)
             c_abi = {"error": str(e), "verified": False}
         gathered_bytes = world * per * c0 * E
         res = {"field": FIELD_NAMES[fkey], "n": n, "t": t, "secrets": N, "chunk": c0, "parties_per_rank": per, "c_abi": c_abi,
@@ -618,11 +633,71 @@ def main():
         torch.cuda.empty_cache()
         return res
 
+    def c4_rank_shape(N, chunk):
+        """What ONE rank of BASELINE configs[3] on 8 GPUs does per open by scl_hip_open_partial_gather: its 5 of the 40 parties'
+        share vectors of all N = 10^8 GF(2^128) secrets (an 8 GB slab) go through the reconstruct kernel at m = 5 (one partial
+        sum per secret), and each gathered chunk of 8 partial rows through k_additive_recover (Vector::sum per secret).  The
+        kernels of the 8-GPU configuration that fit one GPU, at their real size; the all-gather between them is xGMI time
+        (DESIGN.md section 5)."""
+        f_, L = tag_limbs("gf2_128")
+        E = 8 * L
+        world8, per = 8, 5
+        lam = scl.lagrange_basis(f_, 40)
+        local = scl.empty(f_, per, N)
+        fill_random(local, f_, b"scl-bench-c4-rank")
+        partial = scl.empty(f_, N)
+        c = min(chunk, N)
+        gathered = scl.empty(f_, world8, c)
+        fill_random(gathered, f_, b"scl-bench-c4-rank-g")
+        outc = scl.empty(f_, c)
+        reps = 3
+        t1, t2 = scl.Timer(), scl.Timer()
+        scl.shamir_recover(f_, local, lam[:per], out=partial)
+        t1.start()
+        for _ in range(reps):
+            scl.shamir_recover(f_, local, lam[:per], out=partial)
+        t1.stop()
+        scl.additive_recover(f_, gathered, out=outc)
+        t2.start()
+        for _ in range(reps * 4):
+            scl.additive_recover(f_, gathered, out=outc)
+        t2.stop()
+        p_ms, s_ms = t1.elapsed_ms() / reps, t2.elapsed_ms() / (reps * 4)
+        # linearity as the check: the partial over 5 rows + the partial over the same rows with lambda' = the sum over five
+        # other coefficients ... kept simple: partial(lam) + partial(lam2) == partial(lam + lam2), all three by the kernel
+        lam2 = lam[per:2 * per]
+        lam3 = scl.to_host(scl.ew(f_, scl.ADD, scl.to_device(lam[:per]), scl.to_device(lam2)))
+        w = min(N, 1 << 20)
+        pa = scl.shamir_recover(f_, local[:, :w], lam[:per])
+        pb = scl.shamir_recover(f_, local[:, :w], lam2)
+        pc = scl.shamir_recover(f_, local[:, :w], lam3)
+        ok = bool(scl.equals(f_, scl.ew(f_, scl.ADD, pa, pb), pc))
+        pbytes, sbytes = (per + 1) * E, (world8 + 1) * E
+        sums_ms_total = s_ms * (N / c)
+        res = {"workload": f"one rank's kernels of BASELINE configs[3] on 8 GPUs by the partial-sum open: {per} parties x {N} "
+                           f"GF(2^128) secrets -> partial sums (reconstruct kernel, m = {per}), then Vector::sum over {world8} "
+                           f"gathered partial rows per chunk of {c}",
+               "partial_ms": p_ms, "partial_bytes_per_secret": pbytes, "partial_GBps": pbytes * N / p_ms / 1e6,
+               "partial_frac": pbytes * N / p_ms / 1e6 / HBM_PEAK_GBPS,
+               "sum_ms_per_chunk": s_ms, "sum_bytes_per_secret": sbytes, "sum_GBps": sbytes * c / s_ms / 1e6,
+               "sum_frac": sbytes * c / s_ms / 1e6 / HBM_PEAK_GBPS,
+               "kernels_ms_per_open": p_ms + sums_ms_total, "opened_secrets_per_s_kernels_only": N / ((p_ms + sums_ms_total) * 1e-3),
+               "xgmi_bytes_received_per_rank": (world8 - 1) * E * N, "verified": ok}
+        del local, partial, gathered, outc
+        torch.cuda.empty_cache()
+        return res
+
     def open_report():
         N_open = args.open_secrets or 12_500_000 * world
         N_ps = (args.secrets // world) * world
         rep = {"c4_all_gather": open_step("gf2_128", 40, 13, N_open, args.open_chunk, 3, 1, b"scl-bench-open"),
                "m61_partial_sums": open_partial_sums(10, 3, N_ps, 3, 1, b"scl-bench-open")}
+        if world == 1 and args.c4_rank_secrets:
+            try:
+                rep["c4_rank_shape"] = c4_rank_shape(args.c4_rank_secrets, args.open_chunk)
+            except Exception as e:
+                rep["c4_rank_shape"] = {"error": str(e), "verified": False}
+                torch.cuda.empty_cache()
         return rep
 
     if pl["key"] == "c4":
@@ -742,6 +817,8 @@ def main():
     ach = kernels[dom]["GBps"]
     roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args),
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes run by the builder over this command, stamped "
+                                  "with a hash of the kernel sources; null once they differ) -- not observed by this run",
                 "algorithmic_bytes": kernels[dom]["bytes_per_secret"] * N,
                 "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": ach / copy_gbps}
     if dom == "shamir_share" and args.share_mode == "coeffs" and on_matrix_cores(args.field, n, t):
@@ -783,14 +860,14 @@ def main():
     if world == 1 and args.configs:
         # the other BASELINE configurations at the size ONE GPU holds of them (C4, C5: an eighth), after the timed region
         cfgs = {}
-        for key, (fk, n_, t_, N_, st) in {
-            "C3_mersenne127_10_3": ("m127", 10, 3, 10_000_000, 5),
-            "C3_mont128_10_3": ("mont128", 10, 3, 10_000_000, 5),
-            "C4_shard_gf2_128_40_13": ("gf2_128", 40, 13, 12_500_000, 3),
-            "C5_shard_mersenne61_128_42": ("m61", 128, 42, 125_000_000, 2),
+        for key, (fk, n_, t_, N_, st, wu) in {
+            "C3_mersenne127_10_3": ("m127", 10, 3, 10_000_000, 50, 10),
+            "C3_mont128_10_3": ("mont128", 10, 3, 10_000_000, 50, 10),
+            "C4_shard_gf2_128_40_13": ("gf2_128", 40, 13, 12_500_000, 5, 2),
+            "C5_shard_mersenne61_128_42": ("m61", 128, 42, 125_000_000, 2, 1),
         }.items():
             try:
-                cfgs[key] = share_recover_config(fk, n_, t_, N_, st, b"scl-bench-" + key.encode())
+                cfgs[key] = share_recover_config(fk, n_, t_, N_, st, b"scl-bench-" + key.encode(), warmup=wu)
                 cfgs[key]["traffic"] = pmc_config_traffic(key)
             except Exception as e:  # a failed side configuration is reported, not hidden, and never fails the headline
                 cfgs[key] = {"error": str(e), "verified": False}
@@ -798,9 +875,52 @@ def main():
         line["configs"] = cfgs
     if world == 1 and args.cpu_sample > 0:
         line["cpu_baseline"] = cpu_baseline(args.field, n, t, args.cpu_sample)
+    # the line tells the truth about its side legs: `verified` is the AND over the headline and every leg that ran, and a
+    # leg that failed (an {"error": ..} object anywhere in the line) makes the process exit non-zero AFTER the line is out
+    legs, errors = side_legs(line)
+    line["verified_headline"] = verified
+    line["verified"] = verified and all(legs.values())
+    line["verified_legs"] = legs
+    if errors:
+        line["errors"] = errors
     emit(line)
     if world > 1:
         dist.destroy_process_group()
+    if errors or not line["verified"]:
+        print("bench.py: " + ("; ".join(errors) if errors else "a leg did not verify: " +
+                               ", ".join(k for k, v in legs.items() if not v)), file=sys.stderr)
+        sys.exit(1)
+
+
+def side_legs(line):
+    """({leg path: verified}, [error strings]) over every object of the result line that carries a `verified` or an `error`
+    key below the top level (configs.*, prg_mode, c1_additive, open.* and open.*.c_abi / partial_gather ..)"""
+    legs, errors = {}, []
+
+    def walk(obj, path):
+        if isinstance(obj, dict):
+            if path:
+                if "error" in obj:
+                    errors.append(f"{path}: {obj['error']}")
+                    legs[path] = False
+                elif "verified" in obj:
+                    legs[path] = bool(obj["verified"])
+            for k, v in obj.items():
+                if k not in ("cpu_baseline", "verified_legs"):
+                    walk(v, f"{path}.{k}" if path else k)
+    walk(line, "")
+    return legs, errors
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 if __name__ == "__main__":

@@ -6,6 +6,7 @@
 #include "hip/open.h"
 #include "math/fields/ff_ops.h"
 #include "math/ff.h"
+#include "math/array.h"
 #include "math/lagrange.h"
 #include "math/matrix.h"
 #include "math/poly.h"

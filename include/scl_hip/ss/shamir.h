@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../hip/device.h"
+#include "../math/array.h"
 #include "../math/lagrange.h"
 #include "../math/matrix.h"
 #include "../math/poly.h"
@@ -67,6 +68,52 @@ hip::ShareMatrix<T> shamirSecretShare(const hip::DeviceVector<T>& secrets,
                                   n, nullptr, nullptr));
   hip::check(scl_hip_stream_sync(nullptr));
   return shares;
+}
+
+// ---- sharing over math::Array<FF, W> for a whole batch (what pedersenSecretShare shares: {secret, blinding}) ----------
+/// W components of N secrets each in HBM, component-major: component j of secret s is element j * N + s.
+template <typename F, std::size_t W>
+struct ArrayVector {
+  hip::DeviceVector<F> components;  ///< W * N elements
+  std::size_t secrets = 0;
+
+  ArrayVector() = default;
+  explicit ArrayVector(const math::Vector<math::Array<F, W>>& host) : secrets(host.size()) {
+    std::vector<F> flat(W * secrets);
+    for (std::size_t s = 0; s < secrets; ++s)
+      for (std::size_t j = 0; j < W; ++j) flat[j * secrets + s] = host[s][j];
+    components = hip::DeviceVector<F>(flat);
+  }
+};
+
+/// the shares of a batch over Array<F, W>: component j of party i's share of secret s is row j * n + i, column s
+template <typename F, std::size_t W>
+struct ArrayShares {
+  hip::ShareMatrix<F> rows;  ///< [W * n][N]
+  std::size_t parties = 0;
+
+  /// the shares of secret s as shamirSecretShare(Array, t, n, prg) returns them: n Arrays
+  math::Vector<math::Array<F, W>> sharesOf(std::size_t s) const {
+    const auto col = rows.sharesOf(s);  // W * n elements, row order
+    std::vector<math::Array<F, W>> out(parties);
+    for (std::size_t i = 0; i < parties; ++i)
+      for (std::size_t j = 0; j < W; ++j) out[i][j] = col[j * parties + i];
+    return math::Vector<math::Array<F, W>>(std::move(out));
+  }
+};
+
+/// shamirSecretShare(Array<F, W>{..}, t, n, prg) (shamir.h:51-68 with T = Array, pedersen.h:137-138) for every secret of
+/// the batch on ONE prg, in order: Vector<Array>::random(t + 1) is one draw of (t + 1) * W elements per secret, component j
+/// of coefficient k is element k * W + j, arithmetic is component-wise, nodes 1..n.  The PRG is advanced.
+template <typename F, std::size_t W>
+ArrayShares<F, W> shamirSecretShare(const ArrayVector<F, W>& secrets, std::size_t t, std::size_t n, util::PRG& prg) {
+  const std::size_t N = secrets.secrets;
+  ArrayShares<F, W> out{hip::ShareMatrix<F>(W * n, N), n};
+  const auto seed = prg.Seed();
+  hip::check(scl_hip_shamir_share_prg_packed(F::Field::TAG, out.rows.data(), out.rows.stride(), secrets.components.data(), N, N,
+                                             t, n, W, seed.data(), seed.size(), prg.counter(), nullptr));
+  prg.advance(N * (((t + 1) * W * F::byteSize() + 15) / 16));
+  return out;
 }
 
 namespace shamir_detail {

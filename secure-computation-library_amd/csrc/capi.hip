@@ -83,6 +83,7 @@ SCL_STATE(thread_local Knob g_stream_block, {64});
 SCL_STATE(thread_local Knob g_stream_waves, {-1});
 // the same cap for the Mersenne61 small-node share kernel ("share_waves"; 0 = the 256-thread kernel without a cap)
 SCL_STATE(thread_local Knob g_share_waves, {9});
+SCL_STATE(thread_local Knob g_share_waves128, {12});  // .. and for the 16-byte fields' small-node share kernel ("share_waves128")
 SCL_STATE(thread_local Knob g_aes_blocks, {0});
 // Mont128 modulus: a process-wide default, latched per host thread at its first use (mont_ctx below)
 SCL_STATE(thread_local Mont128::Ctx g_mont, = {0, 0, 0, 0});  // p == 0: this thread has not latched a modulus yet
@@ -1120,6 +1121,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "stream_block") g_stream_block = (value == 256 ? 256 : 64);
   else if (k == "stream_waves") g_stream_waves = value;
   else if (k == "share_waves") g_share_waves = value;
+  else if (k == "share_waves128") g_share_waves128 = value;
   else if (k == "mfma") g_mfma = value;
   else if (k == "gf_tiles") g_gf_tiles = value;
   else if (k == "prg_t3") g_prg_t3 = value;
@@ -1608,9 +1610,12 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
           // "share_waves" 0 or "stream_block" 256 give the 256-thread kernel with the threshold at run time
           const long sw = g_share_waves.load();
           bool launched = false;
-          if constexpr (F::TAG <= 1) {  // (Mersenne127: 12 resident waves per CU, 0.39 -> 0.37 ms at C3's size and steadier)
-            if (sw > 0 && g_stream_block.load() == 64) {
-              const size_t pad = residency_pad(F::LIMBS == 1 ? sw : 12, 64, sizeof(u32) * SmallVdm::CAP);
+          // (Mersenne127: 12 resident waves per CU, 0.39 -> 0.37 ms at C3's size and steadier; Mont128 -- the Barrett fold --
+          // the same kernel since round 4, "share_waves128" = the cap of the 16-byte fields, 0 = the 256-thread kernel)
+          if constexpr (F::TAG <= 2) {
+            const long sw128 = g_share_waves128.load();
+            if (sw > 0 && g_stream_block.load() == 64 && (F::LIMBS == 1 || sw128 > 0)) {
+              const size_t pad = residency_pad(F::LIMBS == 1 ? sw : sw128, 64, sizeof(u32) * SmallVdm::CAP);
               const dim3 g(grid_for_block(npacks, 64));
 #define SST_CASE(TT)                                                                                                     \
   case TT:                                                                                                               \

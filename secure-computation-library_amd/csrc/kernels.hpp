@@ -456,15 +456,15 @@ __global__ __launch_bounds__(BLOCK) void k_recover_gf128(u64* out, const u64* sh
 // then add up with no shifting of the accumulator at all, and the four word sums are combined by three x^32 steps at the
 // very end -- k_recover_gf128 pays 32 x^4 steps per group of 8 parties -- so a group can be small (few registers, many
 // waves).  A lookup is one v_add_u32_sdwa (table base + a byte of the word masked to its high or low nibbles), one
-// conflict-free ds_read_b128 and four xors.  The LDS reads are issued by hand one batch (4 lookups) ahead of the xors that
-// consume them (s_waitcnt lgkmcnt(4): LDS returns in order; the compiler would wait for each batch right after issuing
-// it), and the next group's shares are fetched while this group is worked on.
+// conflict-free ds_read_b128 and four xors.  The LDS reads of batch k + 1 (4 lookups) are in flight while batch k is folded
+// (s_waitcnt lgkmcnt(4): LDS returns in order) -- left to itself the compiler waits for each batch right after issuing it;
+// rounds 2-3 issued the reads from inline assembly for that, since round 4 they are plain loads between scheduling barriers
+// (gfpos_pipe_cv) -- and the next group's shares are fetched while this group is worked on.
 // Counters at (40,13), profiles/r2_pmc_gf128.txt: LDS array 68 % busy (4 cycles per ds_read_b128, no bank conflicts),
 // vector ALU 60 % (5.8 instructions per lookup); the two overlap only partly, so neither saturates:
 // 2.12 -> 2.44 TB/s.  At 100 % of the LDS array the form would reach 4.4 TB/s.
-// The hand-issued reads below are covered by their s_waitcnt only as far as the compiler leaves the destination registers
-// alone in between; capi.hip therefore checks this kernel against k_recover_gf128 once per process before it is used
-// (gfpos_usable) and falls back to that kernel if the two ever disagree.
+// capi.hip still checks this kernel against k_recover_gf128 once per process before it is used (gfpos_usable: the guard the
+// hand-issued reads needed) and falls back to that kernel if the two ever disagree.
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 template <int B>
@@ -476,19 +476,18 @@ __device__ __forceinline__ u32 add_byte(u32 base, u32 word) {  // base + byte B 
   if constexpr (B == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(base), "v"(word));
   return d;
 }
-template <int OFF>
-__device__ __forceinline__ void lds_read128(u32x4& d, u32 addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-// batch IDX of a group of G parties: word wd = IDX / (2G), party j = (IDX / 2) % G, half = IDX & 1 (0: the odd nibbles)
+// The same batch with loads the COMPILER sees (plain LDS loads through an address-space-3 pointer): it then tracks the
+// destination registers itself and places the s_waitcnt; gfpos_pipe_cv pins the order -- batch IDX + 1 issued, then batch IDX
+// folded -- with scheduling barriers, which is all the hand-written form needed the assembly for.
+typedef __attribute__((address_space(3))) const u32x4* lds_u32x4_ptr;
 template <int G, int IDX>
-__device__ __forceinline__ void gfpos_issue4(u32x4 (&buf)[4], u32 gbase, const u32 (&w)[G][4]) {
+__device__ __forceinline__ void gfpos_issue4_cv(u32x4 (&buf)[4], u32 gbase, const u32 (&w)[G][4]) {
   constexpr int wd = IDX / (2 * G), j = (IDX / 2) % G, half = IDX & 1;
   const u32 m = half ? ((w[j][wd] << 4) & 0xF0F0F0F0u) : (w[j][wd] & 0xF0F0F0F0u);
-  lds_read128<j * 2048 + (0 + (1 - half)) * 256>(buf[0], add_byte<0>(gbase, m));
-  lds_read128<j * 2048 + (2 + (1 - half)) * 256>(buf[1], add_byte<1>(gbase, m));
-  lds_read128<j * 2048 + (4 + (1 - half)) * 256>(buf[2], add_byte<2>(gbase, m));
-  lds_read128<j * 2048 + (6 + (1 - half)) * 256>(buf[3], add_byte<3>(gbase, m));
+  buf[0] = *(lds_u32x4_ptr)(uintptr_t)(add_byte<0>(gbase, m) + (u32)(j * 2048 + (0 + (1 - half)) * 256));
+  buf[1] = *(lds_u32x4_ptr)(uintptr_t)(add_byte<1>(gbase, m) + (u32)(j * 2048 + (2 + (1 - half)) * 256));
+  buf[2] = *(lds_u32x4_ptr)(uintptr_t)(add_byte<2>(gbase, m) + (u32)(j * 2048 + (4 + (1 - half)) * 256));
+  buf[3] = *(lds_u32x4_ptr)(uintptr_t)(add_byte<3>(gbase, m) + (u32)(j * 2048 + (6 + (1 - half)) * 256));
 }
 // acc ^= the four table entries of a batch: two three-way xors per word (v_bitop3_b32, 3.0 cycles each) where four two-way
 // ones stood (2.7 each) -- the xors were two thirds of the kernel's vector instructions
@@ -501,45 +500,17 @@ __device__ __forceinline__ void gfpos_fold(u32x4& acc, const u32x4 (&cur)[4]) {
   acc ^= (cur[0] ^ cur[1]) ^ (cur[2] ^ cur[3]);
 #endif
 }
+// compiler-visible form of gfpos_pipe: nothing crosses a scheduling barrier, so the four reads of batch IDX + 1 are in
+// flight while batch IDX is folded, and the compiler's own wait (lgkmcnt(4): LDS returns in order) covers exactly batch IDX
 template <int G, int IDX>
-__device__ __forceinline__ void gfpos_pipe(u32x4 (&A)[4], u32x4 (&B)[4], u32x4 (&acc)[4], u32 gbase, const u32 (&w)[G][4]) {
+__device__ __forceinline__ void gfpos_pipe_cv(u32x4 (&A)[4], u32x4 (&B)[4], u32x4 (&acc)[4], u32 gbase, const u32 (&w)[G][4]) {
   constexpr int NB = 8 * G;
   if constexpr (IDX < NB) {
-    if constexpr (IDX + 1 < NB) gfpos_issue4<G, IDX + 1>((IDX & 1) ? A : B, gbase, w);
-    u32x4(&cur)[4] = (IDX & 1) ? B : A;
-    if constexpr (IDX + 1 < NB) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
-    gfpos_fold(acc[IDX / (2 * G)], cur);
-    gfpos_pipe<G, IDX + 1>(A, B, acc, gbase, w);
-  }
-}
-// the same pipeline NBUF - 1 batches deep: batch IDX + NBUF - 1 is issued before batch IDX is waited for (all but the
-// 4 (NBUF - 1) newest reads: LDS returns in order)
-template <int I>
-__device__ __forceinline__ void gfpos_wait(u32x4 (&cur)[4]) {
-  static_assert(I >= 0 && I <= 12 && I % 4 == 0, "lgkmcnt is a 4-bit counter");
-  if constexpr (I == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
-  if constexpr (I == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
-  if constexpr (I == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
-  if constexpr (I == 12) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
-}
-template <int G, int IDX, int NBUF>
-__device__ __forceinline__ void gfpos_pipe_n(u32x4 (&buf)[NBUF][4], u32x4 (&acc)[4], u32 gbase, const u32 (&w)[G][4]) {
-  constexpr int NB = 8 * G;
-  if constexpr (IDX < NB) {
-    if constexpr (IDX + NBUF - 1 < NB) gfpos_issue4<G, IDX + NBUF - 1>(buf[(IDX + NBUF - 1) % NBUF], gbase, w);
-    constexpr int younger = (NB - 1 - IDX) < (NBUF - 1) ? (NB - 1 - IDX) : (NBUF - 1);
-    u32x4(&cur)[4] = buf[IDX % NBUF];
-    gfpos_wait<4 * younger>(cur);
-    gfpos_fold(acc[IDX / (2 * G)], cur);
-    gfpos_pipe_n<G, IDX + 1, NBUF>(buf, acc, gbase, w);
-  }
-}
-template <int G, int IDX, int NBUF>
-__device__ __forceinline__ void gfpos_prologue_n(u32x4 (&buf)[NBUF][4], u32 gbase, const u32 (&w)[G][4]) {
-  if constexpr (IDX < NBUF - 1) {
-    gfpos_issue4<G, IDX>(buf[IDX], gbase, w);
-    gfpos_prologue_n<G, IDX + 1, NBUF>(buf, gbase, w);
+    if constexpr (IDX + 1 < NB) gfpos_issue4_cv<G, IDX + 1>((IDX & 1) ? A : B, gbase, w);
+    __builtin_amdgcn_sched_barrier(0);
+    gfpos_fold(acc[IDX / (2 * G)], (IDX & 1) ? B : A);
+    __builtin_amdgcn_sched_barrier(0);
+    gfpos_pipe_cv<G, IDX + 1>(A, B, acc, gbase, w);
   }
 }
 __device__ __forceinline__ void gf_mulx32(u32 (&r)[4]) {  // r * x^32: the word that leaves the top times x^7 + x^2 + x + 1
@@ -550,10 +521,23 @@ __device__ __forceinline__ void gf_mulx32(u32 (&r)[4]) {  // r * x^32: the word 
   r[0] = t ^ (t << 1) ^ (t << 2) ^ (t << 7);
 }
 
+// how a group's 8 G batches are read and folded: the policy of k_recover_gf128_pos.  The library's is the compiler-visible
+// pipeline above; tools/gfpos_asm.hpp has the hand-issued forms of rounds 2-3 (inline-assembly ds_read_b128 one, two or
+// three batches ahead of an s_waitcnt in a later statement) for A/B runs -- same speed within 1.5 %
+// (profiles/r4_gfpos_bench.txt), and the compiler could not know their destination registers were still in flight.
+struct GfposPipeCV {
+  template <int G>
+  static __device__ __forceinline__ void group(u32x4 (&acc)[4], u32 gbase, const u32 (&w)[G][4]) {
+    u32x4 A[4], B[4];
+    gfpos_issue4_cv<G, 0>(A, gbase, w);
+    gfpos_pipe_cv<G, 0>(A, B, acc, gbase, w);
+  }
+};
+
 constexpr int GFPOS_G = 5;  // parties per group: 8 G batches of 4 lookups, 20 share words + 20 prefetched
 inline size_t gfpos_lds_bytes(size_t m) { return (m + GFPOS_G - 1) / GFPOS_G * GFPOS_G * 2048; }
 
-template <int BLK, int WPS, int NBUF = 2>
+template <int BLK, int WPS, class PIPE = GfposPipeCV>
 __global__ __launch_bounds__(BLK, WPS) void k_recover_gf128_pos(u64* out, const u64* shares, size_t stride,
                                                                 BigTable<Gf128> tab, int m, size_t N) {
   constexpr int G = GFPOS_G;
@@ -581,22 +565,21 @@ __global__ __launch_bounds__(BLK, WPS) void k_recover_gf128_pos(u64* out, const 
       w[j][3] = (u32)(v.y >> 32);
     }
   };
-  for (size_t s = (size_t)blockIdx.x * BLK + threadIdx.x; s < N; s += (size_t)gridDim.x * BLK) {
+  const size_t step = (size_t)gridDim.x * BLK;
+  size_t s = (size_t)blockIdx.x * BLK + threadIdx.x;
+  if (s >= N) return;
+  u32 w[G][4], wn[G][4];
+  load_group(w, 0, s);
+  for (;; s += step) {
     u32x4 acc[4] = {0, 0, 0, 0};
-    u32 w[G][4], wn[G][4];
-    load_group(w, 0, s);
     for (int i0 = 0; i0 < m; i0 += G) {
+      // the next group's shares are fetched while this group is worked on: the next group of this secret, or -- round 4 --
+      // the first group of this lane's NEXT secret (at m = 5, one rank's share of C4 on eight GPUs, every group is a
+      // secret's only one and its load latency was exposed once per secret)
       if (i0 + G < m) load_group(wn, i0 + G, s);
+      else if (s + step < N) load_group(wn, 0, s + step);
       const u32 gbase = tbase + (u32)i0 * 2048u;
-      if constexpr (NBUF == 2) {
-        u32x4 A[4], B[4];
-        gfpos_issue4<G, 0>(A, gbase, w);
-        gfpos_pipe<G, 0>(A, B, acc, gbase, w);
-      } else {
-        u32x4 buf[NBUF][4];
-        gfpos_prologue_n<G, 0, NBUF>(buf, gbase, w);
-        gfpos_pipe_n<G, 0, NBUF>(buf, acc, gbase, w);
-      }
+      PIPE::template group<G>(acc, gbase, w);
 #pragma unroll
       for (int j = 0; j < G; ++j)
 #pragma unroll
@@ -615,6 +598,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_recover_gf128_pos(u64* out, const 
     o.x = (u64)r[0] | ((u64)r[1] << 32);
     o.y = (u64)r[2] | ((u64)r[3] << 32);
     __builtin_nontemporal_store(o, reinterpret_cast<u64x2*>(out + s * 2));
+    if (s + step >= N) break;
   }
 }
 

@@ -865,6 +865,117 @@ static void open_one_rank(std::size_t N, std::size_t n, std::size_t t, std::size
   REQUIRE(math::Vector<F>(partial) == math::Vector<F>(secrets));
 }
 
+// ---------------------------------------------------------------------------- math::Array<T, N>
+// test/scl/math/test_array.cc restated (the reference runs it over EC points and their scalar field; curve points are out of
+// scope here, so the value types are the scalar field FF<Secp256k1Scalar> and Fp<61>) and the sharing step of
+// pedersenSecretShare (include/scl/ss/pedersen.h:127-140): shamirSecretShare over Array<FF, 2>{{secret, randomness}}.
+TEST_CASE(array_host, "math::Array: default init / operations / text / read-write (test_array.cc)", HOST) {
+  using F = math::FF<math::ff::Secp256k1Scalar>;
+  const auto zero = F::zero();
+  math::Array<F, 3> q0;  // "Array default init"
+  REQUIRE(q0 == math::Array<F, 3>{{zero, zero, zero}});
+  math::Array<F, 3> p = {{F(1), F(2), F(4)}};  // "Array operations"
+  math::Array<F, 3> q = {{F(4), F(2), F(1)}};
+  REQUIRE(p + q == math::Array<F, 3>{{F(5), F(4), F(5)}});
+  REQUIRE(p - q == math::Array<F, 3>{{F(-3), F(0), F(3)}});
+  REQUIRE(p * q == math::Array<F, 3>{{F(4), F(4), F(4)}});
+  REQUIRE(q * p == math::Array<F, 3>{{F(4), F(4), F(4)}});
+  // scalar forms, increments, inverses, division (array.h:173-345)
+  REQUIRE(p * F(3) == math::Array<F, 3>{{F(3), F(6), F(12)}});
+  auto r = p;
+  r *= q;
+  REQUIRE(r == math::Array<F, 3>(F(4)));
+  REQUIRE((r / q) == p && (p.Inverse() * p) == math::Array<F, 3>::one());
+  auto inc = p;
+  REQUIRE((inc++) == p && inc == math::Array<F, 3>{{F(2), F(3), F(5)}} && (--inc) == p);
+  REQUIRE(math::Array<F, 3>(7) == math::Array<F, 3>{{F(7), F(7), F(7)}});
+  REQUIRE(math::Array<F, 3>(p).negate() + p == math::Array<F, 3>::zero());
+  REQUIRE(p != q && p[2] == F(4));
+  using A3F = math::Array<F, 3>;
+  REQUIRE_THROWS_MSG(A3F::zero().Inverse(), std::logic_error, "0 not invertible modulo prime");
+  // "Array to string": P{v0, v1}
+  math::Array<F61, 2> two = {{F61(10), F61(255)}};
+  REQUIRE(two.toString() == "P{a, ff}");
+  // "Array serialization": write / read round trip of a random Array (the reference goes through Serializer<Array>, which is
+  // these two members, array.h:439-455)
+  auto prg = util::PRG::create("prod seri");
+  const auto prod = math::Array<F, 3>::random(prg);
+  static_assert(math::Array<F, 3>::byteSize() == 96);
+  unsigned char buf[96];
+  prod.write(buf);
+  math::Array<F, 3> back;
+  REQUIRE(back != prod);
+  back = math::Array<F, 3>::read(buf);
+  REQUIRE(back == prod);
+  // Array::random draws its components one T::random at a time: for an FF that is one AES block each (array.h:93-101)
+  auto prg2 = util::PRG::create("prod seri");
+  REQUIRE(F::random(prg2) == prod[0] && F::random(prg2) == prod[1] && F::random(prg2) == prod[2]);
+}
+
+static const char* const kArray3Secrets[9] = {"064f6919aafaccbc", "0a629d5ac3357b6b", "0c74b1711771d2ae", "13dd036d5aec9b11", "13c6d3e817308642",
+                                              "03cdba09cbbe4853", "0f62b7361096e632", "1fa19d614c0ebb84", "15db71edd4bfd95b"};
+static const char* const kArray3Shares[45] = {
+    "14de80fe0bbb0370", "099cde9b097aec65", "09215287bd5784bd", "0df56060348d0b99", "10b65eee9a0e300f", "17996d10c5d924a3", "119407402570e536",
+    "1faf1e5574ef4669", "17dd010c30f6b261", "1fba759dde669047", "16871ccf9a1e2f74", "09ec0e79feb02df7", "1868ab795f6e0ccd", "153e5a5d099aeb2f",
+    "0dc6955a2f059764", "1f802f196ba120cf", "10510148e052db9f", "1a3bbbce52843fa9", "10b2adc223cbcb88", "1993121789c5868c", "030fe12528cf54d5",
+    "07747f67836c9b3b", "0f8d06541388870a", "1e4a2a0e4e9f87d4", "03c5a4098a838fe8", "123eddfe7d9bdd18", "0bea9689c3f4d8a9", "05a61ba83910a98f",
+    "01a89916c7ff88b7", "0bf1269788cf4752", "0ab21234697894c4", "0d365d9cda97bc28", "08fba206a5183b46", "1c66e10e8193a8b2", "0ee7907b22f6c374",
+    "1e2f0393673c1862", "048123c458e821fe", "04b535fc252bd169", "157596941b2b70b1", "0300da55ef7600a6", "0e9f4e1fe136e606", "0ecf5b08c0e64432",
+    "17e604c3453d44aa", "0ca5d8e65718014c", "0a3c50f1586c92e5"};
+
+TEST_CASE(array_sharing, "ss::shamirSecretShare over math::Array (the sharing step of pedersenSecretShare)", BOTH) {
+  // known answer from the reference itself (tests/golden/golden_v1.json, Mersenne61 shamir_packed[2]): W = 3, n = 5, t = 2,
+  // three secrets shared one after the other on PRG::create("array3")
+  using A3 = math::Array<F61, 3>;
+  auto prg = util::PRG::create("array3");
+  for (int s = 0; s < 3; ++s) {
+    const A3 secret = {{F61::fromString(kArray3Secrets[3 * s]), F61::fromString(kArray3Secrets[3 * s + 1]), F61::fromString(kArray3Secrets[3 * s + 2])}};
+    const auto shares = ss::shamirSecretShare(secret, 2, 5, prg);
+    REQUIRE(shares.size() == 5);
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 3; ++j) REQUIRE(shares[i][j] == F61::fromString(kArray3Shares[(s * 5 + i) * 3 + j]));
+    REQUIRE(ss::shamirRecoverP(shares) == secret);  // interpolation is component-wise too
+  }
+  // pedersen.h:137-138 as written there: {secret, randomness} over the curve's scalar field
+  using F = math::FF<math::ff::Secp256k1Scalar>;
+  auto prg2 = util::PRG::create("pedersen");
+  const F secret(123), randomness(456);
+  const math::Array<F, 2> sr = {{secret, randomness}};
+  const auto shares = ss::shamirSecretShare(sr, 3, 10, prg2);
+  REQUIRE(shares.size() == 10);
+  math::Vector<F> first(10), second(10);
+  for (std::size_t i = 0; i < 10; ++i) {
+    first[i] = shares[i][0];
+    second[i] = shares[i][1];
+  }
+  REQUIRE(ss::shamirRecoverP(first) == secret && ss::shamirRecoverP(second) == randomness);
+  REQUIRE(ss::shamirRecoverD(first.subVector(0, 7), 3) == secret);
+}
+
+TEST_CASE(array_sharing_gpu, "ss::shamirSecretShare over math::Array, batch (scl_hip_shamir_share_prg_packed)", GPU) {
+  // the batch form against the per-secret one on the same PRG, every secret, both components: Mersenne61 and secp256k1's order
+  auto run = [](auto tag, std::size_t N, std::size_t t, std::size_t n, const char* seed) {
+    using F = decltype(tag);
+    using A2 = math::Array<F, 2>;
+    auto src = util::PRG::create(std::string(seed) + "-secrets");
+    std::vector<A2> host;
+    for (std::size_t s = 0; s < N; ++s) host.push_back(A2::random(src));
+    auto prg_host = util::PRG::create(seed), prg_dev = util::PRG::create(seed);
+    const ss::ArrayVector<F, 2> dev{math::Vector<A2>(host)};
+    const auto batch = ss::shamirSecretShare(dev, t, n, prg_dev);
+    REQUIRE(batch.parties == n && batch.rows.parties() == 2 * n && batch.rows.secrets() == N);
+    std::size_t bad = 0;
+    for (std::size_t s = 0; s < N; ++s) {
+      const auto want = ss::shamirSecretShare(host[s], t, n, prg_host);
+      if (s % 37 == 0 || s + 1 == N) bad += !batch.sharesOf(s).equals(want);
+    }
+    REQUIRE(bad == 0);
+    REQUIRE(prg_dev.counter() == prg_host.counter());  // the batch advanced the PRG exactly as the N calls did
+  };
+  run(F61{}, 1501, 3, 10, "array-batch-61");
+  run(math::FF<math::ff::Secp256k1Scalar>{}, 301, 2, 7, "array-batch-secp");
+}
+
 TEST_CASE(open_rccl, "hip::open / openByPartialSums over a one-rank RCCL communicator", GPU) {
   // test/scl/protocol/beaver.h:43-55 opens by send-to-all / recv-from-all; the batch form over RCCL
   open_one_rank<F61>(5001, 10, 3, 2048, "open61");          // three chunks, the last one ragged and odd

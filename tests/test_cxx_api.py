@@ -72,3 +72,27 @@ def test_per_secret_signatures_through_the_kernels_for_comparison():
     host = _per_secret(["2000"])
     assert dev["mode"] == "device" and dev["mismatches"] == "0" and host["mismatches"] == "0"
     assert float(dev["share_ns"]) + float(dev["recover_ns"]) > 10 * (float(host["share_ns"]) + float(host["recover_ns"]))
+
+
+def test_reference_gf7_compiles_in_place_against_the_mirror(tmp_path):
+    """The reference's own example of its field plug-in boundary -- /root/reference/test/scl/gf7.h + gf7.cc:26-103, the traits
+    struct and the ff:: specialisations of the integers modulo 7 -- handed to the compiler WHERE THEY LIE, with an include
+    directory in which `scl` links to include/scl_hip: the reference's `#include "scl/math/fields/ff_ops.h"` resolves to the
+    mirror's.  Runs the reference's Berlekamp-Welch Wikipedia case (test/scl/ss/test_shamir.cc:144-160) and field / Vector /
+    sharing identities through FF<GaloisField7> on the mirror's generic host paths.  No reference file is copied."""
+    ref = "/root/reference/test/scl"
+    if not os.path.exists(os.path.join(ref, "gf7.cc")):
+        pytest.skip("the reference is not on this machine")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "secure-computation-library_amd", "csrc"), "-j8"], check=True)
+    alias = tmp_path / "alias"
+    alias.mkdir()
+    os.symlink(os.path.join(ROOT, "include", "scl_hip"), alias / "scl")
+    lib = os.path.join(ROOT, "secure-computation-library_amd", "scl_amd")
+    exe = str(tmp_path / "ref_gf7_inplace")
+    cmd = ["g++", "-std=c++20", "-O1", "-Wall", "-Wextra", "-Wno-unknown-pragmas", f"-I{alias}", f"-I{ROOT}/include", f"-I{ref}",
+           "-o", exe, os.path.join(CXX, "ref_gf7_inplace.cc"), os.path.join(ref, "gf7.cc"),
+           f"-L{lib}", "-lscl_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-4000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout + r.stderr

@@ -1081,6 +1081,21 @@ def test_open_step_on_one_rank_rccl(scl, port):
         dist.destroy_process_group()
 
 
+def test_reference_binding_compiled_against_the_reference():
+    """integration/include/scl/hip/binding.h -- the header INTEGRATION.md section 2 tells a maintainer of the reference to add --
+    compiled against the REAL reference (/root/reference/include + its translation units, oracle/Makefile `binding`; the
+    static_asserts on sizeof / alignment / standard layout of FF<Mersenne61 | Mersenne127 | Secp256k1Scalar | Secp256k1Field>
+    held at that build) and run here: reference Vector<FF> -> C ABI -> reference Vector<FF> equals the reference's own
+    multiplyEntryWise, N sequential shamirSecretShare calls on one PRG, and shamirRecoverP.  The binary is built where the
+    reference is and travels like oracle/_ref/libscl_ref.so."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "binding_check")
+    assert os.path.exists(exe), "oracle/_ref/binding_check is built by `make -C oracle binding` where /root/reference exists"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("[ ok ]") == 4 and "0 failure(s)" in r.stdout
+
+
 @pytest.mark.parametrize("world,f,n,t,N,chunk", [
     (2, O.M61, 10, 3, 5001, 1000),      # BASELINE configs[1]'s shape: 6 chunks, the last one a single (odd) secret
     (4, O.M61, 7, 2, 3001, 700),        # 7 parties on 4 ranks: two rows per rank, one padding row on the last
@@ -1443,10 +1458,27 @@ def test_bench_contract_small(scl):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--secrets", "300000", "--steps", "2", "--warmup", "1",
-                        "--cpu-sample", "2000", "--configs", "0", "--open-secrets", "50000", "--open-chunk", "20000"],
+                        "--cpu-sample", "2000", "--configs", "0", "--open-secrets", "50000", "--open-chunk", "20000",
+                        "--c4-rank-secrets", "60001"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
+    # the line tells the truth about its side legs: top-level verified = AND over the headline and every leg, the CPU model
+    # beside the core count, where the traffic figure comes from, and (below) a failed leg -> error listed, exit code 1
+    assert line["verified_headline"] is True and line["verified_legs"] and all(line["verified_legs"].values())
+    assert {"open.c4_all_gather", "open.c4_all_gather.c_abi", "open.c4_all_gather.partial_gather", "open.m61_partial_sums",
+            "open.c4_rank_shape"} <= set(line["verified_legs"])
+    assert "errors" not in line
+    assert line["cpu_baseline"]["cpu_model"] and line["cpu_baseline"]["host_cores_available"] >= 1
+    assert "pmc_traffic.json" in line["roofline"]["traffic_source"]
+    rs = line["open"]["c4_rank_shape"]
+    assert rs["verified"] is True and rs["partial_bytes_per_secret"] == 96 and rs["sum_bytes_per_secret"] == 144
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--secrets", "300000", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample", "0", "--configs", "0", "--open-secrets", "50000", "--open-chunk", "20000",
+                          "--c4-rank-secrets", "0", "--inject-error", "c_abi"], capture_output=True, text=True, timeout=600)
+    bl = json.loads(bad.stdout.strip().splitlines()[-1])
+    assert bad.returncode != 0 and bl["verified"] is False and bl["verified_headline"] is True
+    assert any("c_abi" in e for e in bl["errors"]) and bl["verified_legs"]["open.c4_all_gather.c_abi"] is False
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
@@ -1505,7 +1537,7 @@ def test_bench_two_ranks_rehearsal_on_one_device(scl):
     assert c4["verified"] and c4["parties_per_rank"] == 20 and c4["collective"] == "all_gather_into_tensor"
     assert c4["rccl_busbw_GBps"] > 0 and ps["verified"] and ps["collective"].startswith("reduce_scatter_tensor")
     assert "cpu_baseline" not in line and "configs" not in line
-    assert "skipped in the one-device rehearsal" in c4["c_abi"]["error"]
+    assert "skipped in the one-device rehearsal" in c4["c_abi"]["skipped"] and "errors" not in line
 
 
 @pytest.mark.parametrize("config,extra,check", [

@@ -1,5 +1,5 @@
-// tools/gfpos_bench.hip -- k_recover_gf128_pos (csrc/kernels.hpp) with its LDS reads one, two or three batches ahead of the
-// s_waitcnt that covers them (NBUF = 2, 3, 4), at C4's shard size, against k_recover_gf128 word for word.
+// tools/gfpos_bench.hip -- k_recover_gf128_pos (csrc/kernels.hpp) with compiler-visible LDS reads (the library's) and with the
+// hand-issued reads of rounds 2-3 one, two or three batches ahead of their s_waitcnt (tools/gfpos_asm.hpp, NBUF = 2, 3, 4), at C4's shard size, against k_recover_gf128 word for word.
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/_build/gfpos_bench tools/gfpos_bench.hip
 // usage: gfpos_bench [N=12500000] [m=40]
 #include <hip/hip_runtime.h>
@@ -8,7 +8,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../secure-computation-library_amd/csrc/kernels.hpp"
+#include "gfpos_asm.hpp"
 using namespace sclhip;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1);} } while (0)
 
@@ -68,10 +68,13 @@ int main(int argc, char** argv) {
     std::printf("%-46s %7.3f ms  %5.2f G secrets/s  %5.2f TB/s-equivalent (%.3f of 8)  differing words: %zu\n", name, ms, N / ms / 1e6,
                 (double)(m + 1) * 16 * N / ms / 1e9, (double)(m + 1) * 16 * N / ms / 1e9 / 8, diff);
   };
-  run(&k_recover_gf128_pos<512, 2, 2>, 512, 512, "pos tables, reads 1 batch ahead (shipped)");
-  run(&k_recover_gf128_pos<512, 2, 3>, 512, 512, "pos tables, reads 2 batches ahead");
-  run(&k_recover_gf128_pos<512, 2, 4>, 512, 512, "pos tables, reads 3 batches ahead");
-  run(&k_recover_gf128_pos<1024, 1, 3>, 1024, 256, "pos tables, 2 ahead, one 1024-thread workgroup");
-  run(&k_recover_gf128_pos<512, 2, 2>, 512, 512, "pos tables, reads 1 batch ahead (again)");
+  run(&k_recover_gf128_pos<512, 2>, 512, 512, "pos tables, compiler-visible reads (NBUF 0)");
+  run(&k_recover_gf128_pos<512, 2, GfposPipeAsm<2>>, 512, 512, "pos tables, asm reads 1 batch ahead (round 3)");
+  run(&k_recover_gf128_pos<512, 2>, 512, 512, "pos tables, compiler-visible reads (again)");
+  run(&k_recover_gf128_pos<1024, 1>, 1024, 256, "compiler-visible, one 1024-thread workgroup");
+  run(&k_recover_gf128_pos<512, 2, GfposPipeAsm<3>>, 512, 512, "pos tables, reads 2 batches ahead");
+  run(&k_recover_gf128_pos<512, 2, GfposPipeAsm<4>>, 512, 512, "pos tables, reads 3 batches ahead");
+  run(&k_recover_gf128_pos<1024, 1, GfposPipeAsm<3>>, 1024, 256, "pos tables, 2 ahead, one 1024-thread workgroup");
+  run(&k_recover_gf128_pos<512, 2, GfposPipeAsm<2>>, 512, 512, "pos tables, asm reads 1 batch ahead (again)");
   return 0;
 }
