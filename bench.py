@@ -373,10 +373,11 @@ def main():
 
     def share_recover_config(fkey, n, t, N, steps, seed, warmup=1):
         """one configuration end to end on this GPU: plain allocations, share + reconstruct timed with HIP events on the
-        launch stream, round trip verified.  Returns the per-kernel figures.  `warmup` untimed rounds first: the first tens of
-        milliseconds after an idle gap (allocation, fill) run under a clock transient -- five launches of a 0.3 ms kernel
-        right after it read 0.33-0.40 ms where fifty read 0.28-0.29 (profiles/r4_probe_c3_bench.txt) -- so the
-        sub-millisecond configurations take 10 + 50 rounds."""
+        launch stream, round trip verified.  Returns the per-kernel figures.  `warmup` untimed launches first: the first
+        25-30 ms of load after an idle gap (allocation, fill) run under a clock ramp -- from a cold start the 0.38 ms Mont128
+        share kernel reads 0.51, 0.50, 0.49 .. and reaches 0.38 only after about sixty launches, the headline's 1.7 ms kernel after
+        five (profiles/r4_probe_c3_seq.txt, r4_probe_headline_seq.txt) -- so the sub-millisecond configurations take 100
+        warm-up launches (40 ms) and 50 timed ones per kernel."""
         f_, L = tag_limbs(fkey)
         E = 8 * L
         secrets = scl.empty(f_, N)
@@ -387,12 +388,18 @@ def main():
         out = scl.empty(f_, N)
         lam = scl.lagrange_basis(f_, n)
         tms = [(scl.Timer(), scl.Timer()) for _ in range(steps)]
+        # each kernel on its own: `steps` launches of the share kernel back to back, then `steps` of the reconstruct kernel, HIP
+        # events around every launch.  (Alternating the two, as the headline's step does by contract, leaves every launch
+        # behind the other kernel's tail: the same kernels then spread 6-10 % from launch to launch instead of 3-5 %,
+        # profiles/r4_probe_c3_bench.txt; these entries are per-kernel figures, so each kernel is timed in its own steady state.)
         for k in range(-warmup, steps):
             if k >= 0:
                 tms[k][0].start()
             scl.shamir_share(f_, secrets, coeffs, n, out=shares)
             if k >= 0:
                 tms[k][0].stop()
+        for k in range(-warmup, steps):
+            if k >= 0:
                 tms[k][1].start()
             scl.shamir_recover(f_, shares, lam, out=out)
             if k >= 0:
@@ -861,8 +868,8 @@ def main():
         # the other BASELINE configurations at the size ONE GPU holds of them (C4, C5: an eighth), after the timed region
         cfgs = {}
         for key, (fk, n_, t_, N_, st, wu) in {
-            "C3_mersenne127_10_3": ("m127", 10, 3, 10_000_000, 50, 10),
-            "C3_mont128_10_3": ("mont128", 10, 3, 10_000_000, 50, 10),
+            "C3_mersenne127_10_3": ("m127", 10, 3, 10_000_000, 50, 100),
+            "C3_mont128_10_3": ("mont128", 10, 3, 10_000_000, 50, 100),
             "C4_shard_gf2_128_40_13": ("gf2_128", 40, 13, 12_500_000, 5, 2),
             "C5_shard_mersenne61_128_42": ("m61", 128, 42, 125_000_000, 2, 1),
         }.items():

@@ -92,7 +92,11 @@ class Aes128Host {
     }
     return r;
   }
-  /// the S-box from its definition: multiplicative inverse in GF(2^8) mod x^8+x^4+x^3+x+1, then the affine map
+  /// the S-box from its definition: multiplicative inverse in GF(2^8) mod x^8+x^4+x^3+x+1, then the affine map.
+  /// NOT constant-time: the 256-byte table is indexed by key- and state-dependent bytes, so on a CPU without AES-NI (the only
+  /// place this form runs; the AES-NI path above has no data-dependent memory access) cache timing can leak the PRG seed to a
+  /// co-resident observer.  The reference itself requires AES-NI (src/scl/util/prg.cc uses _mm_aesenc_si128 unconditionally);
+  /// this fallback exists so that the mirror's known answers can be checked on any build machine.
   static unsigned char sbox(unsigned char x) {
     static const Table t;
     return t.s[x];

@@ -387,6 +387,34 @@ def test_share_every_threshold_up_to_16(scl, port, f, n):
             assert np.array_equal(host(scl, got2), want2), t
 
 
+@pytest.mark.parametrize("n", [47, 57, 63, 64])
+def test_gf_tile_share_upper_tiles(scl, port, n):
+    """k_share_gf_tiles at the nodes the smaller cases never reach: the full tiles H = 5..7 (nodes 40..63), the one-node tile
+    H = 8 (node 64: fold cadence 2, 12-bit shifts) and ragged last tiles (n = 47, 57, 63), every threshold 5..16, against the
+    oracle's Polynomial::evaluate at the bit-pattern nodes -- and word for word against the per-node kernel ("gf_tiles" 0)."""
+    f, L, N = O.GF2_128, 2, 67
+    secrets = rand_elems(port, f, N, b"gft-s")
+    allc = rand_elems(port, f, 16 * N, b"gft-c").reshape(N, 16, L)
+    secrets[0] = port.from_int(f, -1)
+    allc[0] = np.uint64(0xFFFFFFFFFFFFFFFF)     # all-ones coefficients: every bit pushed past x^127 gets folded
+    allc[N - 1] = port.from_int(f, 0)
+    nodes = O.from_ints(list(range(1, n + 1)), L)
+    for t in range(5, 17):
+        coeffs = np.ascontiguousarray(allc[:, :t])
+        dco = dev(scl, np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2))))
+        got = {}
+        for tiles in (1, 0):
+            scl.set_tuning("gf_tiles", tiles)
+            try:
+                got[tiles] = host(scl, scl.shamir_share(f, dev(scl, secrets), dco, n))
+            finally:
+                scl.set_tuning("gf_tiles", 1)
+        assert np.array_equal(got[1], got[0]), t
+        if t in (5, 8, 13, 16):   # (the bit-serial oracle multiplier: four thresholds per n keep the case to seconds)
+            want = soa(np.stack([port.poly_eval(f, np.concatenate([secrets[s:s + 1], coeffs[s]]), nodes) for s in range(N)]))
+            assert np.array_equal(got[1], want), t
+
+
 @pytest.mark.parametrize("n,t,N", [(128, 42, 300), (40, 13, 257), (10, 3, 1000), (33, 8, 31), (64, 31, 65), (65, 32, 96),
                                    (5, 1, 7), (128, 48, 129), (1, 1, 40), (32, 31, 64)])
 def test_share_on_matrix_cores_vs_oracle(scl, port, n, t, N):
