@@ -41,6 +41,50 @@ __global__ __launch_bounds__(1024) void k_lds(u32* out, int iters) {
   out[blockIdx.x * 1024 + threadIdx.x] = acc;
 }
 
+// ---- 16-byte accesses (round 4): what a 64-lane ds_read_b128 / ds_write_b128 costs by address pattern ----------------------
+// MODE 0: lane l at byte 16 l (1 KiB contiguous per instruction: k_share_gf_tiles' per-lane coefficient slots)
+// MODE 1: lane l at byte 16 (hash(l) & 15) of a 256-byte table (k_recover_gf128_pos: a random entry of one bank row)
+// MODE 2: lane l at byte 16 l with the 16-byte slots of lanes 4 apart swapped in bank order ((l ^ (l >> 2 & 3)) ...): a swizzle
+// MODE 3: as 0, but ds_write_b128
+typedef u32 u32x4v __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_lds128(u32* out, int iters) {
+  __shared__ __attribute__((aligned(16))) u32 t[16384];
+  for (int i = threadIdx.x; i < 16384; i += 1024) t[i] = i * 2654435761u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  u32 slot = lane;
+  if (MODE == 1) slot = (lane * 2654435761u >> 13) & 15;
+  if (MODE == 2) slot = lane ^ ((lane >> 3) & 7);
+  const u32 a = (u32)(uintptr_t)t + 16 * slot;
+  u32x4v acc = {0, 0, 0, 0};
+  for (int i = 0; i < iters; ++i) {
+    if (MODE == 3) {
+      u32x4v v = acc;
+      asm volatile(
+          "ds_write_b128 %0, %1 offset:0\n\tds_write_b128 %0, %1 offset:1024\n\tds_write_b128 %0, %1 offset:2048\n\t"
+          "ds_write_b128 %0, %1 offset:3072\n\tds_write_b128 %0, %1 offset:4096\n\tds_write_b128 %0, %1 offset:5120\n\t"
+          "ds_write_b128 %0, %1 offset:6144\n\tds_write_b128 %0, %1 offset:7168\n\ts_waitcnt lgkmcnt(0)"
+          :
+          : "v"(a), "v"(v)
+          : "memory");
+      acc.x += 1;
+    } else {
+      u32x4v v[8];
+      asm volatile(
+          "ds_read_b128 %0, %8 offset:0\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\t"
+          "ds_read_b128 %3, %8 offset:3072\n\tds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\t"
+          "ds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:7168\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+          : "v"(a)
+          : "memory");
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc ^= v[u];
+    }
+  }
+  out[blockIdx.x * 1024 + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+
 int main() {
   u32* out;
   CK(hipMalloc(&out, 256 * 1024 * 4));
@@ -64,6 +108,22 @@ int main() {
   run(k_lds<1>, "lanes l and l+32: same word index mod 64, different address");
   run(k_lds<2>, "lanes l and l+32: word indices 32 apart mod 64");
   run(k_lds<3>, "all lanes one word");
+  auto run128 = [&](auto kern, const char* name) {
+    hipLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, out, iters);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, out, iters);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double instr_per_cu = 16.0 * iters * 8;
+    std::printf("%-64s %7.3f ms  %5.2f cycles per 16-byte instruction per CU at 2.4 GHz\n", name, ms, ms * 1e-3 * 2.4e9 / instr_per_cu);
+  };
+  run128(k_lds128<0>, "ds_read_b128, lane l at byte 16 l (1 KiB contiguous)");
+  run128(k_lds128<1>, "ds_read_b128, every lane a random entry of one 256-byte table");
+  run128(k_lds128<2>, "ds_read_b128, 16 l with slots swizzled within groups of 8");
+  run128(k_lds128<3>, "ds_write_b128, lane l at byte 16 l (1 KiB contiguous)");
   CK(hipGetLastError());
   return 0;
 }
