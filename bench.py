@@ -93,6 +93,9 @@ def parse_args(argv=None):
     ap.add_argument("--total-secrets", type=int, default=0, help="--config c4 / c5: total over all ranks (default 10^8 / 10^9)")
     ap.add_argument("--c4-rank-secrets", type=int, default=100_000_000,
                     help="open.c4_rank_shape: secrets of the one-rank-of-eight shape of BASELINE configs[3] (0 = skip)")
+    ap.add_argument("--pmc-live", type=int, default=1,
+                    help="1: roofline.traffic observed in THIS run -- two child runs of the headline under rocprofv3 --pmc FETCH_SIZE / "
+                         "WRITE_SIZE after everything else (one GPU, BASELINE configs[1] only; falls back to profiles/pmc_traffic.json)")
     ap.add_argument("--inject-error", default="", choices=["", "c_abi"],
                     help="tests only: make the named side leg fail, to see the line report it and the exit code follow")
     return ap.parse_args(argv)
@@ -270,6 +273,76 @@ def pmc_config_traffic(key):
                 "share_kernel": c["share"]["kernel"], "recover_kernel": c["recover"]["kernel"]}
     except Exception:
         return None
+
+
+PMC_NEEDLES = {"shamir_share": "k_share_small_t<sclhip::M61", "shamir_recover": "k_recover_fixed<sclhip::M61"}
+
+
+def live_pmc_traffic(args, timeout_s=150):
+    """HBM bytes per launch of the headline's two kernels, OBSERVED in this run: two child processes run the headline alone
+    (3 steps, no side legs) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (the two cannot share a pass on gfx950;
+    no trace domain is combined with --pmc), and the per-kernel counter means are read from their CSVs.  FETCH_SIZE is doubled
+    as MI355X_MICROARCH.md's HBM section prescribes for 16-byte-per-lane streaming reads, and that factor is CHECKED in the
+    same pass on k_copy16 (the bench's copy probe, whose byte count is known).  The program itself follows `--`.  Children of
+    this process, started after every timed region; any failure returns None (the stamped figure is then quoted)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ):   # this process is itself being profiled: no nesting
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--configs", "0", "--open", "0", "--cpu-sample", "0", "--pmc-live", "0",
+             "--steps", "3", "--warmup", "1", "--field", args.field, "--n", str(args.n), "--t", str(args.t),
+             "--secrets", str(args.secrets), "--share-mode", args.share_mode]
+    env = dict(os.environ, TMPDIR="/tmp")
+    out = {}
+    work = tempfile.mkdtemp(prefix="scl_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            p = subprocess.Popen([exe, "--pmc", counter, "-d", d, "--output-format", "csv", "--"] + child, cwd="/tmp", env=env,
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)      # exactly the process group this call started
+                p.wait()
+                return None
+            if rc != 0:
+                return None
+            acc = defaultdict(list)
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter:
+                            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            means = {}
+            for k, v in acc.items():
+                big = [x for x in v if x >= 0.5 * max(v)]   # launches of the largest size only
+                means[k] = (sum(big) / len(big), len(big))
+            out[counter] = means
+
+        def pick(counter, needle):
+            hits = [v for k, v in out[counter].items() if needle in k]
+            return hits[0] if len(hits) == 1 else None
+        copy_bytes = float(min(4 << 30, args.n * args.secrets * 8 * (1 if args.field == "m61" else 2) // 2) & ~15)
+        cf = pick("FETCH_SIZE", "k_copy16")
+        res = {"fetch_doubled": True, "fetch_correction_measured_on_k_copy16": (copy_bytes / (cf[0] * 1024.0)) if cf else None}
+        for key, needle in PMC_NEEDLES.items():
+            f, w = pick("FETCH_SIZE", needle), pick("WRITE_SIZE", needle)
+            if f is None or w is None:
+                return None
+            res[key] = {"bytes": int(round(2 * f[0] * 1024 + w[0] * 1024)), "fetch_kib_reported": f[0], "write_kib": w[0],
+                        "launches": min(f[1], w[1])}
+        return res
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def main():
@@ -882,6 +955,19 @@ def main():
         line["configs"] = cfgs
     if world == 1 and args.cpu_sample > 0:
         line["cpu_baseline"] = cpu_baseline(args.field, n, t, args.cpu_sample)
+    if (world == 1 and args.pmc_live and pl["key"] == "c2" and roofline.get("bound") == "hbm"
+            and (args.field, args.n, args.t, args.share_mode) == ("m61", 10, 3, "coeffs") and args.secrets >= 10_000_000):
+        torch.cuda.empty_cache()
+        live = live_pmc_traffic(args)
+        if live is not None:
+            roofline["traffic_stamped"] = roofline["traffic"]
+            roofline["traffic"] = live[dom]["bytes"]
+            roofline["traffic_over_algorithmic"] = live[dom]["bytes"] / roofline["algorithmic_bytes"]
+            roofline["traffic_live"] = live
+            roofline["traffic_source"] = ("observed in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over two "
+                                          "child runs of this command's headline (3 steps each, after the timed region), mean per launch; "
+                                          "FETCH_SIZE doubled per MI355X_MICROARCH.md and checked on k_copy16 in the same pass; "
+                                          "traffic_stamped = the builder's figure from profiles/pmc_traffic.json")
     # the line tells the truth about its side legs: `verified` is the AND over the headline and every leg that ran, and a
     # leg that failed (an {"error": ..} object anywhere in the line) makes the process exit non-zero AFTER the line is out
     legs, errors = side_legs(line)

@@ -1521,6 +1521,28 @@ def test_bench_contract_small(scl):
     assert line["roofline"]["traffic"] is None
 
 
+def test_bench_observes_its_hbm_traffic(scl):
+    """roofline.traffic is OBSERVED by the run that prints it: after its timed regions bench.py runs the headline alone twice
+    as a child under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (no trace domain beside --pmc; the program itself after
+    `--`) and reads the two kernels' counters; the doubling of FETCH_SIZE is checked on k_copy16 in the same pass.  At 10^7
+    secrets here: traffic = the algorithmic bytes within 1 %."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--secrets", "10000000", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "0", "--configs", "0", "--open", "0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    rf = line["roofline"]
+    assert "observed in this run" in rf["traffic_source"], rf["traffic_source"]
+    live = rf["traffic_live"]
+    assert abs(live["fetch_correction_measured_on_k_copy16"] - 2.0) < 0.02
+    assert abs(live["shamir_share"]["bytes"] / (112 * 10**7) - 1) < 1e-2 and abs(live["shamir_recover"]["bytes"] / (88 * 10**7) - 1) < 1e-2
+    assert rf["traffic"] == live[rf["kernel"]]["bytes"] and abs(rf["traffic_over_algorithmic"] - 1) < 1e-2
+    assert rf["traffic_stamped"] is None     # the stamped file describes 10^8 secrets only
+
+
 def test_bench_open_mode_line(scl):
     """--mode open: the exchange step alone (reference: Network::send + Network::recv, include/scl/net/network.h:148-185),
     with the collective's bandwidth fields beside the reconstruct kernel's HBM fraction"""
