@@ -276,32 +276,89 @@ def pmc_config_traffic(key):
 
 
 PMC_NEEDLES = {"shamir_share": "k_share_small_t<sclhip::M61", "shamir_recover": "k_recover_fixed<sclhip::M61"}
+# the side configurations by the kernels they launch, with their algorithmic bytes per launch (share, reconstruct)
+PMC_CONFIGS = {
+    "C3_mersenne127_10_3": ("k_share_small_t<sclhip::M127", "k_recover_fixed<sclhip::M127", (224 * 10**7, 176 * 10**7)),
+    "C3_mont128_10_3": ("k_share_small_t<sclhip::Mont128", "k_recover_table<sclhip::Mont128", (224 * 10**7, 176 * 10**7)),
+    "C4_shard_gf2_128_40_13": ("k_share_gf_tiles<13>", "k_recover_gf128_pos<512", (864 * 125 * 10**5, 656 * 125 * 10**5)),
+    "C5_shard_mersenne61_128_42": ("k_share_mfma_m61", "k_recover_table<sclhip::M61", (1368 * 125 * 10**6, 1032 * 125 * 10**6)),
+}
 
 
-def live_pmc_traffic(args, timeout_s=150):
-    """HBM bytes per launch of the headline's two kernels, OBSERVED in this run: two child processes run the headline alone
-    (3 steps, no side legs) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (the two cannot share a pass on gfx950;
-    no trace domain is combined with --pmc), and the per-kernel counter means are read from their CSVs.  FETCH_SIZE is doubled
-    as MI355X_MICROARCH.md's HBM section prescribes for 16-byte-per-lane streaming reads, and that factor is CHECKED in the
-    same pass on k_copy16 (the bench's copy probe, whose byte count is known).  The program itself follows `--`.  Children of
-    this process, started after every timed region; any failure returns None (the stamped figure is then quoted)."""
+def pmc_means(d, counter):
+    """{kernel name: (mean counter value over the launches of the largest size, their number)} from a rocprofv3 --pmc output
+    directory.  One kernel may run at several sizes in a bench run (the first-use self-check of the GF(2^128) reconstruct kernel
+    is a 4096-secret launch of the kernel C4 then runs at 1.25e7): launches within a factor of two of the maximum count."""
     import csv
     import glob
+    from collections import defaultdict
+    acc = defaultdict(list)
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] == counter:
+                    acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    out = {}
+    for k, v in acc.items():
+        big = [x for x in v if x >= 0.5 * max(v)]
+        out[k] = (sum(big) / len(big), len(big))
+    return out
+
+
+def pmc_report(fetch, write, copy_bytes):
+    """HBM bytes per launch of the headline's two kernels and of every side configuration's whose kernels are in the passes,
+    from the two tables of pmc_means.  Counters are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: it reports
+    half the bytes of 16-byte-per-lane streaming reads) and the factor is checked on k_copy16, whose byte count is known."""
+    def pick(table, needle):
+        hits = [(k, v) for k, v in table.items() if needle in k]
+        return hits[0] if len(hits) == 1 else None
+
+    def entry(needle):
+        f, w = pick(fetch, needle), pick(write, needle)
+        if f is None or w is None:
+            return None
+        name, (f_kib, nl) = f
+        w_kib = w[1][0]
+        return {"kernel": name.split("(")[0].replace("void ", ""), "launches": nl, "fetch_kib_reported": f_kib, "write_kib": w_kib,
+                "bytes": int(round(2 * f_kib * 1024 + w_kib * 1024))}
+    out = {}
+    cf, cw = pick(fetch, "k_copy16"), pick(write, "k_copy16")
+    if cf and cw:
+        out["calibration_k_copy16"] = {"bytes_read_per_launch": copy_bytes, "fetch_kib_reported": cf[1][0], "write_kib": cw[1][0],
+                                       "fetch_correction": copy_bytes / (cf[1][0] * 1024.0), "launches": cf[1][1]}
+    for key, needle in PMC_NEEDLES.items():
+        out[key] = entry(needle)
+    out["configs"] = {}
+    for cfg, (share_needle, rec_needle, algo) in PMC_CONFIGS.items():
+        sh, rc = entry(share_needle), entry(rec_needle)
+        if sh is None or rc is None:
+            continue
+        sh["algorithmic_bytes"], rc["algorithmic_bytes"] = algo
+        sh["traffic_over_algorithmic"], rc["traffic_over_algorithmic"] = sh["bytes"] / algo[0], rc["bytes"] / algo[1]
+        out["configs"][cfg] = {"share": sh, "recover": rc}
+    return out
+
+
+def live_pmc_traffic(args, timeout_s=240):
+    """HBM bytes per launch OBSERVED in this run: two child processes run this command's GPU legs once more (headline 3 steps,
+    the side configurations when --configs is on; no open step, no CPU baseline) under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (the two cannot share a pass on gfx950; no trace domain is combined with --pmc), and pmc_report reads the
+    kernels' counter means from their CSVs.  The program itself follows `--`.  Children of this process, started after every
+    timed region; any failure returns None (the stamped figures are then quoted)."""
     import shutil
     import tempfile
-    from collections import defaultdict
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
     if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ):   # this process is itself being profiled: no nesting
         return None
-    child = [sys.executable, os.path.abspath(__file__), "--configs", "0", "--open", "0", "--cpu-sample", "0", "--pmc-live", "0",
-             "--steps", "3", "--warmup", "1", "--field", args.field, "--n", str(args.n), "--t", str(args.t),
+    child = [sys.executable, os.path.abspath(__file__), "--configs", str(args.configs), "--open", "0", "--cpu-sample", "0",
+             "--pmc-live", "0", "--steps", "3", "--warmup", "1", "--field", args.field, "--n", str(args.n), "--t", str(args.t),
              "--secrets", str(args.secrets), "--share-mode", args.share_mode]
     env = dict(os.environ, TMPDIR="/tmp")
-    out = {}
     work = tempfile.mkdtemp(prefix="scl_pmc_", dir="/tmp")
     try:
+        tables = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(work, counter)
             p = subprocess.Popen([exe, "--pmc", counter, "-d", d, "--output-format", "csv", "--"] + child, cwd="/tmp", env=env,
@@ -314,31 +371,12 @@ def live_pmc_traffic(args, timeout_s=150):
                 return None
             if rc != 0:
                 return None
-            acc = defaultdict(list)
-            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                with open(path) as fh:
-                    for row in csv.DictReader(fh):
-                        if row["Counter_Name"] == counter:
-                            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
-            means = {}
-            for k, v in acc.items():
-                big = [x for x in v if x >= 0.5 * max(v)]   # launches of the largest size only
-                means[k] = (sum(big) / len(big), len(big))
-            out[counter] = means
-
-        def pick(counter, needle):
-            hits = [v for k, v in out[counter].items() if needle in k]
-            return hits[0] if len(hits) == 1 else None
+            tables[counter] = pmc_means(d, counter)
         copy_bytes = float(min(4 << 30, args.n * args.secrets * 8 * (1 if args.field == "m61" else 2) // 2) & ~15)
-        cf = pick("FETCH_SIZE", "k_copy16")
-        res = {"fetch_doubled": True, "fetch_correction_measured_on_k_copy16": (copy_bytes / (cf[0] * 1024.0)) if cf else None}
-        for key, needle in PMC_NEEDLES.items():
-            f, w = pick("FETCH_SIZE", needle), pick("WRITE_SIZE", needle)
-            if f is None or w is None:
-                return None
-            res[key] = {"bytes": int(round(2 * f[0] * 1024 + w[0] * 1024)), "fetch_kib_reported": f[0], "write_kib": w[0],
-                        "launches": min(f[1], w[1])}
-        return res
+        rep = pmc_report(tables["FETCH_SIZE"], tables["WRITE_SIZE"], copy_bytes)
+        if rep.get("shamir_share") is None or rep.get("shamir_recover") is None:
+            return None
+        return rep
     except Exception:
         return None
     finally:
@@ -960,14 +998,24 @@ def main():
         torch.cuda.empty_cache()
         live = live_pmc_traffic(args)
         if live is not None:
+            cal = live.get("calibration_k_copy16", {})
             roofline["traffic_stamped"] = roofline["traffic"]
             roofline["traffic"] = live[dom]["bytes"]
             roofline["traffic_over_algorithmic"] = live[dom]["bytes"] / roofline["algorithmic_bytes"]
-            roofline["traffic_live"] = live
+            roofline["traffic_live"] = {"fetch_doubled": True, "fetch_correction_measured_on_k_copy16": cal.get("fetch_correction"),
+                                        "shamir_share": live["shamir_share"], "shamir_recover": live["shamir_recover"]}
             roofline["traffic_source"] = ("observed in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over two "
-                                          "child runs of this command's headline (3 steps each, after the timed region), mean per launch; "
-                                          "FETCH_SIZE doubled per MI355X_MICROARCH.md and checked on k_copy16 in the same pass; "
+                                          "child runs of this command's GPU legs (headline 3 steps, after the timed regions), mean per "
+                                          "launch; FETCH_SIZE doubled per MI355X_MICROARCH.md and checked on k_copy16 in the same pass; "
                                           "traffic_stamped = the builder's figure from profiles/pmc_traffic.json")
+            for key, c in live.get("configs", {}).items():   # the side configurations' kernels, from the same two passes
+                if key in line.get("configs", {}) and "error" not in line["configs"][key]:
+                    line["configs"][key]["traffic_stamped"] = line["configs"][key].get("traffic")
+                    line["configs"][key]["traffic"] = {"share": c["share"]["bytes"], "recover": c["recover"]["bytes"],
+                                                       "share_kernel": c["share"]["kernel"], "recover_kernel": c["recover"]["kernel"],
+                                                       "share_over_algorithmic": c["share"]["traffic_over_algorithmic"],
+                                                       "recover_over_algorithmic": c["recover"]["traffic_over_algorithmic"],
+                                                       "source": "observed in this run (roofline.traffic_source)"}
     # the line tells the truth about its side legs: `verified` is the AND over the headline and every leg that ran, and a
     # leg that failed (an {"error": ..} object anywhere in the line) makes the process exit non-zero AFTER the line is out
     legs, errors = side_legs(line)
