@@ -434,7 +434,7 @@ struct Mont128 {
   struct Ctx {
     u128 p, mc, one, r2;  // modulus, -p^-1 mod R, R mod p, R^2 mod p
     u128 k32;             // 2^32 * R mod p (undoes the extra word of the lazy accumulator's reduction)
-    u64 bmu;              // floor(2^160 / p) for a full-width modulus (p >= 2^127), else 0: the small-node quotient estimate
+    u64 bmu;              // floor(2^162 / p) for a full-width modulus (p >= 2^127), else 0: the small-node quotient estimate
   };
   enum { LIMBS = 2, ACC_TERMS = 1 << 24, TAG = 2 };
 
@@ -455,10 +455,10 @@ struct Mont128 {
     c.r2 = r;
     c.k32 = mul(c, (u128)1 << 32, c.r2);
     c.bmu = 0;
-    if (p >> 127) {  // long division of 2^160 by p: the quotient has 33 or 34 bits
+    if (p >> 127) {  // long division of 2^162 by p: the quotient has 35 or 36 bits
       u128 rem = 1;
       u64 q = 0;
-      for (int i = 0; i < 160; ++i) {
+      for (int i = 0; i < 162; ++i) {
         const bool top = (rem >> 127) != 0;
         rem <<= 1;
         q <<= 1;
@@ -510,9 +510,10 @@ struct Mont128 {
   // Montgomery form, (x R) v = (x v) R, so share_i = sum_k c_k v_ik needs no Montgomery product: four 32 x 32
   // multiply-adds per term into per-limb 64-bit sums (seven terms of v < 2^29 cannot overflow them), then ONE reduction
   // of the < 2^160 sum S.  For a full-width modulus (2^127 <= p < 2^128, Ctx::bmu != 0) that is a Barrett step:
-  // q' = floor(floor(S / 2^96) * bmu / 2^64) satisfies q - 2 <= q' <= q for q = floor(S / p) < 2^32, so
-  // S - q' p < 3p takes two conditional subtractions.  (ff_ops_gmp.h:174-191 reaches the same residue one
-  // montyModMul and one montyModAdd at a time.)
+  // q' = floor(floor(S / 2^96) * bmu / 2^66), bmu = floor(2^162 / p), satisfies q - 1 <= q' <= q for q = floor(S / p) < 2^32
+  // (both factors are rounded down, so q' <= q; the truncation of S costs < 2^96 / p <= 2^-31 and that of bmu
+  // < floor(S / 2^96) / 2^66 < 1/4), so S - q' p < 2p takes ONE conditional subtraction (round 4; two with bmu = floor(2^160 / p)).
+  // (ff_ops_gmp.h:174-191 reaches the same residue one montyModMul and one montyModAdd at a time.)
   struct SAcc {
     u64 a[4];
   };
@@ -536,7 +537,7 @@ struct Mont128 {
     l4 += l3 >> 32;  // < 2^32: S < p * 2^32 < 2^160
     const u128 slo = (u128)((u64)(u32)l0 | (l1 << 32)) | ((u128)((u64)(u32)l2 | (l3 << 32)) << 64);
     const u64 sh = (u64)(u32)l3 | (l4 << 32);  // floor(S / 2^96)
-    const u32 q = (u32)(u64)(((u128)sh * c.bmu) >> 64);
+    const u32 q = (u32)(u64)(((u128)sh * c.bmu) >> 66);
     const u32 p0 = (u32)c.p, p1 = (u32)(c.p >> 32), p2 = (u32)(c.p >> 64), p3 = (u32)(c.p >> 96);
     u64 t0 = 0, t1, t2, t3;
     mad32(t0, q, p0);
@@ -548,14 +549,8 @@ struct Mont128 {
     mad32(t3, q, p3);
     const u128 qlo = (u128)((u64)(u32)t0 | (t1 << 32)) | ((u128)((u64)(u32)t2 | (t3 << 32)) << 64);
     u128 r = slo - qlo;
-    u32 rh = (u32)l4 - (u32)(t3 >> 32) - (slo < qlo ? 1u : 0u);  // S - q p < 3p: rh <= 2
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (rh || r >= c.p) {
-        rh -= r < c.p ? 1u : 0u;
-        r -= c.p;
-      }
-    }
+    const u32 rh = (u32)l4 - (u32)(t3 >> 32) - (slo < qlo ? 1u : 0u);  // S - q p < 2p: rh <= 1
+    if (rh || r >= c.p) r -= c.p;
     return r;
   }
   enum { SMALL_NODE_VALUE_BITS = 29 };

@@ -96,3 +96,16 @@ def test_reference_gf7_compiles_in_place_against_the_mirror(tmp_path):
     assert b.returncode == 0, b.stderr[-4000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout + r.stderr
+
+
+def test_mont128_small_node_fold_against_long_arithmetic(tmp_path):
+    """Mont128::sacc_fold -- the one reduction of the small-node share kernel for the 128-bit Montgomery prime, since round 4 with
+    a quotient estimate sharp enough for ONE conditional subtraction -- on two million sums with extreme operands and five
+    full-width moduli, against a 192-bit sum reduced bit by bit (tests/cxx/mont128_fold_check.cc).  The GPU half of the same
+    arithmetic: tests/test_plugin_field_pins.py (Python big integers) and every Mont128 sharing test."""
+    exe = str(tmp_path / "mont128_fold_check")
+    b = subprocess.run(["g++", "-std=c++20", "-O2", f"-I{ROOT}/include", "-o", exe, os.path.join(CXX, "mont128_fold_check.cc")],
+                       capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout + r.stderr
