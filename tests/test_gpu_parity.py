@@ -1109,6 +1109,81 @@ def test_open_step_on_one_rank_rccl(scl, port):
         dist.destroy_process_group()
 
 
+def test_six_host_threads_on_their_own_streams(scl, port):
+    """include/scl_hip.h, Conventions: "callable concurrently from several host threads on different streams"; the only mutable
+    state is per thread (tuning knobs, the Mont128 modulus, scratch and temporary arenas, the last error) or behind a mutex
+    (device table caches).  Since round 4 that state lives in ONE translation unit and is `extern thread_local` in the six
+    others -- this is its test: six threads, each on its own torch stream with its own field, shape, knobs and (for Mont128)
+    modulus, run share -> reconstruct -> detect / sum / dot loops at the same time; every result must equal what the same
+    calls give one after the other on the main thread, which in turn is checked against the oracle on a window.  Two of the
+    threads share (128, 42) Mersenne61 on the matrix cores at once (one cached table, pinned by both), two set different
+    Mont128 primes, one provokes an error and must read ITS text from scl_hip_last_error."""
+    import threading
+    jobs = [
+        dict(f=O.M61, n=10, t=3, N=200_001, knobs={}),
+        dict(f=O.M61, n=128, t=42, N=4_097, knobs={"stream_block": 256}),
+        dict(f=O.M61, n=128, t=42, N=3_001, knobs={"nontemporal": 0}),
+        dict(f=O.MONT128, n=10, t=3, N=50_001, knobs={}, prime=2 ** 128 - 159),
+        dict(f=O.MONT128, n=7, t=2, N=40_001, knobs={"share_waves128": 0}, prime=2 ** 127 - 1),   # (below 2^127: the Vandermonde-row share kernel instead of the small-node one)
+        dict(f=O.GF2_128, n=40, t=13, N=9_001, knobs={"gf_tiles": 0}),
+    ]
+
+    def run(job, seed):
+        f, n, t, N = job["f"], job["n"], job["t"], job["N"]
+        for k, v in job["knobs"].items():
+            scl.set_tuning(k, v)
+        if "prime" in job:
+            scl.set_mont128_prime(job["prime"])
+        out = []
+        for rep in range(3):
+            secrets = scl.vector_random(f, N, seed + b"-s%d" % rep)
+            coeffs = scl.vector_random(f, t * N, seed + b"-c%d" % rep).reshape(t, N, -1)
+            shares = scl.shamir_share(f, secrets, coeffs, n)
+            rec = scl.shamir_recover(f, shares)
+            assert scl.equals(f, rec, secrets)
+            out.append((scl.to_host(shares[n - 1, :64]).copy(), scl.vsum(f, rec).copy(), scl.dot(f, shares[0], shares[1]).copy()))
+        if f == O.M61 and n == 10:   # an error on this thread: its own text, whatever the others are doing
+            with pytest.raises(scl.SclError) as ei:
+                scl.ew(f, scl.INV, scl.to_device(np.zeros((4, 1), dtype=np.uint64)))
+            assert "0 not invertible modulo prime" in str(ei.value)
+            out.append(scl.lib.scl_hip_last_error())
+        for k in job["knobs"]:
+            scl.set_tuning(k, {"stream_block": 64, "nontemporal": 1, "share_waves128": 12, "gf_tiles": 1}[k])
+        return out
+
+    want = [run(job, b"thr%d" % i) for i, job in enumerate(jobs)]      # one after the other, main thread
+    scl.set_mont128_prime(2 ** 128 - 159)
+    # oracle window on the first job (the others' kernels have their own oracle tests)
+    sec = port.vector_random(O.M61, b"thr0-s0", 64)
+    co = port.vector_random(O.M61, b"thr0-c0", 3 * 200_001).reshape(3, 200_001, 1)[:, :64]
+    assert np.array_equal(want[0][0][0], soa(port.shamir_share_coeffs(O.M61, sec, np.ascontiguousarray(np.transpose(co, (1, 0, 2))), 10))[9])
+    got, errs = [None] * len(jobs), []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                got[i] = run(jobs[i], b"thr%d" % i)
+                torch.cuda.current_stream().synchronize()
+            scl.lib.scl_hip_thread_cleanup()
+        except BaseException as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    for _ in range(2):
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join(timeout=300)
+        assert not errs and not any(th.is_alive() for th in ths), errs
+        for i in range(len(jobs)):
+            for a, b in zip(got[i], want[i]):
+                if isinstance(a, tuple):
+                    assert all(np.array_equal(x, y) for x, y in zip(a, b)), i
+                else:
+                    assert a == b, i
+
+
 def test_reference_binding_compiled_against_the_reference():
     """integration/include/scl/hip/binding.h -- the header INTEGRATION.md section 2 tells a maintainer of the reference to add --
     compiled against the REAL reference (/root/reference/include + its translation units, oracle/Makefile `binding`; the
