@@ -11,6 +11,7 @@
 #include <functional>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <scl_hip/scl.h>
@@ -865,6 +866,64 @@ static void open_one_rank(std::size_t N, std::size_t n, std::size_t t, std::size
   REQUIRE(math::Vector<F>(partial) == math::Vector<F>(secrets));
 }
 
+// The same two opens with world > 1: the ranks are host threads of this process on one device, RCCL is the test-only stand-in
+// tests/cxx/fake_rccl.cc (the library binds it when SCL_HIP_RCCL_LIBRARY names it; tests/test_cxx_api.py runs this binary
+// with it and `--open-world`).  Each rank holds its block of parties' rows (plus padding rows of ones), every rank must end
+// with every secret -- through hip::Communicator / hip::open / hip::openByPartialSums, the C++ mirror of the C ABI's open.
+template <typename F>
+static void open_world(int world, std::size_t N, std::size_t n, std::size_t t, std::size_t chunk, const char* seed) {
+  constexpr std::size_t L = hip::limbsOf<F>();
+  std::vector<F> secrets;
+  for (std::size_t s = 0; s < N; ++s) secrets.emplace_back((int)(s * 2246822519u >> 1));
+  auto prg = util::PRG::create(seed);
+  const hip::DeviceVector<F> dsec(secrets);
+  const auto full = ss::shamirSecretShare(dsec, t, n, prg);  // [n][N] on the device
+  std::vector<std::uint64_t> host(n * N * L);                // .. and on the host: the ranks upload their rows from it
+  hip::check(scl_hip_memcpy_d2h(host.data(), full.data(), host.size() * 8, nullptr));
+  const auto lambda = math::computeLagrangeBasis(math::Vector<F>::range(1, n + 1), F{});
+  const auto id = hip::Communicator::uniqueId();
+  std::vector<int> ok(world, 0);
+  std::vector<std::string> errs(world);
+  std::vector<std::thread> ranks;
+  for (int r = 0; r < world; ++r)
+    ranks.emplace_back([&, r] {
+      try {
+        hip::Communicator comm(world, r, id);
+        const std::size_t per = comm.partiesPerRank(n);
+        const auto [first, count] = comm.partySlab(n);
+        hip::ShareMatrix<F> slab(per, N), mine(count, N);
+        hip::check(scl_hip_memset(slab.data(), 0xFF, per * N * L * 8, nullptr));  // padding rows: never read, never sent
+        if (count) {
+          hip::check(scl_hip_memcpy_h2d(slab.data(), host.data() + first * N * L, count * N * L * 8, nullptr));
+          hip::check(scl_hip_memcpy_h2d(mine.data(), host.data() + first * N * L, count * N * L * 8, nullptr));
+        }
+        hip::check(scl_hip_stream_sync(nullptr));
+        const auto a = hip::open(comm, slab, n, chunk).toHost();
+        const auto b = hip::openByPartialSums(comm, mine, n, lambda, chunk).toHost();
+        ok[r] = math::Vector<F>(a) == math::Vector<F>(secrets) && math::Vector<F>(b) == math::Vector<F>(secrets);
+      } catch (const std::exception& e) {
+        errs[r] = e.what();
+      }
+    });
+  for (auto& th : ranks) th.join();
+  for (int r = 0; r < world; ++r) {
+    if (!errs[r].empty()) std::printf("  rank %d: %s\n", r, errs[r].c_str());
+    REQUIRE(ok[r] == 1);
+  }
+}
+
+TEST_CASE(open_world_threads, "hip::open / openByPartialSums over a world of host threads (fake RCCL)", GPU) {
+  if (!std::getenv("SCL_HIP_RCCL_LIBRARY")) {
+    std::printf("  (skipped: SCL_HIP_RCCL_LIBRARY does not name the stand-in; tests/test_cxx_api.py runs it)\n");
+    return;
+  }
+  open_world<F61>(2, 5001, 10, 3, 2048, "world61");                              // three chunks, a ragged odd last one
+  open_world<F61>(4, 3001, 7, 2, 1000, "world61b");                              // 7 parties on 4 ranks: a padding row
+  open_world<F127>(3, 2001, 10, 3, 512, "world127");
+  open_world<math::FF<math::ff::GF2_128>>(8, 1501, 40, 13, 400, "worldgf");       // five parties per rank
+  open_world<F61>(8, 1001, 10, 3, 300, "world61c");                              // ranks 5..7 hold nothing
+}
+
 // ---------------------------------------------------------------------------- math::Array<T, N>
 // test/scl/math/test_array.cc restated (the reference runs it over EC points and their scalar field; curve points are out of
 // scope here, so the value types are the scalar field FF<Secp256k1Scalar> and Fp<61>) and the sharing step of
@@ -1005,9 +1064,15 @@ int main(int argc, char** argv) {
     std::printf("[%s] %s%s\n", g_fail == before ? " ok " : "FAIL", c.name, suffix);
     ++ran;
   };
+  const bool only_world = argc > 1 && std::string(argv[1]) == "--open-world";
   for (const auto& c : cases()) {
     if (host_only && c.where == GPU) continue;
+    if (only_world && std::string(c.name).find("world of host threads") == std::string::npos) continue;
     run(c, "");
+  }
+  if (only_world) {
+    std::printf("%d cases, %d checks, %d failures\n", ran, g_checks, g_fail);
+    return g_fail ? 1 : 0;
   }
   if (!host_only) {  // the same host-container cases with every Vector / Matrix / PRG member on its kernel
     const std::size_t keep = hip::hostThreshold();

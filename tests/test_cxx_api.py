@@ -30,6 +30,20 @@ def test_cxx_api_full():
     assert "0 failures" in r.stdout and "ss::shamir*" in r.stdout
 
 
+@pytest.mark.gpu
+def test_cxx_open_over_a_world_of_threads():
+    """hip::Communicator / hip::open / hip::openByPartialSums -- the C++ mirror of the C ABI's open step -- with worlds of 2, 3,
+    4 and 8: the ranks are std::threads of the test binary on this one GPU, RCCL is tests/cxx/fake_rccl.cc bound through
+    SCL_HIP_RCCL_LIBRARY (an all-gather = rendezvous + device-to-device copies).  Every rank must end with every secret."""
+    fake = os.path.join(CXX, "_build", "libfake_rccl.so")
+    exe = _build()
+    assert os.path.exists(fake)
+    r = subprocess.run([exe, "--open-world"], capture_output=True, text=True, env=dict(os.environ, SCL_HIP_RCCL_LIBRARY=fake),
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "1 cases" in r.stdout and "0 failures" in r.stdout and "skipped" not in r.stdout
+
+
 def _per_secret(args):
     subprocess.run(["make", "-s", "-C", CXX], check=True)
     r = subprocess.run([os.path.join(CXX, "_build", "bench_per_secret")] + args, capture_output=True, text=True)
