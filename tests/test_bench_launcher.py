@@ -128,3 +128,38 @@ def test_matrix_core_share_is_priced_against_the_matrix_pipe():
     assert r["algorithmic_ops"] == 2 * 64 * 43 * 128 * 1_000_000           # 64 digit pairs, 43 coefficients, 128 parties
     assert abs(r["achieved"] - r["algorithmic_ops"] / 1e-3 / 1e12) < 1e-9 and abs(r["frac"] - r["achieved"] / 5000.0) < 1e-12
     assert abs(r["executed_frac"] / r["frac"] - 64 / 43) < 1e-9             # K padded from 43 to 64 slots
+
+
+def test_side_legs_and_pmc_parsing_are_pure_functions():
+    """bench.side_legs: `verified` of the line = AND over the headline and every leg, an {"error": ..} object anywhere is listed
+    and counts as unverified, a {"skipped": ..} leg is neither; bench.pmc_means / pmc_report: the parsing of rocprofv3's
+    counter CSVs that both the live passes and tools/make_pmc_traffic.py use (KiB counters, FETCH_SIZE doubled, the launches of
+    the largest size only)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    line = {"verified": True, "roofline": {"frac": 0.8}, "cpu_baseline": {"all_cores": {"error": "x"}},
+            "configs": {"A": {"verified": True, "share_roofline": {"frac": 0.3}}, "B": {"error": "boom", "verified": False}},
+            "open": {"c4": {"verified": True, "c_abi": {"skipped": "why"}, "partial_gather": {"verified": False}}}}
+    legs, errors = bench.side_legs(line)
+    assert legs == {"configs.A": True, "configs.B": False, "open.c4": True, "open.c4.partial_gather": False}
+    assert errors == ["configs.B: boom"]
+    assert bench.cpu_model() and isinstance(bench.cpu_model(), str)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for counter, rows in (("FETCH_SIZE", [("void sclhip::k_share_small_t<sclhip::M61, 2, 3, 64>(a)", 1562500.0),
+                                              ("void sclhip::k_share_small_t<sclhip::M61, 2, 3, 64>(a)", 10.0),      # a tiny launch
+                                              ("void sclhip::k_recover_fixed<sclhip::M61, 2, 10, true, 64>(b)", 3906250.0),
+                                              ("void sclhip::k_copy16<0>(c)", 1953125.0)]),
+                              ("WRITE_SIZE", [("void sclhip::k_share_small_t<sclhip::M61, 2, 3, 64>(a)", 7812500.0),
+                                              ("void sclhip::k_recover_fixed<sclhip::M61, 2, 10, true, 64>(b)", 781250.0),
+                                              ("void sclhip::k_copy16<0>(c)", 3906250.0)])):
+            os.makedirs(os.path.join(d, counter, "host"))
+            with open(os.path.join(d, counter, "host", "1_counter_collection.csv"), "w") as fh:
+                fh.write("Kernel_Name,Counter_Name,Counter_Value\n")
+                for k, v in rows:
+                    fh.write(f'"{k}",{counter},{v}\n')
+        f, w = bench.pmc_means(os.path.join(d, "FETCH_SIZE"), "FETCH_SIZE"), bench.pmc_means(os.path.join(d, "WRITE_SIZE"), "WRITE_SIZE")
+        rep = bench.pmc_report(f, w, 4e9)
+    assert rep["shamir_share"]["bytes"] == 112 * 10**8 and rep["shamir_share"]["launches"] == 1
+    assert rep["shamir_recover"]["bytes"] == 88 * 10**8
+    assert abs(rep["calibration_k_copy16"]["fetch_correction"] - 2.0) < 1e-9 and rep["configs"] == {}
