@@ -482,55 +482,66 @@ def main():
         for k in range(rows.shape[0]):
             scl.vector_random(f_, N_, seed, counter0=counter0 + k * per_row, out=rows[k])
 
-    def share_recover_config(fkey, n, t, N, steps, seed, warmup=1):
+    def share_recover_config(fkey, n, t, N, steps, seed, warmup=1, allocations=1):
         """one configuration end to end on this GPU: plain allocations, share + reconstruct timed with HIP events on the
         launch stream, round trip verified.  Returns the per-kernel figures.  `warmup` untimed launches first: the first
         25-30 ms of load after an idle gap (allocation, fill) run under a clock ramp -- from a cold start the 0.38 ms Mont128
         share kernel reads 0.51, 0.50, 0.49 .. and reaches 0.38 only after about sixty launches, the headline's 1.7 ms kernel after
         five (profiles/r4_probe_c3_seq.txt, r4_probe_headline_seq.txt) -- so the sub-millisecond configurations take 100
-        warm-up launches (40 ms) and 50 timed ones per kernel."""
+        warm-up launches (40 ms) and 50 timed ones per kernel.  `allocations` > 1: the whole measurement on that many
+        independently allocated operand sets, all alive at once (so they are different memory); the figures are the MEAN over
+        all of them -- where the operands land moves these kernels by up to 10 % (Placement), and one
+        1.6 GB set says more about the allocation than about the kernel -- with the per-allocation means beside it."""
         f_, L = tag_limbs(fkey)
         E = 8 * L
-        secrets = scl.empty(f_, N)
-        coeffs = scl.empty(f_, t, N)
-        fill_random(secrets, f_, seed + b"-secrets")
-        fill_random(coeffs, f_, seed + b"-coeffs")
-        shares = scl.empty(f_, n, N)
-        out = scl.empty(f_, N)
         lam = scl.lagrange_basis(f_, n)
-        tms = [(scl.Timer(), scl.Timer()) for _ in range(steps)]
-        # each kernel on its own: `steps` launches of the share kernel back to back, then `steps` of the reconstruct kernel, HIP
-        # events around every launch.  (Alternating the two, as the headline's step does by contract, leaves every launch
-        # behind the other kernel's tail: the same kernels then spread 6-10 % from launch to launch instead of 3-5 %,
-        # profiles/r4_probe_c3_bench.txt; these entries are per-kernel figures, so each kernel is timed in its own steady state.)
-        for k in range(-warmup, steps):
-            if k >= 0:
-                tms[k][0].start()
-            scl.shamir_share(f_, secrets, coeffs, n, out=shares)
-            if k >= 0:
-                tms[k][0].stop()
-        for k in range(-warmup, steps):
-            if k >= 0:
-                tms[k][1].start()
-            scl.shamir_recover(f_, shares, lam, out=out)
-            if k >= 0:
-                tms[k][1].stop()
-        torch.cuda.synchronize()
-        sm = sum(tm[0].elapsed_ms() for tm in tms) / steps
-        rm = sum(tm[1].elapsed_ms() for tm in tms) / steps
-        ok = bool(scl.equals(f_, out, secrets))
+        sets = []
+        for a in range(allocations):
+            secrets = scl.empty(f_, N)
+            coeffs = scl.empty(f_, t, N)
+            fill_random(secrets, f_, seed + b"-secrets%d" % a)
+            fill_random(coeffs, f_, seed + b"-coeffs%d" % a)
+            sets.append((secrets, coeffs, scl.empty(f_, n, N), scl.empty(f_, N)))
+        share_all, rec_all, share_by, rec_by, ok = [], [], [], [], True
+        for secrets, coeffs, shares, out in sets:
+            tms = [(scl.Timer(), scl.Timer()) for _ in range(steps)]
+            # each kernel on its own: `steps` launches of the share kernel back to back, then `steps` of the reconstruct kernel,
+            # HIP events around every launch.  (Alternating the two, as the headline's step does by contract, leaves every
+            # launch behind the other kernel's tail: the same kernels then spread 6-10 % from launch to launch instead of 3-5 %,
+            # profiles/r4_probe_c3_bench.txt; these entries are per-kernel figures: each kernel in its own steady state.)
+            for k in range(-warmup, steps):
+                if k >= 0:
+                    tms[k][0].start()
+                scl.shamir_share(f_, secrets, coeffs, n, out=shares)
+                if k >= 0:
+                    tms[k][0].stop()
+            for k in range(-warmup, steps):
+                if k >= 0:
+                    tms[k][1].start()
+                scl.shamir_recover(f_, shares, lam, out=out)
+                if k >= 0:
+                    tms[k][1].stop()
+            torch.cuda.synchronize()
+            sh, rc = [tm[0].elapsed_ms() for tm in tms], [tm[1].elapsed_ms() for tm in tms]
+            share_all += sh
+            rec_all += rc
+            share_by.append(sum(sh) / steps)
+            rec_by.append(sum(rc) / steps)
+            ok = ok and bool(scl.equals(f_, out, secrets))
+        sm, rm = sum(share_all) / len(share_all), sum(rec_all) / len(rec_all)
         sb, rb = (1 + t + n) * E, (n + 1) * E
         res = {"field": FIELD_NAMES[fkey], "n": n, "t": t, "secrets": N, "dtype": {1: "u64", 2: "u128", 4: "u256"}[L],
                "share_ms": sm, "recover_ms": rm, "bytes_per_secret": {"share": sb, "recover": rb},
                "share_GBps": sb * N / sm / 1e6, "recover_GBps": rb * N / rm / 1e6,
                "share_frac": sb * N / sm / 1e6 / HBM_PEAK_GBPS, "recover_frac": rb * N / rm / 1e6 / HBM_PEAK_GBPS,
                "round_trips_per_s": N / ((sm + rm) * 1e-3), "reconstructions_per_s": N / (rm * 1e-3), "verified": ok,
-               "steps": steps, "warmup": warmup,
-               "share_ms_min_max": [min(tm[0].elapsed_ms() for tm in tms), max(tm[0].elapsed_ms() for tm in tms)],
-               "recover_ms_min_max": [min(tm[1].elapsed_ms() for tm in tms), max(tm[1].elapsed_ms() for tm in tms)]}
+               "steps": steps, "warmup": warmup, "allocations": allocations,
+               "share_ms_min_max": [min(share_all), max(share_all)], "recover_ms_min_max": [min(rec_all), max(rec_all)]}
+        if allocations > 1:
+            res["share_ms_by_allocation"], res["recover_ms_by_allocation"] = share_by, rec_by
         if on_matrix_cores(fkey, n, t):
             res["share_roofline"] = mfma_share_roofline(n, t, N, sm)   # share_frac above is its HBM-equivalent rate only
-        del secrets, coeffs, shares, out
+        del sets, secrets, coeffs, shares, out
         torch.cuda.empty_cache()
         return res
 
@@ -978,14 +989,14 @@ def main():
     if world == 1 and args.configs:
         # the other BASELINE configurations at the size ONE GPU holds of them (C4, C5: an eighth), after the timed region
         cfgs = {}
-        for key, (fk, n_, t_, N_, st, wu) in {
-            "C3_mersenne127_10_3": ("m127", 10, 3, 10_000_000, 50, 100),
-            "C3_mont128_10_3": ("mont128", 10, 3, 10_000_000, 50, 100),
-            "C4_shard_gf2_128_40_13": ("gf2_128", 40, 13, 12_500_000, 5, 2),
-            "C5_shard_mersenne61_128_42": ("m61", 128, 42, 125_000_000, 2, 1),
+        for key, (fk, n_, t_, N_, st, wu, na) in {
+            "C3_mersenne127_10_3": ("m127", 10, 3, 10_000_000, 50, 100, 3),
+            "C3_mont128_10_3": ("mont128", 10, 3, 10_000_000, 50, 100, 3),
+            "C4_shard_gf2_128_40_13": ("gf2_128", 40, 13, 12_500_000, 5, 2, 1),
+            "C5_shard_mersenne61_128_42": ("m61", 128, 42, 125_000_000, 2, 1, 1),
         }.items():
             try:
-                cfgs[key] = share_recover_config(fk, n_, t_, N_, st, b"scl-bench-" + key.encode(), warmup=wu)
+                cfgs[key] = share_recover_config(fk, n_, t_, N_, st, b"scl-bench-" + key.encode(), warmup=wu, allocations=na)
                 cfgs[key]["traffic"] = pmc_config_traffic(key)
             except Exception as e:  # a failed side configuration is reported, not hidden, and never fails the headline
                 cfgs[key] = {"error": str(e), "verified": False}
