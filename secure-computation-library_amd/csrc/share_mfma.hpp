@@ -732,7 +732,8 @@ __device__ __forceinline__ void mf16_recombine_units(const v4acc (&acc)[4][2], c
   }
 }
 // MF16_ABL: ablation switches for tools/mfma_bench.hip (1 no matrix instructions, 2 no recombination, 4 no stores, 8 no recode /
-// fetch, 16 no fragment loads, 32 no barriers; results are then wrong by construction); the library builds with 0
+// fetch, 16 no fragment loads, 32 no barriers, 64 twenty of the trip's 128 matrix instructions left out; results are then wrong by
+// construction); the library builds with 0
 #ifndef MF16_ABL
 #define MF16_ABL 0
 #endif
@@ -750,7 +751,9 @@ __device__ __forceinline__ void mf16_pipe_op(const v4i (&vfrag)[MF_LIMBS], const
   constexpr MfOp16 op = mf16_word_op<A>(I);
   constexpr bool first = mf16_word_first<A>(I);
   const v4acc zero = {0, 0, 0, 0};
-  if constexpr (!(MF16_ABL & 1))
+  // (MF16_ABL & 64: 5 of every 32 matrix instructions left out -- 20 of a trip's 128, the 54-of-64 an un-padded K would issue)
+  constexpr bool dropped = (MF16_ABL & 64) != 0 && (I * 5) % 32 < 5;
+  if constexpr (!(MF16_ABL & 1) && !dropped)
     accN[op.j][op.ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(vfrag[op.l], cfrag[op.ct][op.m], first ? zero : accN[op.j][op.ct], 0, 0, 0);
   else if constexpr (first)
     accN[op.j][op.ct] = cfrag[op.ct][op.m] ^ vfrag[op.l];
