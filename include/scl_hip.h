@@ -115,6 +115,8 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the sto
  *                elements and 12 for wider ones
  *   share_waves  (default 9) the same cap for the Mersenne61 small-node share kernel (threshold compiled in, stream_block
  *                workgroups); 0 = the 256-thread kernel with the threshold at run time, no cap
+ *   share_waves128 (default 12) the same for the 16-byte fields' small-node share kernel (Mersenne127, Mont128); 0 = the
+ *                256-thread kernel
  *   mfma         1: force the matrix-core share / matmul / recover_detect path, -1: never use it
  *   open_gather_always (default 0) scl_hip_open_all_gather on a ONE-rank communicator: 1 = through the collective path all the
  *                same (tests); 0 = reconstruct straight from the slab
