@@ -1184,6 +1184,46 @@ def test_six_host_threads_on_their_own_streams(scl, port):
                     assert a == b, i
 
 
+def test_batch_calls_capture_into_a_hip_graph(scl, port):
+    """The batch entry points that take their tables as kernel arguments neither synchronise nor allocate nor copy from pageable
+    memory once their per-thread arenas exist, so a caller can capture them on its stream (hipStreamBeginCapture; here through
+    torch.cuda.CUDAGraph, which captures the stream the library launches on) and replay the step: (10,3) Mersenne61 share +
+    reconstruct and PRG-driven additive share + sum, replayed on NEW secrets written into the captured input buffer, equal the
+    oracle.  (What replay buys is small: ~12 us against ~20 us per two-kernel step, profiles/r4_probe_graph.txt -- the floor is the
+    device's own dispatch.)"""
+    f, N = O.M61, 4097
+    secrets = dev(scl, rand_elems(port, f, N, b"graph-s0"))
+    coeffs = dev(scl, np.ascontiguousarray(np.transpose(rand_elems(port, f, 3 * N, b"graph-c").reshape(N, 3, 1), (1, 0, 2))))
+    sh10, out, sh3, out3 = scl.empty(f, 10, N), scl.empty(f, N), scl.empty(f, 3, N), scl.empty(f, N)
+    lam = scl.lagrange_basis(f, 10)
+
+    def step():
+        scl.shamir_share(f, secrets, coeffs, 10, out=sh10)
+        scl.shamir_recover(f, sh10, lam, out=out)
+        scl.additive_share_prg(f, secrets, 3, b"graph-seed", out=sh3)
+        scl.additive_recover(f, sh3, out=out3)
+
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            step()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        fresh = rand_elems(port, f, N, b"graph-s%d" % (rep + 1))
+        secrets.copy_(dev(scl, fresh))
+        out.zero_()
+        out3.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(host(scl, out), fresh) and np.array_equal(host(scl, out3), fresh)
+        co = host(scl, coeffs)
+        want = soa(port.shamir_share_coeffs(f, fresh, np.ascontiguousarray(np.transpose(co, (1, 0, 2))), 10))
+        assert np.array_equal(host(scl, sh10), want)
+        assert np.array_equal(host(scl, sh3), soa(port.additive_share(f, b"graph-seed", fresh, 3)))
+
+
 def test_reference_binding_compiled_against_the_reference():
     """integration/include/scl/hip/binding.h -- the header INTEGRATION.md section 2 tells a maintainer of the reference to add --
     compiled against the REAL reference (/root/reference/include + its translation units, oracle/Makefile `binding`; the
