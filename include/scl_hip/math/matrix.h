@@ -233,6 +233,119 @@ class Matrix {
   std::vector<ELEMENT> m_values;
 };
 
+// ---- linear systems (include/scl/math/matrix.h:585-828) -- what shamirRecoverC's Berlekamp-Welch is written against ----------
+// Host scalars, any field (the batched Berlekamp-Welch solves its systems in LDS: kernels.hpp, k_bw_solve); the helpers
+// keep the reference's behaviour on degenerate input -- which row counts as a pivot, what a free variable is set to.
+
+/// [A | B]: B's columns appended to A's (matrix.h:774-789)
+template <typename ELEMENT>
+Matrix<ELEMENT> createAugmentedMatrix(const Matrix<ELEMENT>& A, const Matrix<ELEMENT>& B) {
+  const std::size_t n = A.rows(), m = A.cols(), k = B.cols();
+  Matrix<ELEMENT> aug(n, m + k);
+  for (std::size_t i = 0; i < n; ++i)
+    for (std::size_t j = 0; j < m + k; ++j) aug(i, j) = j < m ? A(i, j) : B(i, j - m);
+  return aug;
+}
+template <typename ELEMENT>
+Matrix<ELEMENT> createAugmentedMatrix(const Matrix<ELEMENT>& A, const Vector<ELEMENT>& b) {
+  return createAugmentedMatrix(A, b.toColumnMatrix());
+}
+
+/// reduced row echelon form in place (matrix.h:597-639): per column the first non-zero entry at or below the current row
+/// becomes the pivot, its row is swapped up and scaled to a leading 1, every other row loses its multiple of it
+template <typename ELEMENT>
+void rowReduceInPlace(Matrix<ELEMENT>& A) {
+  const std::size_t n = A.rows(), m = A.cols();
+  const ELEMENT zero;
+  for (std::size_t r = 0, c = 0; r < n && c < m; ++c) {
+    std::size_t pivot = r;
+    while (pivot < n && A(pivot, c) == zero) ++pivot;
+    if (pivot == n) continue;  // nothing in this column: the row stays for the next one
+    for (std::size_t j = 0; j < m; ++j) std::swap(A(pivot, j), A(r, j));
+    const ELEMENT scale = A(r, c).inverse();
+    for (std::size_t j = 0; j < m; ++j) A(r, j) *= scale;
+    for (std::size_t k = 0; k < n; ++k) {
+      if (k == r) continue;
+      const ELEMENT t = A(k, c);
+      if (t == zero) continue;
+      for (std::size_t j = 0; j < m; ++j) A(k, j) -= A(r, j) * t;
+    }
+    ++r;
+  }
+}
+
+/// the row of the pivot of column `col` in a reduced matrix, -1 if the column has none (matrix.h:646-662): the LOWEST row
+/// with a non-zero entry there, provided the columns 0 .. col - 2 of that row are zero (the reference's loop bound)
+template <typename ELEMENT>
+int getPivotInColumn(const Matrix<ELEMENT>& A, int col) {
+  const ELEMENT zero = ELEMENT::zero();
+  for (int i = static_cast<int>(A.rows()) - 1; i >= 0; --i) {
+    if (A(i, col) == zero) continue;
+    for (int k = 0; k < col - 1; ++k)
+      if (A(i, k) != zero) return -1;
+    return i;
+  }
+  return -1;
+}
+
+/// index of the last row that is not all zero (matrix.h:673-691); rows() - 1 .. 0, and size_t(-1) for a zero matrix
+template <typename ELEMENT>
+std::size_t findFirstNonZeroRow(const Matrix<ELEMENT>& A) {
+  const ELEMENT zero = ELEMENT::zero();
+  std::size_t row = A.rows();
+  while (row-- > 0) {
+    bool any = false;
+    for (std::size_t j = 0; j < A.cols() && !any; ++j) any = A(row, j) != zero;
+    if (any) break;
+  }
+  return row;
+}
+
+/// a solution read off a reduced augmented matrix (matrix.h:703-731): back-substitution from the last non-zero row; a free
+/// variable is set to 1, the variables of dropped all-zero rows stay 0
+template <typename ELEMENT>
+Vector<ELEMENT> extractSolution(const Matrix<ELEMENT>& A) {
+  const std::size_t n = A.rows(), m = A.cols();
+  Vector<ELEMENT> x(m - 1);
+  std::size_t i = findFirstNonZeroRow(A);
+  for (int c = static_cast<int>(m) - 2 - static_cast<int>(n - i - 1); c >= 0; --c) {
+    const int p = getPivotInColumn(A, c);
+    if (p == -1) {
+      x[static_cast<std::size_t>(c)] = ELEMENT{1};
+      continue;
+    }
+    ELEMENT sum = ELEMENT::zero();
+    for (std::size_t j = static_cast<std::size_t>(p) + 1; j < n; ++j) sum += A(i, j) * x[j];
+    x[static_cast<std::size_t>(c)] = A(i, m - 1) - sum;
+    --i;
+  }
+  return x;
+}
+
+/// does the reduced augmented matrix describe a solvable system (matrix.h:740-765)?  unique_only: no row of the coefficient
+/// part may be all zero; otherwise only a zero row with a non-zero right-hand side rules a solution out
+template <typename ELEMENT>
+bool hasSolution(const Matrix<ELEMENT>& A, bool unique_only) {
+  const ELEMENT zero;
+  for (std::size_t i = 0; i < A.rows(); ++i) {
+    bool all_zero = true;
+    for (std::size_t j = 0; j + 1 < A.cols(); ++j) all_zero &= A(i, j) == zero;
+    if (all_zero && (unique_only || A(i, A.cols() - 1) != zero)) return false;
+  }
+  return true;
+}
+
+/// A x = b with a unique solution: true and x set, false otherwise (matrix.h:811-828)
+template <typename ELEMENT>
+bool solveLinearSystem(Vector<ELEMENT>& x, const Matrix<ELEMENT>& A, const Vector<ELEMENT>& b) {
+  if (A.rows() != b.size()) throw std::invalid_argument("malformed system of equations");
+  auto aug = createAugmentedMatrix(A, b);
+  rowReduceInPlace(aug);
+  if (!hasSolution(aug, true)) return false;
+  x = extractSolution(aug);
+  return true;
+}
+
 }  // namespace scl::math
 
 #endif

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <functional>
 #include <iostream>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -448,6 +449,119 @@ TEST_CASE(gf7_berlekamp_welch, "user-defined field GF(7): the Wikipedia Berlekam
   // the same algebra through explicit nodes (shamir.h:202-250)
   const auto s2 = ss::shamirRecoverC(received, math::Vector<G7>::range(1, 8));
   REQUIRE(s2.f.constantTerm() == s.f.constantTerm());
+}
+
+// the text forms and argument checks the reference's tests pin: "Matrix ToString" (test_matrix.cc:110-126), "Vector to string"
+// (test_vector.cc:102-110), "Polynomial to string" (test_poly.cc:73-85), "PRG invalid calls" / "PRG truncate seed on create"
+// (test_prg.cc:106-125), "Z2k truncation" (test_z2k.cc:167-190)
+TEST_CASE(text_and_checks, "text forms and argument checks pinned by the reference's tests", HOST) {
+  using Matrix = math::Matrix<F61>;
+  Matrix m(3, 2);
+  const int vals[6] = {1, 2, 44444, 5, 6, 7};
+  for (int i = 0; i < 6; ++i) m(i / 2, i % 2) = F61(vals[i]);
+  const std::string expected = "\n[    1  2 ]\n[ ad9c  5 ]\n[    6  7 ]";
+  REQUIRE(m.toString() == expected);
+  std::stringstream ss;
+  ss << m;
+  REQUIRE(ss.str() == expected);
+  REQUIRE(Matrix().toString() == "[ EMPTY MATRIX ]");
+  const math::Vector<F61> v0 = {F61(1), F61(2), F61(3)}, v1 = {F61(2), F61(123), F61(5)};
+  REQUIRE(v0.toString() == "[1, 2, 3]" && v1.toString() == "[2, 7b, 5]");
+  std::stringstream sv;
+  sv << v0;
+  REQUIRE(sv.str() == "[1, 2, 3]" && math::Vector<F61>().toString() == "[ EMPTY VECTOR ]");
+  const auto p = math::Polynomial<F61>::create(math::Vector<F61>{F61(4), F61(5), F61(1)});
+  REQUIRE(p.toString() == "f(x) = 4 + 5x + 1x^2" && p.toString("g", "y") == "g(y) = 4 + 5y + 1y^2");
+  std::stringstream sp;
+  sp << p;
+  REQUIRE(sp.str() == "f(x) = 4 + 5x + 1x^2");
+  auto prg = util::PRG::create();
+  std::vector<unsigned char> buf(10);
+  REQUIRE_THROWS_MSG(prg.next(buf, 11), std::invalid_argument, "n exceeds buffer.size()");
+  auto prg0 = util::PRG::create("0123456789abcdef_bar"), prg1 = util::PRG::create("0123456789abcdef_foo");
+  REQUIRE(prg0.next(100) == prg1.next(100));  // seeds are cut to 16 bytes
+  using Z32 = math::Z2k<32>;
+  const Z32 a(0x34abcdef11), b(0x00abcdef11);
+  REQUIRE(a == b);
+  unsigned char ba[Z32::byteSize() + 2] = {0}, bb[Z32::byteSize() + 2] = {0};
+  ba[4] = ba[5] = bb[4] = bb[5] = 0xff;
+  a.write(ba);
+  b.write(bb);
+  REQUIRE(std::memcmp(ba, bb, sizeof ba) == 0 && ba[4] == 0xff && ba[5] == 0xff);  // write touches byteSize() bytes only
+}
+
+// test/scl/math/test_la.cc restated over GF(7): the helpers of solveLinearSystem (matrix.h:585-828) keep the reference's answers,
+// degenerate inputs included
+TEST_CASE(linalg_gf7, "LinAlg: getPivotInColumn / findFirstNonZeroRow / extractSolution / solve / hasSolution (test_la.cc)", HOST) {
+  using FF = math::FF<usr::Gf7>;
+  using Matrix = math::Matrix<FF>;
+  using Vector = math::Vector<FF>;
+  const FF zero = FF::zero(), one = FF::one();
+  {  // "LinAlg GetPivot"
+    Matrix A = Matrix::fromVector(3, 3, {one, zero, one, zero, one, zero, zero, zero, zero});
+    REQUIRE(math::getPivotInColumn(A, 2) == -1);
+    REQUIRE(math::getPivotInColumn(A, 1) == 1);
+    REQUIRE(math::getPivotInColumn(A, 0) == 0);
+    A(2, 2) = one;
+    REQUIRE(math::getPivotInColumn(A, 2) == 2);
+    Matrix B(2, 2);
+    REQUIRE(math::getPivotInColumn(B, 0) == -1);
+  }
+  {  // "LinAlg FindFirstNonZeroRow"
+    Matrix A = Matrix::fromVector(3, 3, {one, zero, one, zero, one, zero, zero, zero, zero});
+    REQUIRE(math::findFirstNonZeroRow(A) == 1);
+    A(2, 1) = one;
+    REQUIRE(math::findFirstNonZeroRow(A) == 2);
+  }
+  {  // "LinAlg ExtractSolution"
+    Matrix A = Matrix::fromVector(3, 4, {one, zero, zero, FF(3), zero, one, zero, FF(5), zero, zero, one, FF(2)});
+    REQUIRE(math::extractSolution(A).equals(Vector{FF(3), FF(5), FF(2)}));
+    Matrix B = Matrix::fromVector(3, 4, {FF(1), FF(3), FF(1), FF(2), FF(0), FF(0), FF(1), FF(4), FF(0), FF(0), FF(0), FF(0)});
+    REQUIRE(math::extractSolution(B).equals(Vector{FF(4), FF(4), FF(0)}));
+    Matrix C(3, 4);
+    C(1, 0) = FF(2);
+    REQUIRE(math::extractSolution(C).equals(Vector{zero, one, zero}));
+  }
+  {  // "LinAlg Solve random" (over GF(7) a random 10 x 10 matrix is singular about one time in seven: seeds until one is not)
+    int solved = 0;
+    for (int seed = 0; seed < 12 && solved < 3; ++seed) {
+      auto prg = util::PRG::create("la-" + std::to_string(seed));
+      Matrix A = Matrix::random(10, 10, prg);
+      Vector b = Vector::random(10, prg), x(10);
+      if (!math::solveLinearSystem(x, A, b)) continue;
+      ++solved;
+      REQUIRE(A.multiply(x.toColumnMatrix()).equals(b.toColumnMatrix()));
+      REQUIRE(A.multiply(A.invert()).isIdentity());
+    }
+    REQUIRE(solved == 3);
+  }
+  {  // "LinAlg malformed systems"
+    Vector x;
+    Matrix A(2, 2);
+    Vector b(3);
+    REQUIRE_THROWS_MSG(math::solveLinearSystem(x, A, b), std::invalid_argument, "malformed system of equations");
+  }
+  {  // "LinAlg HasSolution"
+    Matrix A(2, 3);
+    REQUIRE(!math::hasSolution(A, true));   // an all-zero row: no unique solution
+    REQUIRE(math::hasSolution(A, false));   // .. but a free variable: many
+    A(0, 2) = FF(1);
+    REQUIRE(!math::hasSolution(A, false));  // 0 = 1
+  }
+  {  // rowReduceInPlace + createAugmentedMatrix: [A | I] -> [I | A^-1], as Matrix::invert does it there (matrix.h:830-850)
+    Matrix A = Matrix::fromVector(3, 3, {FF(2), FF(1), FF(0), FF(1), FF(3), FF(1), FF(0), FF(1), FF(4)});
+    auto aug = math::createAugmentedMatrix(A, Matrix::identity(3));
+    math::rowReduceInPlace(aug);
+    Matrix inv(3, 3);
+    for (std::size_t i = 0; i < 3; ++i)
+      for (std::size_t j = 0; j < 3; ++j) {
+        REQUIRE(aug(i, j) == (i == j ? one : zero));
+        inv(i, j) = aug(i, 3 + j);
+      }
+    REQUIRE(inv == A.invert() && A.multiply(inv).isIdentity());
+    REQUIRE_THROWS_MSG(Matrix(2, 3).resize(4, 2), std::invalid_argument, "cannot resize matrix");
+    REQUIRE(Matrix(2, 3).resize(3, 2).rows() == 3);
+  }
 }
 
 TEST_CASE(prg_gpu, "util::PRG stream", BOTH) {
