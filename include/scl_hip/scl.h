@@ -12,6 +12,7 @@
 #include "math/poly.h"
 #include "math/vector.h"
 #include "math/z2k.h"
+#include "serialization/serializer.h"
 #include "ss/additive.h"
 #include "ss/shamir.h"
 #include "util/prg.h"

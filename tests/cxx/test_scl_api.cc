@@ -490,6 +490,92 @@ TEST_CASE(text_and_checks, "text forms and argument checks pinned by the referen
   REQUIRE(std::memcmp(ba, bb, sizeof ba) == 0 && ba[4] == 0xff && ba[5] == 0xff);  // write touches byteSize() bytes only
 }
 
+// seri::Serializer (test/scl/serialization/test_serializer.cc:60-123 for the types of the path; ff.h:355-391, vector.h:595-629,
+// matrix.h:910-963, array.h:424-455): sizes, byte layout, round trips
+TEST_CASE(serializer_host, "seri::Serializer: trivially copyable / std::vector / FF / Vector / Matrix / Array images", HOST) {
+  using Si = seri::Serializer<int>;
+  unsigned char ibuf[sizeof(int)];
+  REQUIRE(Si::sizeOf(1234) == sizeof(int) && Si::write(1234, ibuf) == sizeof(int));
+  int back = 0;
+  REQUIRE(Si::read(back, ibuf) == sizeof(int) && back == 1234);
+  // "Serialization vector of vectors"-style nesting: every level carries its u32 count
+  using Svv = seri::Serializer<std::vector<std::vector<int>>>;
+  const std::vector<std::vector<int>> vv = {{1, 2, 3}, {}, {7}};
+  REQUIRE(Svv::sizeOf(vv) == 4 + (4 + 12) + 4 + (4 + 4));
+  std::vector<unsigned char> vbuf(Svv::sizeOf(vv));
+  REQUIRE(Svv::write(vv, vbuf.data()) == vbuf.size());
+  std::vector<std::vector<int>> ww;
+  REQUIRE(Svv::read(ww, vbuf.data()) == vbuf.size() && ww == vv);
+  // "Serialization Vec": std::vector<Fp<61>> = count + 3 x 8 bytes, canonical little-endian values
+  using Sv = seri::Serializer<std::vector<F61>>;
+  const std::vector<F61> v = {F61(1), F61(2), F61(-1)};
+  REQUIRE(Sv::sizeOf(v) == 4 + 3 * F61::byteSize());
+  unsigned char buf[28];
+  REQUIRE(Sv::write(v, buf) == 28);
+  const unsigned char want[28] = {3, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0xfe, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0x1f};
+  REQUIRE(std::memcmp(buf, want, 28) == 0);  // p - 1 = 0x1ffffffffffffffe
+  std::vector<F61> w;
+  REQUIRE(Sv::read(w, buf) == 28 && w == v);
+  // Vector<FF> is its std::vector; Matrix adds u32 rows, u32 cols in front
+  using SV = seri::Serializer<math::Vector<F61>>;
+  const math::Vector<F61> mv(v);
+  unsigned char buf2[28];
+  REQUIRE(SV::sizeOf(mv) == 28 && SV::write(mv, buf2) == 28 && std::memcmp(buf2, want, 28) == 0);
+  math::Vector<F61> mv2;
+  REQUIRE(SV::read(mv2, buf2) == 28 && mv2 == mv);
+  using SM = seri::Serializer<math::Matrix<F127>>;
+  auto prg = util::PRG::create("seri");
+  const auto M = math::Matrix<F127>::random(3, 2, prg);
+  REQUIRE(SM::sizeOf(M) == 8 + 4 + 6 * 16);
+  std::vector<unsigned char> mbuf(SM::sizeOf(M));
+  REQUIRE(SM::write(M, mbuf.data()) == mbuf.size());
+  REQUIRE(mbuf[0] == 3 && mbuf[4] == 2 && mbuf[8] == 6);
+  math::Matrix<F127> M2;
+  REQUIRE(SM::read(M2, mbuf.data()) == mbuf.size() && M2 == M);
+  // "Array serialization" (test_array.cc:64-80) through the Serializer itself; no count: N is in the type
+  using F = math::FF<math::ff::Secp256k1Scalar>;
+  using SA = seri::Serializer<math::Array<F, 3>>;
+  const auto prod = math::Array<F, 3>::random(prg);
+  unsigned char abuf[96];
+  REQUIRE(SA::sizeOf(prod) == 96 && SA::write(prod, abuf) == 96);
+  math::Array<F, 3> p2;
+  REQUIRE(p2 != prod && SA::read(p2, abuf) == 96 && p2 == prod);
+  // a ring element: Z2k<K> writes byteSize() = ceil(K / 8) bytes
+  using Z = math::Z2k<62>;
+  using SZ = seri::Serializer<Z>;
+  const Z z(0x123456789abcdefll);
+  unsigned char zbuf[8];
+  Z z2;
+  REQUIRE(SZ::sizeOf(z) == Z::byteSize() && SZ::write(z, zbuf) == Z::byteSize() && SZ::read(z2, zbuf) == Z::byteSize() && z2 == z);
+}
+
+TEST_CASE(serializer_gpu, "seri::Serializer<Vector / Matrix> == the device wire kernels, byte for byte", GPU) {
+  // what scl_hip_wire_pack / _pack_matrix write from SoA rows in HBM is what the host Serializer writes, for every field width
+  auto check = [](auto tag, std::size_t n, const char* seed) {
+    using FF = decltype(tag);
+    auto prg = util::PRG::create(seed);
+    const auto v = math::Vector<FF>::random(n, prg);
+    using SV = seri::Serializer<math::Vector<FF>>;
+    std::vector<unsigned char> host(SV::sizeOf(v));
+    SV::write(v, host.data());
+    const hip::DeviceVector<FF> dv(v.toStlVector());
+    REQUIRE(scl_hip_wire_size(FF::Field::TAG, n) == host.size());
+    hip::DeviceBuffer raw(host.size());
+    hip::check(scl_hip_wire_pack(FF::Field::TAG, static_cast<unsigned char*>(raw.get()), dv.data(), n, nullptr));
+    std::vector<unsigned char> dev(host.size());
+    hip::check(scl_hip_memcpy_d2h(dev.data(), raw.get(), dev.size(), nullptr));
+    REQUIRE(dev == host);
+    // and back through the device unpack
+    hip::DeviceVector<FF> du(n);
+    std::size_t got = 0;
+    hip::check(scl_hip_wire_unpack(FF::Field::TAG, du.data(), n, static_cast<const unsigned char*>(raw.get()), dev.size(), &got, nullptr));
+    REQUIRE(got == n && math::Vector<FF>(du.toHost()) == v);
+  };
+  check(F61{}, 1001, "seri-61");
+  check(F127{}, 333, "seri-127");
+  check(math::FF<math::ff::Secp256k1Scalar>{}, 77, "seri-secp");
+}
+
 // test/scl/math/test_la.cc restated over GF(7): the helpers of solveLinearSystem (matrix.h:585-828) keep the reference's answers,
 // degenerate inputs included
 TEST_CASE(linalg_gf7, "LinAlg: getPivotInColumn / findFirstNonZeroRow / extractSolution / solve / hasSolution (test_la.cc)", HOST) {
