@@ -220,6 +220,8 @@ class Matrix {
   friend std::ostream& operator<<(std::ostream& os, const Matrix& m) { return os << m.toString(); }
 
   const std::vector<ELEMENT>& values() const { return m_values; }
+  /// bytes of the elements' images, without any header (matrix.h:415-417)
+  std::size_t byteSize() const { return m_rows * m_cols * ELEMENT::byteSize(); }
 
  private:
   Matrix(std::size_t r, std::size_t c, std::vector<ELEMENT> v) : m_rows(r), m_cols(c), m_values(std::move(v)) {}
@@ -236,6 +238,22 @@ class Matrix {
 // ---- linear systems (include/scl/math/matrix.h:585-828) -- what shamirRecoverC's Berlekamp-Welch is written against ----------
 // Host scalars, any field (the batched Berlekamp-Welch solves its systems in LDS: kernels.hpp, k_bw_solve); the helpers
 // keep the reference's behaviour on degenerate input -- which row counts as a pivot, what a free variable is set to.
+
+/// the three elementary row operations (matrix.h:551-591)
+template <typename ELEMENT>
+void swapRows(Matrix<ELEMENT>& A, std::size_t k, std::size_t h) {
+  if (k == h) return;
+  for (std::size_t j = 0; j < A.cols(); ++j) std::swap(A(k, j), A(h, j));
+}
+template <typename ELEMENT>
+void multiplyRow(Matrix<ELEMENT>& A, std::size_t row, const ELEMENT& m) {
+  for (std::size_t j = 0; j < A.cols(); ++j) A(row, j) *= m;
+}
+/// row dst += m * row op
+template <typename ELEMENT>
+void addRows(Matrix<ELEMENT>& A, std::size_t dst, std::size_t op, const ELEMENT& m) {
+  for (std::size_t j = 0; j < A.cols(); ++j) A(dst, j) += A(op, j) * m;
+}
 
 /// [A | B]: B's columns appended to A's (matrix.h:774-789)
 template <typename ELEMENT>
@@ -261,14 +279,12 @@ void rowReduceInPlace(Matrix<ELEMENT>& A) {
     std::size_t pivot = r;
     while (pivot < n && A(pivot, c) == zero) ++pivot;
     if (pivot == n) continue;  // nothing in this column: the row stays for the next one
-    for (std::size_t j = 0; j < m; ++j) std::swap(A(pivot, j), A(r, j));
-    const ELEMENT scale = A(r, c).inverse();
-    for (std::size_t j = 0; j < m; ++j) A(r, j) *= scale;
+    swapRows(A, pivot, r);
+    multiplyRow(A, r, A(r, c).inverse());
     for (std::size_t k = 0; k < n; ++k) {
       if (k == r) continue;
       const ELEMENT t = A(k, c);
-      if (t == zero) continue;
-      for (std::size_t j = 0; j < m; ++j) A(k, j) -= A(r, j) * t;
+      if (t != zero) addRows(A, k, r, -t);
     }
     ++r;
   }

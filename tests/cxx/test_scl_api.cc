@@ -645,6 +645,12 @@ TEST_CASE(linalg_gf7, "LinAlg: getPivotInColumn / findFirstNonZeroRow / extractS
         inv(i, j) = aug(i, 3 + j);
       }
     REQUIRE(inv == A.invert() && A.multiply(inv).isIdentity());
+    Matrix R = A;
+    math::swapRows(R, 0, 2);
+    math::multiplyRow(R, 1, FF(2));
+    math::addRows(R, 0, 1, FF(3));   // row 0 = old row 2 + 3 * (2 * old row 1)
+    REQUIRE(R(1, 0) == FF(2) * A(1, 0) && R(0, 2) == A(2, 2) + FF(6) * A(1, 2) && R(2, 1) == A(0, 1));
+    REQUIRE(A.byteSize() == 9 * FF::byteSize());
     REQUIRE_THROWS_MSG(Matrix(2, 3).resize(4, 2), std::invalid_argument, "cannot resize matrix");
     REQUIRE(Matrix(2, 3).resize(3, 2).rows() == 3);
   }
