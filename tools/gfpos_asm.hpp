@@ -80,4 +80,33 @@ struct GfposPipeAsm {
   }
 };
 
+// ---- vector-ALU slack probe (round 4): the library's compiler-visible pipeline with NF extra, independent three-input
+// operations per batch stage -- how much vector work fits under the table reads before the kernel slows down?  (What a hybrid
+// that multiplies a few parties' shares by their coefficients on the vector ALU, 5 instructions per share bit, would add.)
+template <int G, int IDX, int NF>
+__device__ __forceinline__ void gfpos_pipe_fill(u32x4 (&A)[4], u32x4 (&B)[4], u32x4 (&acc)[4], u32 gbase, const u32 (&w)[G][4],
+                                                u32 (&f)[4]) {
+  constexpr int NB = 8 * G;
+  if constexpr (IDX < NB) {
+    if constexpr (IDX + 1 < NB) gfpos_issue4_cv<G, IDX + 1>((IDX & 1) ? A : B, gbase, w);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NF; ++q) f[q & 3] = xor3(f[q & 3], f[(q + 1) & 3], w[q % G][q & 3]);
+    gfpos_fold(acc[IDX / (2 * G)], (IDX & 1) ? B : A);
+    __builtin_amdgcn_sched_barrier(0);
+    gfpos_pipe_fill<G, IDX + 1, NF>(A, B, acc, gbase, w, f);
+  }
+}
+template <int NF>
+struct GfposPipeFill {
+  template <int G>
+  static __device__ __forceinline__ void group(u32x4 (&acc)[4], u32 gbase, const u32 (&w)[G][4]) {
+    u32x4 A[4], B[4];
+    u32 f[4] = {w[0][0], w[0][1], w[0][2], w[0][3]};
+    gfpos_issue4_cv<G, 0>(A, gbase, w);
+    gfpos_pipe_fill<G, 0, NF>(A, B, acc, gbase, w, f);
+    asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]));  // (kept alive; the results are not used)
+  }
+};
+
 }  // namespace sclhip

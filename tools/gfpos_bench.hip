@@ -72,6 +72,10 @@ int main(int argc, char** argv) {
   run(&k_recover_gf128_pos<512, 2, GfposPipeAsm<2>>, 512, 512, "pos tables, asm reads 1 batch ahead (round 3)");
   run(&k_recover_gf128_pos<512, 2>, 512, 512, "pos tables, compiler-visible reads (again)");
   run(&k_recover_gf128_pos<1024, 1>, 1024, 256, "compiler-visible, one 1024-thread workgroup");
+  run(&k_recover_gf128_pos<512, 2, GfposPipeFill<4>>, 512, 512, "compiler-visible + 4 filler vector ops per stage");
+  run(&k_recover_gf128_pos<512, 2, GfposPipeFill<8>>, 512, 512, "compiler-visible + 8 filler vector ops per stage");
+  run(&k_recover_gf128_pos<512, 2, GfposPipeFill<12>>, 512, 512, "compiler-visible + 12 filler vector ops per stage");
+  run(&k_recover_gf128_pos<512, 2, GfposPipeFill<16>>, 512, 512, "compiler-visible + 16 filler vector ops per stage");
   run(&k_recover_gf128_pos<512, 2, GfposPipeAsm<3>>, 512, 512, "pos tables, reads 2 batches ahead");
   run(&k_recover_gf128_pos<512, 2, GfposPipeAsm<4>>, 512, 512, "pos tables, reads 3 batches ahead");
   run(&k_recover_gf128_pos<1024, 1, GfposPipeAsm<3>>, 1024, 256, "pos tables, 2 ahead, one 1024-thread workgroup");
