@@ -650,8 +650,30 @@ struct Gf128 {
     const u64 t = (u64)(a >> 127);
     return (a << 1) ^ (u128)(t * 0x87);
   }
-  // 4-bit windows over b, branch-free: tab = {a, a*x, a*x^2, a*x^3}
+  // 256 -> 128 bits with x^128 = x^7 + x^2 + x + 1: lo ^ hi*r; the seven bits hi*r pushes past x^127 come down once more
+  static SCL_HD E reduce256(E lo, E hi) {
+    const u64 top = (u64)(hi >> 121) ^ (u64)(hi >> 126) ^ (u64)(hi >> 127);  // < 2^7
+    const E hr = (hi << 7) ^ (hi << 2) ^ (hi << 1) ^ hi;
+    return lo ^ hr ^ (E)((top << 7) ^ (top << 2) ^ (top << 1) ^ top);
+  }
+  // the multiples u(x)*a mod f of a for the sixteen polynomials u of degree < 4 (the window table of the comb product)
+  static SCL_HD void window_table(E a, E* t) {
+    t[0] = 0;
+    t[1] = a;
+    t[2] = mulx(a);
+    t[4] = mulx(t[2]);
+    t[8] = mulx(t[4]);
+    t[3] = t[2] ^ a;
+    t[5] = t[4] ^ a;
+    t[6] = t[4] ^ t[2];
+    t[7] = t[6] ^ a;
+#pragma unroll
+    for (int u = 9; u < 16; ++u) t[u] = t[8] ^ t[u - 8];
+  }
   static SCL_HD E mul(const Ctx&, E a, E b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // 4-bit windows over b, branch-free: tab = {a, a*x, a*x^2, a*x^3}.  The register-only form for device code that has no
+    // LDS to spare; the element-wise kernels use the comb product below on a window table in LDS (k_ew_gf128, kernels.hpp)
     const E a1 = mulx(a), a2 = mulx(a1), a3 = mulx(a2);
     E r = 0;
     for (int k = 31; k >= 0; --k) {
@@ -660,8 +682,41 @@ struct Gf128 {
       r ^= (nib & 1 ? a : (E)0) ^ (nib & 2 ? a1 : (E)0) ^ (nib & 4 ? a2 : (E)0) ^ (nib & 8 ? a3 : (E)0);
     }
     return r;
+#else
+    // Lopez-Dahab comb with 4-bit windows: nibble k of every 32-bit word of b selects a multiple of a that lands at that
+    // word's offset; the 256-bit sum moves up four bits between nibble positions (seven shifts instead of thirty-one)
+    E t[16];
+    window_table(a, t);
+    E lo = 0, hi = 0;
+    for (int k = 7; k >= 0; --k) {
+      for (int j = 0; j < 4; ++j) {
+        const E m = t[(u32)(b >> (32 * j + 4 * k)) & 15u];
+        lo ^= m << (32 * j);
+        if (j) hi ^= m >> (128 - 32 * j);
+      }
+      if (k) {
+        hi = (hi << 4) | (lo >> 124);
+        lo <<= 4;
+      }
+    }
+    return reduce256(lo, hi);
+#endif
   }
-  static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
+  // Squaring is linear in characteristic 2: the bits of a move to the even positions of a 256-bit value (a zero between
+  // every two), which is then reduced -- about a twentieth of a general product.
+  static SCL_HD u32 spread16(u32 x) {  // bit i of the low half -> bit 2i
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+  }
+  static SCL_HD u64 spread32(u32 x) { return (u64)spread16(x & 0xFFFFu) | ((u64)spread16(x >> 16) << 32); }
+  static SCL_HD E sqr(const Ctx&, E a) {
+    const E lo = (E)spread32((u32)a) | ((E)spread32((u32)(a >> 32)) << 64);
+    const E hi = (E)spread32((u32)(a >> 64)) | ((E)spread32((u32)(a >> 96)) << 64);
+    return reduce256(lo, hi);
+  }
   // y*x + c for a small polynomial x (< 2^16, wave-uniform on the GPU): shift-xor per set bit of x,
   // then the <= 16 overflow bits are reduced with x^128 = x^7 + x^2 + x + 1.
   enum { SMALL_BITS = 16 };
@@ -723,13 +778,32 @@ struct Gf128 {
   static SCL_HD E acc_fold(const Ctx&, const Acc& acc) { return acc.v; }
   SCL_KC_IS_ACC()
 
-  static SCL_HD E inv(const Ctx& c, E a) {  // a^(2^128-2) = prod_{i=1..127} a^(2^i)
-    E r = 1, sq = a;
-    for (int i = 1; i < 128; ++i) {
-      sq = sqr(c, sq);
-      r = mul(c, r, sq);
+  // Inverse a^(2^128 - 2) = (a^(2^127 - 1))^2 by Itoh-Tsujii: with b_k = a^(2^k - 1), b_(j+k) = b_j^(2^k) * b_k.  The chain
+  // 1, 2, 3, 6, 12, 24, 48, 96, 120, 126, 127 takes 10 products and 127 squarings (254 products as a plain ladder); MUL is
+  // the product to use (the LDS comb in the element-wise kernels, mul elsewhere).  inv(0) = 0 (callers flag the zero).
+  template <class MUL>
+  static SCL_HD E inv_chain(const Ctx& c, E a, MUL&& product) {
+    // step s: cur <- cur^(2^k) * y with k = 1, 1, 3, 6, 12, 24, 48, 24, 6, 1 and y = a, a, then the step's own input five times,
+    // then b24, b6, a.  One rolled loop (one copy of the product and of the squaring in the code, not ten and 127).
+    E cur = a, b6 = 0, b24 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int s = 0; s < 10; ++s) {
+      const int k = s < 2 ? 1 : s == 2 ? 3 : s == 3 ? 6 : s == 4 ? 12 : s == 5 ? 24 : s == 6 ? 48 : s == 7 ? 24 : s == 8 ? 6 : 1;
+      const E y = (s < 2 || s == 9) ? a : s == 7 ? b24 : s == 8 ? b6 : cur;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+      for (int i = 0; i < k; ++i) cur = sqr(c, cur);
+      cur = product(cur, y);
+      if (s == 2) b6 = cur;
+      if (s == 4) b24 = cur;
     }
-    return a == 0 ? (E)0 : r;
+    return sqr(c, cur);
+  }
+  static SCL_HD E inv(const Ctx& c, E a) {
+    return inv_chain(c, a, [&](E x, E y) { return mul(c, x, y); });
   }
 };
 

@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "tu_config.hpp"
@@ -85,6 +86,10 @@ SCL_STATE(thread_local Knob g_stream_waves, {-1});
 SCL_STATE(thread_local Knob g_share_waves, {9});
 SCL_STATE(thread_local Knob g_share_waves128, {12});  // .. and for the 16-byte fields' small-node share kernel ("share_waves128")
 SCL_STATE(thread_local Knob g_aes_blocks, {0});
+// element-wise inverse / divide: 0 auto = Montgomery's simultaneous inversion with the chain length chosen by the batch, N > 0 =
+// that chain length (8, 32 or 128; Mersenne61: any N = its register kernel), -1 = one Fermat chain per element (k_ew, the kernels
+// of rounds 1-4); GF(2^128) multiply: -1 = the register-only product ("inv_batch")
+SCL_STATE(thread_local Knob g_inv_batch, {0});
 // Mont128 modulus: a process-wide default, latched per host thread at its first use (mont_ctx below)
 SCL_STATE(thread_local Mont128::Ctx g_mont, = {0, 0, 0, 0});  // p == 0: this thread has not latched a modulus yet
 SCL_STATE(std::mutex g_mont_default_mu);
@@ -954,6 +959,52 @@ static int share_chunked(int field, uint64_t* shares, size_t share_stride, const
   });
 }
 
+// Inverse / divide by Montgomery's simultaneous inversion (kernels.hpp, k_ew_inv / k_ew_inv_rolled).  Chain length: Mersenne61
+// keeps 32 elements per lane in registers (16-byte packs); the other fields keep the chain in memory and take the longest of
+// 8 / 32 / 128 that still leaves ~2000 single-wave workgroups (the inversion's share of a chain is I / L products per element,
+// I = 138 for Mersenne127 up to ~450 for secp256k1, against 3 for the walk).
+template <class F, class ARITH, bool DIV, int L>
+int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, unsigned* flag, hipStream_t st) {
+  constexpr int BLK = 64;
+  auto kern = &k_ew_inv_rolled<F, ARITH, DIV, L, BLK>;
+  const size_t tiles = (n + (size_t)BLK * L - 1) / ((size_t)BLK * L);
+  hipLaunchKernelGGL(kern, dim3(grid_for_block(tiles, 1)), dim3(BLK), (size_t)BLK * ARITH::LDS_PER_LANE, st, ctx, dst, a, b, n, flag);
+  LAUNCH_CHECK();
+  return SCL_OK;
+}
+
+template <class F, bool DIV>
+int ew_inverse_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, long want, unsigned* flag, hipStream_t st) {
+  using A = std::conditional_t<F::TAG == 3, GfLdsArith<64>, FieldArith<F>>;
+  int L = n >= ((size_t)1 << 24) ? 128 : n >= ((size_t)1 << 22) ? 32 : 8;
+  if (want > 0) L = want >= 128 ? 128 : want >= 32 ? 32 : 8;
+  if (L == 128) return launch_inv_rolled<F, A, DIV, 128>(ctx, dst, a, b, n, flag, st);
+  if (L == 32) return launch_inv_rolled<F, A, DIV, 32>(ctx, dst, a, b, n, flag, st);
+  return launch_inv_rolled<F, A, DIV, 8>(ctx, dst, a, b, n, flag, st);
+}
+
+template <class F>
+int ew_inverse(const typename F::Ctx& ctx, bool div, u64* dst, const u64* a, const u64* b, size_t n, int vec, long want, unsigned* flag,
+               hipStream_t st) {
+  if constexpr (F::LIMBS == 1) {
+    if (vec == 2 && n >= 2) {
+      const size_t npacks = n / 2, tiles = (npacks + (size_t)BLOCK * 16 - 1) / ((size_t)BLOCK * 16);
+      const dim3 g(grid_for_block(tiles, 1)), blk(BLOCK);
+      if (div) hipLaunchKernelGGL((k_ew_inv<F, true, 2, 16, true>), g, blk, 0, st, ctx, dst, a, b, npacks, flag);
+      else hipLaunchKernelGGL((k_ew_inv<F, false, 2, 16, true>), g, blk, 0, st, ctx, dst, a, b, npacks, flag);
+      LAUNCH_CHECK();
+      if (n & 1) {  // the odd element out
+        const size_t o = n - 1;
+        if (div) hipLaunchKernelGGL((k_ew<F, 5, 1, true>), dim3(1), dim3(BLOCK), 0, st, ctx, dst + o, a + o, b + o, (size_t)1, flag);
+        else hipLaunchKernelGGL((k_ew<F, 4, 1, true>), dim3(1), dim3(BLOCK), 0, st, ctx, dst + o, a + o, b, (size_t)1, flag);
+        LAUNCH_CHECK();
+      }
+      return SCL_OK;
+    }
+  }
+  return div ? ew_inverse_rolled<F, true>(ctx, dst, a, b, n, want, flag, st) : ew_inverse_rolled<F, false>(ctx, dst, a, b, n, want, flag, st);
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -1118,6 +1169,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "mfma_pipe") g_mfma_pipe = value;
   else if (k == "mfma_tpb") g_mfma_tpb = value;
   else if (k == "aes_blocks") g_aes_blocks = value;
+  else if (k == "inv_batch") g_inv_batch = value;
   else if (k == "stream_block") g_stream_block = (value == 256 ? 256 : 64);
   else if (k == "stream_waves") g_stream_waves = value;
   else if (k == "share_waves") g_share_waves = value;
@@ -1158,24 +1210,39 @@ int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64
     }
     const int vec = vec_width<F>({dst, a, binary ? b : nullptr}, {});
     const bool nt = g_nontemporal.load() != 0;
-    const int rc_ = split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
-      constexpr int VEC = decltype(V)::value;
-      u64* d = dst + first * F::LIMBS;
-      const u64* pa = a + first * F::LIMBS;
-      const u64* pb = binary ? b + first * F::LIMBS : nullptr;
-      const dim3 g(grid_for(npacks)), blk(BLOCK);
+    const long batch = g_inv_batch.load();
+    int rc_ = SCL_OK;
+    constexpr bool is_field = F::TAG != 5 && F::TAG != 6;
+    if (needs_flag && batch >= 0 && is_field) {
+      // FF::invert / operator/ (ff.h:203-246) over the batch by simultaneous inversion -- fields only: a ring's Newton inverse
+      // (z2k_ops.h:80-93) is a handful of products already
+      if constexpr (is_field) rc_ = ew_inverse<F>(ctx, op == SCL_OP_DIV, dst, a, b, n, vec, batch, flag, S(stream));
+    } else if (op == SCL_OP_MUL && F::TAG == 3 && batch >= 0) {
+      if constexpr (F::TAG == 3) {  // GF(2^128) products on the window table in LDS
+        auto kern = &k_ew_gf128_mul<64>;
+        hipLaunchKernelGGL(kern, dim3(grid_for_block(n, 64)), dim3(64), 64 * 256, S(stream), dst, a, b, n);
+        LAUNCH_CHECK();
+      }
+    } else {
+      rc_ = split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
+        constexpr int VEC = decltype(V)::value;
+        u64* d = dst + first * F::LIMBS;
+        const u64* pa = a + first * F::LIMBS;
+        const u64* pb = binary ? b + first * F::LIMBS : nullptr;
+        const dim3 g(grid_for(npacks)), blk(BLOCK);
 #define EW_CASE(OP)                                                                                             \
   case OP:                                                                                                      \
     if (nt) hipLaunchKernelGGL((k_ew<F, OP, VEC, true>), g, blk, 0, S(stream), ctx, d, pa, pb, npacks, flag);   \
     else hipLaunchKernelGGL((k_ew<F, OP, VEC, false>), g, blk, 0, S(stream), ctx, d, pa, pb, npacks, flag);     \
     break;
-      switch (op) {
-        EW_CASE(0) EW_CASE(1) EW_CASE(2) EW_CASE(3) EW_CASE(4) EW_CASE(5)
-      }
+        switch (op) {
+          EW_CASE(0) EW_CASE(1) EW_CASE(2) EW_CASE(3) EW_CASE(4) EW_CASE(5)
+        }
 #undef EW_CASE
-      LAUNCH_CHECK();
-      return SCL_OK;
-    });
+        LAUNCH_CHECK();
+        return SCL_OK;
+      });
+    }
     SCL_TRY(rc_);
     if (needs_flag) {
       unsigned h = 0;

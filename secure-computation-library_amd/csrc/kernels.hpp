@@ -166,6 +166,230 @@ __global__ __launch_bounds__(BLOCK) void k_ew(typename F::Ctx ctx, u64* dst, con
   }
 }
 
+// ---- FF::invert / operator/ over a batch: Montgomery's simultaneous inversion, one chain per lane -------------------------
+// The reference inverts element by element (extended Euclid, small_ff.h:61-92; Fermat for the mpn family,
+// ff_ops_gmp.h:250-260; operator/ = multiply by the inverse, ff.h:203-205).  An inverse is unique, so any route to it gives the
+// same bits (SURVEY 8a note C): a lane takes L = R * VEC elements, forms the prefix products c_i = x_0 ... x_i, inverts c_(L-1)
+// ONCE (the field's Fermat chain) and walks back, x_i^-1 = c_(i-1) * (c_i)^-1, (c_(i-1))^-1 = (c_i)^-1 * x_i:
+// 3 (L - 1) products and one inversion for L elements where k_ew<F, 4 | 5> spends 70 (Mersenne61) to 380 (secp256k1) products
+// on each.  A zero sets the flag and goes through the chain as a one; its slot gets 0, which is what F::inv(0) returns.
+// A workgroup owns BLOCK * R consecutive packs, lane l the packs l, l + BLOCK, ...: every access is a whole line.
+template <class F, bool DIV, int VEC, int R, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_ew_inv(typename F::Ctx ctx, u64* dst, const u64* a, const u64* b, size_t npacks,
+                                                  unsigned* zero_flag) {
+  typedef typename F::E E;
+  constexpr int L = R * VEC;
+  const u64* src = DIV ? b : a;  // the operand that is inverted
+  for (size_t tile = blockIdx.x; tile * ((size_t)BLOCK * R) < npacks; tile += gridDim.x) {
+    const size_t q0 = tile * ((size_t)BLOCK * R) + threadIdx.x;
+    E x[L], c[L];
+    unsigned zmask = 0;  // which slots held a zero (L <= 32)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const size_t q = q0 + (size_t)r * BLOCK;
+      Pack<F, VEC> pk;
+      if (q < npacks) {
+        pk = load_pack<F, VEC, NT>(src + q * VEC * F::LIMBS);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) pk.v[v] = F::one(ctx);
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const bool z = F::is_zero(pk.v[v]);
+        zmask |= z ? (1u << (r * VEC + v)) : 0u;
+        x[r * VEC + v] = z ? F::one(ctx) : pk.v[v];
+      }
+    }
+    if (zmask) atomicOr(zero_flag, 1u);
+    c[0] = x[0];
+#pragma unroll
+    for (int i = 1; i < L; ++i) c[i] = F::mul(ctx, c[i - 1], x[i]);
+    E inv = F::inv(ctx, c[L - 1]);
+#pragma unroll
+    for (int i = L - 1; i > 0; --i) {
+      const E o = F::mul(ctx, inv, c[i - 1]);
+      inv = F::mul(ctx, inv, x[i]);
+      x[i] = o;
+    }
+    x[0] = inv;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const size_t q = q0 + (size_t)r * BLOCK;
+      if (q < npacks) {
+        Pack<F, VEC> o;
+        Pack<F, VEC> num;
+        if constexpr (DIV) num = load_pack<F, VEC, NT>(a + q * VEC * F::LIMBS);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const int i = r * VEC + v;
+          E y = ((zmask >> i) & 1u) ? F::zero() : x[i];
+          if constexpr (DIV) y = F::mul(ctx, num.v[v], y);
+          o.v[v] = y;
+        }
+        store_pack<F, VEC, NT>(dst + q * VEC * F::LIMBS, o);
+      }
+    }
+  }
+}
+
+// ---- GF(2^128) element-wise products on a window table in LDS --------------------------------------------------------------
+// gfx950 has no carry-less multiply.  Gf128::mul spends ~1.9 k vector instructions per product selecting among four shifted
+// copies of a for every nibble of b; the comb product keeps the sixteen multiples u(x) a (deg u < 4) of THIS lane's a in LDS
+// (256 bytes per lane, entry u of lane l at (u * BLK + l) * 16: the ds_read_b128 of a wave are 64 consecutive 16-byte slots
+// whichever entries the lanes pick, so neither the writes nor the reads conflict) and adds, for nibble position k = 7..0, the
+// entry picked by nibble k of each 32-bit word of b at that word's offset; the 256-bit sum moves up four bits between
+// positions.  32 reads, 7 shifts, one fold: ~0.35 k vector instructions and 48 LDS accesses per product.
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BLK>
+__device__ __forceinline__ void gf_table_store(u32x4* mine, u128 a) {  // mine = table base + this lane
+  u128 t[16];
+  Gf128::window_table(a, t);
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    u32x4 w;
+    w.x = (u32)t[u];
+    w.y = (u32)(t[u] >> 32);
+    w.z = (u32)(t[u] >> 64);
+    w.w = (u32)(t[u] >> 96);
+    mine[u * BLK] = w;
+  }
+}
+
+template <int BLK>
+__device__ __forceinline__ u128 gf_comb(const u32x4* mine, u128 b) {  // (the a of the table) * b
+  const u32 bw[4] = {(u32)b, (u32)(b >> 32), (u32)(b >> 64), (u32)(b >> 96)};
+  u32 c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 7; k >= 0; --k) {
+    u32x4 m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = mine[((bw[j] >> (4 * k)) & 15u) * BLK];
+    // word j + i of the sum takes word i of the entry picked for word j of b: sixteen terms as ten three-input xors
+    c[0] ^= m[0].x;
+    c[1] = xor3(c[1], m[0].y, m[1].x);
+    c[2] = xor3(c[2], m[0].z, m[1].y) ^ m[2].x;
+    c[3] = xor3(xor3(c[3], m[0].w, m[1].z), m[2].y, m[3].x);
+    c[4] = xor3(c[4], m[1].w, m[2].z) ^ m[3].y;
+    c[5] = xor3(c[5], m[2].w, m[3].z);
+    c[6] ^= m[3].w;
+    if (k) {
+#pragma unroll
+      for (int i = 7; i > 0; --i) c[i] = __builtin_amdgcn_alignbit(c[i], c[i - 1], 28);
+      c[0] <<= 4;
+    }
+  }
+  const u128 lo = (u128)c[0] | ((u128)c[1] << 32) | ((u128)c[2] << 64) | ((u128)c[3] << 96);
+  const u128 hi = (u128)c[4] | ((u128)c[5] << 32) | ((u128)c[6] << 64) | ((u128)c[7] << 96);
+  return Gf128::reduce256(lo, hi);
+}
+
+// multiplyEntryWise over GF(2^128) on the LDS table.  Dynamic LDS: BLK * 256 bytes.
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k_ew_gf128_mul(u64* dst, const u64* a, const u64* b, size_t n) {
+  extern __shared__ u32x4 gf_tbl[];
+  u32x4* mine = gf_tbl + threadIdx.x;
+  typedef Gf128 F;
+  for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < n; q += (size_t)gridDim.x * BLK) {
+    const Pack<F, 1> x = load_pack<F, 1, true>(a + q * 2), y = load_pack<F, 1, true>(b + q * 2);
+    gf_table_store<BLK>(mine, x.v[0]);
+    Pack<F, 1> r;
+    r.v[0] = gf_comb<BLK>(mine, y.v[0]);
+    store_pack<F, 1, true>(dst + q * 2, r);
+  }
+}
+
+// ---- simultaneous inversion with the chain in memory: the fields whose ONE inversion is dear ------------------------------------
+// k_ew_inv keeps 2 L elements in registers, which stops at L = 16..32; for Mont128 (~250 products per Fermat inversion), secp256k1
+// (~450) and GF(2^128) the inversion's share I / L still dominates there.  Here the loops over the chain stay rolled: the prefix
+// products live in a per-lane array the compiler places in scratch memory (L1 / L2 traffic these compute-bound kernels have
+// room for), the operand is read a second time on the walk back (an L2 hit: a workgroup's tile is BLK * L elements), the code is
+// one copy of the product (the unrolled form of these fields runs to 60-130 KB, past the instruction cache) and L is free.
+// ARITH supplies the products: the field's own (FieldArith) or GF(2^128)'s on the LDS window table (GfLdsArith).
+template <class F>
+struct FieldArith {
+  typedef typename F::E E;
+  enum { LDS_PER_LANE = 0 };
+  typename F::Ctx ctx;
+  __device__ __forceinline__ FieldArith(const typename F::Ctx& c, int) : ctx(c) {}
+  __device__ __forceinline__ E one() const { return F::one(ctx); }
+  __device__ __forceinline__ E product(const E& a, const E& b) const { return F::mul(ctx, a, b); }
+  __device__ __forceinline__ void product2(const E& a, const E& b1, const E& b2, E& r1, E& r2) const {
+    r1 = F::mul(ctx, a, b1);
+    r2 = F::mul(ctx, a, b2);
+  }
+  __device__ __forceinline__ E inverse(const E& a) const { return F::inv(ctx, a); }
+};
+
+template <int BLK>
+struct GfLdsArith {
+  typedef u128 E;
+  enum { LDS_PER_LANE = 256 };
+  u32x4* mine;
+  __device__ __forceinline__ GfLdsArith(const Gf128::Ctx&, int tid) {
+    extern __shared__ u32x4 gf_tbl[];
+    mine = gf_tbl + tid;
+  }
+  __device__ __forceinline__ E one() const { return 1; }
+  __device__ __forceinline__ E product(E a, E b) const {
+    gf_table_store<BLK>(mine, a);
+    return gf_comb<BLK>(mine, b);
+  }
+  __device__ __forceinline__ void product2(E a, E b1, E b2, E& r1, E& r2) const {  // one table, two combs
+    gf_table_store<BLK>(mine, a);
+    r1 = gf_comb<BLK>(mine, b1);
+    r2 = gf_comb<BLK>(mine, b2);
+  }
+  __device__ __forceinline__ E inverse(E a) const {
+    return Gf128::inv_chain(Gf128::Ctx{}, a, [&](E x, E y) { return product(x, y); });
+  }
+};
+
+template <class F, class ARITH, bool DIV, int L, int BLK>
+__global__ __launch_bounds__(BLK) void k_ew_inv_rolled(typename F::Ctx ctx, u64* dst, const u64* a, const u64* b, size_t n,
+                                                       unsigned* zero_flag) {
+  typedef typename F::E E;
+  const ARITH ar(ctx, (int)threadIdx.x);
+  const u64* src = DIV ? b : a;
+  for (size_t tile = blockIdx.x; tile * ((size_t)BLK * L) < n; tile += gridDim.x) {
+    const size_t q0 = tile * ((size_t)BLK * L) + threadIdx.x;
+    E c[L];
+    E run = ar.one();
+    bool any_zero = false;
+#pragma unroll 1
+    for (int i = 0; i < L; ++i) {
+      const size_t q = q0 + (size_t)i * BLK;
+      E v = ar.one();
+      if (q < n) v = load_pack<F, 1, false>(src + q * F::LIMBS).v[0];  // (read again on the walk back: keep it cached)
+      if (F::is_zero(v)) {
+        any_zero = true;
+        v = ar.one();
+      }
+      run = i ? ar.product(run, v) : v;
+      c[i] = run;
+    }
+    if (any_zero) atomicOr(zero_flag, 1u);
+    E inv = ar.inverse(run);
+#pragma unroll 1
+    for (int i = L - 1; i >= 0; --i) {
+      const size_t q = q0 + (size_t)i * BLK;
+      E v = ar.one();
+      if (q < n) v = load_pack<F, 1, true>(src + q * F::LIMBS).v[0];
+      const bool z = F::is_zero(v);
+      if (z) v = ar.one();
+      E o = inv;
+      if (i) ar.product2(inv, c[i - 1], v, o, inv);
+      if (q < n) {
+        Pack<F, 1> out;
+        out.v[0] = z ? F::zero() : o;
+        if constexpr (DIV) out.v[0] = ar.product(load_pack<F, 1, true>(a + q * F::LIMBS).v[0], out.v[0]);
+        store_pack<F, 1, true>(dst + q * F::LIMBS, out);
+      }
+    }
+  }
+}
+
 // Vector::scalarMultiply (vector.h:274-301)
 template <class F, int VEC, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_scalar_mul(typename F::Ctx ctx, u64* dst, const u64* a,

@@ -93,6 +93,112 @@ def test_elementwise_vs_oracle(scl, port, f, n):
         assert np.array_equal(host(scl, scl.ew(f, O.DIV, dev(scl, nz), dev(scl, nzb))), port.ew(f, O.DIV, nz, nzb))
 
 
+def _plant_zeros(port, f, a, chain):
+    """zeros where a lane's chain, a wave, a workgroup tile (64 lanes x chain) and the batch begin and end"""
+    n, tile = len(a), 64 * chain
+    spots = {0, 1, 63, 64, 65, tile - 1, tile, tile + 1, 2 * tile - 1, n - 1, n - 2, n // 2}
+    spots |= {(7919 * k) % n for k in range(1, 40)}
+    spots = sorted(s_ for s_ in spots if 0 <= s_ < n)
+    a[spots] = port.from_int(f, 0)
+    return np.array(spots)
+
+
+@pytest.mark.parametrize("f", [O.M61, O.M127])
+@pytest.mark.parametrize("n", [1_000_003, 1 << 20])
+def test_batched_inverse_against_the_oracle_at_a_million(scl, port, f, n):
+    """FF::invert / operator/ over 10^6 elements (k_ew_inv / k_ew_inv_rolled: one Fermat chain per lane-chain instead of one per
+    element, ff.h:203-246, small_ff.h:61-92) against the oracle's extended Euclid, element for element; then the same batch with zeros
+    at every lane / wave / tile / batch boundary: the reference's error, every other slot still the inverse, the zeros' slots 0."""
+    a, b = rand_elems(port, f, n, b"inv-1e6-a"), rand_elems(port, f, n, b"inv-1e6-b")
+    zero = port.from_int(f, 0)
+    for x, sub in ((a, 7), (b, 9)):
+        x[np.all(x == zero, axis=1)] = port.from_int(f, sub)
+    want_inv, want_div = port.ew(f, O.INV, a), port.ew(f, O.DIV, b, a)
+    for chain in ([0] if f == O.M61 else [0, 8, 32, 128]):
+        scl.set_tuning("inv_batch", chain)
+        try:
+            da = dev(scl, a)
+            assert np.array_equal(host(scl, scl.ew(f, O.INV, da)), want_inv), (f, n, chain)
+            assert np.array_equal(host(scl, scl.ew(f, O.DIV, dev(scl, b), da)), want_div), (f, n, chain)
+            assert np.array_equal(host(scl, scl.ew(f, O.INV, da, out=da)), want_inv), "in place"
+            z = a.copy()
+            spots = _plant_zeros(port, f, z, chain or (32 if f == O.M61 else 8))
+            out = scl.empty(f, n)
+            with pytest.raises(scl.SclError) as ei:
+                scl.ew(f, O.INV, dev(scl, z), out=out)
+            assert ei.value.status == scl.ERR_ZERO_INVERSE
+            got, keep = host(scl, out), np.ones(n, bool)
+            keep[spots] = False
+            assert np.array_equal(got[keep], want_inv[keep]) and not got[spots].any()
+        finally:
+            scl.set_tuning("inv_batch", 0)
+    scl.set_tuning("inv_batch", -1)  # the per-element kernels of rounds 1-4 give the same bits
+    try:
+        assert np.array_equal(host(scl, scl.ew(f, O.INV, dev(scl, a[:4099]))), want_inv[:4099])
+    finally:
+        scl.set_tuning("inv_batch", 0)
+
+
+@pytest.mark.parametrize("f", [O.MONT128, O.GF2_128, O.SECP256K1_SCALAR, O.SECP256K1_FIELD])
+@pytest.mark.parametrize("chain", [0, 8, 32, 128])
+def test_batched_inverse_slow_oracle_fields(scl, port, f, chain):
+    """The fields whose oracle inversion is slow: x * x^-1 = 1 and (b / x) * x = b over 2^20 + 5 elements (products are pinned by the
+    oracle on their own; an inverse is unique), an oracle window of 200 elements across the first tile boundary, the per-element
+    kernel on a prefix, zeros planted at the chain / wave / tile boundaries."""
+    n = (1 << 20) + 5
+    a, b = rand_elems(port, f, n, b"inv-slow-a"), rand_elems(port, f, n, b"inv-slow-b")
+    zero = port.from_int(f, 0)
+    a[np.all(a == zero, axis=1)] = port.from_int(f, 7)
+    one = np.broadcast_to(port.from_int(f, 1), a.shape)
+    scl.set_tuning("inv_batch", chain)
+    try:
+        da, db = dev(scl, a), dev(scl, b)
+        inv = scl.ew(f, O.INV, da)
+        assert np.array_equal(host(scl, scl.ew(f, O.MUL, inv, da)), one)
+        quo = scl.ew(f, O.DIV, db, da)
+        assert np.array_equal(host(scl, scl.ew(f, O.MUL, quo, da)), b)
+        tile = 64 * (chain or 8)
+        lo = max(0, tile - 100)
+        assert np.array_equal(host(scl, inv)[lo:lo + 200], port.ew(f, O.INV, a[lo:lo + 200]))
+        assert np.array_equal(host(scl, quo)[lo:lo + 200], port.ew(f, O.DIV, b[lo:lo + 200], a[lo:lo + 200]))
+        assert np.array_equal(host(scl, inv)[-100:], port.ew(f, O.INV, a[-100:]))
+        scl.set_tuning("inv_batch", -1)
+        assert np.array_equal(host(scl, scl.ew(f, O.INV, dev(scl, a[:8191]))), host(scl, inv)[:8191])
+        scl.set_tuning("inv_batch", chain)
+        z = a.copy()
+        spots = _plant_zeros(port, f, z, chain or 8)
+        out = scl.empty(f, n)
+        with pytest.raises(scl.SclError) as ei:
+            scl.ew(f, O.INV, dev(scl, z), out=out)
+        assert ei.value.status == scl.ERR_ZERO_INVERSE
+        got, keep = host(scl, out), np.ones(n, bool)
+        keep[spots] = False
+        assert np.array_equal(got[keep], host(scl, inv)[keep]) and not got[spots].any()
+    finally:
+        scl.set_tuning("inv_batch", 0)
+
+
+def test_gf2_128_products_on_the_lds_table(scl, port):
+    """multiplyEntryWise over GF(2^128): the comb product on the per-lane window table in LDS (k_ew_gf128_mul) against the oracle's
+    shift-xor product and against the register-only kernel, sparse / dense corner operands included."""
+    f, n = O.GF2_128, 100_003
+    a, b = rand_elems(port, f, n, b"gfmul-a"), rand_elems(port, f, n, b"gfmul-b")
+    corners = [0, 1, 2, 0x87, 1 << 127, (1 << 128) - 1, (1 << 127) | 1, 0xF << 124, 0xFFFFFFFF << 96]
+    k = 0
+    for x in corners:
+        for y in corners:
+            a[k], b[k] = O.from_ints([x], 2)[0], O.from_ints([y], 2)[0]
+            k += 1
+    got = host(scl, scl.ew(f, O.MUL, dev(scl, a), dev(scl, b)))
+    assert np.array_equal(got[:3000], port.ew(f, O.MUL, a[:3000], b[:3000]))
+    assert np.array_equal(got[-500:], port.ew(f, O.MUL, a[-500:], b[-500:]))
+    scl.set_tuning("inv_batch", -1)
+    try:
+        assert np.array_equal(host(scl, scl.ew(f, O.MUL, dev(scl, a), dev(scl, b))), got)
+    finally:
+        scl.set_tuning("inv_batch", 0)
+
+
 @pytest.mark.parametrize("f", ALL_FIELDS)
 def test_inverse_of_zero_is_the_reference_error(scl, port, f):
     a = rand_elems(port, f, 100, b"z")
