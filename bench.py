@@ -93,6 +93,11 @@ def parse_args(argv=None):
     ap.add_argument("--total-secrets", type=int, default=0, help="--config c4 / c5: total over all ranks (default 10^8 / 10^9)")
     ap.add_argument("--c4-rank-secrets", type=int, default=100_000_000,
                     help="open.c4_rank_shape: secrets of the one-rank-of-eight shape of BASELINE configs[3] (0 = skip)")
+    ap.add_argument("--allocations", type=int, default=0,
+                    help="independently allocated operand sets the headline's steps rotate over (0 = three for BASELINE configs[1] at "
+                         "up to 10^8 secrets per GPU, one otherwise): where the operands land moves the kernels by up to 10 percent")
+    ap.add_argument("--ew", type=int, default=1,
+                    help="1: after the headline, the element-wise add / mul / inverse path (Mersenne61 10^8, Mersenne127 and GF(2^128) 10^7)")
     ap.add_argument("--pmc-live", type=int, default=1,
                     help="1: roofline.traffic observed in THIS run -- two child runs of the headline under rocprofv3 --pmc FETCH_SIZE / "
                          "WRITE_SIZE after everything else (one GPU, BASELINE configs[1] only; falls back to profiles/pmc_traffic.json)")
@@ -204,23 +209,27 @@ def cpu_baseline(field_key, n, t, sample):
                   f"share {r['share_s']:.2f}s + recover {r['recover_s']:.2f}s",
         "recover_only_per_s": sample / r["recover_s"], "share_only_per_s": sample / r["share_s"],
     }
-    # SURVEY.md section 8d asks for two more figures beside the faithful single-thread run (SCL itself is single-threaded;
-    # the threads below are this harness's, one PRG and one slab of secrets each):
-    #   all_cores  the same per-secret path on the host cores that go with one GPU (at most 16 threads)
-    #   hoisted    one thread, Lagrange basis computed once instead of per secret (reference library only)
-    try:
-        from concurrent.futures import ThreadPoolExecutor
-        cores = min(len(os.sched_getaffinity(0)), 16)   # the CPU share that goes with one GPU on the bench boxes
-        per = max(1, sample // 4)          # a quarter of the sample per thread keeps the leg to a few seconds
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL for the duration of each call
-            rs = list(ex.map(lambda i: lib.time_shamir(f, per, t, n, b"scl-bench-%d" % i), range(cores)))
-        wall = time.perf_counter() - t0
-        if not any(x["mismatches"] for x in rs):
-            out["all_cores"] = {"value": per * cores / wall, "cores": cores,
-                                "sample": f"{per} secrets on each of {cores} threads, wall {wall:.2f}s"}
-    except Exception as e:  # the extra legs never fail the bench line
-        out["all_cores"] = {"error": str(e)}
+    # SURVEY.md section 8d / BASELINE.md section 2 ask for more figures beside the faithful single-thread run (SCL itself is
+    # single-threaded; the threads below are this harness's, one PRG and one slab of secrets each):
+    #   all_cores      the same per-secret path on every PHYSICAL core this process may run on, count stated (a container's
+    #                  cgroup quota, when there is one, is stated beside it: it caps what those threads get)
+    #   cores_per_gpu  the same on the 16 host threads that go with one GPU on the bench boxes
+    #   hoisted_basis  one thread, Lagrange basis computed once instead of per secret (reference library only)
+    from concurrent.futures import ThreadPoolExecutor
+    phys = physical_cores()
+    out["physical_cores"], out["cgroup_cpu_limit"] = phys, cgroup_cpu_limit()
+    for key, cores in (("all_cores", phys), ("cores_per_gpu", min(len(os.sched_getaffinity(0)), 16))):
+        try:
+            per = max(1, sample // 4)          # a quarter of the sample per thread keeps the leg to a few seconds
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL for the duration of each call
+                rs = list(ex.map(lambda i: lib.time_shamir(f, per, t, n, b"scl-bench-%d" % i), range(cores)))
+            wall = time.perf_counter() - t0
+            if not any(x["mismatches"] for x in rs):
+                out[key] = {"value": per * cores / wall, "cores": cores,
+                            "sample": f"{per} secrets on each of {cores} threads, wall {wall:.2f}s"}
+        except Exception as e:  # the extra legs never fail the bench line
+            out[key] = {"error": str(e)}
     if kind == "reference":
         try:
             hr = lib.time_shamir_hoisted(f, sample, t, n)
@@ -230,6 +239,36 @@ def cpu_baseline(field_key, n, t, sample):
         except Exception as e:
             out["hoisted_basis"] = {"error": str(e)}
     return out
+
+
+def physical_cores():
+    """physical cores among the logical CPUs this process may run on (distinct (socket, core) pairs of /proc/cpuinfo)"""
+    allowed = os.sched_getaffinity(0)
+    cores, cpu, phys = set(), None, 0
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                k, _, v = ln.partition(":")
+                k = k.strip()
+                if k == "processor":
+                    cpu = int(v)
+                elif k == "physical id":
+                    phys = int(v)
+                elif k == "core id" and cpu in allowed:
+                    cores.add((phys, int(v)))
+    except (OSError, ValueError):
+        pass
+    return len(cores) or len(allowed)
+
+
+def cgroup_cpu_limit():
+    """CPUs the container may use at once when a cgroup quota says so (cpu.max "quota period"), else None"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
 
 
 def kernel_source_hash():
@@ -344,16 +383,21 @@ def live_pmc_traffic(args, timeout_s=240):
     the side configurations when --configs is on; no open step, no CPU baseline) under `rocprofv3 --pmc FETCH_SIZE` and
     `--pmc WRITE_SIZE` (the two cannot share a pass on gfx950; no trace domain is combined with --pmc), and pmc_report reads the
     kernels' counter means from their CSVs.  The program itself follows `--`.  Children of this process, started after every
-    timed region; any failure returns None (the stamped figures are then quoted)."""
+    timed region.  Returns (report or None, info): info = {"ran", "seconds", "fallback_reason"} goes into the line as
+    `pmc_live`, so a fallback to the stamped figures says why."""
     import shutil
     import tempfile
+    t_begin = time.perf_counter()
+
+    def done(rep, reason=None):
+        return rep, {"ran": rep is not None, "seconds": round(time.perf_counter() - t_begin, 1), "fallback_reason": reason}
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None
+        return done(None, "rocprofv3 not found")
     if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ):   # this process is itself being profiled: no nesting
-        return None
+        return done(None, "this process is itself running under a profiler")
     child = [sys.executable, os.path.abspath(__file__), "--configs", str(args.configs), "--open", "0", "--cpu-sample", "0",
-             "--pmc-live", "0", "--steps", "3", "--warmup", "1", "--field", args.field, "--n", str(args.n), "--t", str(args.t),
+             "--pmc-live", "0", "--ew", "0", "--allocations", "1", "--steps", "3", "--warmup", "1", "--field", args.field, "--n", str(args.n), "--t", str(args.t),
              "--secrets", str(args.secrets), "--share-mode", args.share_mode]
     env = dict(os.environ, TMPDIR="/tmp")
     work = tempfile.mkdtemp(prefix="scl_pmc_", dir="/tmp")
@@ -368,17 +412,17 @@ def live_pmc_traffic(args, timeout_s=240):
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, 9)      # exactly the process group this call started
                 p.wait()
-                return None
+                return done(None, f"the {counter} pass did not finish in {timeout_s} s")
             if rc != 0:
-                return None
+                return done(None, f"the {counter} pass exited with {rc}")
             tables[counter] = pmc_means(d, counter)
         copy_bytes = float(min(4 << 30, args.n * args.secrets * 8 * (1 if args.field == "m61" else 2) // 2) & ~15)
         rep = pmc_report(tables["FETCH_SIZE"], tables["WRITE_SIZE"], copy_bytes)
         if rep.get("shamir_share") is None or rep.get("shamir_recover") is None:
-            return None
-        return rep
-    except Exception:
-        return None
+            return done(None, "the headline's kernels are not in the counter tables")
+        return done(rep)
+    except Exception as e:
+        return done(None, f"{type(e).__name__}: {e}")
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
@@ -437,6 +481,28 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def all_ranks(x):
+        """every rank's value, in rank order (what the driver needs to see that N ranks really ran)"""
+        if world == 1:
+            return [x]
+        xs = [None] * world
+        dist.all_gather_object(xs, float(x))
+        return xs
+
+    def rccl_report():
+        """what the process group itself says about the job: a SCALE record can check that the collective library saw N ranks"""
+        if world == 1:
+            return {"ranks": 1, "backend": None, "devices": [0] if dry else [torch.cuda.current_device()]}
+        devs = [None] * world
+        dist.all_gather_object(devs, -1 if dry else int(torch.cuda.current_device()))
+        rep = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "devices": devs}
+        if not dry and args.backend == "nccl":
+            # one all-reduce of ones through the communicator the timed collectives use: RCCL itself counts the ranks
+            ones = torch.ones(1, dtype=torch.int64, device="cuda")
+            dist.all_reduce(ones)
+            rep["allreduce_of_ones"] = int(ones.item())
+        return rep
+
     def timed_region(step, steps, warmup):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
         for _ in range(warmup):
@@ -446,11 +512,13 @@ def main():
         for k in range(steps):
             step(k)
         sync()
-        return max_over_ranks(time.perf_counter() - t0)
+        mine_s = time.perf_counter() - t0
+        return max_over_ranks(mine_s), all_ranks(mine_s)
 
     pl = plan(args, world, rank)
     if dry:
-        elapsed = timed_region(lambda k: None, args.steps, args.warmup)
+        elapsed, rank_elapsed = timed_region(lambda k: None, args.steps, args.warmup)
+        rccl = rccl_report()
         mine = torch.tensor([pl["mine"]], dtype=torch.int64)
         if world > 1 and pl["key"] != "c4":
             dist.all_reduce(mine)          # the shards add up to the total (c4: every rank opens every secret)
@@ -458,6 +526,7 @@ def main():
             emit({"metric": "shamir_reconstructions_per_sec", "value": 0.0, "unit": "reconstructions/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True,
+                              "ms_per_step_by_rank": [1e3 * x / max(1, args.steps) for x in rank_elapsed], "rccl": rccl,
                               "scaling": pl["scaling"], "vs_baseline": None, "dtype": pl["dtype"] or "u64",
                               "data": "none (dry run)",
                               "config": {"workload": "dry run of the launcher: " + pl["workload"], "n": pl["n"], "t": pl["t"],
@@ -637,6 +706,61 @@ def main():
         rep["verified"] = rep["gpu_1e6"]["verified"] and rep["gpu_1e8"]["verified"]
         return rep
 
+    def ew_report():
+        """The element-wise path north_star names first: Vector::add / multiplyEntryWise (vector.h:199-245) and FF::inverse
+        (ff.h:203-246, small_ff.h:61-92) over Mersenne61 (10^8 elements), Mersenne127 and GF(2^128) (10^7 each) through scl_hip_ew.
+        HIP events around every launch, each kernel in its own steady state (100 warm-up launches for the sub-millisecond
+        sizes, see share_recover_config); algorithmic bytes 3E for a binary op, 2E for a unary one.  The
+        inverse's figure includes its 4-byte zero-flag read-back (the call returns the reference's error for a zero).  Checked
+        against the CPU oracle on a window at each end of the batch and through x * x^-1 = 1, (a + b) - b = a over all of it."""
+        import numpy as np
+        import oracle_lib as O
+        port = O.Port()
+        rep = {"workload": "scl_hip_ew: add, multiplyEntryWise, inverse over whole vectors resident in HBM",
+               "bytes_per_element": "3E for add / mul, 2E for inv (E = element bytes)", "fields": {}}
+        win = 2048
+        for fkey, N_ in (("m61", 100_000_000), ("m127", 10_000_000), ("gf2_128", 10_000_000)):
+            f_, L_ = tag_limbs(fkey)
+            E_ = 8 * L_
+            a, b, out = scl.empty(f_, N_), scl.empty(f_, N_), scl.empty(f_, N_)
+            fill_random(a, f_, b"scl-bench-ew-a-" + fkey.encode())
+            fill_random(b, f_, b"scl-bench-ew-b-" + fkey.encode())
+            ha = np.concatenate([scl.to_host(a[:win]), scl.to_host(a[-win:])])
+            hb = np.concatenate([scl.to_host(b[:win]), scl.to_host(b[-win:])])
+            warm, reps = (100, 50) if N_ * E_ < 400_000_000 else (5, 10)
+            legs, ok_all = {}, True
+            for name, op, nb, two in (("add", scl.ADD, 3 * E_, True), ("mul", scl.MUL, 3 * E_, True), ("inv", scl.INV, 2 * E_, False)):
+                tms = [scl.Timer() for _ in range(reps)]
+                for k in range(-warm, reps):
+                    if k >= 0:
+                        tms[k].start()
+                    scl.ew(f_, op, a, b if two else None, out=out)
+                    if k >= 0:
+                        tms[k].stop()
+                torch.cuda.synchronize()
+                ms = [tm.elapsed_ms() for tm in tms]
+                mean = sum(ms) / reps
+                got = np.concatenate([scl.to_host(out[:win]), scl.to_host(out[-win:])])
+                ok = bool(np.array_equal(got, port.ew(f_, {"add": O.ADD, "mul": O.MUL, "inv": O.INV}[name], ha, hb if two else None)))
+                if name == "add":
+                    ok = ok and bool(scl.equals(f_, scl.ew(f_, scl.SUB, out, b), a))
+                if name == "inv":
+                    prod = scl.ew(f_, scl.MUL, out, a)
+                    one = torch.zeros_like(prod)
+                    one[:, 0] = 1
+                    ok = ok and bool(scl.equals(f_, prod, one))
+                    del prod, one
+                legs[name] = {"ms": mean, "ms_min_max": [min(ms), max(ms)], "elements_per_s": N_ / (mean * 1e-3),
+                              "bytes_per_element": nb, "GBps": nb * N_ / mean / 1e6, "frac": nb * N_ / mean / 1e6 / HBM_PEAK_GBPS,
+                              "verified": ok}
+                ok_all = ok_all and ok
+            rep["fields"][FIELD_NAMES[fkey]] = {"elements": N_, "dtype": {1: "u64", 2: "u128"}[L_], "warmup": warm, "launches": reps,
+                                                **legs, "verified": ok_all}
+            del a, b, out
+            torch.cuda.empty_cache()
+        rep["verified"] = all(v["verified"] for v in rep["fields"].values())
+        return rep
+
     def open_step(fkey, n, t, N, chunk, steps, warmup, seed):
         """The MPC open of N secrets: every rank holds ceil(n/G) parties' share vectors, one all-gather per chunk
         brings all n rows to every rank, every rank reconstructs (as every MPC party does).  Timed three ways:
@@ -667,7 +791,7 @@ def main():
                 dist.all_gather_into_tensor(gathered, piece)
             else:
                 gathered.copy_(piece)
-        t_gather = timed_region(gather_only, steps, warmup) / steps
+        t_gather = timed_region(gather_only, steps, warmup)[0] / steps
         out_c = scl.empty(f_, c0)
         tm = scl.Timer()
         scl.shamir_recover(f_, gathered[:n], lam, out=out_c)
@@ -681,7 +805,7 @@ def main():
         def pipeline(k):
             result["out"] = sd.open_and_reconstruct(f_, local, n, lam, chunk=chunk) if world > 1 else \
                 sd.open_and_reconstruct_local(f_, local, n, lam, chunk=chunk)
-        t_pipe = timed_region(pipeline, steps, warmup) / steps
+        t_pipe = timed_region(pipeline, steps, warmup)[0] / steps
         ok = bool(scl.equals(f_, result["out"], secrets))
         # the same open by partial sums (any field): each rank reduces its own parties, the ranks all-gather one element
         # per secret and rank, every rank adds them -- 1/parties_per_rank of the volume, every rank still learns every secret
@@ -690,7 +814,7 @@ def main():
         def partial_pipeline(k):
             result["pg"] = sd.open_by_partial_gather(f_, mine_rows, lam[first:first + cnt], chunk=chunk) if world > 1 else \
                 sd.open_and_reconstruct_local(f_, local, n, lam, chunk=chunk)
-        t_pg = timed_region(partial_pipeline, steps, warmup) / steps
+        t_pg = timed_region(partial_pipeline, steps, warmup)[0] / steps
         ok_pg = bool(scl.equals(f_, result["pg"], secrets))
         # the same two opens behind the C ABI: RCCL called by the library itself (scl_hip_open_all_gather /
         # scl_hip_open_partial_gather; per-row grouped all-gathers, no packing copy), what a C++ caller of include/scl_hip/ gets
@@ -704,11 +828,11 @@ def main():
             try:
                 def c_pipeline(k):
                     result["c"] = sd.open_all_gather_c(comm, f_, local, n, lam, chunk=chunk)
-                t_c = timed_region(c_pipeline, steps, warmup) / steps
+                t_c = timed_region(c_pipeline, steps, warmup)[0] / steps
 
                 def c_partial(k):
                     result["cp"] = sd.open_partial_gather_c(comm, f_, mine_rows, lam[first:first + cnt], chunk=chunk)
-                t_cp = timed_region(c_partial, steps, warmup) / steps
+                t_cp = timed_region(c_partial, steps, warmup)[0] / steps
                 c_abi = {"pipeline_ms": 1e3 * t_c, "opened_secrets_per_s": N / t_c,
                          "partial_gather_pipeline_ms": 1e3 * t_cp, "partial_gather_opened_secrets_per_s": N / t_cp,
                          "verified": bool(scl.equals(f_, result["c"], secrets)) and bool(scl.equals(f_, result["cp"], secrets))}
@@ -750,7 +874,7 @@ def main():
         def run(k):
             result["mine"] = sd.open_by_partial_sums(local, lam[first:first + cnt]) if world > 1 else \
                 scl.shamir_recover(f_, local, lam)
-        t_ps = timed_region(run, steps, warmup) / steps
+        t_ps = timed_region(run, steps, warmup)[0] / steps
         lo = rank * (N // world)
         ok = bool(scl.equals(f_, result["mine"].reshape(-1, 1), secrets[lo:lo + N // world]))
         moved = N * 8
@@ -883,17 +1007,25 @@ def main():
     seed = f"scl-bench-{args.field}-{rank}".encode()
     lam = scl.lagrange_basis(f, n)
     tc = t if args.share_mode == "coeffs" else 0
-    secrets = scl.empty(f, N)
-    coeffs = scl.empty(f, tc, N) if tc else None
-    fill_random(secrets, f, seed + b"-secrets")
-    if tc:
-        fill_random(coeffs, f, seed + b"-coeffs")
-    shares = scl.empty(f, n, N)
-    out = scl.empty(f, N)
+    # The steps rotate over `nsets` independently allocated operand sets, all alive at once: where a buffer lands moves these
+    # kernels by up to 10 % (Placement), so ONE 12 GB set says as much about the allocation as about the
+    # kernel.  Every step does the same work whichever set it runs on; the line carries the mean and the per-allocation means.
+    nsets = args.allocations or (3 if (pl["key"] == "c2" and N * n * E <= 8_000_000_000) else 1)
+    sets = []
+    for a in range(nsets):
+        secrets = scl.empty(f, N)
+        coeffs = scl.empty(f, tc, N) if tc else None
+        fill_random(secrets, f, seed + (b"-secrets" if a == 0 else b"-secrets%d" % a))
+        if tc:
+            fill_random(coeffs, f, seed + (b"-coeffs" if a == 0 else b"-coeffs%d" % a))
+        sets.append((secrets, coeffs, scl.empty(f, n, N), scl.empty(f, N)))
     timers = [(scl.Timer(), scl.Timer()) for _ in range(args.steps)]
+    turn = [0]
 
     def step(k):
         tm = timers[k] if k is not None else None
+        secrets, coeffs, shares, out = sets[(k if k is not None else turn[0]) % nsets]
+        turn[0] += 1
         if tm:
             tm[0].start()
         if args.share_mode == "coeffs":
@@ -907,12 +1039,22 @@ def main():
         if tm:
             tm[1].stop()
 
-    elapsed = timed_region(step, args.steps, args.warmup)
+    elapsed, rank_elapsed = timed_region(step, args.steps, args.warmup)
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region -------------------
     share_ms = sum(tm[0].elapsed_ms() for tm in timers) / max(1, args.steps)
     rec_ms = sum(tm[1].elapsed_ms() for tm in timers) / max(1, args.steps)
-    verified = bool(scl.equals(f, out, secrets))
+    by_alloc = []
+    for a in range(nsets):
+        mine_ = [tm for k, tm in enumerate(timers) if k % nsets == a]
+        if mine_:
+            by_alloc.append({"steps": len(mine_), "share_ms": sum(tm[0].elapsed_ms() for tm in mine_) / len(mine_),
+                             "recover_ms": sum(tm[1].elapsed_ms() for tm in mine_) / len(mine_)})
+    ran = max(min(nsets, args.steps), min(nsets, args.warmup))      # the sets a step has run on (rotation from set 0)
+    verified = all(bool(scl.equals(f, st[3], st[0])) for st in sets[:ran])
+    secrets, coeffs, shares, out = sets[0]
+    del sets[1:]
+    torch.cuda.empty_cache()
 
     # measured copy bandwidth of the same device (read+write bytes / time), for context
     probe_bytes = min(4 << 30, shares.numel() * 8 // 2) & ~15
@@ -925,9 +1067,10 @@ def main():
         scl.stream_copy(dst, src)
     tm.stop()
     copy_gbps = 2 * probe_bytes * 5 / (tm.elapsed_ms() * 1e-3) / 1e9
-    del secrets, coeffs, shares, out, src, dst
+    del secrets, coeffs, shares, out, src, dst, sets
     torch.cuda.empty_cache()
 
+    rccl = rccl_report()                                 # (collective: every rank)
     open_rep = open_report() if args.open else None      # every rank takes part in the collectives
 
     if rank != 0:
@@ -964,13 +1107,15 @@ def main():
     line = {
         "metric": "shamir_reconstructions_per_sec", "value": total / elapsed, "unit": "reconstructions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step_by_rank": [1e3 * x / args.steps for x in rank_elapsed], "rccl": rccl,
         "higher_is_better": True, "scaling": pl["scaling"], "vs_baseline": None,
         "dtype": {1: "u64", 2: "u128", 4: "u256"}[L], "data": "synthetic",
         "config": {"workload": pl["workload"],
                    "field": FIELD_NAMES[args.field], "n": n, "t": t, "secrets_per_gpu": N, "total_secrets": pl["total"],
-                   "share_mode": args.share_mode, "layout": "SoA [party][secret]", "allocation": "plain",
+                   "share_mode": args.share_mode, "layout": "SoA [party][secret]",
+                   "allocation": f"plain; the steps rotate over {nsets} independently allocated operand set(s)",
                    "parallelism": pl["parallelism"]},
-        "roofline": roofline, "kernels": kernels, "verified": verified,
+        "roofline": roofline, "kernels": kernels, "by_allocation": by_alloc, "verified": verified,
         "reconstruct_only_per_s": N * world / (rec_ms * 1e-3), "share_only_per_s": N * world / (share_ms * 1e-3),
     }
     if open_rep is not None:
@@ -985,6 +1130,12 @@ def main():
             line["c1_additive"] = c1_additive_report()
         except Exception as e:
             line["c1_additive"] = {"error": str(e), "verified": False}
+            torch.cuda.empty_cache()
+    if world == 1 and args.ew and pl["key"] == "c2":
+        try:
+            line["ew"] = ew_report()
+        except Exception as e:
+            line["ew"] = {"error": str(e), "verified": False}
             torch.cuda.empty_cache()
     if world == 1 and args.configs:
         # the other BASELINE configurations at the size ONE GPU holds of them (C4, C5: an eighth), after the timed region
@@ -1007,7 +1158,7 @@ def main():
     if (world == 1 and args.pmc_live and pl["key"] == "c2" and roofline.get("bound") == "hbm"
             and (args.field, args.n, args.t, args.share_mode) == ("m61", 10, 3, "coeffs") and args.secrets >= 10_000_000):
         torch.cuda.empty_cache()
-        live = live_pmc_traffic(args)
+        live, line["pmc_live"] = live_pmc_traffic(args)
         if live is not None:
             cal = live.get("calibration_k_copy16", {})
             roofline["traffic_stamped"] = roofline["traffic"]

@@ -87,7 +87,7 @@ SCL_STATE(thread_local Knob g_share_waves, {9});
 SCL_STATE(thread_local Knob g_share_waves128, {12});  // .. and for the 16-byte fields' small-node share kernel ("share_waves128")
 SCL_STATE(thread_local Knob g_aes_blocks, {0});
 // element-wise inverse / divide: 0 auto = Montgomery's simultaneous inversion with the chain length chosen by the batch, N > 0 =
-// that chain length (8, 32 or 128; Mersenne61: any N = its register kernel), -1 = one Fermat chain per element (k_ew, the kernels
+// that chain length (8, 32, 64 or 128; Mersenne61: any N = its register kernel), -1 = one Fermat chain per element (k_ew, the kernels
 // of rounds 1-4); GF(2^128) multiply: -1 = the register-only product ("inv_batch")
 SCL_STATE(thread_local Knob g_inv_batch, {0});
 // Mont128 modulus: a process-wide default, latched per host thread at its first use (mont_ctx below)
@@ -961,7 +961,7 @@ static int share_chunked(int field, uint64_t* shares, size_t share_stride, const
 
 // Inverse / divide by Montgomery's simultaneous inversion (kernels.hpp, k_ew_inv / k_ew_inv_rolled).  Chain length: Mersenne61
 // keeps 32 elements per lane in registers (16-byte packs); the other fields keep the chain in memory and take the longest of
-// 8 / 32 / 128 that still leaves ~2000 single-wave workgroups (the inversion's share of a chain is I / L products per element,
+// 8 / 32 / 64 / 128 that still leaves ~2000 single-wave workgroups (the inversion's share of a chain is I / L products per element,
 // I = 138 for Mersenne127 up to ~450 for secp256k1, against 3 for the walk).
 template <class F, class ARITH, bool DIV, int L>
 int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, unsigned* flag, hipStream_t st) {
@@ -976,9 +976,10 @@ int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const 
 template <class F, bool DIV>
 int ew_inverse_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, long want, unsigned* flag, hipStream_t st) {
   using A = std::conditional_t<F::TAG == 3, GfLdsArith<64>, FieldArith<F>>;
-  int L = n >= ((size_t)1 << 24) ? 128 : n >= ((size_t)1 << 22) ? 32 : 8;
-  if (want > 0) L = want >= 128 ? 128 : want >= 32 ? 32 : 8;
+  int L = n >= ((size_t)1 << 24) ? 128 : n >= ((size_t)1 << 23) ? 64 : n >= ((size_t)1 << 22) ? 32 : 8;
+  if (want > 0) L = want >= 128 ? 128 : want >= 64 ? 64 : want >= 32 ? 32 : 8;
   if (L == 128) return launch_inv_rolled<F, A, DIV, 128>(ctx, dst, a, b, n, flag, st);
+  if (L == 64) return launch_inv_rolled<F, A, DIV, 64>(ctx, dst, a, b, n, flag, st);
   if (L == 32) return launch_inv_rolled<F, A, DIV, 32>(ctx, dst, a, b, n, flag, st);
   return launch_inv_rolled<F, A, DIV, 8>(ctx, dst, a, b, n, flag, st);
 }

@@ -29,6 +29,10 @@ def test_plain_start_with_gpus_2_launches_two_ranks():
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
     assert line["config"]["parallelism"] == "shard2"
     assert line["metric"] == "shamir_reconstructions_per_sec" and line["scaling"] == "weak"
+    # what the process group itself reports, so that a scaling record can check that N ranks really ran: the collective
+    # library's own world size and backend, each rank's device and each rank's time per step (the line's is their maximum)
+    assert line["rccl"]["ranks"] == 2 and line["rccl"]["backend"] == "gloo" and len(line["rccl"]["devices"]) == 2
+    assert len(line["ms_per_step_by_rank"]) == 2 and abs(max(line["ms_per_step_by_rank"]) - line["ms_per_step"]) < 1e-9
 
 
 def test_single_rank_dry_run_prints_one_line():
@@ -36,6 +40,7 @@ def test_single_rank_dry_run_prints_one_line():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1
+    assert line["rccl"] == {"ranks": 1, "backend": None, "devices": [0]} and len(line["ms_per_step_by_rank"]) == 1
 
 
 def test_world_size_that_disagrees_with_gpus_fails():
