@@ -737,6 +737,38 @@ int matmul_mfma(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size
   return fail(SCL_ERR_BAD_ARG, "matmul_mfma: unsupported shape");
 }
 
+// Any M and K on the matrix cores: row blocks of at most 128 rows of A, column chunks of at most 64 (the kernel's K).  The first
+// chunk of a row block writes C, every later one writes a temporary that one modular add folds into C -- canonical partial sums
+// add exactly (SURVEY 8a note C).  Each (block, chunk) builds its digit planes in the call's temporary arena; the stream orders
+// the launches.
+template <class FieldG>
+int matmul_mfma_blocks(const typename FieldG::Ctx& ctx, u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M,
+                       size_t K, size_t N, hipStream_t st) {
+  if (M <= 128 && K <= 64) return matmul_mfma<FieldG>(C, ldc, A, lda, B, ldb, M, K, N, st);
+  u64* T = nullptr;
+  const size_t ldt = (N + 1) & ~(size_t)1;
+  if (K > 64) {  // (arena 0 holds the digit planes of each launch)
+    void* tmp = nullptr;
+    SCL_TRY(temp_acquire(std::min<size_t>(M, 128) * ldt * 8, st, &tmp, 1));
+    T = static_cast<u64*>(tmp);
+  }
+  int rc = SCL_OK;
+  for (size_t r0 = 0; r0 < M && rc == SCL_OK; r0 += 128) {
+    const size_t mr = std::min<size_t>(128, M - r0);
+    for (size_t k0 = 0; k0 < K && rc == SCL_OK; k0 += 64) {
+      const size_t kc = std::min<size_t>(64, K - k0);
+      u64* dst = k0 ? T : C + r0 * ldc;
+      rc = matmul_mfma<FieldG>(dst, k0 ? ldt : ldc, A + r0 * lda + k0, lda, B + k0 * ldb, ldb, mr, kc, N, st);
+      if (rc == SCL_OK && k0) {
+        hipLaunchKernelGGL((k_mat_add_inplace<FieldG>), dim3(grid_for(mr * N)), dim3(BLOCK), 0, st, ctx, C + r0 * ldc, ldc, T, ldt, mr, N);
+        if (hipGetLastError() != hipSuccess) rc = fail(SCL_ERR_HIP, "matmul: launch failed");
+      }
+    }
+  }
+  if (T) (void)temp_release(st, 1);
+  return rc;
+}
+
 // shamirRecoverD as a contraction (k_detect_compare): L [rows x d1] host elements, rows = nchk + 1.  The product Y is kept
 // for a slab of secrets at a time in the per-thread temporary, next to L and its digit planes.
 template <int KS, int MT>
@@ -2298,26 +2330,41 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
   if (M == 0 || N == 0) return SCL_OK;
   if (!C || (K && (!A || !B))) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (ldc < N || (K && (lda < K || ldb < N))) return fail(SCL_ERR_MATMUL_DIMS, scl_hip_status_message(SCL_ERR_MATMUL_DIMS));
-  if (M > (1u << 20) || K > (1u << 20)) return fail(SCL_ERR_BAD_ARG, "matmul: M or K too large");
+  // No bound on M, K or N, as in matrix.h:477-513.  Paths (DESIGN.md section 3 has their rates):
+  //   one column (Matrix::multiply(Vector), :497-513)           k_matvec: a wavefront per row
+  //   Mersenne61, long right factor, M*K >= 512                 matrix cores: row blocks of 128, k-chunks of 64 (the chunks
+  //                                                             after the first go through a temporary and one modular add)
+  //   left factor within 48 KiB and a long right factor          k_matmul: the left factor in LDS, a thread per column
+  //   anything else                                              k_matmul_tiled: LDS tiles of both factors, K in steps
   return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({C, A, B}));
+    if (K == 0) {  // an empty sum: the zero matrix
+      for (size_t i = 0; i < M; ++i) HIP_TRY(hipMemsetAsync(C + i * ldc * F::LIMBS, 0, N * F::LIMBS * 8, S(stream)));
+      return SCL_OK;
+    }
+    if (N == 1) {
+      const size_t blocks = (M + BLOCK / 64 - 1) / (BLOCK / 64);
+      hipLaunchKernelGGL((k_matvec<F>), dim3(grid_for_block(blocks, 1)), dim3(BLOCK), 0, S(stream), ctx, C, ldc, A, lda, B, ldb, M, K);
+      LAUNCH_CHECK();
+      return SCL_OK;
+    }
     if constexpr (F::TAG == 0) {
-      // small left factor, long right factor (Vandermonde evaluation, share generation): matrix cores
       const long mode = g_mfma.load();
-      if (M <= 128 && K >= 1 && K <= 64 && (mode > 0 || (mode == 0 && M * K >= 512 && N >= 4096)))
-        return matmul_mfma<F>(C, ldc, A, lda, B, ldb, M, K, N, S(stream));
+      if (mode > 0 || (mode == 0 && std::min<size_t>(M, 128) * std::min<size_t>(K, 64) >= 512 && N >= 4096))
+        return matmul_mfma_blocks<F>(ctx, C, ldc, A, lda, B, ldb, M, K, N, S(stream));
     }
     const size_t esz = F::LIMBS * 8;
-    const size_t kk = K ? K : 1;
-    size_t rows_per_tile = (48 * 1024) / (kk * esz);
-    if (rows_per_tile == 0) return fail(SCL_ERR_BAD_ARG, "matmul: K too large for the LDS tile");
-    if (rows_per_tile > M) rows_per_tile = M;
-    const size_t tiles = (M + rows_per_tile - 1) / rows_per_tile;
-    unsigned gx = grid_for(N);
-    const size_t shmem = rows_per_tile * kk * esz;
-    hipLaunchKernelGGL((k_matmul<F, 4>), dim3(gx, (unsigned)tiles), dim3(BLOCK), shmem, S(stream), ctx, C, ldc, A, lda,
-                       B, ldb, (int)M, (int)K, N, (int)rows_per_tile);
+    if (M * K * esz <= 48 * 1024 && N >= 1024) {
+      const unsigned gx = grid_for(N);
+      hipLaunchKernelGGL((k_matmul<F, 4>), dim3(gx, 1), dim3(BLOCK), M * K * esz, S(stream), ctx, C, ldc, A, lda, B, ldb, (int)M,
+                         (int)K, N, (int)M);
+      LAUNCH_CHECK();
+      return SCL_OK;
+    }
+    typedef MatmulShape<F> SH;
+    const size_t tiles = ((M + SH::TM - 1) / SH::TM) * ((N + SH::TN - 1) / SH::TN);
+    hipLaunchKernelGGL((k_matmul_tiled<F>), dim3(grid_for_block(tiles, 1)), dim3(BLOCK), 0, S(stream), ctx, C, ldc, A, lda, B, ldb, M, K, N);
     LAUNCH_CHECK();
     return SCL_OK;
   });

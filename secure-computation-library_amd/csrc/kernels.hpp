@@ -2814,6 +2814,125 @@ __global__ __launch_bounds__(BLOCK) void k_matmul(typename F::Ctx ctx, u64* C, s
   }
 }
 
+// Matrix::multiply(Matrix) for any shape (matrix.h:477-495 is an unbounded i-k-j loop): C tile TM x TN per workgroup, K walked in
+// steps of TK through LDS (A tile row-major, B tile row-major), a thread owns RM x RN outputs -- rows ty*RM + r, columns
+// tx + 16*c, so that a wave's B reads and C stores run along consecutive columns -- each a lazy accumulator folded every
+// F::ACC_TERMS terms.  Edges are zero-filled on the way in and masked on the way out; K has no bound.  The micro-tile follows
+// the accumulator's size (u128 for Mersenne61, column sums for the Montgomery fields): MatmulShape<F>.
+template <class F>
+struct MatmulShape {
+  enum {
+    RM = F::LIMBS == 4 ? 2 : (F::TAG == 2 ? 2 : 4),
+    RN = F::LIMBS == 4 ? 1 : (F::TAG == 2 ? 2 : 4),
+    TM = 16 * RM,
+    TN = 16 * RN,
+    TK = F::LIMBS == 4 ? 8 : 16
+  };
+};
+
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_matmul_tiled(typename F::Ctx ctx, u64* C, size_t ldc, const u64* A, size_t lda,
+                                                        const u64* B, size_t ldb, size_t M, size_t K, size_t N) {
+  typedef typename F::E E;
+  typedef MatmulShape<F> S;
+  constexpr int RM = S::RM, RN = S::RN, TM = S::TM, TN = S::TN, TK = S::TK;
+  __shared__ E As[TM * TK];  // [row][k]
+  __shared__ E Bs[TK * TN];  // [k][col]
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const size_t tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
+  for (size_t tile = blockIdx.x; tile < tiles_m * tiles_n; tile += gridDim.x) {
+    const size_t row0 = (tile / tiles_n) * TM, col0 = (tile % tiles_n) * TN;
+    typename F::Acc acc[RM][RN];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int c = 0; c < RN; ++c) acc[r][c] = F::acc_zero();
+    int terms = 0;
+    for (size_t k0 = 0; k0 < K; k0 += TK) {
+      __syncthreads();  // the previous step's reads are done
+      for (int i = threadIdx.x; i < TM * TK; i += BLOCK) {
+        const size_t r = row0 + i / TK, k = k0 + i % TK;
+        As[i] = (r < M && k < K) ? F::ld(A + (r * lda + k) * F::LIMBS) : F::zero();
+      }
+      for (int i = threadIdx.x; i < TK * TN; i += BLOCK) {
+        const size_t k = k0 + i / TN, c = col0 + i % TN;
+        Bs[i] = (k < K && c < N) ? F::ld(B + (k * ldb + c) * F::LIMBS) : F::zero();
+      }
+      __syncthreads();
+      if (terms + TK > (int)F::ACC_TERMS) {  // fold: the accumulator restarts from its own canonical value
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+          for (int c = 0; c < RN; ++c) {
+            const E f = F::acc_fold(ctx, acc[r][c]);
+            acc[r][c] = F::acc_zero();
+            F::acc_add(ctx, acc[r][c], f);
+          }
+        terms = 1;
+      }
+#pragma unroll 4
+      for (int k = 0; k < TK; ++k) {
+        E a[RM], b[RN];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) a[r] = As[(ty * RM + r) * TK + k];
+#pragma unroll
+        for (int c = 0; c < RN; ++c) b[c] = Bs[k * TN + tx + 16 * c];
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+          for (int c = 0; c < RN; ++c) F::mac(ctx, acc[r][c], a[r], b[c]);
+      }
+      terms += TK;
+    }
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int c = 0; c < RN; ++c) {
+        const size_t row = row0 + ty * RM + r, col = col0 + tx + 16 * c;
+        if (row < M && col < N) F::st(C + (row * ldc + col) * F::LIMBS, F::acc_fold(ctx, acc[r][c]));
+      }
+  }
+}
+
+// Matrix::multiply(Vector) (matrix.h:497-513: one innerProd per row) and any product with ONE column: a wavefront per row, its
+// lanes stride over the row (coalesced), lazy accumulation, a shuffle reduction -- rows spread over the whole chip instead of
+// the single workgroup a one-column launch of the column-per-thread kernels gets.  x is read with stride ldb (a column of B).
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_matvec(typename F::Ctx ctx, u64* y, size_t ldc, const u64* A, size_t lda, const u64* x,
+                                                  size_t ldb, size_t M, size_t K) {
+  typedef typename F::E E;
+  const int lane = threadIdx.x & 63;
+  for (size_t row = (size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); row < M; row += (size_t)gridDim.x * (BLOCK / 64)) {
+    typename F::Acc acc = F::acc_zero();
+    E run = F::zero();
+    int terms = 0;
+    for (size_t k = lane; k < K; k += 64) {
+      if (terms + 1 > (int)F::ACC_TERMS) {
+        run = F::add(ctx, run, F::acc_fold(ctx, acc));
+        acc = F::acc_zero();
+        terms = 0;
+      }
+      F::mac(ctx, acc, F::ld(A + (row * lda + k) * F::LIMBS), F::ld(x + k * ldb * F::LIMBS));
+      ++terms;
+    }
+    run = F::add(ctx, run, F::acc_fold(ctx, acc));
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) run = F::add(ctx, run, shfl_xor_elem<F>(run, m));
+    if (lane == 0) F::st(y + row * ldc * F::LIMBS, run);
+  }
+}
+
+// C += T (canonical sums): the k-chunks of a matrix-core product beyond 64 columns of the left factor
+template <class F>
+__global__ __launch_bounds__(BLOCK) void k_mat_add_inplace(typename F::Ctx ctx, u64* C, size_t ldc, const u64* T, size_t ldt, size_t M,
+                                                           size_t N) {
+  SCL_GRID_STRIDE(q, M * N) {
+    const size_t r = q / N, c = q % N;
+    u64* d = C + (r * ldc + c) * F::LIMBS;
+    F::st(d, F::add(ctx, F::ld(d), F::ld(T + (r * ldt + c) * F::LIMBS)));
+  }
+}
+
 // ---- layout ----------------------------------------------------------------------------------------------
 // AoS [N][n] (reference Vector per secret) <-> SoA [n][stride], staged through LDS so that both the
 // global reads and the global writes are contiguous.  Tile = TS secrets x n parties.

@@ -754,6 +754,40 @@ TEST_CASE(matrix_gpu, "Matrix multiply / vandermonde", BOTH) {
   REQUIRE(him.multiply(him.invert()).isIdentity());
 }
 
+template <typename FF>
+static void matmul_without_bounds(const char* seed) {
+  // matrix.h:477-513 has no bound on the inner dimension: (200 x 7000)(7000 x 300) and a 257 x 10 000 matrix times a vector go
+  // through the device (k_matmul_tiled / k_matvec) and equal the reference's own loops, here restated with scalars on entries
+  // that take in every corner
+  using M = math::Matrix<FF>;
+  auto prg = util::PRG::create(seed);
+  const std::size_t m = 200, k = 7000, n = 300;
+  const M a = M::random(m, k, prg), b = M::random(k, n, prg);
+  const M c = a.multiply(b);
+  REQUIRE(c.rows() == m && c.cols() == n);
+  for (std::size_t i : {std::size_t(0), std::size_t(63), std::size_t(64), m - 1})
+    for (std::size_t j : {std::size_t(0), std::size_t(16), std::size_t(255), n - 1}) {
+      FF want;
+      for (std::size_t l = 0; l < k; ++l) want += a(i, l) * b(l, j);
+      REQUIRE(c(i, j) == want);
+    }
+  const M w = M::random(257, 10000, prg);
+  const auto x = math::Vector<FF>::random(10000, prg);
+  const auto y = w.multiply(x);
+  REQUIRE(y.size() == 257);
+  for (std::size_t i : {std::size_t(0), std::size_t(128), std::size_t(256)}) {
+    FF want;
+    for (std::size_t l = 0; l < 10000; ++l) want += w(i, l) * x[l];
+    REQUIRE(y[i] == want);
+  }
+}
+
+TEST_CASE(matrix_unbounded, "Matrix::multiply has no bound on its shape (matrix.h:477-513)", GPU) {
+  matmul_without_bounds<F61>("mm-unbounded-61");
+  matmul_without_bounds<F127>("mm-unbounded-127");
+  matmul_without_bounds<math::FF<math::ff::Secp256k1Scalar>>("mm-unbounded-secp");
+}
+
 TEST_CASE(shamir_mirror, "ss::shamir* per secret (reference signatures)", BOTH) {
   // test/scl/ss/test_shamir.cc:34-40
   {

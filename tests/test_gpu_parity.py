@@ -829,6 +829,59 @@ def test_matmul_on_matrix_cores(scl, port, M, K, N):
     assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), want)  # automatic choice
 
 
+def _matmul_window_check(scl, port, f, A, B, got, rows, cols):
+    """the product's entries at rows x cols against the oracle's i-k-j loop over exactly those rows of A and columns of B"""
+    want = port.matmul(f, np.ascontiguousarray(A[rows]), np.ascontiguousarray(B[:, cols]))
+    assert np.array_equal(got[np.ix_(rows, cols)], want)
+
+
+@pytest.mark.parametrize("f", ALL_FIELDS)
+@pytest.mark.parametrize("M,K,N", [(200, 7000, 300), (300, 300, 300), (257, 10_000, 1), (3, 20_000, 70), (65, 129, 33), (17, 6145, 16)])
+def test_matmul_has_no_bound_on_its_shape(scl, port, f, M, K, N):
+    """Matrix::multiply(Matrix) is an unbounded i-k-j loop and multiply(Vector) one innerProd per row (matrix.h:477-513): no shape
+    is refused -- K beyond the 48 KiB LDS image the column-per-thread kernel keeps of the left factor goes through k_matmul_tiled
+    (both factors tiled, K in steps), one column through k_matvec (a wavefront per row).  Against the oracle on a window of rows
+    and columns that takes in every edge of the tiling (whole product for the fast-oracle fields at 300^3)."""
+    L = O.LIMBS[f]
+    A = rand_elems(port, f, M * K, b"nb-A").reshape(M, K, L)
+    B = rand_elems(port, f, K * N, b"nb-B").reshape(K, N, L)
+    A[0, 0] = A[M - 1, K - 1] = port.from_int(f, -1)
+    B[0, 0] = B[K - 1, N - 1] = port.from_int(f, -1)
+    got = host(scl, scl.matmul(f, dev(scl, A), dev(scl, B)))
+    assert got.shape == (M, N, L)
+    if f not in SLOW_ORACLE and M * K * N <= 30_000_000:
+        assert np.array_equal(got, port.matmul(f, A, B))
+    rows = sorted({0, 1, M // 2, M - 1} | {r for r in (15, 16, 31, 32, 63, 64, 127, 128, 199) if r < M})[:7 if f in SLOW_ORACLE else 12]
+    cols = sorted({0, N // 2, N - 1} | {c for c in (15, 16, 17, 63, 64, 255, 256, 299) if c < N})[:5 if f in SLOW_ORACLE else 10]
+    if f in SLOW_ORACLE and K > 7000:
+        rows, cols = rows[:3], cols[:3]
+    _matmul_window_check(scl, port, f, A, B, got, rows, cols)
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 200, 5000), (129, 65, 4100), (128, 130, 4096), (1000, 64, 4500), (260, 7000, 4200)])
+def test_matmul_on_matrix_cores_beyond_one_tile(scl, port, M, K, N):
+    """The matrix-core product for left factors of more than 128 rows (row blocks) and more than 64 columns (k-chunks whose
+    canonical partial products one modular add folds together) == the oracle, forced and by the automatic choice."""
+    f, L = O.M61, 1
+    A = rand_elems(port, f, M * K, b"mmb-A").reshape(M, K, L)
+    B = rand_elems(port, f, K * N, b"mmb-B").reshape(K, N, L)
+    A[M - 1, K - 1] = B[K - 1, N - 1] = port.from_int(f, -1)
+    rows = sorted({0, 1, 127, 128, 129, 255, 256, M // 2, M - 1} & set(range(M)))
+    cols = sorted({0, 1, 31, 32, 4095, N // 2, N - 2, N - 1})
+    for mode in (1, 0):
+        scl.set_tuning("mfma", mode)
+        try:
+            got = host(scl, scl.matmul(f, dev(scl, A), dev(scl, B)))
+        finally:
+            scl.set_tuning("mfma", 0)
+        _matmul_window_check(scl, port, f, A, B, got, rows, cols)
+    scl.set_tuning("mfma", -1)   # and the vector-ALU kernels give the same matrix
+    try:
+        assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), got)
+    finally:
+        scl.set_tuning("mfma", 0)
+
+
 def test_vandermonde_matmul_is_sharing(scl, port):
     """test_matrix.cc:342-365: V(n, t+1) x coefficient matrix == Shamir shares at nodes 1..n"""
     f, L, n, t, N = O.M61, 1, 10, 3, 500
