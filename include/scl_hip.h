@@ -343,6 +343,15 @@ int scl_hip_open_partial_gather(void* comm, int field, uint64_t* out_dev, const 
                                 size_t parties_mine, const uint64_t* lambda_local_host, size_t N, size_t chunk,
                                 void* stream);
 
+/* Mersenne61 only: each rank's canonical partial sums go through ncclReduceScatter(ncclSum, ncclUint64)
+ * -- at most 8 ranks, so that the 64-bit sum of values <= 2^61 - 2 cannot wrap -- rank r folds the r-th slice of every chunk
+ * mod p, and (all_ranks != 0) an all-gather of the folded slices gives every rank every secret, bit-identical to
+ * scl_hip_open_all_gather.  all_ranks == 0 writes out_dev[s] only on the rank that owns s: within chunk c (of the even chunk
+ * size in force, cnt_c secrets) the slice index (s mod chunk) / ceil(cnt_c / world).  Arguments as scl_hip_open_partial_gather. */
+int scl_hip_open_reduce_scatter(void* comm, int field, uint64_t* out_dev, const uint64_t* local_dev, size_t stride,
+                                size_t parties_mine, const uint64_t* lambda_local_host, size_t N, size_t chunk, int all_ranks,
+                                void* stream);
+
 /* MONT128: choose the modulus (odd, < 2^128).  The call sets it for the CALLING host thread and as the process-wide
  * default: a thread that has called this keeps its own modulus whatever other threads choose later; a thread that never
  * did (a pool worker started after the main thread chose the prime) LATCHES the default at its first Mont128 call -- the

@@ -109,6 +109,22 @@ DeviceVector<T> openByPartialSums(Communicator& comm, const ShareMatrix<T>& mine
   return out;
 }
 
+/// Mersenne61 only, at most 8 ranks: the partial sums meet in an ncclReduceScatter of plain 64-bit sums (canonical partials
+/// cannot wrap), each rank folds its slice mod p and an all-gather hands every rank every secret -- the same bits as open().
+/// all_ranks = false leaves each secret on the one rank that owns its slice (scl_hip.h, scl_hip_open_reduce_scatter).
+template <typename T>
+DeviceVector<T> openByReduceScatter(Communicator& comm, const ShareMatrix<T>& mine, std::size_t n, const math::Vector<T>& lambda,
+                                    std::size_t chunk = 0, bool all_ranks = true) {
+  const auto [first, count] = comm.partySlab(n);
+  if (lambda.size() < n || mine.parties() != count) detail::raise(SCL_ERR_SIZE_MISMATCH);
+  const auto lam = open_detail::limbsOfVector(lambda, first, count);
+  DeviceVector<T> out(mine.secrets());
+  check(scl_hip_open_reduce_scatter(comm.get(), T::Field::TAG, out.data(), mine.data(), mine.stride(), count, lam.data(),
+                                    mine.secrets(), chunk, all_ranks ? 1 : 0, nullptr));
+  check(scl_hip_stream_sync(nullptr));
+  return out;
+}
+
 }  // namespace scl::hip
 
 #endif

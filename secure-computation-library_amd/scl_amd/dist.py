@@ -250,3 +250,26 @@ def open_partial_gather_c(comm: Communicator, field: int, mine: torch.Tensor, la
     _chk(lib.scl_hip_open_partial_gather(comm._h, field, _dev(out), _dev(mine) if cnt else None, N, cnt,
                                          _hp(lam_h) if cnt else None, N, chunk, _stream()))
     return out
+
+
+def open_reduce_scatter_c(comm: Communicator, field: int, mine: torch.Tensor, lam_local, chunk: int = 1 << 24,
+                          out: torch.Tensor | None = None, all_ranks: bool = True) -> torch.Tensor:
+    """scl_hip_open_reduce_scatter (Mersenne61, at most 8 ranks): the ranks' canonical partial sums meet in an
+    ncclReduceScatter of plain 64-bit sums, each rank folds its slice mod p; all_ranks: an all-gather then hands every rank every
+    secret, else out[s] is written only on the rank that owns s (slice_owner)"""
+    from . import _chk, _dev, _host, _hp, _stream, lib
+    cnt, N, L = mine.shape
+    if out is None:
+        out = torch.zeros((N, L), dtype=mine.dtype, device=mine.device)
+    lam_h = _host(lam_local) if cnt else None
+    _chk(lib.scl_hip_open_reduce_scatter(comm._h, field, _dev(out), _dev(mine) if cnt else None, N, cnt,
+                                         _hp(lam_h) if cnt else None, N, chunk, 1 if all_ranks else 0, _stream()))
+    return out
+
+
+def slice_owner(s: int, N: int, world: int, chunk: int = 1 << 24) -> int:
+    """the rank scl_hip_open_reduce_scatter(all_ranks = 0) leaves secret s on (scl_hip.h)"""
+    chunk = (min(chunk or (1 << 24), N) + 1) & ~1
+    s0 = s // chunk * chunk
+    cnt = min(chunk, N - s0)
+    return (s - s0) // -(-cnt // world)

@@ -1,8 +1,10 @@
-// tests/cxx/fake_rccl.cc -- a TEST-ONLY stand-in for RCCL: the nine entry points csrc/open_rccl.inc binds, for a world
+// tests/cxx/fake_rccl.cc -- a TEST-ONLY stand-in for RCCL: the ten entry points csrc/open_rccl.inc binds, for a world
 // whose ranks are host threads of ONE process on ONE device.  It exists so that the multi-rank code of the open step
 // (scl_hip_open_all_gather / scl_hip_open_partial_gather: permuted lambda, grouped per-row gathers, the two streams and
-// their events, padding rows, a rank without parties) executes with world > 1 on a one-GPU box; the library binds it when
-// SCL_HIP_RCCL_LIBRARY names it.  Not a transport: an all-gather is a device-to-device copy per peer.
+// their events, padding rows, a rank without parties; scl_hip_open_reduce_scatter: the 64-bit sums, the slices) executes with
+// world > 1 on a one-GPU box; the library binds it when SCL_HIP_RCCL_LIBRARY names it.  Not a transport: an all-gather is a
+// device-to-device copy per peer, a reduce-scatter (ncclSum over ncclUint64 only) one small kernel that adds the peers' slices.
+// Compiled with hipcc for that kernel.
 //
 // Semantics kept from the real thing: every rank calls the same collectives in the same order; a collective is enqueued on
 // the caller's stream and is asynchronous for the host apart from a rendezvous with the other ranks' calls (NCCL may block
@@ -71,11 +73,24 @@ unsigned long g_next_id = 1;
 struct Pending {
   const void* send;
   void* recv;
-  size_t count;
+  size_t count;  // all-gather: elements sent; reduce-scatter: elements received
   ncclDataType_t type;
   Comm* comm;
   hipStream_t stream;
+  bool reduce_scatter = false;
 };
+
+struct Peers {
+  const unsigned long long* send[MAX_RANKS];
+};
+// out[i] = sum over the ranks q of send_q[slice * count + i], wrapping 64-bit adds (ncclSum on ncclUint64)
+__global__ void k_fake_reduce_slice(unsigned long long* out, Peers peers, int n, size_t slice, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long acc = 0;
+    for (int q = 0; q < n; ++q) acc += peers.send[q][slice * count + i];
+    out[i] = acc;
+  }
+}
 thread_local int t_group_depth = 0;
 thread_local std::vector<Pending> t_group;
 
@@ -121,8 +136,17 @@ ncclResult_t all_gather_now(const Pending& p) {
       return ncclInvalidArgument;
     }
     if (q != r) FAKE_HIP(hipStreamWaitEvent(p.stream, W.ready[q], 0));
+    if (p.reduce_scatter) continue;
     char* dst = static_cast<char*>(p.recv) + (size_t)q * bytes;
     if (dst != W.send[q] && bytes) FAKE_HIP(hipMemcpyAsync(dst, W.send[q], bytes, hipMemcpyDeviceToDevice, p.stream));
+  }
+  if (p.reduce_scatter && p.count) {  // my slice of the element-wise sum of everybody's send buffer
+    Peers peers;
+    for (int q = 0; q < n; ++q) peers.send[q] = static_cast<const unsigned long long*>(W.send[q]);
+    const unsigned grid = (unsigned)((p.count + 255) / 256 < 4096 ? (p.count + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_fake_reduce_slice, dim3(grid), dim3(256), 0, p.stream, static_cast<unsigned long long*>(p.recv), peers, n,
+                       (size_t)r, p.count);
+    FAKE_HIP(hipGetLastError());
   }
   FAKE_HIP(hipEventRecord(done, p.stream));
   W.done[r] = done;
@@ -209,7 +233,20 @@ ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
 ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm,
                            hipStream_t stream) {
   if (!comm || (sendcount && (!sendbuff || !recvbuff))) return ncclInvalidArgument;
-  const Pending p{sendbuff, recvbuff, sendcount, datatype, reinterpret_cast<Comm*>(comm), stream};
+  const Pending p{sendbuff, recvbuff, sendcount, datatype, reinterpret_cast<Comm*>(comm), stream, false};
+  if (t_group_depth > 0) {
+    t_group.push_back(p);
+    return ncclSuccess;
+  }
+  return all_gather_now(p);
+}
+
+ncclResult_t ncclReduceScatter(const void* sendbuff, void* recvbuff, size_t recvcount, ncclDataType_t datatype, ncclRedOp_t op,
+                               ncclComm_t comm, hipStream_t stream) {
+  if (!comm || (recvcount && (!sendbuff || !recvbuff))) return ncclInvalidArgument;
+  if (datatype != ncclUint64 || op != ncclSum) return ncclInvalidArgument;  // all the open step asks for
+  Pending p{sendbuff, recvbuff, recvcount, datatype, reinterpret_cast<Comm*>(comm), stream};
+  p.reduce_scatter = true;
   if (t_group_depth > 0) {
     t_group.push_back(p);
     return ncclSuccess;

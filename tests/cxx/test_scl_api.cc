@@ -13,6 +13,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include <scl_hip/scl.h>
@@ -1141,6 +1142,10 @@ static void open_world(int world, std::size_t N, std::size_t n, std::size_t t, s
         const auto a = hip::open(comm, slab, n, chunk).toHost();
         const auto b = hip::openByPartialSums(comm, mine, n, lambda, chunk).toHost();
         ok[r] = math::Vector<F>(a) == math::Vector<F>(secrets) && math::Vector<F>(b) == math::Vector<F>(secrets);
+        if constexpr (std::is_same_v<F, F61>) {  // Mersenne61: the partial sums through ncclReduceScatter as 64-bit sums
+          const auto c = hip::openByReduceScatter(comm, mine, n, lambda, chunk).toHost();
+          ok[r] = ok[r] && math::Vector<F>(c) == math::Vector<F>(secrets);
+        }
       } catch (const std::exception& e) {
         errs[r] = e.what();
       }
@@ -1152,7 +1157,7 @@ static void open_world(int world, std::size_t N, std::size_t n, std::size_t t, s
   }
 }
 
-TEST_CASE(open_world_threads, "hip::open / openByPartialSums over a world of host threads (fake RCCL)", GPU) {
+TEST_CASE(open_world_threads, "hip::open / openByPartialSums / openByReduceScatter over a world of host threads (fake RCCL)", GPU) {
   if (!std::getenv("SCL_HIP_RCCL_LIBRARY")) {
     std::printf("  (skipped: SCL_HIP_RCCL_LIBRARY does not name the stand-in; tests/test_cxx_api.py runs it)\n");
     return;

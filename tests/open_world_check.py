@@ -1,5 +1,5 @@
 """Child process of tests/test_gpu_parity.py::test_c_abi_open_with_a_world_of_threads: the open step behind the C ABI
-(scl_hip_open_all_gather / scl_hip_open_partial_gather, csrc/open_rccl.inc) with world > 1 on ONE GPU.
+(scl_hip_open_all_gather / scl_hip_open_partial_gather / scl_hip_open_reduce_scatter, csrc/open_rccl.inc) with world > 1 on ONE GPU.
 
 The ranks are host threads of this process, all on device 0; the library is told (SCL_HIP_RCCL_LIBRARY, set by the
 caller before this process starts) to bind tests/cxx/_build/libfake_rccl.so instead of RCCL, whose all-gather is a
@@ -48,6 +48,7 @@ def main():
     order = sd.open_row_order(n, world)
     assert len(order) == per * world and sorted(p for p in order if p >= 0) == list(range(n))
 
+    reduce_scatter = field == O.M61 and world <= 8
     ident = (C.c_ubyte * 128)()
     torch.cuda.set_device(0)
     torch.zeros(1, device="cuda")  # the context exists before the threads start
@@ -68,7 +69,7 @@ def main():
             slab[:cnt] = full[first:first + cnt]
             local = torch.from_numpy(slab.view(np.int64)).cuda()
             sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
-            outs = [torch.full((N, L), -1, dtype=torch.int64, device="cuda") for _ in range(4)]
+            outs = [torch.full((N, L), -1, dtype=torch.int64, device="cuda") for _ in range(6 if reduce_scatter else 4)]
             torch.cuda.synchronize()
             lam_h = np.ascontiguousarray(lam)
             lam_p = lam_h.ctypes.data_as(C.c_void_p)
@@ -86,6 +87,14 @@ def main():
                                                      C.c_size_t(cnt), mine_p, C.c_size_t(N), C.c_size_t(chunk),
                                                      C.c_void_p(s.cuda_stream))
                 assert rc == 0, lib.scl_hip_last_error()
+            if reduce_scatter:
+                # Mersenne61, world <= 8: the partial sums through ncclReduceScatter as plain 64-bit sums, slices folded mod p;
+                # outs[4] every secret on every rank, outs[5] each secret only on its owner (the rest stays -1)
+                for out, s, every in ((outs[4], sA, 1), (outs[5], sB, 0)):
+                    rc = lib.scl_hip_open_reduce_scatter(h, field, dp(out), dp(local) if cnt else None, C.c_size_t(N),
+                                                         C.c_size_t(cnt), mine_p, C.c_size_t(N), C.c_size_t(chunk), every,
+                                                         C.c_void_p(s.cuda_stream))
+                    assert rc == 0, lib.scl_hip_last_error()
             sA.synchronize()
             sB.synchronize()
             results[r] = [o.cpu().numpy().view(np.uint64) for o in outs]
@@ -102,14 +111,18 @@ def main():
     ok = not errors and not hung and len(results) == world
     bad = []
     if ok:
+        owner = np.array([sd.slice_owner(s_, N, world, chunk) for s_ in range(N)])
         for r in range(world):
             for k, got in enumerate(results[r]):
-                if not np.array_equal(got, secrets):
-                    bad.append((r, k, int((got != secrets).any(axis=1).sum())))
+                want = secrets
+                if k == 5:  # reconstruct-to-one-owner: this rank's slices hold the secrets, every other slot is untouched
+                    want = np.where((owner == r)[:, None], secrets, np.uint64(0xFFFFFFFFFFFFFFFF))
+                if not np.array_equal(got, want):
+                    bad.append((r, k, int((got != want).any(axis=1).sum())))
         ok = not bad
     print(json.dumps({"ok": ok, "world": world, "field": field, "n": n, "t": t, "N": N, "chunk": chunk, "per": per,
                       "chunks": -(-N // ((min(chunk, N) + 1) & ~1)), "ranks_without_parties": sum(1 for r in range(world) if sd.party_slab(n, r, world)[1] == 0),
-                      "padding_rows": per * world - n, "errors": errors, "hung": hung, "mismatches": bad}))
+                      "padding_rows": per * world - n, "reduce_scatter": reduce_scatter, "errors": errors, "hung": hung, "mismatches": bad}))
     sys.stdout.flush()
     os._exit(0 if ok else 1)  # (daemon threads stuck at a rendezvous must not keep the process)
 

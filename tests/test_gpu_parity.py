@@ -1408,7 +1408,8 @@ def test_reference_binding_compiled_against_the_reference():
     (8, O.GF2_128, 40, 13, 1001, 300),  # .. on the world BASELINE quotes it on: five parties per rank
 ])
 def test_c_abi_open_with_a_world_of_threads(scl, world, f, n, t, N, chunk):
-    """scl_hip_open_all_gather / scl_hip_open_partial_gather with world = 2, 3, 4, 8 on this one GPU: the ranks are host threads
+    """scl_hip_open_all_gather / scl_hip_open_partial_gather (and, over Mersenne61, scl_hip_open_reduce_scatter in both its
+    forms) with world = 2, 3, 4, 8 on this one GPU: the ranks are host threads
     of a child process and the library binds tests/cxx/_build/libfake_rccl.so (SCL_HIP_RCCL_LIBRARY), whose all-gather is a
     rendezvous + device-to-device copies.  The permuted lambda (row q = j * world + r), the grouped per-row gathers, the two
     streams and their events across >= 3 chunks and across calls from different streams, padding rows (sent as zeros, filled
@@ -1426,6 +1427,7 @@ def test_c_abi_open_with_a_world_of_threads(scl, world, f, n, t, N, chunk):
     rep = json.loads(lines[-1])
     assert r.returncode == 0 and rep["ok"], (rep, r.stderr[-2000:])
     assert rep["chunks"] >= 3 and rep["padding_rows"] == -(-n // world) * world - n
+    assert rep["reduce_scatter"] == (f == O.M61)
 
 
 @pytest.mark.parametrize("n,counter0", [(1003, 0), (1004, 5), (1, 0), (2, 7)])
@@ -1467,6 +1469,9 @@ def test_open_step_behind_the_c_abi_one_rank_rccl(scl, port):
         for chunk in (2048, 1 << 24):
             assert np.array_equal(host(scl, sd.open_all_gather_c(comm, f, shares, n, lam, chunk=chunk)), secrets)
             assert np.array_equal(host(scl, sd.open_partial_gather_c(comm, f, shares, lam, chunk=chunk)), secrets)
+            # the Mersenne61 reduce-scatter form through the real ncclReduceScatter / in-place ncclAllGather (one rank)
+            assert np.array_equal(host(scl, sd.open_reduce_scatter_c(comm, f, shares, lam, chunk=chunk)), secrets)
+            assert np.array_equal(host(scl, sd.open_reduce_scatter_c(comm, f, shares, lam, chunk=chunk, all_ranks=False)), secrets)
         f2, n2, t2, N2 = O.GF2_128, 40, 13, 6001
         sec2 = scl.vector_random(f2, N2, b"copen-gf")
         sh2 = scl.shamir_share(f2, sec2, scl.vector_random(f2, t2 * N2, b"copen-gfc").reshape(t2, N2, -1), n2)
@@ -1480,6 +1485,8 @@ def test_open_step_behind_the_c_abi_one_rank_rccl(scl, port):
         assert not torch.any(z).item()
         with pytest.raises(ValueError):
             sd.open_all_gather_c(comm, f2, sh2[:5], n2, lam2)
+        with pytest.raises(scl.SclError):     # no 128-bit RCCL type: the reduce-scatter form is Mersenne61's alone
+            sd.open_reduce_scatter_c(comm, f2, sh2, lam2)
         scl.set_tuning("open_gather_always", 0)  # and the one-rank shortcut gives the same secrets
         assert scl.equals(f2, sd.open_all_gather_c(comm, f2, sh2, n2, lam2, chunk=2500), sec2)
     finally:
