@@ -355,10 +355,15 @@ int scl_hip_open_reduce_scatter(void* comm, int field, uint64_t* out_dev, const 
 /* MONT128: choose the modulus (odd, < 2^128).  The call sets it for the CALLING host thread and as the process-wide
  * default: a thread that has called this keeps its own modulus whatever other threads choose later; a thread that never
  * did (a pool worker started after the main thread chose the prime) LATCHES the default at its first Mont128 call -- the
- * modulus set last by any thread before that, 2^128 - 159 if none was -- and keeps it from then on: a worker between a
- * share and its recover does not change field because another thread picked a different prime. */
+ * modulus set last by any thread before that, 2^128 - 159 if none was -- and keeps it: a worker between a share and its
+ * recover does not change field because another thread picked a different prime.  It does not go on silently either: once
+ * the default has changed after a thread latched it, that thread's next Mont128 call returns SCL_ERR_BAD_ARG (its buffers may
+ * hold residues of either modulus) until the thread calls scl_hip_mont128_set_prime (a modulus of its own) or
+ * scl_hip_mont128_relatch (take the current default).  scl_hip_mont128_get_prime reports the calling thread's modulus
+ * (latching it if need be) and never fails. */
 int scl_hip_mont128_set_prime(const uint64_t p[2]);
 int scl_hip_mont128_get_prime(uint64_t p[2]);
+int scl_hip_mont128_relatch(void);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,10 @@ SCL_STATE(thread_local Knob g_inv_batch, {0});
 SCL_STATE(thread_local Mont128::Ctx g_mont, = {0, 0, 0, 0});  // p == 0: this thread has not latched a modulus yet
 SCL_STATE(std::mutex g_mont_default_mu);
 SCL_STATE(Mont128::Ctx g_mont_default, = {0, 0, 0, 0});
+// how often the default has been set, and where this thread stands: the generation it latched (or set its own modulus) at
+SCL_STATE(unsigned long g_mont_default_gen, = 0);
+SCL_STATE(thread_local unsigned long g_mont_gen, = 0);
+SCL_STATE(thread_local bool g_mont_own, = false);
 // per-thread device scratch (only used by calls that synchronise before returning)
 SCL_STATE(thread_local Scratch g_scratch);
 // arena 0: tables, queues and products of one call; arena 1: the coefficient rows of a two-pass PRG sharing (whose second
@@ -197,22 +201,44 @@ unsigned grid_aes4(size_t work_items) {
 // ---- Mont128 modulus: a process-wide default, latched per host thread ---------------------------------------
 // scl_hip_mont128_set_prime sets the CALLING thread's modulus and the process-wide default.  A thread that has set its own
 // keeps it whatever other threads do; a thread that never set one LATCHES the default at its first use (the modulus set last
-// by any thread before that, 2^128 - 159 if none was) and keeps that value for the rest of its life: a worker in the middle
-// of a share-then-recover sequence does not switch modulus because some other thread set a different prime.
+// by any thread before that, 2^128 - 159 if none was) and keeps that value: a worker in the middle of a share-then-recover
+// sequence does not switch modulus because some other thread set a different prime.  What it must not do either is go on
+// SILENTLY: once the default has changed after a thread latched it, that thread's next Mont128 call fails with
+// SCL_ERR_BAD_ARG (its data may be residues of either modulus -- only the caller knows) until the thread says which it means:
+// scl_hip_mont128_set_prime (its own) or scl_hip_mont128_relatch (the current default).
 int mont_set(u128 p) {
   if (!(p & 1) || p < 3) return fail(SCL_ERR_BAD_ARG, "mont128: modulus must be odd and >= 3");
   g_mont = Mont128::make_ctx(p);
+  g_mont_own = true;
   std::lock_guard<std::mutex> lk(g_mont_default_mu);
   g_mont_default = g_mont;
+  g_mont_gen = ++g_mont_default_gen;
   return SCL_OK;
+}
+
+void mont_latch_locked() {  // (g_mont_default_mu held)
+  if (!g_mont_default.p)
+    g_mont_default = Mont128::make_ctx((((u128)0xFFFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFF61ull);  // 2^128 - 159
+  g_mont = g_mont_default;
+  g_mont_gen = g_mont_default_gen;
+  g_mont_own = false;
+}
+
+// SCL_OK, or the stale-latch error described above
+int mont_check() {
+  if (!g_mont.p || g_mont_own) return SCL_OK;
+  std::lock_guard<std::mutex> lk(g_mont_default_mu);
+  if (g_mont_gen == g_mont_default_gen) return SCL_OK;
+  return fail(SCL_ERR_BAD_ARG,
+              "mont128: this thread latched the process-wide default modulus at its first Mont128 call and the default has been "
+              "changed since (scl_hip_mont128_set_prime on another thread); call scl_hip_mont128_set_prime or "
+              "scl_hip_mont128_relatch on this thread to say which modulus it computes over");
 }
 
 Mont128::Ctx mont_ctx() {
   if (g_mont.p) return g_mont;
   std::lock_guard<std::mutex> lk(g_mont_default_mu);
-  if (!g_mont_default.p)
-    g_mont_default = Mont128::make_ctx((((u128)0xFFFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFF61ull);  // 2^128 - 159
-  g_mont = g_mont_default;
+  mont_latch_locked();
   return g_mont;
 }
 
@@ -229,8 +255,12 @@ int with_field(int field, Fn&& fn) {
       if constexpr (SCL_TU_HAS(1)) return fn(M127{}, M127::Ctx{});
       else return not_in_this_unit();
     case SCL_MONT128:
-      if constexpr (SCL_TU_HAS(2)) return fn(Mont128{}, mont_ctx());
-      else return not_in_this_unit();
+      if constexpr (SCL_TU_HAS(2)) {
+        SCL_TRY(mont_check());
+        return fn(Mont128{}, mont_ctx());
+      } else {
+        return not_in_this_unit();
+      }
     case SCL_GF2_128:
       if constexpr (SCL_TU_HAS(3)) return fn(Gf128{}, Gf128::Ctx{});
       else return not_in_this_unit();
@@ -1216,6 +1246,11 @@ int scl_hip_set_tuning(const char* key, long value) {
 }
 
 int scl_hip_mont128_set_prime(const uint64_t p[2]) { return mont_set(((u128)p[1] << 64) | p[0]); }
+int scl_hip_mont128_relatch(void) {
+  std::lock_guard<std::mutex> lk(g_mont_default_mu);
+  mont_latch_locked();
+  return SCL_OK;
+}
 int scl_hip_mont128_get_prime(uint64_t p[2]) {
   const Mont128::Ctx c = mont_ctx();
   p[0] = (u64)c.p;

@@ -179,11 +179,24 @@ def set_tuning(key: str, value: int):
 
 
 def set_mont128_prime(p: int):
-    """Modulus of the MONT128 field for the calling thread AND the process-wide default (scl_hip.h): threads that never
-    call this -- ThreadPoolExecutor workers, say -- compute over the modulus set last by any thread; a thread that has
-    called it keeps its own."""
+    """Modulus of the MONT128 field for the calling thread AND the process-wide default (scl_hip.h).  A thread that never
+    calls this -- a ThreadPoolExecutor worker, say -- LATCHES the default at its first Mont128 call and keeps it; when the
+    default changes afterwards that worker's next Mont128 call raises SclError (ERR_BAD_ARG) instead of computing on over
+    the old modulus in silence: the worker then calls set_mont128_prime (its own modulus) or mont128_relatch (the current
+    default).  A thread that has called this keeps its own modulus whatever the others do."""
     a = np.array([p & (2 ** 64 - 1), p >> 64], dtype=np.uint64)
     _chk(lib.scl_hip_mont128_set_prime(_hp(a)))
+
+
+def mont128_relatch():
+    """the calling thread takes the current process-wide MONT128 modulus (see set_mont128_prime)"""
+    _chk(lib.scl_hip_mont128_relatch())
+
+
+def mont128_prime() -> int:
+    a = np.zeros(2, dtype=np.uint64)
+    _chk(lib.scl_hip_mont128_get_prime(_hp(a)))
+    return int(a[0]) | (int(a[1]) << 64)
 
 
 # ---- element-wise: scl::math::Vector<FF> ------------------------------------------------------------

@@ -32,6 +32,17 @@ def test_every_declared_symbol_is_exported(scl):
     assert not missing, missing
 
 
+def test_nothing_but_the_declared_symbols_is_exported(scl):
+    """The library's dynamic symbol table is the header's prototypes and nothing else (csrc/exports.map, written by
+    tools/gen_capi_route.py): the per-family unit names (scl_hip_ew__m61 ..) and the state the units share cannot be called
+    or interposed from outside."""
+    import subprocess
+    so = os.path.join(ROOT, "secure-computation-library_amd", "scl_amd", "libscl_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == set(declared_symbols()), sorted(exported ^ set(declared_symbols()))
+
+
 def test_metadata_and_messages(scl):
     assert scl.lib.scl_hip_abi_version() == 1
     assert [scl.limbs(f) for f in range(6)] == [1, 2, 2, 2, 4, 4]
@@ -77,6 +88,36 @@ def test_mont128_prime_roundtrip(scl):
     assert O.to_ints(p.reshape(1, 2))[0] == 2 ** 128 - 159
     with pytest.raises(scl.SclError):
         scl.set_mont128_prime(2 ** 100)  # even
+
+
+def test_mont128_default_latch_goes_stale_loudly(scl):
+    """The Mont128 modulus rule (scl_hip.h): a thread that never set a prime latches the process-wide default at its first
+    Mont128 call and keeps it -- and when another thread changes the default afterwards, the latched thread's next Mont128
+    call fails (SCL_ERR_BAD_ARG) instead of computing over the old modulus in silence, until it re-latches or sets its own.
+    A thread that set its own modulus is never disturbed.  Host-only entry point (the Lagrange table), so this runs on CPU."""
+    from concurrent.futures import ThreadPoolExecutor
+    p0, p1, p2 = 2 ** 128 - 159, 2 ** 127 - 1, 2 ** 61 - 1
+    f = scl.MONT128
+    try:
+        scl.set_mont128_prime(p0)
+        with ThreadPoolExecutor(max_workers=1) as worker:          # one thread, reused for every submit
+            assert worker.submit(scl.mont128_prime).result() == p0     # the worker latches the default
+            base0 = worker.submit(scl.lagrange_basis, f, 3).result()
+            scl.set_mont128_prime(p1)                                  # the main thread moves the default
+            with pytest.raises(scl.SclError) as ei:
+                worker.submit(scl.lagrange_basis, f, 3).result()
+            assert ei.value.status == scl.ERR_BAD_ARG and "latched" in str(ei.value)
+            assert worker.submit(scl.mont128_prime).result() == p0     # (reporting the thread's modulus never fails)
+            worker.submit(scl.mont128_relatch).result()
+            assert worker.submit(scl.mont128_prime).result() == p1
+            base1 = worker.submit(scl.lagrange_basis, f, 3).result()
+            assert not np.array_equal(base0, base1) and np.array_equal(base1, scl.lagrange_basis(f, 3))
+            worker.submit(scl.set_mont128_prime, p2).result()          # a modulus of the worker's own (also the new default)
+            scl.set_mont128_prime(p0)
+            assert worker.submit(scl.mont128_prime).result() == p2
+            worker.submit(scl.lagrange_basis, f, 3).result()           # undisturbed by the main thread's change
+    finally:
+        scl.set_mont128_prime(p0)
 
 
 def test_batch_calls_fail_loudly_without_a_gpu(scl):

@@ -123,3 +123,16 @@ def test_mont128_small_node_fold_against_long_arithmetic(tmp_path):
     assert b.returncode == 0, b.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
+def test_gf2_128_host_arithmetic_against_a_bit_serial_multiplier(tmp_path):
+    """Gf128::mul (4-bit-window comb), sqr (bit spread + fold) and inv (Itoh-Tsujii chain) of detail/field.hpp -- the code behind
+    FF<GF2_128> on the host and, for sqr / inv, in the kernels -- against a shift-xor multiplier and the 254-product ladder
+    (tests/cxx/gf128_host_check.cc): 400 k comparisons, corners included.  CPU only."""
+    exe = str(tmp_path / "gf128_host_check")
+    b = subprocess.run(["g++", "-std=c++20", "-O2", "-w", f"-I{ROOT}/include", "-o", exe, os.path.join(CXX, "gf128_host_check.cc")],
+                       capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout
+

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../secure-computation-library_amd/csrc/kernels.hpp"
+#include "gfpos_asm.hpp"  // lds_read128 and the hand-issued read pipelines (A/B only)
 using namespace sclhip;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1);} } while (0)
 
@@ -556,7 +557,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 44; ++i) key.rk[i] = 0x9E3779B9u * (i + 1);
     for (int i = 0; i < 256; ++i) key.te0[i] = 0x85EBCA6Bu * (i + 7) ^ (i << 13);
     aes_key_round1(key);
-    auto kern = &k_prg_blocks;
+    auto kern = &k_prg_blocks<>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AES4_LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, sh, key, 1ull, (size_t)M * N);
     hipLaunchKernelGGL(kern, dim3(AES4_GRID_CAP), dim3(ABLOCK), AES4_LDS_BYTES, 0, cf, key, 1ull << 40, (size_t)(TT + 1) * N);
