@@ -761,6 +761,47 @@ def main():
         rep["verified"] = all(v["verified"] for v in rep["fields"].values())
         return rep
 
+    def layout_report():
+        """The bridge every reference-layout caller crosses: AoS [secret][party] (the Vector per secret shamirSecretShare returns,
+        shamir.h:52-68) <-> SoA [party][secret] (what the kernels stream), scl_hip_aos_to_soa / scl_hip_soa_to_aos at n = 10.
+        Algorithmic bytes: every element read once and written once, 2 n E per secret."""
+        rep = {"workload": "scl_hip_aos_to_soa / scl_hip_soa_to_aos, n = 10 parties", "bytes_per_secret": "2 n E", "fields": {}}
+        for fkey, N_ in (("m61", 100_000_000), ("m127", 10_000_000), ("secp256k1", 10_000_000)):
+            f_, L_ = tag_limbs(fkey)
+            n_, E_ = 10, 8 * L_
+            soa_ = scl.empty(f_, n_, N_)
+            fill_random(soa_, f_, b"scl-bench-layout-" + fkey.encode())
+            warm, reps = (100, 50) if N_ * n_ * E_ < 2_000_000_000 else (5, 10)
+            legs = {}
+            aos_ = scl.soa_to_aos(f_, soa_)
+            back = scl.aos_to_soa(f_, aos_)
+            ok = bool(scl.equals(f_, back.view(-1, L_), soa_.view(-1, L_)))
+            # (AoS order checked against the definition on a window: aos[s][i] = soa[i][s])
+            ok = ok and bool(torch.equal(aos_[:4096].transpose(0, 1), soa_[:, :4096])) and bool(torch.equal(aos_[-4096:].transpose(0, 1), soa_[:, -4096:]))
+            del back
+            for name in ("soa_to_aos", "aos_to_soa"):
+                tms = [scl.Timer() for _ in range(reps)]
+                for k in range(-warm, reps):
+                    if k >= 0:
+                        tms[k].start()
+                    if name == "soa_to_aos":
+                        scl.lib.scl_hip_soa_to_aos(f_, scl._dev(aos_), scl._dev(soa_), N_, N_, n_, scl._stream())
+                    else:
+                        scl.lib.scl_hip_aos_to_soa(f_, scl._dev(soa_), N_, scl._dev(aos_), N_, n_, scl._stream())
+                    if k >= 0:
+                        tms[k].stop()
+                torch.cuda.synchronize()
+                ms = [tm.elapsed_ms() for tm in tms]
+                mean = sum(ms) / reps
+                nb = 2 * n_ * E_
+                legs[name] = {"ms": mean, "ms_min_max": [min(ms), max(ms)], "GBps": nb * N_ / mean / 1e6,
+                              "frac": nb * N_ / mean / 1e6 / HBM_PEAK_GBPS}
+            rep["fields"][FIELD_NAMES[fkey]] = {"secrets": N_, "n": n_, **legs, "verified": ok}
+            del soa_, aos_
+            torch.cuda.empty_cache()
+        rep["verified"] = all(v["verified"] for v in rep["fields"].values())
+        return rep
+
     def open_step(fkey, n, t, N, chunk, steps, warmup, seed):
         """The MPC open of N secrets: every rank holds ceil(n/G) parties' share vectors, one all-gather per chunk
         brings all n rows to every rank, every rank reconstructs (as every MPC party does).  Timed three ways:
@@ -1137,12 +1178,19 @@ def main():
         except Exception as e:
             line["ew"] = {"error": str(e), "verified": False}
             torch.cuda.empty_cache()
+    if world == 1 and args.ew and pl["key"] == "c2":
+        try:
+            line["layout"] = layout_report()
+        except Exception as e:
+            line["layout"] = {"error": str(e), "verified": False}
+            torch.cuda.empty_cache()
     if world == 1 and args.configs:
         # the other BASELINE configurations at the size ONE GPU holds of them (C4, C5: an eighth), after the timed region
         cfgs = {}
         for key, (fk, n_, t_, N_, st, wu, na) in {
             "C3_mersenne127_10_3": ("m127", 10, 3, 10_000_000, 50, 100, 3),
             "C3_mont128_10_3": ("mont128", 10, 3, 10_000_000, 50, 100, 3),
+            "F3_secp256k1_scalar_10_3": ("secp256k1", 10, 3, 10_000_000, 50, 100, 1),   # Feldman / Pedersen's field
             "C4_shard_gf2_128_40_13": ("gf2_128", 40, 13, 12_500_000, 5, 2, 1),
             "C5_shard_mersenne61_128_42": ("m61", 128, 42, 125_000_000, 2, 1, 1),
         }.items():

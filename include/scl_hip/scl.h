@@ -16,5 +16,6 @@
 #include "ss/additive.h"
 #include "ss/shamir.h"
 #include "util/prg.h"
+#include "names.h"
 
 #endif

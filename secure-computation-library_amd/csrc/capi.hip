@@ -932,6 +932,53 @@ int split_vec(int vec, size_t N, Body&& body) {
   return SCL_OK;
 }
 
+// The Lagrange coefficients as small signed integers, when they are (k_recover_small): every lambda_i or p - lambda_i below
+// 2^32 as a plain integer and both signed sums below 2^32 (the lazy limb sums then cannot wrap and stay below p * 2^32).
+template <class F>
+bool small_lambda(const typename F::Ctx& ctx, const u64* lambda_host, size_t m, SmallLam& sl) {
+  if constexpr (F::TAG == 2 || F::LIMBS == 4) {
+    if (m > (size_t)FIXED_M_MAX || g_force_table.load()) return false;
+    u64 sum_pos = 0, sum_neg = 0;
+    sl.neg = 0;
+    for (size_t i = 0; i < m; ++i) {
+      const typename F::E e = F::ld(lambda_host + i * F::LIMBS);
+      u128 v;
+      if (node_value<F>(ctx, e, v) && v < ((u128)1 << 32)) {
+        sum_pos += (u64)v;
+      } else if (node_value<F>(ctx, F::neg(ctx, e), v) && v < ((u128)1 << 32)) {
+        sum_neg += (u64)v;
+        sl.neg |= 1u << i;
+      } else {
+        return false;
+      }
+      sl.v[i] = (u32)v;
+    }
+    for (size_t i = m; i < (size_t)FIXED_M_MAX; ++i) sl.v[i] = 0;
+    return sum_pos < ((u64)1 << 32) && sum_neg < ((u64)1 << 32);
+  } else {
+    (void)ctx; (void)lambda_host; (void)m; (void)sl;
+    return false;
+  }
+}
+
+template <class F, int M>
+struct RecoverSmall {
+  static int run(const typename F::Ctx& ctx, u64* out, const u64* shares, size_t stride, const SmallLam& lam, int m, size_t n,
+                 hipStream_t st) {
+    if (m == M) {
+      // single-wave workgroups under the residency cap of the (m <= 16) stream kernels (kernels.hpp, "Launch geometry")
+      const long sw = g_stream_waves.load();
+      const size_t pad = residency_pad(sw < 0 ? 12 : sw, 64, 0);
+      hipLaunchKernelGGL((k_recover_small<F, M, true, 64>), dim3(grid_for_block(n, 64)), dim3(64), pad, st, ctx, out, shares, stride,
+                         lam, n);
+      HIP_TRY(hipGetLastError());
+      return SCL_OK;
+    }
+    if constexpr (M > 1) return RecoverSmall<F, M - 1>::run(ctx, out, shares, stride, lam, m, n, st);
+    return fail(SCL_ERR_BAD_ARG, "recover: internal");
+  }
+};
+
 template <class F, int M>
 struct RecoverFixed {
   template <int VEC>
@@ -1642,6 +1689,12 @@ static int recover_block(int field, uint64_t* out, const uint64_t* shares, size_
       for (size_t i = 0; i < m; ++i) lam.v[i] = F::ld(lambda_host + i * F::LIMBS);
     } else {
       for (size_t i = 0; i < m; ++i) big.v[i] = F::ld(lambda_host + i * F::LIMBS);
+    }
+    if constexpr (F::TAG == 2 || F::LIMBS == 4) {
+      // Montgomery fields: coefficients that are small signed integers (the default nodes' binomials) need no Montgomery product
+      SmallLam sl;
+      if (!prev && small_lambda<F>(ctx, lambda_host, m, sl))
+        return RecoverSmall<F, FIXED_M_MAX>::run(ctx, out, shares, stride, sl, (int)m, N, S(stream));
     }
     if constexpr (F::TAG == 3) {
       const long ft = g_force_table.load();
@@ -2413,6 +2466,33 @@ static int transpose_impl(int field, uint64_t* dst, const uint64_t* src, size_t 
   if (N == 0 || n == 0) return SCL_OK;
   if (!dst || !src) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   if (stride < N) return fail(SCL_ERR_SIZE_MISMATCH, "stride < N");
+  // 16-byte accesses on both sides (k_transpose16) where the layout allows: aligned bases, an even row stride for one-limb
+  // fields, and a tile of at least 64 secrets within 40 KiB of LDS ("force_scalar" 1: the 8-byte kernel, for A/B runs)
+  {
+    size_t t16 = (40 * 1024) / (n * (size_t)L * 8);
+    if (t16 > 512) t16 = 512;
+    t16 &= ~(size_t)63;
+    if (t16 >= 64 && aligned16(dst) && aligned16(src) && (L != 1 || (stride & 1) == 0) && !g_force_scalar.load()) {
+      const size_t ntiles16 = (N + t16 - 1) / t16;
+      const unsigned g16 = (unsigned)(ntiles16 < (1u << 20) ? ntiles16 : (1u << 20));
+      const size_t shmem16 = t16 * n * (size_t)L * 8;
+#define TR16_LAUNCH(LL, SOA) \
+  hipLaunchKernelGGL((k_transpose16<LL, SOA>), dim3(g16), dim3(BLOCK), shmem16, S(stream), dst, src, stride, N, (int)n, (int)t16)
+      if (L == 1) {
+        if (to_soa) TR16_LAUNCH(1, true);
+        else TR16_LAUNCH(1, false);
+      } else if (L == 2) {
+        if (to_soa) TR16_LAUNCH(2, true);
+        else TR16_LAUNCH(2, false);
+      } else {
+        if (to_soa) TR16_LAUNCH(4, true);
+        else TR16_LAUNCH(4, false);
+      }
+#undef TR16_LAUNCH
+      LAUNCH_CHECK();
+      return SCL_OK;
+    }
+  }
   size_t tile = (32 * 1024) / (n * (size_t)L * 8);
   if (tile == 0) return fail(SCL_ERR_BAD_ARG, "transpose: n too large");
   if (tile > 1024) tile = 1024;

@@ -557,6 +557,50 @@ __global__ __launch_bounds__(BLK) void k_recover_fixed(typename F::Ctx ctx, u64*
   }
 }
 
+// shamirRecoverP at the default nodes 1..n, x = 0, over a Montgomery field: there the Lagrange coefficients are the signed
+// binomials lambda_i = (-1)^(i-1) C(n, i) -- prod_{j != i} j / (j - i) = (n! / i) / ((-1)^(i-1) (i-1)! (n-i)!) -- i.e. SMALL
+// integers, and a residue x R times a plain integer v stays in Montgomery form ((x R) v = (x v) R): the sum needs no Montgomery
+// product at all.  Positive and negative coefficients go to two lazy sums of limb x v products (the small-node accumulator of
+// the share kernels, SAcc: one 32 x 32 multiply-add per 32-bit limb and term against the 64 + 64 of a full lazy product over
+// secp256k1), each reduced once, then one modular subtraction -- the same residue shamirRecoverP reaches (shamir.h:81-104).
+// The host takes this path whenever every coefficient, as an integer or as p minus one, is below 2^32 and both signed sums are
+// (any nodes and evaluation point that happen to give such coefficients, not just the default ones).
+struct SmallLam {
+  u32 v[FIXED_M_MAX];  // |lambda_i|
+  u32 neg;             // bit i: lambda_i = p - v[i]
+};
+
+template <class F, int M, bool NT, int BLK>
+__global__ __launch_bounds__(BLK) void k_recover_small(typename F::Ctx ctx, u64* out, const u64* shares, size_t stride, SmallLam lam,
+                                                       size_t n) {
+  typedef typename F::E E;
+  for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < n; q += (size_t)gridDim.x * BLK) {
+    const size_t off = q * F::LIMBS;
+    Pack<F, 1> x[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) x[i] = load_pack<F, 1, NT>(shares + (size_t)i * stride * F::LIMBS + off);
+    typename F::SAcc pos, neg;
+    F::sacc_zero(pos);
+    F::sacc_zero(neg);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      if ((lam.neg >> i) & 1u) F::sacc_mac(neg, x[i].v[0], lam.v[i]);  // (wave-uniform: a scalar branch)
+      else F::sacc_mac(pos, x[i].v[0], lam.v[i]);
+    }
+    E a, b;
+    if constexpr (F::TAG == 2) {
+      a = F::sacc_fold(ctx, pos, F::zero());
+      b = F::sacc_fold(ctx, neg, F::zero());
+    } else {
+      a = F::sacc_fold(pos, F::zero());
+      b = F::sacc_fold(neg, F::zero());
+    }
+    Pack<F, 1> r;
+    r.v[0] = F::sub(ctx, a, b);
+    store_pack<F, 1, NT>(out + off, r);
+  }
+}
+
 // Any m <= BigTable::CAP: lambda staged in LDS, rows consumed 8 at a time.
 // prev != nullptr: out = prev + this block of parties' terms -- how more parties than one table holds are summed
 // over several launches (canonical partial sums add exactly)
@@ -2966,6 +3010,69 @@ __global__ __launch_bounds__(BLOCK) void k_transpose(u64* dst, const u64* src, s
       for (int w = threadIdx.x; w < words; w += BLOCK) a[w] = tile[w];
     }
     __syncthreads();
+  }
+}
+
+// The same bridge with 16-byte global accesses on BOTH sides (k_transpose moves 8 bytes per lane on its strided side).  The
+// LDS tile is the AoS image of TS secrets, copied linearly 16 bytes per lane; on the SoA side a lane owns 16 consecutive bytes
+// of ONE party's row -- two consecutive secrets of a one-limb field, one element of a two-limb field, half an element of a
+// four-limb one -- so every global instruction of a wave is 1 KiB of whole lines, and the strided walk happens in LDS
+// (n x LIMBS x 8 bytes between a lane's neighbours: a few-way bank conflict the array has room for at these rates).
+// Needs 16-byte aligned bases and, for one-limb fields, an even row stride; ragged last tiles take the scalar tail below.
+template <int LIMBS, bool TO_SOA>
+__global__ __launch_bounds__(BLOCK) void k_transpose16(u64* dst, const u64* src, size_t stride, size_t N, int n, int tile_secrets) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u64* tile = reinterpret_cast<u64*>(smem_raw);  // [tile_secrets][n][LIMBS] words, AoS order
+  u64x2* tile16 = reinterpret_cast<u64x2*>(smem_raw);
+  const size_t ntiles = (N + tile_secrets - 1) / tile_secrets;
+  for (size_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const size_t s0 = tix * tile_secrets;
+    const int ts = (int)min((size_t)tile_secrets, N - s0);
+    const int words = ts * n * LIMBS;          // (s0 * n * LIMBS is even: tile_secrets is)
+    u64* aos = (TO_SOA ? const_cast<u64*>(src) : dst) + s0 * n * LIMBS;
+    if constexpr (TO_SOA) {
+      for (int c = threadIdx.x; c < words / 2; c += BLOCK) tile16[c] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(aos) + c);
+      if ((words & 1) && threadIdx.x == 0) tile[words - 1] = aos[words - 1];
+      __syncthreads();
+    }
+    // SoA side: party i, 16-byte piece p of its row segment [s0, s0 + ts)
+    constexpr int PER = LIMBS == 1 ? 2 : 1;        // secrets per 16-byte piece (one-limb fields)
+    constexpr int PIECES = LIMBS == 1 ? 1 : LIMBS / 2;  // 16-byte pieces per element
+    const int npieces = LIMBS == 1 ? ts / 2 : ts * PIECES;
+    for (int i = 0; i < n; ++i) {
+      u64* row = (TO_SOA ? dst : const_cast<u64*>(src)) + ((size_t)i * stride + s0) * LIMBS;
+      for (int p = threadIdx.x; p < npieces; p += BLOCK) {
+        if constexpr (LIMBS == 1) {
+          const int s = p * PER;
+          if constexpr (TO_SOA) {
+            u64x2 v;
+            v.x = tile[s * n + i];
+            v.y = tile[(s + 1) * n + i];
+            __builtin_nontemporal_store(v, reinterpret_cast<u64x2*>(row) + p);
+          } else {
+            const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(row) + p);
+            tile[s * n + i] = v.x;
+            tile[(s + 1) * n + i] = v.y;
+          }
+        } else {
+          const int s = p / PIECES, c = p % PIECES;
+          if constexpr (TO_SOA) __builtin_nontemporal_store(tile16[(s * n + i) * PIECES + c], reinterpret_cast<u64x2*>(row) + p);
+          else tile16[(s * n + i) * PIECES + c] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(row) + p);
+        }
+      }
+      if constexpr (LIMBS == 1) {
+        if ((ts & 1) && threadIdx.x == 0) {  // the odd secret out of a ragged last tile
+          if constexpr (TO_SOA) row[ts - 1] = tile[(ts - 1) * n + i];
+          else tile[(ts - 1) * n + i] = row[ts - 1];
+        }
+      }
+    }
+    if constexpr (!TO_SOA) {
+      __syncthreads();
+      for (int c = threadIdx.x; c < words / 2; c += BLOCK) __builtin_nontemporal_store(tile16[c], reinterpret_cast<u64x2*>(aos) + c);
+      if ((words & 1) && threadIdx.x == 0) aos[words - 1] = tile[words - 1];
+    }
+    __syncthreads();  // the tile is free for the next trip
   }
 }
 

@@ -789,6 +789,38 @@ TEST_CASE(matrix_unbounded, "Matrix::multiply has no bound on its shape (matrix.
   matmul_without_bounds<math::FF<math::ff::Secp256k1Scalar>>("mm-unbounded-secp");
 }
 
+TEST_CASE(baseline_names, "scl::Vec / ss::ShamirShare / ShamirReconstruct / AdditiveSS (the names of BASELINE.json and of shamir.h:94,167)", BOTH) {
+  // the same calls as test/scl/ss/test_shamir.cc:34-40 and test_additive.cc:26-41 under the other spelling: same shares, same secret
+  {
+    auto prg = util::PRG::create("shamir passive");
+    const Vec<F61> shares = ss::ShamirShare(F61(123), 3, 4, prg);
+    REQUIRE(shares.size() == 4 && shares[0] == F61::fromString("068de5f6897f1180") && shares[3] == F61::fromString("1ca17e1ae3ddfdde"));
+    REQUIRE(ss::ShamirReconstruct(shares) == F61(123) && ss::ShamirRecoverP(shares) == F61(123));
+    auto prg2 = util::PRG::create("shamir passive");
+    REQUIRE(ss::shamirSecretShare(F61(123), 3, 4, prg2) == shares);
+    static_assert(std::is_same_v<Vec<F61>, math::Vector<F61>> && std::is_same_v<math::Vec<F61>, math::Vector<F61>> &&
+                  std::is_same_v<Mat<F127>, math::Matrix<F127>>);
+  }
+  {
+    auto prg = util::PRG::create();
+    const auto shares = ss::AdditiveSS(F61(12345), 3, prg);
+    REQUIRE(shares[0] == F61::fromString("10c9a04e00a8277a") && shares[1] == F61::fromString("0e0c7bcabdee0f5b"));
+    REQUIRE(ss::AdditiveReconstruct(shares) == F61(12345) && shares.sum() == F61(12345));
+  }
+  {  // the batch forms through the same names (kernels above the host threshold)
+    std::vector<F61> secrets;
+    for (int s = 0; s < 3000; ++s) secrets.emplace_back(s * 7 + 1);
+    auto prg = util::PRG::create("names-batch");
+    if (hip::hostThreshold() == 0) {
+      const hip::DeviceVector<F61> d(secrets);
+      const auto sh = ss::ShamirShare(d, 3, 10, prg);
+      REQUIRE(math::Vector<F61>(ss::ShamirReconstruct(sh).toHost()) == math::Vector<F61>(secrets));
+      const auto ad = ss::AdditiveSS(d, 3, prg);
+      REQUIRE(math::Vector<F61>(ss::AdditiveReconstruct(ad).toHost()) == math::Vector<F61>(secrets));
+    }
+  }
+}
+
 TEST_CASE(shamir_mirror, "ss::shamir* per secret (reference signatures)", BOTH) {
   // test/scl/ss/test_shamir.cc:34-40
   {

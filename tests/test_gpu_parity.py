@@ -882,6 +882,72 @@ def test_matmul_on_matrix_cores_beyond_one_tile(scl, port, M, K, N):
         scl.set_tuning("mfma", 0)
 
 
+@pytest.mark.parametrize("f", ALL_FIELDS)
+@pytest.mark.parametrize("n,N", [(10, 5000), (10, 1027), (3, 513), (7, 64), (1, 100), (40, 1301), (128, 300), (10, 1)])
+def test_layout_bridge_both_ways(scl, port, f, n, N):
+    """AoS [secret][party] (the reference's Vector per secret, shamir.h:52-68) <-> SoA [party][secret] through the 16-byte kernel
+    (k_transpose16: ragged last tiles, odd secret counts, one party) and the 8-byte one ("force_scalar"), against numpy's
+    transpose; a window of a wider SoA matrix through the raw ABI (row stride > N, rows 16-byte aligned or not)."""
+    import ctypes as C
+    L = O.LIMBS[f]
+    aos = rand_elems(port, f, N * n, b"layout").reshape(N, n, L)
+    want = soa(aos)
+    for scalar in (0, 1):
+        scl.set_tuning("force_scalar", scalar)
+        try:
+            got = scl.aos_to_soa(f, dev(scl, aos))
+            assert np.array_equal(host(scl, got), want), (f, n, N, scalar)
+            assert np.array_equal(host(scl, scl.soa_to_aos(f, got)), aos), (f, n, N, scalar)
+        finally:
+            scl.set_tuning("force_scalar", 0)
+    for stride, off in ((N + 6, 0), (N + 3, 0), (N + 4, 1)):      # even stride, odd stride, rows that start 8 bytes into a line
+        buf = torch.full((n * stride * L + 4,), -1, dtype=torch.int64, device="cuda")
+        base = C.c_void_p(buf.data_ptr() + 8 * off)
+        src = dev(scl, aos)
+        st = scl.lib.scl_hip_aos_to_soa(f, base, C.c_size_t(stride), C.c_void_p(src.data_ptr()), C.c_size_t(N), C.c_size_t(n), None)
+        assert st == 0, scl.lib.scl_hip_last_error()
+        torch.cuda.synchronize()
+        flat = buf.cpu().numpy().view(np.uint64)[off:off + n * stride * L].reshape(n, stride, L)
+        assert np.array_equal(flat[:, :N], want) and (flat[:, N:] == np.uint64(2 ** 64 - 1)).all()
+        back = torch.zeros((N, n, L), dtype=torch.int64, device="cuda")
+        st = scl.lib.scl_hip_soa_to_aos(f, C.c_void_p(back.data_ptr()), base, C.c_size_t(stride), C.c_size_t(N), C.c_size_t(n), None)
+        assert st == 0, scl.lib.scl_hip_last_error()
+        assert np.array_equal(host(scl, back), aos)
+
+
+@pytest.mark.parametrize("f", [O.MONT128, O.SECP256K1_SCALAR, O.SECP256K1_FIELD])
+@pytest.mark.parametrize("n", [1, 2, 3, 10, 16])
+def test_reconstruct_with_small_integer_coefficients(scl, port, f, n):
+    """At the default nodes 1..n and x = 0 the Lagrange coefficients are the signed binomials (-1)^(i-1) C(n, i): over the
+    Montgomery fields the reconstruct kernel then multiplies residues by plain small integers (k_recover_small) instead of
+    running Montgomery products -- the same residues as the oracle's shamirRecoverP (shamir.h:81-104) and as the table kernel
+    ("force_table"), ragged sizes and a window of a wider matrix included; coefficients that are not small take the table kernel."""
+    from math import comb
+    L, N, t = O.LIMBS[f], 4099, min(3, n - 1)
+    lam = scl.lagrange_basis(f, n)
+    for i in range(n):   # lambda_i = (-1)^(i) C(n, i + 1) for party i + 1
+        assert np.array_equal(lam[i], port.from_int(f, (-1) ** i * comb(n, i + 1))), (n, i)
+    secrets = rand_elems(port, f, N, b"small-lam-s")
+    shares = scl.shamir_share_prg(f, dev(scl, secrets), t, n, b"small-lam")
+    aos = np.ascontiguousarray(np.transpose(host(scl, shares), (1, 0, 2)))
+    want = port.shamir_recover(f, aos[:300])
+    got = host(scl, scl.shamir_recover(f, shares, lam))
+    assert np.array_equal(got, secrets) and np.array_equal(got[:300], want)
+    scl.set_tuning("force_table", 1)
+    try:
+        assert np.array_equal(host(scl, scl.shamir_recover(f, shares, lam)), got)
+    finally:
+        scl.set_tuning("force_table", 0)
+    if n >= 3:   # explicit nodes / an evaluation point whose coefficients are full-size residues: the general kernel
+        nodes = rand_elems(port, f, n, b"small-lam-nodes")
+        x = rand_elems(port, f, 1, b"small-lam-x")[0]
+        lam2 = scl.lagrange_basis(f, n, nodes, x)
+        sh2 = scl.shamir_share(f, dev(scl, secrets), dev(scl, rand_elems(port, f, t * N, b"small-lam-c").reshape(t, N, L)), n, alphas=nodes)
+        got2 = host(scl, scl.shamir_recover(f, sh2, lam2))
+        aos2 = np.ascontiguousarray(np.transpose(host(scl, sh2), (1, 0, 2)))
+        assert np.array_equal(got2[:200], port.shamir_recover_lambda(f, aos2[:200], lam2))
+
+
 def test_vandermonde_matmul_is_sharing(scl, port):
     """test_matrix.cc:342-365: V(n, t+1) x coefficient matrix == Shamir shares at nodes 1..n"""
     f, L, n, t, N = O.M61, 1, 10, 3, 500
