@@ -87,9 +87,10 @@ SCL_STATE(thread_local Knob g_share_waves, {9});
 SCL_STATE(thread_local Knob g_share_waves128, {12});  // .. and for the 16-byte fields' small-node share kernel ("share_waves128")
 SCL_STATE(thread_local Knob g_aes_blocks, {0});
 // element-wise inverse / divide: 0 auto = Montgomery's simultaneous inversion with the chain length chosen by the batch, N > 0 =
-// that chain length (8, 32, 64 or 128; Mersenne61: any N = its register kernel), -1 = one Fermat chain per element (k_ew, the kernels
+// that chain length (8, 16, 32, 64 or 128; Mersenne61: any N = its register kernel), -1 = one Fermat chain per element (k_ew, the kernels
 // of rounds 1-4); GF(2^128) multiply: -1 = the register-only product ("inv_batch")
 SCL_STATE(thread_local Knob g_inv_batch, {0});
+SCL_STATE(thread_local Knob g_transpose_tile, {0});  // secrets per LDS tile of the 16-byte layout bridge (0 = 512 within 40 KiB) ("transpose_tile")
 // Mont128 modulus: a process-wide default, latched per host thread at its first use (mont_ctx below)
 SCL_STATE(thread_local Mont128::Ctx g_mont, = {0, 0, 0, 0});  // p == 0: this thread has not latched a modulus yet
 SCL_STATE(std::mutex g_mont_default_mu);
@@ -969,7 +970,8 @@ struct RecoverSmall {
       // single-wave workgroups under the residency cap of the (m <= 16) stream kernels (kernels.hpp, "Launch geometry")
       const long sw = g_stream_waves.load();
       const size_t pad = residency_pad(sw < 0 ? 12 : sw, 64, 0);
-      hipLaunchKernelGGL((k_recover_small<F, M, true, 64>), dim3(grid_for_block(n, 64)), dim3(64), pad, st, ctx, out, shares, stride,
+      const size_t lanes = F::LIMBS == 4 ? 2 * n : n;  // 32-byte elements: a pair of lanes per secret
+      hipLaunchKernelGGL((k_recover_small<F, M, true, 64>), dim3(grid_for_block(lanes, 64)), dim3(64), pad, st, ctx, out, shares, stride,
                          lam, n);
       HIP_TRY(hipGetLastError());
       return SCL_OK;
@@ -1070,7 +1072,7 @@ static int share_chunked(int field, uint64_t* shares, size_t share_stride, const
 
 // Inverse / divide by Montgomery's simultaneous inversion (kernels.hpp, k_ew_inv / k_ew_inv_rolled).  Chain length: Mersenne61
 // keeps 32 elements per lane in registers (16-byte packs); the other fields keep the chain in memory and take the longest of
-// 8 / 32 / 64 / 128 that still leaves ~2000 single-wave workgroups (the inversion's share of a chain is I / L products per element,
+// 8 / 16 / 32 / 64 / 128 that still leaves ~4000 single-wave workgroups (the inversion's share of a chain is I / L products per element,
 // I = 138 for Mersenne127 up to ~450 for secp256k1, against 3 for the walk).
 template <class F, class ARITH, bool DIV, int L>
 int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, unsigned* flag, hipStream_t st) {
@@ -1085,11 +1087,16 @@ int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const 
 template <class F, bool DIV>
 int ew_inverse_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, long want, unsigned* flag, hipStream_t st) {
   using A = std::conditional_t<F::TAG == 3, GfLdsArith<64>, FieldArith<F>>;
-  int L = n >= ((size_t)1 << 24) ? 128 : n >= ((size_t)1 << 23) ? 64 : n >= ((size_t)1 << 22) ? 32 : 8;
-  if (want > 0) L = want >= 128 ? 128 : want >= 64 ? 64 : want >= 32 ? 32 : 8;
+  // the longest chain that still leaves ~4000 single-wave workgroups (four per SIMD): measured optimum 32 at 10^7 elements and
+  // 128 at 10^8 (profiles/r5_ew_bench.txt)
+  int L = 8;
+  for (int cand : {16, 32, 64, 128})
+    if (n >= (size_t)cand * 64 * 4096) L = cand;
+  if (want > 0) L = want >= 128 ? 128 : want >= 64 ? 64 : want >= 32 ? 32 : want >= 16 ? 16 : 8;
   if (L == 128) return launch_inv_rolled<F, A, DIV, 128>(ctx, dst, a, b, n, flag, st);
   if (L == 64) return launch_inv_rolled<F, A, DIV, 64>(ctx, dst, a, b, n, flag, st);
   if (L == 32) return launch_inv_rolled<F, A, DIV, 32>(ctx, dst, a, b, n, flag, st);
+  if (L == 16) return launch_inv_rolled<F, A, DIV, 16>(ctx, dst, a, b, n, flag, st);
   return launch_inv_rolled<F, A, DIV, 8>(ctx, dst, a, b, n, flag, st);
 }
 
@@ -1280,6 +1287,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "mfma_tpb") g_mfma_tpb = value;
   else if (k == "aes_blocks") g_aes_blocks = value;
   else if (k == "inv_batch") g_inv_batch = value;
+  else if (k == "transpose_tile") g_transpose_tile = value;
   else if (k == "stream_block") g_stream_block = (value == 256 ? 256 : 64);
   else if (k == "stream_waves") g_stream_waves = value;
   else if (k == "share_waves") g_share_waves = value;
@@ -2470,8 +2478,14 @@ static int transpose_impl(int field, uint64_t* dst, const uint64_t* src, size_t 
   // fields, and a tile of at least 64 secrets within 40 KiB of LDS ("force_scalar" 1: the 8-byte kernel, for A/B runs)
   {
     size_t t16 = (40 * 1024) / (n * (size_t)L * 8);
-    if (t16 > 512) t16 = 512;
-    t16 &= ~(size_t)63;
+    const long want_tile = g_transpose_tile.load();
+    if (t16 > (want_tile > 0 ? (size_t)want_tile : 512)) t16 = want_tile > 0 ? (size_t)want_tile : 512;
+    for (size_t pw = 512; pw >= 64; pw >>= 1)  // a power of two: the kernel splits its flat (party, piece) index with a shift
+      if (t16 >= pw) {
+        t16 = pw;
+        break;
+      }
+    if (t16 < 64) t16 = 0;
     if (t16 >= 64 && aligned16(dst) && aligned16(src) && (L != 1 || (stride & 1) == 0) && !g_force_scalar.load()) {
       const size_t ntiles16 = (N + t16 - 1) / t16;
       const unsigned g16 = (unsigned)(ntiles16 < (1u << 20) ? ntiles16 : (1u << 20));

@@ -574,30 +574,67 @@ template <class F, int M, bool NT, int BLK>
 __global__ __launch_bounds__(BLK) void k_recover_small(typename F::Ctx ctx, u64* out, const u64* shares, size_t stride, SmallLam lam,
                                                        size_t n) {
   typedef typename F::E E;
-  for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < n; q += (size_t)gridDim.x * BLK) {
-    const size_t off = q * F::LIMBS;
-    Pack<F, 1> x[M];
+  if constexpr (F::LIMBS == 4) {
+    // 32-byte elements: a PAIR of lanes per secret, lane h of the pair holding limbs 2h, 2h + 1 -- a wave's loads and stores are
+    // then 1 KiB of consecutive bytes each (a lane per element reads 16 bytes out of every 32 twice over), and the ten shares
+    // cost a lane 40 registers instead of 80.  The limb sums are linear, so each lane accumulates its own four 32-bit columns;
+    // the halves meet over DPP (quad_perm 1,0,3,2) before the two reductions, which both lanes run, each storing its half.
+    for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < 2 * n; q += (size_t)gridDim.x * BLK) {
+      const int h = (int)(q & 1);
+      const size_t off = (q >> 1) * 4 + 2 * h;
+      u64x2 x[M];
 #pragma unroll
-    for (int i = 0; i < M; ++i) x[i] = load_pack<F, 1, NT>(shares + (size_t)i * stride * F::LIMBS + off);
-    typename F::SAcc pos, neg;
-    F::sacc_zero(pos);
-    F::sacc_zero(neg);
+      for (int i = 0; i < M; ++i) x[i] = ldg<NT>(reinterpret_cast<const u64x2*>(shares + (size_t)i * stride * 4 + off));
+      u64 pos[4] = {0, 0, 0, 0}, neg[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-      if ((lam.neg >> i) & 1u) F::sacc_mac(neg, x[i].v[0], lam.v[i]);  // (wave-uniform: a scalar branch)
-      else F::sacc_mac(pos, x[i].v[0], lam.v[i]);
+      for (int i = 0; i < M; ++i) {
+        auto term = [&](u64 (&acc)[4]) {
+          mad32(acc[0], (u32)x[i].x, lam.v[i]);
+          mad32(acc[1], (u32)(x[i].x >> 32), lam.v[i]);
+          mad32(acc[2], (u32)x[i].y, lam.v[i]);
+          mad32(acc[3], (u32)(x[i].y >> 32), lam.v[i]);
+        };
+        if ((lam.neg >> i) & 1u) term(neg);  // (wave-uniform: a scalar branch)
+        else term(pos);
+      }
+      auto partner = [](u64 v) {
+        const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0xB1, 0xF, 0xF, false);
+        const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0xB1, 0xF, 0xF, false);
+        return ((u64)hi << 32) | lo;
+      };
+      typename F::SAcc sp, sn;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u64 pp = partner(pos[j]), pn = partner(neg[j]);
+        sp.a[j] = h ? pp : pos[j];
+        sp.a[4 + j] = h ? pos[j] : pp;
+        sn.a[j] = h ? pn : neg[j];
+        sn.a[4 + j] = h ? neg[j] : pn;
+      }
+      const E r = F::sub(ctx, F::sacc_fold(sp, F::zero()), F::sacc_fold(sn, F::zero()));
+      u64x2 o;
+      o.x = h ? r.w[2] : r.w[0];
+      o.y = h ? r.w[3] : r.w[1];
+      stg<NT>(reinterpret_cast<u64x2*>(out + off), o);
     }
-    E a, b;
-    if constexpr (F::TAG == 2) {
-      a = F::sacc_fold(ctx, pos, F::zero());
-      b = F::sacc_fold(ctx, neg, F::zero());
-    } else {
-      a = F::sacc_fold(pos, F::zero());
-      b = F::sacc_fold(neg, F::zero());
+  } else {
+    for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < n; q += (size_t)gridDim.x * BLK) {
+      const size_t off = q * F::LIMBS;
+      Pack<F, 1> x[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) x[i] = load_pack<F, 1, NT>(shares + (size_t)i * stride * F::LIMBS + off);
+      typename F::SAcc pos, neg;
+      F::sacc_zero(pos);
+      F::sacc_zero(neg);
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        if ((lam.neg >> i) & 1u) F::sacc_mac(neg, x[i].v[0], lam.v[i]);  // (wave-uniform: a scalar branch)
+        else F::sacc_mac(pos, x[i].v[0], lam.v[i]);
+      }
+      Pack<F, 1> r;
+      r.v[0] = F::sub(ctx, F::sacc_fold(ctx, pos, F::zero()), F::sacc_fold(ctx, neg, F::zero()));
+      store_pack<F, 1, NT>(out + off, r);
     }
-    Pack<F, 1> r;
-    r.v[0] = F::sub(ctx, a, b);
-    store_pack<F, 1, NT>(out + off, r);
   }
 }
 
@@ -1610,6 +1647,10 @@ __global__ __launch_bounds__(BLK) void k_share_small_t(typename F::Ctx ctx, u64*
   }
 }
 
+// (A lane-pair form of this kernel for the 32-byte fields -- halves of the secret and of every coefficient per lane, the column
+// sums exchanged over DPP as in k_recover_small, both lanes reducing -- was built and measured in round 5: 0.94 ms against 0.88 ms
+// for secp256k1 (10,3) at 10^7 secrets, profiles/r5_probe_secp_share_pair_no_gain.txt: ten duplicated reductions per secret cost
+// more than the whole-line stores gain.  Not kept.)
 // Blocked form of the small-node evaluation for larger t: the polynomial is cut into groups of G coefficients,
 //   f(x) = sum_j x^(G j) * g_j(x),   g_j(x) = sum_{r<G} c_{Gj+r} x^r,
 // each g_j(x_i) summed lazily against the small powers x_i^r < 2^29 (one v_mad_u64_u32 per 32-bit limb and
@@ -3039,29 +3080,37 @@ __global__ __launch_bounds__(BLOCK) void k_transpose16(u64* dst, const u64* src,
     constexpr int PER = LIMBS == 1 ? 2 : 1;        // secrets per 16-byte piece (one-limb fields)
     constexpr int PIECES = LIMBS == 1 ? 1 : LIMBS / 2;  // 16-byte pieces per element
     const int npieces = LIMBS == 1 ? ts / 2 : ts * PIECES;
-    for (int i = 0; i < n; ++i) {
+    // one flat index over (party, piece): every thread has work whatever the tile size, and all of a tile's strided-side
+    // accesses are in flight together.  npieces is a power of two on full tiles (tile_secrets is): a shift splits the index.
+    const int total = n * npieces;
+    const bool pow2 = (npieces & (npieces - 1)) == 0 && npieces > 0;
+    const int sh = pow2 ? __builtin_ctz((unsigned)npieces) : 0;
+    for (int idx = threadIdx.x; idx < total; idx += BLOCK) {
+      const int i = pow2 ? idx >> sh : idx / npieces;
+      const int p = pow2 ? idx & (npieces - 1) : idx % npieces;
       u64* row = (TO_SOA ? dst : const_cast<u64*>(src)) + ((size_t)i * stride + s0) * LIMBS;
-      for (int p = threadIdx.x; p < npieces; p += BLOCK) {
-        if constexpr (LIMBS == 1) {
-          const int s = p * PER;
-          if constexpr (TO_SOA) {
-            u64x2 v;
-            v.x = tile[s * n + i];
-            v.y = tile[(s + 1) * n + i];
-            __builtin_nontemporal_store(v, reinterpret_cast<u64x2*>(row) + p);
-          } else {
-            const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(row) + p);
-            tile[s * n + i] = v.x;
-            tile[(s + 1) * n + i] = v.y;
-          }
-        } else {
-          const int s = p / PIECES, c = p % PIECES;
-          if constexpr (TO_SOA) __builtin_nontemporal_store(tile16[(s * n + i) * PIECES + c], reinterpret_cast<u64x2*>(row) + p);
-          else tile16[(s * n + i) * PIECES + c] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(row) + p);
-        }
-      }
       if constexpr (LIMBS == 1) {
-        if ((ts & 1) && threadIdx.x == 0) {  // the odd secret out of a ragged last tile
+        const int s = p * PER;
+        if constexpr (TO_SOA) {
+          u64x2 v;
+          v.x = tile[s * n + i];
+          v.y = tile[(s + 1) * n + i];
+          __builtin_nontemporal_store(v, reinterpret_cast<u64x2*>(row) + p);
+        } else {
+          const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(row) + p);
+          tile[s * n + i] = v.x;
+          tile[(s + 1) * n + i] = v.y;
+        }
+      } else {
+        const int s = p / PIECES, c = p % PIECES;
+        if constexpr (TO_SOA) __builtin_nontemporal_store(tile16[(s * n + i) * PIECES + c], reinterpret_cast<u64x2*>(row) + p);
+        else tile16[(s * n + i) * PIECES + c] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(row) + p);
+      }
+    }
+    if constexpr (LIMBS == 1) {
+      if (ts & 1) {  // the odd secret out of a ragged last tile
+        for (int i = threadIdx.x; i < n; i += BLOCK) {
+          u64* row = (TO_SOA ? dst : const_cast<u64*>(src)) + ((size_t)i * stride + s0) * LIMBS;
           if constexpr (TO_SOA) row[ts - 1] = tile[(ts - 1) * n + i];
           else tile[(ts - 1) * n + i] = row[ts - 1];
         }

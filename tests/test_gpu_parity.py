@@ -114,7 +114,7 @@ def test_batched_inverse_against_the_oracle_at_a_million(scl, port, f, n):
     for x, sub in ((a, 7), (b, 9)):
         x[np.all(x == zero, axis=1)] = port.from_int(f, sub)
     want_inv, want_div = port.ew(f, O.INV, a), port.ew(f, O.DIV, b, a)
-    for chain in ([0] if f == O.M61 else [0, 8, 32, 64, 128]):
+    for chain in ([0] if f == O.M61 else [0, 8, 16, 32, 64, 128]):
         scl.set_tuning("inv_batch", chain)
         try:
             da = dev(scl, a)
@@ -140,7 +140,7 @@ def test_batched_inverse_against_the_oracle_at_a_million(scl, port, f, n):
 
 
 @pytest.mark.parametrize("f", [O.MONT128, O.GF2_128, O.SECP256K1_SCALAR, O.SECP256K1_FIELD])
-@pytest.mark.parametrize("chain", [0, 8, 32, 64, 128])
+@pytest.mark.parametrize("chain", [0, 8, 16, 32, 64, 128])
 def test_batched_inverse_slow_oracle_fields(scl, port, f, chain):
     """The fields whose oracle inversion is slow: x * x^-1 = 1 and (b / x) * x = b over 2^20 + 5 elements (products are pinned by the
     oracle on their own; an inverse is unique), an oracle window of 200 elements across the first tile boundary, the per-element
