@@ -98,6 +98,8 @@ def parse_args(argv=None):
                          "up to 10^8 secrets per GPU, one otherwise): where the operands land moves the kernels by up to 10 percent")
     ap.add_argument("--ew", type=int, default=1,
                     help="1: after the headline, the element-wise add / mul / inverse path (Mersenne61 10^8, Mersenne127 and GF(2^128) 10^7)")
+    ap.add_argument("--ew-elements", type=int, default=0,
+                    help="tests only: run the element-wise and layout legs on this many elements per field instead of 10^8 / 10^7")
     ap.add_argument("--pmc-live", type=int, default=1,
                     help="1: roofline.traffic observed in THIS run -- two child runs of the headline under rocprofv3 --pmc FETCH_SIZE / "
                          "WRITE_SIZE after everything else (one GPU, BASELINE configs[1] only; falls back to profiles/pmc_traffic.json)")
@@ -718,8 +720,9 @@ def main():
         port = O.Port()
         rep = {"workload": "scl_hip_ew: add, multiplyEntryWise, inverse over whole vectors resident in HBM",
                "bytes_per_element": "3E for add / mul, 2E for inv (E = element bytes)", "fields": {}}
-        win = 2048
+        win = min(2048, args.ew_elements) if args.ew_elements else 2048
         for fkey, N_ in (("m61", 100_000_000), ("m127", 10_000_000), ("gf2_128", 10_000_000)):
+            N_ = args.ew_elements or N_
             f_, L_ = tag_limbs(fkey)
             E_ = 8 * L_
             a, b, out = scl.empty(f_, N_), scl.empty(f_, N_), scl.empty(f_, N_)
@@ -767,6 +770,7 @@ def main():
         Algorithmic bytes: every element read once and written once, 2 n E per secret."""
         rep = {"workload": "scl_hip_aos_to_soa / scl_hip_soa_to_aos, n = 10 parties", "bytes_per_secret": "2 n E", "fields": {}}
         for fkey, N_ in (("m61", 100_000_000), ("m127", 10_000_000), ("secp256k1", 10_000_000)):
+            N_ = args.ew_elements or N_
             f_, L_ = tag_limbs(fkey)
             n_, E_ = 10, 8 * L_
             soa_ = scl.empty(f_, n_, N_)
@@ -777,7 +781,8 @@ def main():
             back = scl.aos_to_soa(f_, aos_)
             ok = bool(scl.equals(f_, back.view(-1, L_), soa_.view(-1, L_)))
             # (AoS order checked against the definition on a window: aos[s][i] = soa[i][s])
-            ok = ok and bool(torch.equal(aos_[:4096].transpose(0, 1), soa_[:, :4096])) and bool(torch.equal(aos_[-4096:].transpose(0, 1), soa_[:, -4096:]))
+            w_ = min(4096, N_)
+            ok = ok and bool(torch.equal(aos_[:w_].transpose(0, 1), soa_[:, :w_])) and bool(torch.equal(aos_[-w_:].transpose(0, 1), soa_[:, -w_:]))
             del back
             for name in ("soa_to_aos", "aos_to_soa"):
                 tms = [scl.Timer() for _ in range(reps)]

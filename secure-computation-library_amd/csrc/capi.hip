@@ -1074,30 +1074,34 @@ static int share_chunked(int field, uint64_t* shares, size_t share_stride, const
 // keeps 32 elements per lane in registers (16-byte packs); the other fields keep the chain in memory and take the longest of
 // 8 / 16 / 32 / 64 / 128 that still leaves ~4000 single-wave workgroups (the inversion's share of a chain is I / L products per element,
 // I = 138 for Mersenne127 up to ~450 for secp256k1, against 3 for the walk).
-template <class F, class ARITH, bool DIV, int L>
+template <class F, bool DIV, int L>
 int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, unsigned* flag, hipStream_t st) {
-  constexpr int BLK = 64;
+  // single-wave workgroups; GF(2^128): 256 threads around a 64 KiB window table (16.0 against 14.1 G inversions/s with 64,
+  // profiles/r5_ew_bench.txt)
+  constexpr int BLK = F::TAG == 3 ? 256 : 64;
+  using ARITH = std::conditional_t<F::TAG == 3, GfLdsArith<BLK>, FieldArith<F>>;
   auto kern = &k_ew_inv_rolled<F, ARITH, DIV, L, BLK>;
+  const size_t lds = (size_t)BLK * ARITH::LDS_PER_LANE;
+  if (lds) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const size_t tiles = (n + (size_t)BLK * L - 1) / ((size_t)BLK * L);
-  hipLaunchKernelGGL(kern, dim3(grid_for_block(tiles, 1)), dim3(BLK), (size_t)BLK * ARITH::LDS_PER_LANE, st, ctx, dst, a, b, n, flag);
+  hipLaunchKernelGGL(kern, dim3(grid_for_block(tiles, 1)), dim3(BLK), lds, st, ctx, dst, a, b, n, flag);
   LAUNCH_CHECK();
   return SCL_OK;
 }
 
 template <class F, bool DIV>
 int ew_inverse_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, long want, unsigned* flag, hipStream_t st) {
-  using A = std::conditional_t<F::TAG == 3, GfLdsArith<64>, FieldArith<F>>;
   // the longest chain that still leaves ~4000 single-wave workgroups (four per SIMD): measured optimum 32 at 10^7 elements and
   // 128 at 10^8 (profiles/r5_ew_bench.txt)
   int L = 8;
   for (int cand : {16, 32, 64, 128})
     if (n >= (size_t)cand * 64 * 4096) L = cand;
   if (want > 0) L = want >= 128 ? 128 : want >= 64 ? 64 : want >= 32 ? 32 : want >= 16 ? 16 : 8;
-  if (L == 128) return launch_inv_rolled<F, A, DIV, 128>(ctx, dst, a, b, n, flag, st);
-  if (L == 64) return launch_inv_rolled<F, A, DIV, 64>(ctx, dst, a, b, n, flag, st);
-  if (L == 32) return launch_inv_rolled<F, A, DIV, 32>(ctx, dst, a, b, n, flag, st);
-  if (L == 16) return launch_inv_rolled<F, A, DIV, 16>(ctx, dst, a, b, n, flag, st);
-  return launch_inv_rolled<F, A, DIV, 8>(ctx, dst, a, b, n, flag, st);
+  if (L == 128) return launch_inv_rolled<F, DIV, 128>(ctx, dst, a, b, n, flag, st);
+  if (L == 64) return launch_inv_rolled<F, DIV, 64>(ctx, dst, a, b, n, flag, st);
+  if (L == 32) return launch_inv_rolled<F, DIV, 32>(ctx, dst, a, b, n, flag, st);
+  if (L == 16) return launch_inv_rolled<F, DIV, 16>(ctx, dst, a, b, n, flag, st);
+  return launch_inv_rolled<F, DIV, 8>(ctx, dst, a, b, n, flag, st);
 }
 
 template <class F>
@@ -2447,7 +2451,10 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
     }
     if constexpr (F::TAG == 0) {
       const long mode = g_mfma.load();
-      if (mode > 0 || (mode == 0 && std::min<size_t>(M, 128) * std::min<size_t>(K, 64) >= 512 && N >= 4096))
+      // (a (row block, k-chunk) launch needs ~10^5 columns to outweigh its three launches: 4096^3 runs at 1.5 T multiply-adds/s
+      // this way and at 3.3 through k_matmul_tiled, profiles/r5_probe_matmul.txt)
+      const bool one_tile = M <= 128 && K <= 64;
+      if (mode > 0 || (mode == 0 && std::min<size_t>(M, 128) * std::min<size_t>(K, 64) >= 512 && N >= (one_tile ? 4096u : 131072u)))
         return matmul_mfma_blocks<F>(ctx, C, ldc, A, lda, B, ldb, M, K, N, S(stream));
     }
     const size_t esz = F::LIMBS * 8;
@@ -2460,7 +2467,29 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
     }
     typedef MatmulShape<F> SH;
     const size_t tiles = ((M + SH::TM - 1) / SH::TM) * ((N + SH::TN - 1) / SH::TN);
-    hipLaunchKernelGGL((k_matmul_tiled<F>), dim3(grid_for_block(tiles, 1)), dim3(BLOCK), 0, S(stream), ctx, C, ldc, A, lda, B, ldb, M, K, N);
+    // few output tiles and a long inner dimension: slices of K go to workgroups of their own (at least 256 columns each, about
+    // 2048 workgroups in all), their partial products to a temporary that one Vector::sum per entry adds up
+    size_t split = 1;
+    if (tiles < 1024 && K >= 512 && ldc == N) {
+      split = std::min<size_t>(K / 256, (2048 + tiles - 1) / tiles);
+      if (split > 65535) split = 65535;
+    }
+    if (split > 1) {
+      const size_t kslice = ((K + split - 1) / split + SH::TK - 1) / SH::TK * SH::TK;
+      split = (K + kslice - 1) / kslice;
+      const size_t slice_elems = (M * N + 1) & ~(size_t)1;  // (16-byte aligned slices)
+      void* tmp = nullptr;
+      SCL_TRY(temp_acquire(split * slice_elems * esz, S(stream), &tmp));
+      u64* part = static_cast<u64*>(tmp);
+      hipLaunchKernelGGL((k_matmul_tiled<F>), dim3(grid_for_block(tiles, 1), (unsigned)split), dim3(BLOCK), 0, S(stream), ctx, part, N, A, lda,
+                         B, ldb, M, K, N, kslice, slice_elems * F::LIMBS);
+      int rc = hipGetLastError() == hipSuccess ? SCL_OK : fail(SCL_ERR_HIP, "matmul: launch failed");
+      if (rc == SCL_OK) rc = scl_hip_additive_recover(field, C, part, slice_elems, split, M * N, stream);
+      (void)temp_release(S(stream));
+      return rc;
+    }
+    hipLaunchKernelGGL((k_matmul_tiled<F>), dim3(grid_for_block(tiles, 1)), dim3(BLOCK), 0, S(stream), ctx, C, ldc, A, lda, B, ldb, M, K, N,
+                       K, (size_t)0);
     LAUNCH_CHECK();
     return SCL_OK;
   });

@@ -350,6 +350,10 @@ template <class F, class ARITH, bool DIV, int L, int BLK>
 __global__ __launch_bounds__(BLK) void k_ew_inv_rolled(typename F::Ctx ctx, u64* dst, const u64* a, const u64* b, size_t n,
                                                        unsigned* zero_flag) {
   typedef typename F::E E;
+  // U elements per loop trip: their loads are issued together, ahead of the (sequentially dependent) products -- one memory
+  // round trip per U elements on a wave's critical path instead of one per element; the code holds U copies of the product
+  // (GF(2^128) on the LDS table stays at one: two interleaved comb products take 260 registers, and its waves are few already)
+  constexpr int U = ARITH::LDS_PER_LANE ? 1 : (L % 4 == 0 && F::LIMBS <= 2) ? 4 : (L % 2 == 0 ? 2 : 1);
   const ARITH ar(ctx, (int)threadIdx.x);
   const u64* src = DIV ? b : a;
   for (size_t tile = blockIdx.x; tile * ((size_t)BLK * L) < n; tile += gridDim.x) {
@@ -358,33 +362,52 @@ __global__ __launch_bounds__(BLK) void k_ew_inv_rolled(typename F::Ctx ctx, u64*
     E run = ar.one();
     bool any_zero = false;
 #pragma unroll 1
-    for (int i = 0; i < L; ++i) {
-      const size_t q = q0 + (size_t)i * BLK;
-      E v = ar.one();
-      if (q < n) v = load_pack<F, 1, false>(src + q * F::LIMBS).v[0];  // (read again on the walk back: keep it cached)
-      if (F::is_zero(v)) {
-        any_zero = true;
-        v = ar.one();
+    for (int i0 = 0; i0 < L; i0 += U) {
+      E v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t q = q0 + (size_t)(i0 + u) * BLK;
+        v[u] = ar.one();
+        if (q < n) v[u] = load_pack<F, 1, false>(src + q * F::LIMBS).v[0];  // (read again on the walk back: keep it cached)
       }
-      run = i ? ar.product(run, v) : v;
-      c[i] = run;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (F::is_zero(v[u])) {
+          any_zero = true;
+          v[u] = ar.one();
+        }
+        run = (i0 + u) ? ar.product(run, v[u]) : v[u];
+        c[i0 + u] = run;
+      }
     }
     if (any_zero) atomicOr(zero_flag, 1u);
     E inv = ar.inverse(run);
 #pragma unroll 1
-    for (int i = L - 1; i >= 0; --i) {
-      const size_t q = q0 + (size_t)i * BLK;
-      E v = ar.one();
-      if (q < n) v = load_pack<F, 1, true>(src + q * F::LIMBS).v[0];
-      const bool z = F::is_zero(v);
-      if (z) v = ar.one();
-      E o = inv;
-      if (i) ar.product2(inv, c[i - 1], v, o, inv);
-      if (q < n) {
-        Pack<F, 1> out;
-        out.v[0] = z ? F::zero() : o;
-        if constexpr (DIV) out.v[0] = ar.product(load_pack<F, 1, true>(a + q * F::LIMBS).v[0], out.v[0]);
-        store_pack<F, 1, true>(dst + q * F::LIMBS, out);
+    for (int i0 = L - U; i0 >= 0; i0 -= U) {
+      E v[U], num[U], cp[U];
+#pragma unroll
+      for (int u = U - 1; u >= 0; --u) {
+        const size_t q = q0 + (size_t)(i0 + u) * BLK;
+        v[u] = ar.one();
+        if (q < n) {
+          v[u] = load_pack<F, 1, true>(src + q * F::LIMBS).v[0];
+          if constexpr (DIV) num[u] = load_pack<F, 1, true>(a + q * F::LIMBS).v[0];
+        }
+        if (i0 + u) cp[u] = c[i0 + u - 1];
+      }
+#pragma unroll
+      for (int u = U - 1; u >= 0; --u) {
+        const size_t q = q0 + (size_t)(i0 + u) * BLK;
+        const bool z = F::is_zero(v[u]);
+        if (z) v[u] = ar.one();
+        E o = inv;
+        if (i0 + u) ar.product2(inv, cp[u], v[u], o, inv);
+        if (q < n) {
+          Pack<F, 1> out;
+          out.v[0] = z ? F::zero() : o;
+          if constexpr (DIV) out.v[0] = ar.product(num[u], out.v[0]);
+          store_pack<F, 1, true>(dst + q * F::LIMBS, out);
+        }
       }
     }
   }
@@ -2915,9 +2938,13 @@ struct MatmulShape {
   };
 };
 
+// ksplit > 1: gridDim.y workgroups share a tile, each taking a slice of K of `kslice` columns (a multiple of TK) and writing its
+// canonical partial product to C + blockIdx.y * cslice: short-and-wide-K shapes ((200 x 7000)(7000 x 300) is 20 tiles) then fill
+// the chip, and one pass of Vector::sum over the slices finishes the product (canonical partial sums add exactly).
 template <class F>
 __global__ __launch_bounds__(BLOCK) void k_matmul_tiled(typename F::Ctx ctx, u64* C, size_t ldc, const u64* A, size_t lda,
-                                                        const u64* B, size_t ldb, size_t M, size_t K, size_t N) {
+                                                        const u64* B, size_t ldb, size_t M, size_t K, size_t N, size_t kslice,
+                                                        size_t cslice) {
   typedef typename F::E E;
   typedef MatmulShape<F> S;
   constexpr int RM = S::RM, RN = S::RN, TM = S::TM, TN = S::TN, TK = S::TK;
@@ -2933,15 +2960,16 @@ __global__ __launch_bounds__(BLOCK) void k_matmul_tiled(typename F::Ctx ctx, u64
 #pragma unroll
       for (int c = 0; c < RN; ++c) acc[r][c] = F::acc_zero();
     int terms = 0;
-    for (size_t k0 = 0; k0 < K; k0 += TK) {
+    const size_t kbeg = blockIdx.y * kslice, kend = kbeg + kslice < K ? kbeg + kslice : K;
+    for (size_t k0 = kbeg; k0 < kend; k0 += TK) {
       __syncthreads();  // the previous step's reads are done
       for (int i = threadIdx.x; i < TM * TK; i += BLOCK) {
         const size_t r = row0 + i / TK, k = k0 + i % TK;
-        As[i] = (r < M && k < K) ? F::ld(A + (r * lda + k) * F::LIMBS) : F::zero();
+        As[i] = (r < M && k < kend) ? F::ld(A + (r * lda + k) * F::LIMBS) : F::zero();
       }
       for (int i = threadIdx.x; i < TK * TN; i += BLOCK) {
         const size_t k = k0 + i / TN, c = col0 + i % TN;
-        Bs[i] = (k < K && c < N) ? F::ld(B + (k * ldb + c) * F::LIMBS) : F::zero();
+        Bs[i] = (k < kend && c < N) ? F::ld(B + (k * ldb + c) * F::LIMBS) : F::zero();
       }
       __syncthreads();
       if (terms + TK > (int)F::ACC_TERMS) {  // fold: the accumulator restarts from its own canonical value
@@ -2974,7 +3002,7 @@ __global__ __launch_bounds__(BLOCK) void k_matmul_tiled(typename F::Ctx ctx, u64
 #pragma unroll
       for (int c = 0; c < RN; ++c) {
         const size_t row = row0 + ty * RM + r, col = col0 + tx + 16 * c;
-        if (row < M && col < N) F::st(C + (row * ldc + col) * F::LIMBS, F::acc_fold(ctx, acc[r][c]));
+        if (row < M && col < N) F::st(C + blockIdx.y * cslice + (row * ldc + col) * F::LIMBS, F::acc_fold(ctx, acc[r][c]));
       }
   }
 }

@@ -1834,7 +1834,7 @@ def test_bench_contract_small(scl):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--secrets", "300000", "--steps", "2", "--warmup", "1",
                         "--cpu-sample", "2000", "--configs", "0", "--open-secrets", "50000", "--open-chunk", "20000",
-                        "--c4-rank-secrets", "60001"],
+                        "--c4-rank-secrets", "60001", "--ew-elements", "300001"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -1850,7 +1850,7 @@ def test_bench_contract_small(scl):
     assert rs["verified"] is True and rs["partial_bytes_per_secret"] == 96 and rs["sum_bytes_per_secret"] == 144
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--secrets", "300000", "--steps", "2", "--warmup", "1",
                           "--cpu-sample", "0", "--configs", "0", "--open-secrets", "50000", "--open-chunk", "20000",
-                          "--c4-rank-secrets", "0", "--inject-error", "c_abi"], capture_output=True, text=True, timeout=600)
+                          "--c4-rank-secrets", "0", "--ew", "0", "--inject-error", "c_abi"], capture_output=True, text=True, timeout=600)
     bl = json.loads(bad.stdout.strip().splitlines()[-1])
     assert bad.returncode != 0 and bl["verified"] is False and bl["verified_headline"] is True
     assert any("c_abi" in e for e in bl["errors"]) and bl["verified_legs"]["open.c4_all_gather.c_abi"] is False
@@ -1860,7 +1860,20 @@ def test_bench_contract_small(scl):
     assert line["verified"] is True and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["cores"] == 1
-    assert line["config"]["allocation"] == "plain" and "configs" not in line
+    assert line["config"]["allocation"].startswith("plain") and "configs" not in line
+    # the headline's steps rotate over independently allocated operand sets; the per-allocation kernel times ride along
+    assert len(line["by_allocation"]) == 2 and all(b["steps"] == 1 and b["share_ms"] > 0 for b in line["by_allocation"])
+    assert line["rccl"]["ranks"] == 1 and len(line["ms_per_step_by_rank"]) == 1
+    # the element-wise path north_star names first, and the layout bridge: add / mul / inv per field with their rooflines
+    ew = line["ew"]
+    assert ew["verified"] is True and set(ew["fields"]) == {"Mersenne61", "Mersenne127", "GF(2^128)"}
+    for fld in ew["fields"].values():
+        assert fld["elements"] == 300001 and all(fld[op]["verified"] and fld[op]["GBps"] > 0 for op in ("add", "mul", "inv"))
+        assert fld["add"]["bytes_per_element"] == 3 * fld["inv"]["bytes_per_element"] // 2
+    lay = line["layout"]
+    assert lay["verified"] is True and all(v["soa_to_aos"]["frac"] > 0 and v["aos_to_soa"]["frac"] > 0 for v in lay["fields"].values())
+    cb = line["cpu_baseline"]
+    assert cb["physical_cores"] >= 1 and cb["all_cores"]["cores"] == cb["physical_cores"] and cb["cores_per_gpu"]["cores"] <= 16
     c4 = line["open"]["c4_all_gather"]
     assert c4["verified"] is True and c4["secrets"] == 50000 and c4["chunk"] == 20000 and c4["parties_per_rank"] == 40
     assert line["open"]["m61_partial_sums"]["verified"] is True
