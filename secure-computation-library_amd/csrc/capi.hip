@@ -1394,6 +1394,13 @@ int scl_hip_scalar_mul(int field, uint64_t* dst, const uint64_t* a, const uint64
     Table<F> sc;
     sc.v[0] = F::ld(scalar_host);
     const int vec = vec_width<F>({dst, a}, {});
+    if constexpr (F::TAG == 3) {
+      if (g_inv_batch.load() >= 0) {  // GF(2^128): one shared window table of the scalar in LDS
+        hipLaunchKernelGGL(k_scalar_mul_gf128<BLOCK>, dim3(grid_for(n)), dim3(BLOCK), 0, S(stream), dst, a, sc, n);
+        LAUNCH_CHECK();
+        return SCL_OK;
+      }
+    }
     return split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;
       hipLaunchKernelGGL((k_scalar_mul<F, VEC, true>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx,
@@ -1423,7 +1430,21 @@ static int reduce_impl(int field, uint64_t* out_host, const uint64_t* a, const u
     SCL_TRY(scratch(((size_t)max1 + 2 + 2 * (size_t)max2) * F::LIMBS * 8 + 64, &sc));
     u64* part1 = static_cast<u64*>(sc);
     unsigned used1 = 0;
-    SCL_TRY((split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
+    bool staged = false;
+    if constexpr (F::TAG == 3) {
+      if (is_dot && g_inv_batch.load() >= 0) {  // GF(2^128): the products on per-lane window tables in LDS (k_dot_gf128)
+        constexpr int BLK = 256;
+        auto kern = &k_dot_gf128<BLK>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BLK * 256));
+        size_t g = (n + BLK - 1) / BLK;
+        if (g > 4096) g = 4096;  // resident workgroups that stride: each partial costs a host-side add
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(BLK), BLK * 256, S(stream), part1, a, b, n);
+        LAUNCH_CHECK();
+        used1 = (unsigned)g;
+        staged = true;
+      }
+    }
+    if (!staged) SCL_TRY((split_vec<F>(vec, n, [&](auto V, size_t first, size_t npacks) -> int {
       constexpr int VEC = decltype(V)::value;
       size_t g = (npacks + (size_t)BLOCK * RED_UNROLL - 1) / ((size_t)BLOCK * RED_UNROLL);
       const long cap = g_max_blocks.load();

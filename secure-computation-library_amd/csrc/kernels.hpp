@@ -300,6 +300,50 @@ __global__ __launch_bounds__(BLK) void k_ew_gf128_mul(u64* dst, const u64* a, co
   }
 }
 
+// Vector::scalarMultiply over GF(2^128): ONE window table, the scalar's, shared by the workgroup -- the sixteen entries fill the
+// 64 banks exactly, so lanes that pick different entries read different banks and lanes that pick the same one share a broadcast.
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k_scalar_mul_gf128(u64* dst, const u64* a, Table<Gf128> scalar, size_t n) {
+  __shared__ u32x4 tbl[16];
+  if (threadIdx.x == 0) gf_table_store<1>(tbl, scalar.v[0]);
+  __syncthreads();
+  for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < n; q += (size_t)gridDim.x * BLK) {
+    Pack<Gf128, 1> x = load_pack<Gf128, 1, true>(a + q * 2);
+    x.v[0] = gf_comb<1>(tbl, x.v[0]);
+    store_pack<Gf128, 1, true>(dst + q * 2, x);
+  }
+}
+
+// Vector::dot / innerProd over GF(2^128) (vector.h:45-52, 252-255): the products on the per-lane LDS table, the sum an xor
+// (wavefront shuffles, then one LDS slot per wave); per-workgroup partials like k_dot.  Dynamic LDS: BLK * 256 bytes.
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k_dot_gf128(u64* partial, const u64* a, const u64* b, size_t n) {
+  extern __shared__ u32x4 gf_tbl[];
+  __shared__ u128 red[BLK / 64];
+  u32x4* mine = gf_tbl + threadIdx.x;
+  u128 acc = 0;
+  for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < n; q += (size_t)gridDim.x * BLK) {
+    const u128 x = load_pack<Gf128, 1, true>(a + q * 2).v[0], y = load_pack<Gf128, 1, true>(b + q * 2).v[0];
+    gf_table_store<BLK>(mine, x);
+    acc ^= gf_comb<BLK>(mine, y);
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    u32 w[4] = {(u32)acc, (u32)(acc >> 32), (u32)(acc >> 64), (u32)(acc >> 96)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] ^= (u32)__shfl_xor((int)w[i], m, 64);
+    acc = (u128)w[0] | ((u128)w[1] << 32) | ((u128)w[2] << 64) | ((u128)w[3] << 96);
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u128 tot = red[0];
+#pragma unroll
+    for (int w = 1; w < BLK / 64; ++w) tot ^= red[w];
+    Gf128::st(partial + (size_t)blockIdx.x * 2, tot);
+  }
+}
+
 // ---- simultaneous inversion with the chain in memory: the fields whose ONE inversion is dear ------------------------------------
 // k_ew_inv keeps 2 L elements in registers, which stops at L = 16..32; for Mont128 (~250 products per Fermat inversion), secp256k1
 // (~450) and GF(2^128) the inversion's share I / L still dominates there.  Here the loops over the chain stay rolled: the prefix

@@ -192,9 +192,17 @@ def test_gf2_128_products_on_the_lds_table(scl, port):
     got = host(scl, scl.ew(f, O.MUL, dev(scl, a), dev(scl, b)))
     assert np.array_equal(got[:3000], port.ew(f, O.MUL, a[:3000], b[:3000]))
     assert np.array_equal(got[-500:], port.ew(f, O.MUL, a[-500:], b[-500:]))
+    # Vector::dot (per-lane tables, xor reduction) and Vector::scalarMultiply (one shared table of the scalar) the same way
+    da, db = dev(scl, a), dev(scl, b)
+    k = 3000
+    d_small = scl.dot(f, da[:k], db[:k])
+    assert np.array_equal(d_small.reshape(1, 2), port.dot(f, a[:k], b[:k]).reshape(1, 2))
+    d_all, sm = scl.dot(f, da, db), host(scl, scl.scalar_mul(f, da, b[7]))
+    assert np.array_equal(sm[:2000], port.scalar_mul(f, a[:2000], b[7])) and np.array_equal(sm[-300:], port.scalar_mul(f, a[-300:], b[7]))
     scl.set_tuning("inv_batch", -1)
     try:
         assert np.array_equal(host(scl, scl.ew(f, O.MUL, dev(scl, a), dev(scl, b))), got)
+        assert np.array_equal(scl.dot(f, da, db), d_all) and np.array_equal(host(scl, scl.scalar_mul(f, da, b[7])), sm)
     finally:
         scl.set_tuning("inv_batch", 0)
 

@@ -10,7 +10,7 @@ import torch  # noqa: E402
 import scl_amd as scl  # noqa: E402
 
 for f, name, N in ((scl.M61, "Mersenne61", 400_000_000), (scl.M127, "Mersenne127", 200_000_000), (scl.Z2K(64), "Z2k<64>", 400_000_000),
-                   (scl.MONT128, "Mont128", 200_000_000)):
+                   (scl.MONT128, "Mont128", 200_000_000), (scl.GF2_128, "GF(2^128)", 100_000_000)):
     E = 8 * scl.limbs(f)
     a = scl.empty(f, N)
     b = scl.empty(f, N)
@@ -24,7 +24,8 @@ for f, name, N in ((scl.M61, "Mersenne61", 400_000_000), (scl.M127, "Mersenne127
     tm = scl.Timer()
     for label, fn, bytes_per in (("sum", lambda: scl.vsum(f, a), E), ("dot", lambda: scl.dot(f, a, b), 2 * E),
                                  ("add", lambda: scl.ew(f, scl.ADD, a, b, out=out), 3 * E),
-                                 ("mul", lambda: scl.ew(f, scl.MUL, a, b, out=out), 3 * E)):
+                                 ("mul", lambda: scl.ew(f, scl.MUL, a, b, out=out), 3 * E),
+                                 ("smul", lambda: scl.scalar_mul(f, a, scl.to_host(b[7]), out=out), 2 * E)):
         fn()
         torch.cuda.synchronize()
         tm.start()
