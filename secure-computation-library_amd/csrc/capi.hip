@@ -1851,6 +1851,26 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
 #undef SST_CASE
             }
           }
+          if constexpr (F::LIMBS == 4) {
+            // 32-byte elements: a pair of lanes per secret (k_share_small_pair), single-wave workgroups under the 16-byte
+            // fields' residency cap; "share_waves128" 0 = the lane-per-element kernel
+            const long sw128 = g_share_waves128.load();
+            if (sw128 > 0 && g_stream_block.load() == 64) {
+              const size_t pad = residency_pad(sw128, 64, sizeof(u32) * SmallVdm::CAP);
+              const dim3 g(grid_for_block(2 * npacks, 64));
+#define SSP_CASE(TT)                                                                                                     \
+  case TT:                                                                                                               \
+    hipLaunchKernelGGL((k_share_small_pair<F, TT, 64>), g, dim3(64), pad, S(stream), ctx, shares + first * F::LIMBS, share_stride, \
+                       secrets + first * F::LIMBS, coeffs + first * F::LIMBS, coeff_stride, sv, (int)n, npacks);         \
+    launched = true;                                                                                                     \
+    break;
+              switch (t) {
+                SSP_CASE(1) SSP_CASE(2) SSP_CASE(3) SSP_CASE(4) SSP_CASE(5) SSP_CASE(6) SSP_CASE(7)
+                default: break;
+              }
+#undef SSP_CASE
+            }
+          }
           if (!launched)
             hipLaunchKernelGGL((k_share_small<F, VEC>), dim3(grid_for(npacks)), dim3(BLOCK), 0, S(stream), ctx, shares + first * F::LIMBS,
                                share_stride, secrets + first * F::LIMBS, coeffs + first * F::LIMBS, coeff_stride, sv, (int)t, (int)n,

@@ -1714,10 +1714,75 @@ __global__ __launch_bounds__(BLK) void k_share_small_t(typename F::Ctx ctx, u64*
   }
 }
 
-// (A lane-pair form of this kernel for the 32-byte fields -- halves of the secret and of every coefficient per lane, the column
-// sums exchanged over DPP as in k_recover_small, both lanes reducing -- was built and measured in round 5: 0.94 ms against 0.88 ms
-// for secp256k1 (10,3) at 10^7 secrets, profiles/r5_probe_secp_share_pair_no_gain.txt: ten duplicated reductions per secret cost
-// more than the whole-line stores gain.  Not kept.)
+// Small-node sharing over the 256-bit fields with a PAIR of lanes per secret (cf. k_recover_small): lane h of the pair holds
+// limbs 2h, 2h + 1 of the secret and of every coefficient, so each load and each store of a wave is 1 KiB of consecutive bytes.
+// (One lane per 32-byte element writes 16 bytes out of every 32 per instruction: 7 % more bytes written than stored and 4 % more
+// read, by the counters -- profiles/pmc_traffic.json, F3 before this kernel -- and 0.64 of peak.)  The parties go two at a time:
+// each lane sums its own four 32-bit columns for both, the pair swaps columns over DPP so that lane 0 holds party i's eight and
+// lane 1 party i + 1's, each reduces ONE share (as many reductions as a lane per element does; a first form that had both lanes
+// reduce every share lost: 0.94 against 0.88 ms, profiles/r5_probe_secp_share_pair_no_gain.txt), and the halves swap back for the stores.
+template <class F, int T, int BLK>
+__global__ __launch_bounds__(BLK) void k_share_small_pair(typename F::Ctx ctx, u64* shares, size_t stride, const u64* secrets,
+                                                          const u64* coeffs, size_t cstride, SmallVdm tab, int n, size_t N) {
+  static_assert(F::LIMBS == 4, "lane pairs: 32-byte elements");
+  typedef typename F::E E;
+  __shared__ u32 V[SmallVdm::CAP];
+  for (int i = threadIdx.x; i < n * (T + 1); i += BLK) V[i] = tab.v[i];
+  __syncthreads();
+  auto partner = [](u64 v) {
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0xB1, 0xF, 0xF, false);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0xB1, 0xF, 0xF, false);
+    return ((u64)hi << 32) | lo;
+  };
+  for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < 2 * N; q += (size_t)gridDim.x * BLK) {
+    const int h = (int)(q & 1);
+    const size_t off = (q >> 1) * 4 + 2 * h;
+    const u64x2 s = ldg<true>(reinterpret_cast<const u64x2*>(secrets + off));
+    u64x2 c[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) c[k] = ldg<true>(reinterpret_cast<const u64x2*>(coeffs + (size_t)k * cstride * 4 + off));
+    const u64 ox = partner(s.x), oy = partner(s.y);
+    const E c0 = h ? F::make(ox, oy, s.x, s.y) : F::make(s.x, s.y, ox, oy);  // the whole secret: V[i][0] = 1
+    for (int i = 0; i < n; i += 2) {
+      const bool two = i + 1 < n;
+      const u32* row0 = V + i * (T + 1);
+      const u32* row1 = two ? row0 + (T + 1) : row0;
+      u64 col0[4] = {0, 0, 0, 0}, col1[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < T; ++k) {
+        const u32 w0 = row0[k + 1], w1 = row1[k + 1];
+        const u32 l0 = (u32)c[k].x, l1 = (u32)(c[k].x >> 32), l2 = (u32)c[k].y, l3 = (u32)(c[k].y >> 32);
+        mad32(col0[0], l0, w0);
+        mad32(col0[1], l1, w0);
+        mad32(col0[2], l2, w0);
+        mad32(col0[3], l3, w0);
+        mad32(col1[0], l0, w1);
+        mad32(col1[1], l1, w1);
+        mad32(col1[2], l2, w1);
+        mad32(col1[3], l3, w1);
+      }
+      // lane 0 reduces party i, lane 1 party i + 1: each keeps its own columns of "its" party and receives the partner's
+      typename F::SAcc sa;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u64 got = partner(h ? col0[j] : col1[j]);  // what the partner needs from me / what I need from it
+        sa.a[j] = h ? got : col0[j];
+        sa.a[4 + j] = h ? col1[j] : got;
+      }
+      const E y = F::sacc_fold(sa, c0);  // lane 0: share of party i; lane 1: of party i + 1
+      // lane h stores half h of both shares: it keeps half h of its own and receives half h of the partner's
+      const u64 gx = partner(h ? y.w[0] : y.w[2]), gy = partner(h ? y.w[1] : y.w[3]);
+      u64x2 o0, o1;  // my half of party i's share, of party i + 1's
+      o0.x = h ? gx : y.w[0];
+      o0.y = h ? gy : y.w[1];
+      o1.x = h ? y.w[2] : gx;
+      o1.y = h ? y.w[3] : gy;
+      stg<true>(reinterpret_cast<u64x2*>(shares + (size_t)i * stride * 4 + off), o0);
+      if (two) stg<true>(reinterpret_cast<u64x2*>(shares + (size_t)(i + 1) * stride * 4 + off), o1);
+    }
+  }
+}
+
 // Blocked form of the small-node evaluation for larger t: the polynomial is cut into groups of G coefficients,
 //   f(x) = sum_j x^(G j) * g_j(x),   g_j(x) = sum_{r<G} c_{Gj+r} x^r,
 // each g_j(x_i) summed lazily against the small powers x_i^r < 2^29 (one v_mad_u64_u32 per 32-bit limb and

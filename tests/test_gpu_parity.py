@@ -466,6 +466,42 @@ def test_share_with_explicit_nodes(scl, port, f):
             assert np.array_equal(host(scl, scl.shamir_recover(f, got, lam)), secrets)
 
 
+@pytest.mark.parametrize("f", [O.SECP256K1_SCALAR, O.SECP256K1_FIELD])
+@pytest.mark.parametrize("n", [1, 2, 3, 10, 11])
+def test_share_on_lane_pairs_256_bit_fields(scl, port, f, n):
+    """k_share_small_pair (32-byte elements: two lanes per secret, the parties two at a time with the reductions shared out
+    between the lanes): every threshold 1..7 it is compiled for, odd and even party counts (the odd party out of the last pair),
+    odd N, p - 1 / 0 operands, against the oracle; the lane-per-element kernel ("share_waves128" 0) gives the same matrix; a
+    window of a wider share matrix through the raw ABI stays inside its rows."""
+    import ctypes as C
+    L, N = 4, 777
+    secrets = rand_elems(port, f, N, b"pair-s")
+    allc = rand_elems(port, f, 7 * N, b"pair-c").reshape(N, 7, L)
+    secrets[0] = port.from_int(f, -1)
+    allc[0] = port.from_int(f, -1)
+    allc[N - 1] = port.from_int(f, 0)
+    for t in range(1, 8):
+        coeffs = np.ascontiguousarray(allc[:, :t])
+        dco = dev(scl, np.ascontiguousarray(np.transpose(coeffs, (1, 0, 2))))
+        want = soa(port.shamir_share_coeffs(f, secrets, coeffs, n))
+        got = scl.shamir_share(f, dev(scl, secrets), dco, n)
+        assert np.array_equal(host(scl, got), want), (n, t)
+        scl.set_tuning("share_waves128", 0)
+        try:
+            assert np.array_equal(host(scl, scl.shamir_share(f, dev(scl, secrets), dco, n)), want), (n, t, "lane per element")
+        finally:
+            scl.set_tuning("share_waves128", 12)
+    stride = N + 5
+    buf = torch.full((n * stride * L,), -1, dtype=torch.int64, device="cuda")
+    dsec = dev(scl, secrets)
+    st = scl.lib.scl_hip_shamir_share(f, C.c_void_p(buf.data_ptr()), C.c_size_t(stride), C.c_void_p(dsec.data_ptr()), C.c_void_p(dco.data_ptr()),
+                                      C.c_size_t(N), C.c_size_t(N), C.c_size_t(7), C.c_size_t(n), None, None)
+    assert st == 0, scl.lib.scl_hip_last_error()
+    torch.cuda.synchronize()
+    flat = buf.cpu().numpy().view(np.uint64).reshape(n, stride, L)
+    assert np.array_equal(flat[:, :N], want) and (flat[:, N:] == np.uint64(2 ** 64 - 1)).all()
+
+
 @pytest.mark.parametrize("f", [O.M61, O.M127, O.GF2_128])
 @pytest.mark.parametrize("n", [5, 10, 40, 128])
 def test_share_every_threshold_up_to_16(scl, port, f, n):

@@ -35,8 +35,11 @@ for f, name, N in ((scl.SECP256K1_SCALAR, "secp256k1_order", 10_000_000), (scl.M
         assert scl.equals(f, out, secrets)
         print(f"{name:16s} reconstruct force_table={ft}  {ms:7.3f} ms  {(n + 1) * E * N / ms / 1e6:6.0f} GB/s  {(n + 1) * E * N / ms / 8e9:.3f}", flush=True)
     scl.set_tuning("force_table", 0)
-    ms = timed(lambda: scl.shamir_share(f, secrets, coeffs, n, out=shares))
-    print(f"{name:16s} share                     {ms:7.3f} ms  {(1 + t + n) * E * N / ms / 1e6:6.0f} GB/s  {(1 + t + n) * E * N / ms / 8e9:.3f}", flush=True)
+    for sw in (12, 0):    # 0 = the lane-per-element kernel (secp256k1: instead of the lane pairs)
+        scl.set_tuning("share_waves128", sw)
+        ms = timed(lambda: scl.shamir_share(f, secrets, coeffs, n, out=shares))
+        print(f"{name:16s} share share_waves128={sw:2d}    {ms:7.3f} ms  {(1 + t + n) * E * N / ms / 1e6:6.0f} GB/s  {(1 + t + n) * E * N / ms / 8e9:.3f}", flush=True)
+    scl.set_tuning("share_waves128", 12)
     del secrets, coeffs, shares, out
     torch.cuda.empty_cache()
 
