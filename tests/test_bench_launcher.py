@@ -71,7 +71,7 @@ def test_pmc_traffic_is_stamped_and_only_quoted_for_its_own_kernels():
     # the side configurations of the same PMC passes: every BASELINE configuration's two kernels, traffic = algorithmic bytes
     want = {"C3_mersenne127_10_3": ("k_share_small_t<sclhip::M127", "k_recover_fixed<sclhip::M127"),
             "C3_mont128_10_3": ("k_share_small_t<sclhip::Mont128", "k_recover_small<sclhip::Mont128"),
-            "F3_secp256k1_scalar_10_3": ("k_share_small<sclhip::Mont256", "k_recover_small<sclhip::Mont256"),
+            "F3_secp256k1_scalar_10_3": ("k_share_small_pair<sclhip::Mont256", "k_recover_small<sclhip::Mont256"),
             "C4_shard_gf2_128_40_13": ("k_share_gf_tiles<13>", "k_recover_gf128_pos"),
             "C5_shard_mersenne61_128_42": ("k_share_mfma_m61_p16", "k_recover_table<sclhip::M61")}
     for key, (sk, rk) in want.items():
