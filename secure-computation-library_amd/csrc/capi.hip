@@ -666,7 +666,27 @@ int mfma_table(const BigTable<M61>& al, size_t n, size_t t, int KS, int MT, DevP
 
 template <int KS, int MT>
 int launch_share_mfma(u64* shares, size_t stride, const u64* secrets, const u64* coeffs, size_t cstride,
-                      const unsigned char* tab, int t, int n, size_t N, hipStream_t st) {
+                      const unsigned char* tab, int t, int n, size_t N, hipStream_t st, bool accumulate = false) {
+  if (accumulate) {
+    // Matrix::multiply's k-chunks after the first: the same kernels with their stores adding to what the rows hold
+    if constexpr (MT == 4 && KS == 2) {
+      auto kern = &k_share_mfma_m61_p16<M61, true>;
+      const size_t shmem = 2 * mf_b_bytes(KS, MT, 1);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      const size_t nblocks = (N + 31) / 32;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 256 ? nblocks : 256)), dim3(512), shmem, st, shares, stride, secrets, coeffs,
+                         cstride, tab, t, n, N);
+    } else {
+      auto kern = &k_share_mfma_m61<KS, MT, false, 512, true>;
+      const size_t shmem = mf_a_bytes(KS, MT) + mf_b_bytes(KS, MT);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      const size_t cols = (size_t)2 * (4 / MT) * 32, nblocks = (N + cols - 1) / cols;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < 256 ? nblocks : 256)), dim3(512), shmem, st, shares, stride, secrets, coeffs,
+                         cstride, tab, t, n, N);
+    }
+    HIP_TRY(hipGetLastError());
+    return SCL_OK;
+  }
   const bool areg = g_mfma_areg.load() != 0 && MT == 4;
   const long tpb_mode = g_mfma_tpb.load();
   if constexpr (MT == 4 && KS == 2) {
@@ -744,60 +764,46 @@ int mfma_planes_of(void* tab, const u64* A, size_t lda, size_t M, size_t K, hipS
 
 template <int KS, int MT>
 int matmul_mfma_impl(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M, size_t K,
-                     size_t N, hipStream_t st) {
+                     size_t N, hipStream_t st, bool accumulate) {
   void* tab = nullptr;
   SCL_TRY(temp_acquire(mf_a_bytes(KS, MT), st, &tab));
   int rc = mfma_planes_of<KS, MT>(tab, A, lda, M, K, st);
   if (rc == SCL_OK)
     rc = launch_share_mfma<KS, MT>(C, ldc, B, B + ldb, ldb, static_cast<const unsigned char*>(tab), (int)K - 1, (int)M, N,
-                                   st);
+                                   st, accumulate);
   (void)temp_release(st);
   return rc;
 }
 
 template <class FieldG>
 int matmul_mfma(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M, size_t K, size_t N,
-                hipStream_t st) {
+                hipStream_t st, bool accumulate = false) {
   const int KS = K <= 32 ? 1 : 2;
   // (one row tile with two k-steps would need 160 KiB for the staged right factor: such shapes take two row tiles)
   const int MT = (M <= 32 && KS == 1) ? 1 : M <= 64 ? 2 : 4;
 #define MM_CASE(ks, mt) \
-  if (KS == ks && MT == mt) return matmul_mfma_impl<ks, mt>(C, ldc, A, lda, B, ldb, M, K, N, st);
+  if (KS == ks && MT == mt) return matmul_mfma_impl<ks, mt>(C, ldc, A, lda, B, ldb, M, K, N, st, accumulate);
   MM_CASE(1, 1) MM_CASE(1, 2) MM_CASE(1, 4) MM_CASE(2, 2) MM_CASE(2, 4)
 #undef MM_CASE
   return fail(SCL_ERR_BAD_ARG, "matmul_mfma: unsupported shape");
 }
 
 // Any M and K on the matrix cores: row blocks of at most 128 rows of A, column chunks of at most 64 (the kernel's K).  The first
-// chunk of a row block writes C, every later one writes a temporary that one modular add folds into C -- canonical partial sums
-// add exactly (SURVEY 8a note C).  Each (block, chunk) builds its digit planes in the call's temporary arena; the stream orders
-// the launches.
+// chunk of a row block writes C, every later one ADDS its product to C in the kernel's own epilogue (the ACC instantiations of
+// k_share_mfma_m61 / _p16: canonical partial products add exactly, SURVEY 8a note C; a temporary and a separate modular add
+// cost as much as a chunk: 10 against 17 T multiply-adds/s).  Each (block, chunk) builds its digit planes in the call's
+// temporary arena; the stream orders the launches.
 template <class FieldG>
-int matmul_mfma_blocks(const typename FieldG::Ctx& ctx, u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M,
+int matmul_mfma_blocks(const typename FieldG::Ctx&, u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M,
                        size_t K, size_t N, hipStream_t st) {
-  if (M <= 128 && K <= 64) return matmul_mfma<FieldG>(C, ldc, A, lda, B, ldb, M, K, N, st);
-  u64* T = nullptr;
-  const size_t ldt = (N + 1) & ~(size_t)1;
-  if (K > 64) {  // (arena 0 holds the digit planes of each launch)
-    void* tmp = nullptr;
-    SCL_TRY(temp_acquire(std::min<size_t>(M, 128) * ldt * 8, st, &tmp, 1));
-    T = static_cast<u64*>(tmp);
-  }
-  int rc = SCL_OK;
-  for (size_t r0 = 0; r0 < M && rc == SCL_OK; r0 += 128) {
+  for (size_t r0 = 0; r0 < M; r0 += 128) {
     const size_t mr = std::min<size_t>(128, M - r0);
-    for (size_t k0 = 0; k0 < K && rc == SCL_OK; k0 += 64) {
+    for (size_t k0 = 0; k0 < K; k0 += 64) {
       const size_t kc = std::min<size_t>(64, K - k0);
-      u64* dst = k0 ? T : C + r0 * ldc;
-      rc = matmul_mfma<FieldG>(dst, k0 ? ldt : ldc, A + r0 * lda + k0, lda, B + k0 * ldb, ldb, mr, kc, N, st);
-      if (rc == SCL_OK && k0) {
-        hipLaunchKernelGGL((k_mat_add_inplace<FieldG>), dim3(grid_for(mr * N)), dim3(BLOCK), 0, st, ctx, C + r0 * ldc, ldc, T, ldt, mr, N);
-        if (hipGetLastError() != hipSuccess) rc = fail(SCL_ERR_HIP, "matmul: launch failed");
-      }
+      SCL_TRY(matmul_mfma<FieldG>(C + r0 * ldc, ldc, A + r0 * lda + k0, lda, B + k0 * ldb, ldb, mr, kc, N, st, k0 != 0));
     }
   }
-  if (T) (void)temp_release(st, 1);
-  return rc;
+  return SCL_OK;
 }
 
 // shamirRecoverD as a contraction (k_detect_compare): L [rows x d1] host elements, rows = nchk + 1.  The product Y is kept
@@ -2474,7 +2480,7 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
   // No bound on M, K or N, as in matrix.h:477-513.  Paths (DESIGN.md section 3 has their rates):
   //   one column (Matrix::multiply(Vector), :497-513)           k_matvec: a wavefront per row
   //   Mersenne61, long right factor, M*K >= 512                 matrix cores: row blocks of 128, k-chunks of 64 (the chunks
-  //                                                             after the first go through a temporary and one modular add)
+  //                                                             after the first add to C in the kernel's epilogue)
   //   left factor within 48 KiB and a long right factor          k_matmul: the left factor in LDS, a thread per column
   //   anything else                                              k_matmul_tiled: LDS tiles of both factors, K in steps
   return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
@@ -2492,7 +2498,7 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
     }
     if constexpr (F::TAG == 0) {
       const long mode = g_mfma.load();
-      // (a (row block, k-chunk) launch needs ~10^5 columns to outweigh its three launches: 4096^3 runs at 1.5 T multiply-adds/s
+      // (a (row block, k-chunk) launch needs ~10^5 columns to outweigh its launches: 4096^3 runs at 1.5 T multiply-adds/s
       // this way and at 3.3 through k_matmul_tiled, profiles/r5_probe_matmul.txt)
       const bool one_tile = M <= 128 && K <= 64;
       if (mode > 0 || (mode == 0 && std::min<size_t>(M, 128) * std::min<size_t>(K, 64) >= 512 && N >= (one_tile ? 4096u : 131072u)))

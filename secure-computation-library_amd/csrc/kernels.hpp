@@ -3144,17 +3144,6 @@ __global__ __launch_bounds__(BLOCK) void k_matvec(typename F::Ctx ctx, u64* y, s
   }
 }
 
-// C += T (canonical sums): the k-chunks of a matrix-core product beyond 64 columns of the left factor
-template <class F>
-__global__ __launch_bounds__(BLOCK) void k_mat_add_inplace(typename F::Ctx ctx, u64* C, size_t ldc, const u64* T, size_t ldt, size_t M,
-                                                           size_t N) {
-  SCL_GRID_STRIDE(q, M * N) {
-    const size_t r = q / N, c = q % N;
-    u64* d = C + (r * ldc + c) * F::LIMBS;
-    F::st(d, F::add(ctx, F::ld(d), F::ld(T + (r * ldt + c) * F::LIMBS)));
-  }
-}
-
 // ---- layout ----------------------------------------------------------------------------------------------
 // AoS [N][n] (reference Vector per secret) <-> SoA [n][stride], staged through LDS so that both the
 // global reads and the global writes are contiguous.  Tile = TS secrets x n parties.

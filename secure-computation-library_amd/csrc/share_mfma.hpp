@@ -169,7 +169,9 @@ __device__ __forceinline__ void mf_word_r(const v4i (&afrag)[MF_LIMBS][KS], cons
 // TPB = 512: one workgroup of two 4-wave groups per CU.  TPB = 256: one 4-wave group per workgroup, two workgroups
 // per CU -- their barriers are independent, so one workgroup's matrix phase runs under the other's VALU / store
 // phase instead of all eight waves of the CU moving in step.
-template <int KS, int MT, bool AREG = false, int TPB = 512>
+// ACC: the product is ADDED (mod p) to what `shares` holds -- the k-chunks after the first of a Matrix::multiply whose inner
+// dimension is longer than one launch's 64 (canonical partial products add exactly); sharing itself never sets it.
+template <int KS, int MT, bool AREG = false, int TPB = 512, bool ACC = false>
 __global__ __launch_bounds__(TPB, 512 / TPB) void k_share_mfma_m61(u64* shares, size_t stride, const u64* secrets,
                                                         const u64* coeffs, size_t cstride,
                                                         const unsigned char* Atab, int t, int n, size_t N) {
@@ -329,6 +331,10 @@ __global__ __launch_bounds__(TPB, 512 / TPB) void k_share_mfma_m61(u64* shares, 
       const int i = mt * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2) + 4 * h;
       if (i < n) {
         u64* dst = shares + (size_t)i * row_stride + s_even;
+        if constexpr (ACC) {
+          if (s_even < N) out.x = M61::add(M61::Ctx{}, out.x, dst[0]);
+          if (s_even + 1 < N) out.y = M61::add(M61::Ctx{}, out.y, dst[1]);
+        }
         if (s_even + 1 < N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
           __builtin_nontemporal_store(out, reinterpret_cast<u64x2*>(dst));
         } else {  // ragged tail or an 8-byte-aligned row: two scalar stores
@@ -773,7 +779,9 @@ __device__ __forceinline__ void mf16_pipe_word(const v4i (&vfrag)[MF_LIMBS], con
 }
 
 // Atab: the KS = 2, MT = 4 table of mfma_table (rows = parties, 64 k-bytes + pad per row)
-template <class FieldG = M61>  // (a template so that only the unit that launches it compiles it)
+// ACC (Matrix::multiply's k-chunks, see k_share_mfma_m61): the stores add to what the rows hold; the sharing instantiation
+// (ACC = false) is the code it was.
+template <class FieldG = M61, bool ACC = false>  // (a template so that only the unit that launches it compiles it)
 __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size_t stride, const u64* secrets,
                                                                const u64* coeffs, size_t cstride, const unsigned char* Atab,
                                                                int t, int n, size_t N) {
@@ -976,6 +984,11 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
         u64x2 o;
         o.x = finish(i);
         o.y = finish(4 + i);
+        if constexpr (ACC) {
+          const u64x2 was = *reinterpret_cast<const u64x2*>(rowp + (size_t)i * stride);
+          o.x = M61::add(M61::Ctx{}, o.x, was.x);
+          o.y = M61::add(M61::Ctx{}, o.y, was.y);
+        }
         *reinterpret_cast<u64x2*>(rowp + (size_t)i * stride) = o;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -983,15 +996,24 @@ __global__ __launch_bounds__(512, 1) void k_share_mfma_m61_p16(u64* shares, size
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         u64* dst = rowp + (size_t)i * stride;
-        dst[0] = finish(i);
-        dst[1] = finish(4 + i);
+        u64 v0 = finish(i), v1 = finish(4 + i);
+        if constexpr (ACC) {
+          v0 = M61::add(M61::Ctx{}, v0, dst[0]);
+          v1 = M61::add(M61::Ctx{}, v1, dst[1]);
+        }
+        dst[0] = v0;
+        dst[1] = v1;
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         u64* dst = rowp + (size_t)i * stride;
-        const u64 v0 = finish(i), v1 = finish(4 + i);
+        u64 v0 = finish(i), v1 = finish(4 + i);
+        if constexpr (ACC) {
+          if (p0 + i < n && s0 < N) v0 = M61::add(M61::Ctx{}, v0, dst[0]);
+          if (p0 + i < n && s0 + 1 < N) v1 = M61::add(M61::Ctx{}, v1, dst[1]);
+        }
         if (p0 + i < n && s0 < N) dst[0] = v0;
         if (p0 + i < n && s0 + 1 < N) dst[1] = v1;
       }

@@ -3,7 +3,7 @@
 // GF(2^128) multiply / inverse / divide on the LDS window table (k_ew_gf128_mul, k_ew_inv_rolled<GfLdsArith>) against Gf128::mul's register-only form -- word for
 // word on the same inputs (zeros planted at lane, workgroup-tile and batch boundaries), then timed.
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/_build/ew_bench tools/ew_bench.hip
-// usage: ew_bench [N=10000000] [field: m61 m127 m127r mont128 secp gf | all]
+// usage: ew_bench [N=10000000] [field: m61 m61r m127 m127r mont128 secp gf | all]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -250,6 +250,7 @@ int main(int argc, char** argv) {
   if (want("m61")) run_field<M61, 2>("m61", M61::Ctx{}, n);
   if (want("m127")) run_field<M127, 1>("m127", M127::Ctx{}, n);
   const Mont128::Ctx mc = Mont128::make_ctx((((u128)0xFFFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFF61ull);
+  if (want("m61r")) run_field_rolled<M61>("m61", M61::Ctx{}, n);
   if (want("m127r")) run_field_rolled<M127>("m127", M127::Ctx{}, n);
   if (want("mont128")) run_field<Mont128, 1>("mont128", mc, n);
   if (want("mont128")) run_field_rolled<Mont128>("mont128", mc, n);
