@@ -1992,6 +1992,10 @@ def test_bench_two_ranks_rehearsal_on_one_device(scl):
     assert c4["rccl_busbw_GBps"] > 0 and ps["verified"] and ps["collective"].startswith("reduce_scatter_tensor")
     assert "cpu_baseline" not in line and "configs" not in line
     assert "skipped in the one-device rehearsal" in c4["c_abi"]["skipped"] and "errors" not in line
+    # what the process group reports about the job, and every rank's own time per step (the line's is their maximum)
+    assert line["rccl"]["ranks"] == 2 and line["rccl"]["backend"] == "gloo" and line["rccl"]["devices"] == [0, 0]
+    assert len(line["ms_per_step_by_rank"]) == 2 and abs(max(line["ms_per_step_by_rank"]) - line["ms_per_step"]) < 1e-9
+    assert len(line["by_allocation"]) == 2      # two timed steps on the first two of the three operand sets
 
 
 @pytest.mark.parametrize("config,extra,check", [
