@@ -755,9 +755,13 @@ def main():
                     one[:, 0] = 1
                     ok = ok and bool(scl.equals(f_, prod, one))
                     del prod, one
+                # what limits the kernel: the streaming ops are HBM-bound; inverses are vector-ALU work (3 + I / L
+                # modular products per element by simultaneous inversion); GF(2^128) products run on per-lane window tables in LDS
+                bound = ("hbm" if name == "add" or (name == "mul" and fkey != "gf2_128") else
+                         "lds tables + vector ALU" if fkey == "gf2_128" else "vector ALU (near HBM)" if fkey == "m61" else "vector ALU")
                 legs[name] = {"ms": mean, "ms_min_max": [min(ms), max(ms)], "elements_per_s": N_ / (mean * 1e-3),
                               "bytes_per_element": nb, "GBps": nb * N_ / mean / 1e6, "frac": nb * N_ / mean / 1e6 / HBM_PEAK_GBPS,
-                              "verified": ok}
+                              "bound": bound, "verified": ok}
                 ok_all = ok_all and ok
             rep["fields"][FIELD_NAMES[fkey]] = {"elements": N_, "dtype": {1: "u64", 2: "u128"}[L_], "warmup": warm, "launches": reps,
                                                 **legs, "verified": ok_all}
