@@ -1082,10 +1082,10 @@ static int share_chunked(int field, uint64_t* shares, size_t share_stride, const
 // I = 138 for Mersenne127 up to ~450 for secp256k1, against 3 for the walk).
 template <class F, bool DIV, int L>
 int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, unsigned* flag, hipStream_t st) {
-  // single-wave workgroups; GF(2^128): 256 threads around a 64 KiB window table (16.0 against 14.1 G inversions/s with 64,
+  // single-wave workgroups; GF(2^128): 256 threads around a 32 KiB window table (3-bit windows; 16.0 against 14.1 G inversions/s with 64,
   // profiles/r5_ew_bench.txt)
   constexpr int BLK = F::TAG == 3 ? 256 : 64;
-  using ARITH = std::conditional_t<F::TAG == 3, GfLdsArith<BLK>, FieldArith<F>>;
+  using ARITH = std::conditional_t<F::TAG == 3, GfLdsArith<BLK, 3>, FieldArith<F>>;
   auto kern = &k_ew_inv_rolled<F, ARITH, DIV, L, BLK>;
   const size_t lds = (size_t)BLK * ARITH::LDS_PER_LANE;
   if (lds) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1352,8 +1352,8 @@ int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64
       if constexpr (is_field) rc_ = ew_inverse<F>(ctx, op == SCL_OP_DIV, dst, a, b, n, vec, batch, flag, S(stream));
     } else if (op == SCL_OP_MUL && F::TAG == 3 && batch >= 0) {
       if constexpr (F::TAG == 3) {  // GF(2^128) products on the window table in LDS
-        auto kern = &k_ew_gf128_mul<64>;
-        hipLaunchKernelGGL(kern, dim3(grid_for_block(n, 64)), dim3(64), 64 * 256, S(stream), dst, a, b, n);
+        auto kern = &k_ew_gf128_mul<64, 3>;  // 3-bit windows: 128 bytes of table per lane
+        hipLaunchKernelGGL(kern, dim3(grid_for_block(n, 64)), dim3(64), 64 * 128, S(stream), dst, a, b, n);
         LAUNCH_CHECK();
       }
     } else {
@@ -1440,11 +1440,11 @@ static int reduce_impl(int field, uint64_t* out_host, const uint64_t* a, const u
     if constexpr (F::TAG == 3) {
       if (is_dot && g_inv_batch.load() >= 0) {  // GF(2^128): the products on per-lane window tables in LDS (k_dot_gf128)
         constexpr int BLK = 256;
-        auto kern = &k_dot_gf128<BLK>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BLK * 256));
+        auto kern = &k_dot_gf128<BLK, 3>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BLK * 128));
         size_t g = (n + BLK - 1) / BLK;
         if (g > 4096) g = 4096;  // resident workgroups that stride: each partial costs a host-side add
-        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(BLK), BLK * 256, S(stream), part1, a, b, n);
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(BLK), BLK * 128, S(stream), part1, a, b, n);
         LAUNCH_CHECK();
         used1 = (unsigned)g;
         staged = true;

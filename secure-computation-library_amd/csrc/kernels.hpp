@@ -239,15 +239,20 @@ __global__ __launch_bounds__(BLOCK) void k_ew_inv(typename F::Ctx ctx, u64* dst,
 // (256 bytes per lane, entry u of lane l at (u * BLK + l) * 16: the ds_read_b128 of a wave are 64 consecutive 16-byte slots
 // whichever entries the lanes pick, so neither the writes nor the reads conflict) and adds, for nibble position k = 7..0, the
 // entry picked by nibble k of each 32-bit word of b at that word's offset; the 256-bit sum moves up four bits between
-// positions.  32 reads, 7 shifts, one fold: ~0.35 k vector instructions and 48 LDS accesses per product.
+// positions.  32 reads, 7 shifts, one fold: ~0.4 k vector instructions and 48 LDS accesses per product at 4-bit windows.  The
+// kernels run 3-BIT windows: eight entries (128 bytes per lane), 44 reads, 10 shifts -- slightly more instructions, but twice the
+// waves fit beside the tables and the vector ALU issues to five waves per SIMD instead of two and a half: 56-60 -> 76-80 G
+// products/s at 10^7 elements (2-bit windows: 54; profiles/r5_ew_bench_windows.txt).
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BLK>
+// W = window bits: 4 (sixteen entries, 256 bytes per lane: 32 lookups, 7 shifts) or 3 (eight entries, 128 bytes per lane: 44
+// lookups, 10 shifts -- a few more instructions, but twice the waves fit beside the tables)
+template <int BLK, int W = 4>
 __device__ __forceinline__ void gf_table_store(u32x4* mine, u128 a) {  // mine = table base + this lane
   u128 t[16];
-  Gf128::window_table(a, t);
+  Gf128::window_table(a, t);  // (entries 8.. are dead code at W = 3)
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
+  for (int u = 0; u < (1 << W); ++u) {
     u32x4 w;
     w.x = (u32)t[u];
     w.y = (u32)(t[u] >> 32);
@@ -257,15 +262,16 @@ __device__ __forceinline__ void gf_table_store(u32x4* mine, u128 a) {  // mine =
   }
 }
 
-template <int BLK>
+template <int BLK, int W = 4>
 __device__ __forceinline__ u128 gf_comb(const u32x4* mine, u128 b) {  // (the a of the table) * b
   const u32 bw[4] = {(u32)b, (u32)(b >> 32), (u32)(b >> 64), (u32)(b >> 96)};
   u32 c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int NPOS = (32 + W - 1) / W;  // window positions in a 32-bit word (the top one of W = 3 holds two bits)
 #pragma unroll
-  for (int k = 7; k >= 0; --k) {
+  for (int k = NPOS - 1; k >= 0; --k) {
     u32x4 m[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m[j] = mine[((bw[j] >> (4 * k)) & 15u) * BLK];
+    for (int j = 0; j < 4; ++j) m[j] = mine[((bw[j] >> (W * k)) & ((1u << W) - 1)) * BLK];
     // word j + i of the sum takes word i of the entry picked for word j of b: sixteen terms as ten three-input xors
     c[0] ^= m[0].x;
     c[1] = xor3(c[1], m[0].y, m[1].x);
@@ -276,8 +282,8 @@ __device__ __forceinline__ u128 gf_comb(const u32x4* mine, u128 b) {  // (the a 
     c[6] ^= m[3].w;
     if (k) {
 #pragma unroll
-      for (int i = 7; i > 0; --i) c[i] = __builtin_amdgcn_alignbit(c[i], c[i - 1], 28);
-      c[0] <<= 4;
+      for (int i = 7; i > 0; --i) c[i] = __builtin_amdgcn_alignbit(c[i], c[i - 1], 32 - W);
+      c[0] <<= W;
     }
   }
   const u128 lo = (u128)c[0] | ((u128)c[1] << 32) | ((u128)c[2] << 64) | ((u128)c[3] << 96);
@@ -285,17 +291,17 @@ __device__ __forceinline__ u128 gf_comb(const u32x4* mine, u128 b) {  // (the a 
   return Gf128::reduce256(lo, hi);
 }
 
-// multiplyEntryWise over GF(2^128) on the LDS table.  Dynamic LDS: BLK * 256 bytes.
-template <int BLK>
+// multiplyEntryWise over GF(2^128) on the LDS table.  Dynamic LDS: BLK * 16 * 2^W bytes.
+template <int BLK, int W = 4>
 __global__ __launch_bounds__(BLK) void k_ew_gf128_mul(u64* dst, const u64* a, const u64* b, size_t n) {
   extern __shared__ u32x4 gf_tbl[];
   u32x4* mine = gf_tbl + threadIdx.x;
   typedef Gf128 F;
   for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < n; q += (size_t)gridDim.x * BLK) {
     const Pack<F, 1> x = load_pack<F, 1, true>(a + q * 2), y = load_pack<F, 1, true>(b + q * 2);
-    gf_table_store<BLK>(mine, x.v[0]);
+    gf_table_store<BLK, W>(mine, x.v[0]);
     Pack<F, 1> r;
-    r.v[0] = gf_comb<BLK>(mine, y.v[0]);
+    r.v[0] = gf_comb<BLK, W>(mine, y.v[0]);
     store_pack<F, 1, true>(dst + q * 2, r);
   }
 }
@@ -315,8 +321,8 @@ __global__ __launch_bounds__(BLK) void k_scalar_mul_gf128(u64* dst, const u64* a
 }
 
 // Vector::dot / innerProd over GF(2^128) (vector.h:45-52, 252-255): the products on the per-lane LDS table, the sum an xor
-// (wavefront shuffles, then one LDS slot per wave); per-workgroup partials like k_dot.  Dynamic LDS: BLK * 256 bytes.
-template <int BLK>
+// (wavefront shuffles, then one LDS slot per wave); per-workgroup partials like k_dot.  Dynamic LDS: BLK * 16 * 2^W bytes.
+template <int BLK, int W = 3>
 __global__ __launch_bounds__(BLK) void k_dot_gf128(u64* partial, const u64* a, const u64* b, size_t n) {
   extern __shared__ u32x4 gf_tbl[];
   __shared__ u128 red[BLK / 64];
@@ -324,8 +330,8 @@ __global__ __launch_bounds__(BLK) void k_dot_gf128(u64* partial, const u64* a, c
   u128 acc = 0;
   for (size_t q = (size_t)blockIdx.x * BLK + threadIdx.x; q < n; q += (size_t)gridDim.x * BLK) {
     const u128 x = load_pack<Gf128, 1, true>(a + q * 2).v[0], y = load_pack<Gf128, 1, true>(b + q * 2).v[0];
-    gf_table_store<BLK>(mine, x);
-    acc ^= gf_comb<BLK>(mine, y);
+    gf_table_store<BLK, W>(mine, x);
+    acc ^= gf_comb<BLK, W>(mine, y);
   }
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) {
@@ -366,10 +372,10 @@ struct FieldArith {
   __device__ __forceinline__ E inverse(const E& a) const { return F::inv(ctx, a); }
 };
 
-template <int BLK>
+template <int BLK, int W = 4>
 struct GfLdsArith {
   typedef u128 E;
-  enum { LDS_PER_LANE = 256 };
+  enum { LDS_PER_LANE = 16 << W };
   u32x4* mine;
   __device__ __forceinline__ GfLdsArith(const Gf128::Ctx&, int tid) {
     extern __shared__ u32x4 gf_tbl[];
@@ -377,13 +383,13 @@ struct GfLdsArith {
   }
   __device__ __forceinline__ E one() const { return 1; }
   __device__ __forceinline__ E product(E a, E b) const {
-    gf_table_store<BLK>(mine, a);
-    return gf_comb<BLK>(mine, b);
+    gf_table_store<BLK, W>(mine, a);
+    return gf_comb<BLK, W>(mine, b);
   }
   __device__ __forceinline__ void product2(E a, E b1, E b2, E& r1, E& r2) const {  // one table, two combs
-    gf_table_store<BLK>(mine, a);
-    r1 = gf_comb<BLK>(mine, b1);
-    r2 = gf_comb<BLK>(mine, b2);
+    gf_table_store<BLK, W>(mine, a);
+    r1 = gf_comb<BLK, W>(mine, b1);
+    r2 = gf_comb<BLK, W>(mine, b2);
   }
   __device__ __forceinline__ E inverse(E a) const {
     return Gf128::inv_chain(Gf128::Ctx{}, a, [&](E x, E y) { return product(x, y); });

@@ -185,10 +185,11 @@ __global__ void k_gf_inv_ladder(u64* dst, const u64* a, size_t n) {
   Gf128::st(dst + 2 * q, x == 0 ? (u128)0 : r);
 }
 
-template <int BLK>
+template <int BLK, int W = 4>
 static void run_gf_mul(u64* out, const u64* ref, const u64* a, const u64* b, size_t n, double base_ms) {
-  auto kern = &k_ew_gf128_mul<BLK>;
-  const int lds = BLK * 256;
+  auto kern = &k_ew_gf128_mul<BLK, W>;
+  const int lds = BLK * (16 << W);
+  std::printf("(window bits %d)\n", W);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const size_t blocks = (n + BLK - 1) / BLK;
   CK(hipMemset(out, 0xAB, n * 16));
@@ -222,6 +223,10 @@ static void run_gf_all(size_t n) {
   run_gf_mul<64>(out, ref, a, b, n, base);
   run_gf_mul<128>(out, ref, a, b, n, base);
   run_gf_mul<256>(out, ref, a, b, n, base);
+  run_gf_mul<64, 3>(out, ref, a, b, n, base);
+  run_gf_mul<256, 3>(out, ref, a, b, n, base);
+  run_gf_mul<64, 2>(out, ref, a, b, n, base);
+  run_gf_mul<256, 2>(out, ref, a, b, n, base);
   const size_t nl = n / 16;  // the old ladder is slow: a sixteenth of the batch
   double ladder = time_ms([&] { hipLaunchKernelGGL(k_gf_inv_ladder, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, 0, out, a, nl); }, 1);
   std::printf("gf2_128  inv ladder of round 4 (254 register products), %zu elements  %8.3f ms  %7.4f G/s\n", nl, ladder, nl / ladder / 1e6);
@@ -235,6 +240,9 @@ static void run_gf_all(size_t n) {
   run_rolled<Gf128, GfLdsArith<64>, false, 32, 64>("gf2_128", ctx, out, ref, a, b, n, flag, ladder);
   run_rolled<Gf128, GfLdsArith<64>, false, 64, 64>("gf2_128", ctx, out, ref, a, b, n, flag, ladder);
   run_rolled<Gf128, GfLdsArith<256>, false, 32, 256>("gf2_128", ctx, out, ref, a, b, n, flag, ladder);
+  std::printf("(window bits 3)\n");
+  run_rolled<Gf128, GfLdsArith<64, 3>, false, 32, 64>("gf2_128", ctx, out, ref, a, b, n, flag, ladder);
+  run_rolled<Gf128, GfLdsArith<256, 3>, false, 32, 256>("gf2_128", ctx, out, ref, a, b, n, flag, ladder);
   base = time_ms([&] { hipLaunchKernelGGL((k_ew<Gf128, 5, 1, true>), dim3(g), dim3(BLOCK), 0, 0, ctx, ref, a, b, n, flag); }, 1);
   std::printf("gf2_128  div per element (Itoh-Tsujii, register products)  %8.3f ms  %7.3f G/s\n", base, n / base / 1e6);
   run_rolled<Gf128, GfLdsArith<64>, true, 32, 64>("gf2_128", ctx, out, ref, a, b, n, flag, base);
