@@ -139,6 +139,12 @@ __device__ __forceinline__ bool not_invertible(const typename F::E& a) {
   else return F::is_zero(a);
 }
 
+// the batch's "a zero was inverted" flag: set once -- a batch with many zeros (an error path, but 10^5 atomics on one word cost a
+// 0.3 ms kernel another 0.25 ms) reads the word first and leaves it alone when somebody has raised it already
+__device__ __forceinline__ void raise_flag(unsigned* flag) {
+  if (__atomic_load_n(flag, __ATOMIC_RELAXED) == 0) atomicOr(flag, 1u);
+}
+
 // Vector::add/subtract/multiplyEntryWise, FF::negate/invert/operator/ (vector.h:199-245, ff.h:203-246)
 template <class F, int OP, int VEC, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_ew(typename F::Ctx ctx, u64* dst, const u64* a, const u64* b,
@@ -154,11 +160,11 @@ __global__ __launch_bounds__(BLOCK) void k_ew(typename F::Ctx ctx, u64* dst, con
       if constexpr (OP == 2) r.v[v] = F::mul(ctx, x.v[v], y.v[v]);
       if constexpr (OP == 3) r.v[v] = F::neg(ctx, x.v[v]);
       if constexpr (OP == 4) {
-        if (not_invertible<F>(x.v[v])) atomicOr(zero_flag, 1u);
+        if (not_invertible<F>(x.v[v])) raise_flag(zero_flag);
         r.v[v] = F::inv(ctx, x.v[v]);
       }
       if constexpr (OP == 5) {
-        if (not_invertible<F>(y.v[v])) atomicOr(zero_flag, 1u);
+        if (not_invertible<F>(y.v[v])) raise_flag(zero_flag);
         r.v[v] = F::mul(ctx, x.v[v], F::inv(ctx, y.v[v]));
       }
     }
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_ew_inv(typename F::Ctx ctx, u64* dst,
         x[r * VEC + v] = z ? F::one(ctx) : pk.v[v];
       }
     }
-    if (zmask) atomicOr(zero_flag, 1u);
+    if (zmask) raise_flag(zero_flag);
     c[0] = x[0];
 #pragma unroll
     for (int i = 1; i < L; ++i) c[i] = F::mul(ctx, c[i - 1], x[i]);
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(BLK) void k_ew_inv_rolled(typename F::Ctx ctx, u64*
         c[i0 + u] = run;
       }
     }
-    if (any_zero) atomicOr(zero_flag, 1u);
+    if (any_zero) raise_flag(zero_flag);
     E inv = ar.inverse(run);
 #pragma unroll 1
     for (int i0 = L - U; i0 >= 0; i0 -= U) {
