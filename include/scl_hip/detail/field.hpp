@@ -320,7 +320,17 @@ struct M127 {
     const u128 t = mul_lazy(a, b);
     return t >= P() ? t - P() : t;
   }
-  static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
+  // a^2 from three 64 x 64 products instead of four (a = a1 2^64 + a0, a1 < 2^63: a0^2 + 2 a0 a1 2^64 + a1^2 2^128) -- what the
+  // Fermat chain of inv spends 126 of its 138 products on
+  static SCL_HD E sqr(const Ctx&, E a) {
+    const u64 a0 = (u64)a, a1 = (u64)(a >> 64);
+    const u128 p00 = (u128)a0 * a0, mid2 = ((u128)a0 * a1) << 1, p11 = (u128)a1 * a1;  // a0 a1 < 2^127: the doubling fits
+    W256 z;
+    z.lo = p00 + (mid2 << 64);
+    z.hi = p11 + (mid2 >> 64) + (z.lo < p00 ? 1 : 0);
+    const u128 t = ((z.hi << 1) | (z.lo >> 127)) + (z.lo & P());
+    return t >= P() ? t - P() : t;
+  }
   // FF::read = 16-byte little-endian load "% p" (mersenne127.cc:114-118)
   static SCL_HD E from_le_word(const Ctx&, u128 w) {
     const u128 r = (w & P()) + (w >> 127);

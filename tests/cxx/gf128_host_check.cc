@@ -1,7 +1,7 @@
 // tests/cxx/gf128_host_check.cc -- Gf128::mul (4-bit-window comb), Gf128::sqr (bit spread + fold) and Gf128::inv (Itoh-Tsujii
 // chain) of detail/field.hpp on the host against a bit-serial shift-xor multiplier written here (x^128 + x^7 + x^2 + x + 1):
 // random operands, the sparse and the all-ones corners, a * inv(a) = 1, inv(0) = 0, and the 254-product ladder the chain
-// replaces.  Host only; built and run by tests/test_cxx_api.py.
+// replaces; and Mersenne127's dedicated squaring against its general product.  Host only; built and run by tests/test_cxx_api.py.
 #include <cstdint>
 #include <cstdio>
 #include <random>
@@ -55,6 +55,21 @@ int main() {
     bad += Gf128::mul(c, a, i) != 1;
     n += 2;
   }
-  std::printf("gf128 host check: %ld comparisons, %ld mismatches\n", n, bad);
+  // Mersenne127's three-product squaring (what its Fermat inverse runs on) against the general product
+  {
+    const M127::Ctx mc{};
+    const u128 P = M127::P();
+    const u128 mcorners[] = {0, 1, 2, P - 1, P - 2, (u128)1 << 64, ((u128)1 << 64) - 1, (u128)1 << 126, (u128)0x7FFFFFFFFFFFFFFFull << 64};
+    for (u128 a : mcorners) {
+      bad += M127::sqr(mc, a) != M127::mul(mc, a, a);
+      ++n;
+    }
+    for (int it = 0; it < 500000; ++it) {
+      const u128 a = rnd() % P;
+      bad += M127::sqr(mc, a) != M127::mul(mc, a, a);
+      ++n;
+    }
+  }
+  std::printf("gf128 / m127 host check: %ld comparisons, %ld mismatches\n", n, bad);
   return bad != 0;
 }
