@@ -117,7 +117,8 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the sto
  *                workgroups); 0 = the 256-thread kernel with the threshold at run time, no cap
  *   share_waves128 (default 12) the same for the 16-byte fields' small-node share kernel (Mersenne127, Mont128); 0 = the
  *                256-thread kernel
- *   mfma         1: force the matrix-core share / matmul / recover_detect path, -1: never use it
+ *   mfma         1: force the matrix-core share / matmul / recover_detect path, -1: never use it, 2: as 1 with matmul's
+ *                (row block, k-chunk) form on the sharing kernels instead of the general kernel
  *   open_gather_always (default 0) scl_hip_open_all_gather on a ONE-rank communicator: 1 = through the collective path all the
  *                same (tests); 0 = reconstruct straight from the slab
  *   prg_t3       (default 1) PRG-driven sharing at t = 3 over the Mersenne fields: the fused kernel with the threshold
@@ -126,6 +127,10 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the sto
  *                at a time (the kernel that serves any other small nodes)
  *   prg_two_pass PRG-driven sharing: 1 = always draw the coefficient rows into a temporary and share from there, -1 = always the
  *                fused kernels (where one exists), 0 (default) = by shape and field
+ *   inv_batch    element-wise inverse / divide: 0 (default) simultaneous inversion with the chain length chosen by the batch,
+ *                8 | 16 | 32 | 64 | 128 that chain length, -1 one Fermat chain per element and GF(2^128)'s register-only product
+ *   transpose_tile  secrets per LDS tile of the 16-byte layout bridge (0 = up to 512);  gemm_slab_mib  digit planes per factor
+ *                and launch of the general matrix-core product in MiB (0 = 1024)
  *   mfma_areg    (default 1) matrix-core kernel keeps V's digit fragments in registers for 97..128 parties
  *   mfma_pipe    (default 2) matrix-core kernel for 97..128 parties: 2 = two software-pipelined waves per SIMD on
  *                16x16x64 tiles (thresholds 32..63; smaller ones as 1), 1 = one pipelined wave per SIMD, 0 = word bursts */

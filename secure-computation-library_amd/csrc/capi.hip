@@ -25,6 +25,7 @@
 #include "../../include/scl_hip/detail/field.hpp"
 #include "kernels.hpp"
 #include "share_mfma.hpp"
+#include "gemm_mfma.hpp"
 
 using namespace sclhip;
 
@@ -90,6 +91,7 @@ SCL_STATE(thread_local Knob g_aes_blocks, {0});
 // that chain length (8, 16, 32, 64 or 128; Mersenne61: any N = its register kernel), -1 = one Fermat chain per element (k_ew, the kernels
 // of rounds 1-4); GF(2^128) multiply: -1 = the register-only product ("inv_batch")
 SCL_STATE(thread_local Knob g_inv_batch, {0});
+SCL_STATE(thread_local Knob g_gemm_slab_mib, {0});  // digit planes per factor and launch of the general matrix-core product, MiB (0 = 1024) ("gemm_slab_mib")
 SCL_STATE(thread_local Knob g_transpose_tile, {0});  // secrets per LDS tile of the 16-byte layout bridge (0 = 512 within 40 KiB) ("transpose_tile")
 // Mont128 modulus: a process-wide default, latched per host thread at its first use (mont_ctx below)
 SCL_STATE(thread_local Mont128::Ctx g_mont, = {0, 0, 0, 0});  // p == 0: this thread has not latched a modulus yet
@@ -806,6 +808,67 @@ int matmul_mfma_blocks(const typename FieldG::Ctx&, u64* C, size_t ldc, const u6
   return SCL_OK;
 }
 
+// General shapes on the matrix cores (gemm_mfma.hpp): both factors recoded into digit planes in fragment order (a temporary), then
+// one kernel whose inner loop is matrix instructions only, K in super-steps of 8192.  The planes of a launch are kept within
+// 1 GiB per factor: a longer factor goes slab by slab (rows of A outside, columns of B inside), each slab a product of its own.
+template <class FieldG>
+int gemm_mfma_slab(u64* C, size_t ldc, const u64x2* Ap, const u64* B, size_t ldb, u64x2* Bp, size_t M, size_t K, size_t N, hipStream_t st) {
+  const size_t ktiles = (K + 31) / 32, mtiles = (M + 31) / 32, ntiles = (N + 31) / 32;
+  const size_t gb = (ntiles * ktiles * 64 + 255) / 256;
+  hipLaunchKernelGGL(k_gemm_planes_b<>, dim3((unsigned)std::min<size_t>(gb, 1u << 20)), dim3(256), 0, st, Bp, B, ldb, K, N, ktiles);
+  HIP_TRY(hipGetLastError());
+  const size_t wgs = ((mtiles + 1) / 2) * ((ntiles + 1) / 2);
+  // fewer workgroups than CUs and a long inner dimension: slices of the k-steps to workgroups of their own (>= 16 k-steps each),
+  // the partial products into arena 1, one Vector::sum per entry over the slices
+  size_t split = 1;
+  if (wgs < 256 && ktiles >= 32 && ldc == N) split = std::min<size_t>(ktiles / 16, (512 + wgs - 1) / wgs);
+  if (split > 1) {
+    const size_t kslice = (ktiles + split - 1) / split;
+    split = (ktiles + kslice - 1) / kslice;
+    const size_t slice_elems = (M * N + 1) & ~(size_t)1;
+    void* part = nullptr;
+    SCL_TRY(temp_acquire(split * slice_elems * 8, st, &part, 1));
+    hipLaunchKernelGGL(k_gemm_mfma_m61<>, dim3((unsigned)wgs, (unsigned)split), dim3(256), 0, st, static_cast<u64*>(part), N, Ap, Bp, M, N,
+                       ktiles, kslice, slice_elems);
+    int rc2 = hipGetLastError() == hipSuccess ? SCL_OK : fail(SCL_ERR_HIP, "matmul: launch failed");
+    if (rc2 == SCL_OK) rc2 = scl_hip_additive_recover(SCL_M61, C, static_cast<u64*>(part), slice_elems, split, M * N, st);
+    (void)temp_release(st, 1);
+    return rc2;
+  }
+  hipLaunchKernelGGL(k_gemm_mfma_m61<>, dim3((unsigned)std::min<size_t>(wgs, 1u << 24)), dim3(256), 0, st, C, ldc, Ap, Bp, M, N, ktiles,
+                     ktiles, (size_t)0);
+  HIP_TRY(hipGetLastError());
+  return SCL_OK;
+}
+
+template <class FieldG>
+int matmul_gemm_mfma(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B, size_t ldb, size_t M, size_t K, size_t N, hipStream_t st) {
+  const long slab_mib = g_gemm_slab_mib.load();
+  const size_t ktiles = (K + 31) / 32, budget = ((size_t)(slab_mib > 0 ? slab_mib : 1024) << 20) / 16;  // 16-byte units per factor and launch
+  const size_t tile_units = ktiles * MF_LIMBS * 64;                                    // one 32-row (32-column) tile over all of K
+  const size_t max_tiles = std::max<size_t>(1, budget / tile_units);
+  const size_t Ms = std::min<size_t>(M, max_tiles * 32), Ns = std::min<size_t>(N, max_tiles * 32);
+  const size_t a_units = (Ms + 31) / 32 * tile_units, b_units = (Ns + 31) / 32 * tile_units;
+  void* tmp = nullptr;
+  SCL_TRY(temp_acquire((a_units + b_units) * 16, st, &tmp));
+  u64x2* Ap = static_cast<u64x2*>(tmp);
+  u64x2* Bp = Ap + a_units;
+  auto body = [&]() -> int {
+    for (size_t r0 = 0; r0 < M; r0 += Ms) {
+      const size_t mr = std::min(Ms, M - r0), mtiles = (mr + 31) / 32;
+      const size_t ga = (mtiles * ktiles * 64 + 255) / 256;
+      hipLaunchKernelGGL(k_gemm_planes_a<>, dim3((unsigned)std::min<size_t>(ga, 1u << 20)), dim3(256), 0, st, Ap, A + r0 * lda, lda, mr, K, ktiles);
+      HIP_TRY(hipGetLastError());
+      for (size_t c0 = 0; c0 < N; c0 += Ns)
+        SCL_TRY(gemm_mfma_slab<FieldG>(C + r0 * ldc + c0, ldc, Ap, B + c0, ldb, Bp, mr, K, std::min(Ns, N - c0), st));
+    }
+    return SCL_OK;
+  };
+  const int rc = body();
+  (void)temp_release(st);
+  return rc;
+}
+
 // shamirRecoverD as a contraction (k_detect_compare): L [rows x d1] host elements, rows = nchk + 1.  The product Y is kept
 // for a slab of secrets at a time in the per-thread temporary, next to L and its digit planes.
 template <int KS, int MT>
@@ -1298,6 +1361,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "aes_blocks") g_aes_blocks = value;
   else if (k == "inv_batch") g_inv_batch = value;
   else if (k == "transpose_tile") g_transpose_tile = value;
+  else if (k == "gemm_slab_mib") g_gemm_slab_mib = value;
   else if (k == "stream_block") g_stream_block = (value == 256 ? 256 : 64);
   else if (k == "stream_waves") g_stream_waves = value;
   else if (k == "share_waves") g_share_waves = value;
@@ -2479,6 +2543,8 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
   if (ldc < N || (K && (lda < K || ldb < N))) return fail(SCL_ERR_MATMUL_DIMS, scl_hip_status_message(SCL_ERR_MATMUL_DIMS));
   // No bound on M, K or N, as in matrix.h:477-513.  Paths (DESIGN.md section 3 has their rates):
   //   one column (Matrix::multiply(Vector), :497-513)           k_matvec: a wavefront per row
+  //   Mersenne61, all three dimensions sizeable                  matrix cores, general kernel (gemm_mfma.hpp): digit planes of both
+  //                                                             factors, K looped in the kernel
   //   Mersenne61, long right factor, M*K >= 512                 matrix cores: row blocks of 128, k-chunks of 64 (the chunks
   //                                                             after the first add to C in the kernel's epilogue)
   //   left factor within 48 KiB and a long right factor          k_matmul: the left factor in LDS, a thread per column
@@ -2501,6 +2567,13 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
       // (a (row block, k-chunk) launch needs ~10^5 columns to outweigh its launches: 4096^3 runs at 1.5 T multiply-adds/s
       // this way and at 3.3 through k_matmul_tiled, profiles/r5_probe_matmul.txt)
       const bool one_tile = M <= 128 && K <= 64;
+      // beyond one tile: the general kernel (gemm_mfma.hpp) where all three dimensions are sizeable (its digit planes are a
+      // temporary of at most 2 GiB: longer factors go slab by slab); "mfma" 2 forces the (row block, k-chunk) form for A/B runs
+      // (K <= 64 is one k-chunk: row blocks on the sharing kernels need no pass over B and run at 18 T multiply-adds/s against 7;
+      // one row block against a very long right factor: the k-chunk form is as fast and needs no temporary)
+      const bool gemm_ok = K > 64 && M >= 33 && N >= 33 && (M > 128 || N < 131072);
+      if (gemm_ok && mode != 2 && (mode > 0 || (mode == 0 && M * N * K >= ((size_t)1 << 25))))
+        return matmul_gemm_mfma<F>(C, ldc, A, lda, B, ldb, M, K, N, S(stream));
       if (mode > 0 || (mode == 0 && std::min<size_t>(M, 128) * std::min<size_t>(K, 64) >= 512 && N >= (one_tile ? 4096u : 131072u)))
         return matmul_mfma_blocks<F>(ctx, C, ldc, A, lda, B, ldb, M, K, N, S(stream));
     }

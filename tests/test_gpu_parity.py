@@ -902,28 +902,42 @@ def test_matmul_has_no_bound_on_its_shape(scl, port, f, M, K, N):
     _matmul_window_check(scl, port, f, A, B, got, rows, cols)
 
 
-@pytest.mark.parametrize("M,K,N", [(300, 200, 5000), (129, 65, 4100), (128, 130, 4096), (1000, 64, 4500), (260, 7000, 4200)])
+@pytest.mark.parametrize("M,K,N", [(300, 200, 5000), (129, 65, 4100), (128, 130, 4096), (1000, 64, 4500), (260, 7000, 4200),
+                                   (300, 300, 300), (65, 8300, 70), (33, 16500, 33), (97, 33, 131)])
 def test_matmul_on_matrix_cores_beyond_one_tile(scl, port, M, K, N):
-    """The matrix-core product for left factors of more than 128 rows (row blocks) and more than 64 columns (k-chunks whose
-    canonical partial products one modular add folds together) == the oracle, forced and by the automatic choice."""
+    """The matrix-core product beyond one 128 x 64 tile of the left factor == the oracle: the general kernel (gemm_mfma.hpp: digit
+    planes of both factors in fragment order, K looped inside the kernel, super-steps of 8192 inner columns -- "mfma" 1), the
+    (row block, k-chunk) form on the sharing kernels ("mfma" 2: later chunks add to C in the kernel's epilogue), the automatic
+    choice, and the vector-ALU kernels."""
     f, L = O.M61, 1
     A = rand_elems(port, f, M * K, b"mmb-A").reshape(M, K, L)
     B = rand_elems(port, f, K * N, b"mmb-B").reshape(K, N, L)
     A[M - 1, K - 1] = B[K - 1, N - 1] = port.from_int(f, -1)
-    rows = sorted({0, 1, 127, 128, 129, 255, 256, M // 2, M - 1} & set(range(M)))
-    cols = sorted({0, 1, 31, 32, 4095, N // 2, N - 2, N - 1})
-    for mode in (1, 0):
+    rows = sorted({0, 1, 31, 32, 63, 64, 127, 128, 129, 255, 256, M // 2, M - 1} & set(range(M)))
+    cols = sorted({0, 1, 31, 32, 63, 64, 4095, N // 2, N - 2, N - 1} & set(range(N)))
+    first = None
+    for mode in (1, 2, 0):
         scl.set_tuning("mfma", mode)
         try:
             got = host(scl, scl.matmul(f, dev(scl, A), dev(scl, B)))
         finally:
             scl.set_tuning("mfma", 0)
         _matmul_window_check(scl, port, f, A, B, got, rows, cols)
+        first = got if first is None else first
+        assert np.array_equal(got, first), mode
     scl.set_tuning("mfma", -1)   # and the vector-ALU kernels give the same matrix
     try:
         assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), got)
     finally:
         scl.set_tuning("mfma", 0)
+    # factors whose digit planes outgrow one launch's budget go slab by slab (rows of A outside, columns of B inside): 1 MiB here
+    scl.set_tuning("mfma", 1)
+    scl.set_tuning("gemm_slab_mib", 1)
+    try:
+        assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), got)
+    finally:
+        scl.set_tuning("mfma", 0)
+        scl.set_tuning("gemm_slab_mib", 0)
 
 
 @pytest.mark.parametrize("f", ALL_FIELDS)

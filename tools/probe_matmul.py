@@ -38,12 +38,18 @@ M61, M127, SECP, MONT, GF = scl.M61, scl.M127, scl.SECP256K1_SCALAR, scl.MONT128
 run(M61, "Mersenne61", 128, 43, 10_000_000, 1, "matrix cores, one tile")
 run(M61, "Mersenne61", 128, 64, 10_000_000, 1, "matrix cores, one tile (K = 64)")
 run(M61, "Mersenne61", 512, 64, 4_000_000, 1, "matrix cores, 4 row blocks")
-run(M61, "Mersenne61", 128, 256, 4_000_000, 1, "matrix cores, 4 k-chunks")
-run(M61, "Mersenne61", 512, 512, 1_000_000, 1, "matrix cores, 4 x 8 blocks")
+run(M61, "Mersenne61", 128, 256, 4_000_000, 2, "matrix cores, 4 k-chunks")
+run(M61, "Mersenne61", 512, 512, 1_000_000, 2, "matrix cores, 4 x 8 blocks")
+run(M61, "Mersenne61", 512, 512, 1_000_000, 1, "matrix cores, general kernel")
 run(M61, "Mersenne61", 128, 43, 10_000_000, -1, "k_matmul (left factor in LDS)")
 run(M61, "Mersenne61", 10, 4, 100_000_000, -1, "k_matmul (10 x 4: HBM-bound)")
 run(M61, "Mersenne61", 4096, 4096, 4096, -1, "k_matmul_tiled")
-run(M61, "Mersenne61", 4096, 4096, 4096, 1, "matrix cores, 32 x 64 blocks")
+run(M61, "Mersenne61", 4096, 4096, 4096, 2, "matrix cores, 32 x 64 blocks")
+run(M61, "Mersenne61", 4096, 4096, 4096, 1, "matrix cores, general kernel")
+run(M61, "Mersenne61", 8192, 8192, 8192, 1, "matrix cores, general kernel")
+run(M61, "Mersenne61", 1024, 1024, 1024, 1, "matrix cores, general kernel")
+run(M61, "Mersenne61", 512, 16384, 512, 1, "matrix cores, general kernel")
+run(M61, "Mersenne61", 128, 256, 4_000_000, 1, "matrix cores, general kernel")
 run(M61, "Mersenne61", 200, 7000, 300, 0, "k_matmul_tiled (the verdict's shape)")
 run(M61, "Mersenne61", 300, 300, 300, 0, "k_matmul_tiled")
 run(M61, "Mersenne61", 20000, 10000, 1, 0, "k_matvec")
