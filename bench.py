@@ -814,6 +814,50 @@ def main():
         rep["verified"] = all(v["verified"] for v in rep["fields"].values())
         return rep
 
+    def matmul_report():
+        """Matrix::multiply (matrix.h:477-495) beyond the sharing shapes: square Mersenne61 products on the general matrix-core kernel
+        (csrc/gemm_mfma.hpp: 8 signed base-256 digits per value, 64 digit-pair int8 products per 61-bit multiply-add, all fifteen
+        digit diagonals accumulated in int32 over 8192 inner columns at a time), and the reference-shaped (200 x 7000)(7000 x 300).
+        Roofline: the int8 matrix peak on executed operations, 2 x 64 per multiply-add.  Checked against the CPU oracle's i-k-j loop
+        on a window of rows and columns that takes in the tile edges."""
+        import numpy as np
+        import oracle_lib as O
+        port = O.Port()
+        f_ = scl.M61
+        rep = {"workload": "scl_hip_matmul over Mersenne61", "shapes": {}}
+        for (M_, K_, N_) in ((4096, 4096, 4096), (1024, 1024, 1024), (200, 7000, 300)):
+            n_ew = args.ew_elements
+            if n_ew:      # tests: a small cube that still takes the matrix cores' general kernel
+                M_, K_, N_ = (160, 8300, 96) if (M_, K_, N_) == (4096, 4096, 4096) else (M_ // 8 + 1, K_ // 8 + 1, N_ // 8 + 1)
+            A = scl.vector_random(f_, M_ * K_, b"scl-bench-mm-A").reshape(M_, K_, 1)
+            B = scl.vector_random(f_, K_ * N_, b"scl-bench-mm-B").reshape(K_, N_, 1)
+            out = scl.empty(f_, M_, N_)
+            warm, reps = 5, 10
+            tms = [scl.Timer() for _ in range(reps)]
+            for k in range(-warm, reps):
+                if k >= 0:
+                    tms[k].start()
+                scl.matmul(f_, A, B, out=out)
+                if k >= 0:
+                    tms[k].stop()
+            torch.cuda.synchronize()
+            ms = sum(tm.elapsed_ms() for tm in tms) / reps
+            rows = sorted({0, 31, 32, M_ // 2, M_ - 1} & set(range(M_)))
+            cols = sorted({0, 31, 32, 63, 64, N_ // 2, N_ - 1} & set(range(N_)))
+            hA, hB = scl.to_host(A[rows]), scl.to_host(B[:, cols])
+            want = port.matmul(f_, np.ascontiguousarray(hA), np.ascontiguousarray(hB))
+            got = scl.to_host(out)[np.ix_(rows, cols)]
+            macs = M_ * K_ * N_
+            on_cores = K_ > 64 and M_ >= 33 and N_ >= 33 and macs >= (1 << 25)
+            rep["shapes"][f"{M_}x{K_}x{N_}"] = {
+                "ms": ms, "T_multiply_adds_per_s": macs / ms / 1e9, "path": "matrix cores, general kernel" if on_cores else "vector ALU (tiled / split-K)",
+                "int8_TOPs_executed": (2 * 64 * macs / ms / 1e9) if on_cores else None,
+                "frac_of_int8_peak": (2 * 64 * macs / ms / 1e9 / I8_PEAK_TOPS) if on_cores else None, "verified": bool(np.array_equal(got, want))}
+            del A, B, out
+            torch.cuda.empty_cache()
+        rep["verified"] = all(v["verified"] for v in rep["shapes"].values())
+        return rep
+
     def open_step(fkey, n, t, N, chunk, steps, warmup, seed):
         """The MPC open of N secrets: every rank holds ceil(n/G) parties' share vectors, one all-gather per chunk
         brings all n rows to every rank, every rank reconstructs (as every MPC party does).  Timed three ways:
@@ -1195,6 +1239,12 @@ def main():
             line["layout"] = layout_report()
         except Exception as e:
             line["layout"] = {"error": str(e), "verified": False}
+            torch.cuda.empty_cache()
+    if world == 1 and args.ew and pl["key"] == "c2":
+        try:
+            line["matmul"] = matmul_report()
+        except Exception as e:
+            line["matmul"] = {"error": str(e), "verified": False}
             torch.cuda.empty_cache()
     if world == 1 and args.configs:
         # the other BASELINE configurations at the size ONE GPU holds of them (C4, C5: an eighth), after the timed region

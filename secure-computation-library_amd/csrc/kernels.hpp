@@ -3203,59 +3203,60 @@ __global__ __launch_bounds__(BLOCK) void k_transpose16(u64* dst, const u64* src,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u64* tile = reinterpret_cast<u64*>(smem_raw);  // [tile_secrets][n][LIMBS] words, AoS order
   u64x2* tile16 = reinterpret_cast<u64x2*>(smem_raw);
+  constexpr int PER = LIMBS == 1 ? 2 : 1;             // secrets per 16-byte piece (one-limb fields)
+  constexpr int PIECES = LIMBS == 1 ? 1 : LIMBS / 2;  // 16-byte pieces per element
   const size_t ntiles = (N + tile_secrets - 1) / tile_secrets;
   for (size_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
     const size_t s0 = tix * tile_secrets;
     const int ts = (int)min((size_t)tile_secrets, N - s0);
-    const int words = ts * n * LIMBS;          // (s0 * n * LIMBS is even: tile_secrets is)
-    u64* aos = (TO_SOA ? const_cast<u64*>(src) : dst) + s0 * n * LIMBS;
+    const int words = ts * n * LIMBS;  // (s0 * n * LIMBS is even: tile_secrets is)
     if constexpr (TO_SOA) {
+      const u64* aos = src + s0 * n * LIMBS;
       for (int c = threadIdx.x; c < words / 2; c += BLOCK) tile16[c] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(aos) + c);
       if ((words & 1) && threadIdx.x == 0) tile[words - 1] = aos[words - 1];
       __syncthreads();
     }
-    // SoA side: party i, 16-byte piece p of its row segment [s0, s0 + ts)
-    constexpr int PER = LIMBS == 1 ? 2 : 1;        // secrets per 16-byte piece (one-limb fields)
-    constexpr int PIECES = LIMBS == 1 ? 1 : LIMBS / 2;  // 16-byte pieces per element
+    // SoA side: one flat index over (party, 16-byte piece of its row segment [s0, s0 + ts)): every thread has work whatever the
+    // tile size, and all of a tile's strided-side accesses are in flight together.  The piece count is a power of two on full
+    // tiles (tile_secrets is): a shift splits the index.
     const int npieces = LIMBS == 1 ? ts / 2 : ts * PIECES;
-    // one flat index over (party, piece): every thread has work whatever the tile size, and all of a tile's strided-side
-    // accesses are in flight together.  npieces is a power of two on full tiles (tile_secrets is): a shift splits the index.
     const int total = n * npieces;
-    const bool pow2 = (npieces & (npieces - 1)) == 0 && npieces > 0;
+    const bool pow2 = npieces > 0 && (npieces & (npieces - 1)) == 0;
     const int sh = pow2 ? __builtin_ctz((unsigned)npieces) : 0;
     for (int idx = threadIdx.x; idx < total; idx += BLOCK) {
       const int i = pow2 ? idx >> sh : idx / npieces;
       const int p = pow2 ? idx & (npieces - 1) : idx % npieces;
-      u64* row = (TO_SOA ? dst : const_cast<u64*>(src)) + ((size_t)i * stride + s0) * LIMBS;
+      const size_t row_off = ((size_t)i * stride + s0) * LIMBS;  // party i's row segment
       if constexpr (LIMBS == 1) {
         const int s = p * PER;
         if constexpr (TO_SOA) {
           u64x2 v;
           v.x = tile[s * n + i];
           v.y = tile[(s + 1) * n + i];
-          __builtin_nontemporal_store(v, reinterpret_cast<u64x2*>(row) + p);
+          __builtin_nontemporal_store(v, reinterpret_cast<u64x2*>(dst + row_off) + p);
         } else {
-          const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(row) + p);
+          const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(src + row_off) + p);
           tile[s * n + i] = v.x;
           tile[(s + 1) * n + i] = v.y;
         }
       } else {
         const int s = p / PIECES, c = p % PIECES;
-        if constexpr (TO_SOA) __builtin_nontemporal_store(tile16[(s * n + i) * PIECES + c], reinterpret_cast<u64x2*>(row) + p);
-        else tile16[(s * n + i) * PIECES + c] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(row) + p);
+        if constexpr (TO_SOA) __builtin_nontemporal_store(tile16[(s * n + i) * PIECES + c], reinterpret_cast<u64x2*>(dst + row_off) + p);
+        else tile16[(s * n + i) * PIECES + c] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(src + row_off) + p);
       }
     }
     if constexpr (LIMBS == 1) {
       if (ts & 1) {  // the odd secret out of a ragged last tile
         for (int i = threadIdx.x; i < n; i += BLOCK) {
-          u64* row = (TO_SOA ? dst : const_cast<u64*>(src)) + ((size_t)i * stride + s0) * LIMBS;
-          if constexpr (TO_SOA) row[ts - 1] = tile[(ts - 1) * n + i];
-          else tile[(ts - 1) * n + i] = row[ts - 1];
+          const size_t at = (size_t)i * stride + s0 + ts - 1;
+          if constexpr (TO_SOA) dst[at] = tile[(ts - 1) * n + i];
+          else tile[(ts - 1) * n + i] = src[at];
         }
       }
     }
     if constexpr (!TO_SOA) {
       __syncthreads();
+      u64* aos = dst + s0 * n * LIMBS;
       for (int c = threadIdx.x; c < words / 2; c += BLOCK) __builtin_nontemporal_store(tile16[c], reinterpret_cast<u64x2*>(aos) + c);
       if ((words & 1) && threadIdx.x == 0) aos[words - 1] = tile[words - 1];
     }

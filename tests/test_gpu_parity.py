@@ -1928,6 +1928,8 @@ def test_bench_contract_small(scl):
     for fld in ew["fields"].values():
         assert fld["elements"] == 300001 and all(fld[op]["verified"] and fld[op]["GBps"] > 0 for op in ("add", "mul", "inv"))
         assert fld["add"]["bytes_per_element"] == 3 * fld["inv"]["bytes_per_element"] // 2
+    mm = line["matmul"]
+    assert mm["verified"] is True and any(v["path"].startswith("matrix cores") and v["frac_of_int8_peak"] > 0 for v in mm["shapes"].values())
     lay = line["layout"]
     assert lay["verified"] is True and all(v["soa_to_aos"]["frac"] > 0 and v["aos_to_soa"]["frac"] > 0 for v in lay["fields"].values())
     cb = line["cpu_baseline"]
