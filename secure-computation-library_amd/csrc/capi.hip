@@ -1038,7 +1038,7 @@ struct RecoverSmall {
     if (m == M) {
       // single-wave workgroups under the residency cap of the (m <= 16) stream kernels (kernels.hpp, "Launch geometry")
       const long sw = g_stream_waves.load();
-      const size_t pad = residency_pad(sw < 0 ? 12 : sw, 64, 0);
+      const size_t pad = residency_pad(sw < 0 ? (F::LIMBS == 4 ? 10 : 12) : sw, 64, 0);  // (profiles/r5_probe_f3_waves.txt)
       const size_t lanes = F::LIMBS == 4 ? 2 * n : n;  // 32-byte elements: a pair of lanes per secret
       hipLaunchKernelGGL((k_recover_small<F, M, true, 64>), dim3(grid_for_block(lanes, 64)), dim3(64), pad, st, ctx, out, shares, stride,
                          lam, n);
@@ -1926,7 +1926,8 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
             // fields' residency cap; "share_waves128" 0 = the lane-per-element kernel
             const long sw128 = g_share_waves128.load();
             if (sw128 > 0 && g_stream_block.load() == 64) {
-              const size_t pad = residency_pad(sw128, 64, sizeof(u32) * SmallVdm::CAP);
+              // (the default cap of the 16-byte fields is 12; the lane pairs run best at 14-16: profiles/r5_probe_f3_waves.txt)
+              const size_t pad = residency_pad(sw128 == 12 ? 16 : sw128, 64, sizeof(u32) * SmallVdm::CAP);
               const dim3 g(grid_for_block(2 * npacks, 64));
 #define SSP_CASE(TT)                                                                                                     \
   case TT:                                                                                                               \
