@@ -61,7 +61,7 @@ def on_matrix_cores(fkey, n, t):
     """the shapes scl_hip_shamir_share sends to k_share_mfma_m61_p16 (capi.hip: Mersenne61, n > 96, 32 <= t <= 63)"""
     return fkey == "m61" and n > 96 and 32 <= t <= 63
 KERNEL_SOURCES = ("secure-computation-library_amd/csrc/kernels.hpp", "secure-computation-library_amd/csrc/capi.hip",
-                  "secure-computation-library_amd/csrc/share_mfma.hpp", "secure-computation-library_amd/csrc/gemm_mfma.hpp",
+                  "secure-computation-library_amd/csrc/share_mfma.hpp", "secure-computation-library_amd/csrc/gemm_mfma.hpp", "secure-computation-library_amd/csrc/gemm_unit.hip",
                   "include/scl_hip/detail/field.hpp")
 
 

@@ -25,7 +25,14 @@
 #include "../../include/scl_hip/detail/field.hpp"
 #include "kernels.hpp"
 #include "share_mfma.hpp"
-#include "gemm_mfma.hpp"
+
+// the general matrix-core product's kernels live in gemm_unit.hip, compiled without -amdgpu-mfma-vgpr-form (see there)
+namespace sclhip {
+hipError_t gemm_launch_planes_a(u64x2* planes, const u64* A, size_t lda, size_t M, size_t K, size_t ktiles, hipStream_t st);
+hipError_t gemm_launch_planes_b(u64x2* planes, const u64* B, size_t ldb, size_t K, size_t N, size_t ktiles, hipStream_t st);
+hipError_t gemm_launch_main(u64* C, size_t ldc, const u64x2* Ap, const u64x2* Bp, size_t M, size_t N, size_t ktiles, size_t kslice,
+                            size_t cslice, size_t splits, hipStream_t st);
+}  // namespace sclhip
 
 using namespace sclhip;
 
@@ -814,9 +821,7 @@ int matmul_mfma_blocks(const typename FieldG::Ctx&, u64* C, size_t ldc, const u6
 template <class FieldG>
 int gemm_mfma_slab(u64* C, size_t ldc, const u64x2* Ap, const u64* B, size_t ldb, u64x2* Bp, size_t M, size_t K, size_t N, hipStream_t st) {
   const size_t ktiles = (K + 31) / 32, mtiles = (M + 31) / 32, ntiles = (N + 31) / 32;
-  const size_t gb = (ntiles * ktiles * 64 + 255) / 256;
-  hipLaunchKernelGGL(k_gemm_planes_b<>, dim3((unsigned)std::min<size_t>(gb, 1u << 20)), dim3(256), 0, st, Bp, B, ldb, K, N, ktiles);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(gemm_launch_planes_b(Bp, B, ldb, K, N, ktiles, st));
   const size_t wgs = ((mtiles + 1) / 2) * ((ntiles + 1) / 2);
   // fewer workgroups than CUs and a long inner dimension: slices of the k-steps to workgroups of their own (>= 16 k-steps each),
   // the partial products into arena 1, one Vector::sum per entry over the slices
@@ -828,16 +833,14 @@ int gemm_mfma_slab(u64* C, size_t ldc, const u64x2* Ap, const u64* B, size_t ldb
     const size_t slice_elems = (M * N + 1) & ~(size_t)1;
     void* part = nullptr;
     SCL_TRY(temp_acquire(split * slice_elems * 8, st, &part, 1));
-    hipLaunchKernelGGL(k_gemm_mfma_m61<>, dim3((unsigned)wgs, (unsigned)split), dim3(256), 0, st, static_cast<u64*>(part), N, Ap, Bp, M, N,
-                       ktiles, kslice, slice_elems);
-    int rc2 = hipGetLastError() == hipSuccess ? SCL_OK : fail(SCL_ERR_HIP, "matmul: launch failed");
+    int rc2 = gemm_launch_main(static_cast<u64*>(part), N, Ap, Bp, M, N, ktiles, kslice, slice_elems, split, st) == hipSuccess
+                  ? SCL_OK
+                  : fail(SCL_ERR_HIP, "matmul: launch failed");
     if (rc2 == SCL_OK) rc2 = scl_hip_additive_recover(SCL_M61, C, static_cast<u64*>(part), slice_elems, split, M * N, st);
     (void)temp_release(st, 1);
     return rc2;
   }
-  hipLaunchKernelGGL(k_gemm_mfma_m61<>, dim3((unsigned)std::min<size_t>(wgs, 1u << 24)), dim3(256), 0, st, C, ldc, Ap, Bp, M, N, ktiles,
-                     ktiles, (size_t)0);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(gemm_launch_main(C, ldc, Ap, Bp, M, N, ktiles, ktiles, 0, 1, st));
   return SCL_OK;
 }
 
@@ -855,10 +858,8 @@ int matmul_gemm_mfma(u64* C, size_t ldc, const u64* A, size_t lda, const u64* B,
   u64x2* Bp = Ap + a_units;
   auto body = [&]() -> int {
     for (size_t r0 = 0; r0 < M; r0 += Ms) {
-      const size_t mr = std::min(Ms, M - r0), mtiles = (mr + 31) / 32;
-      const size_t ga = (mtiles * ktiles * 64 + 255) / 256;
-      hipLaunchKernelGGL(k_gemm_planes_a<>, dim3((unsigned)std::min<size_t>(ga, 1u << 20)), dim3(256), 0, st, Ap, A + r0 * lda, lda, mr, K, ktiles);
-      HIP_TRY(hipGetLastError());
+      const size_t mr = std::min(Ms, M - r0);
+      HIP_TRY(gemm_launch_planes_a(Ap, A + r0 * lda, lda, mr, K, ktiles, st));
       for (size_t c0 = 0; c0 < N; c0 += Ns)
         SCL_TRY(gemm_mfma_slab<FieldG>(C + r0 * ldc + c0, ldc, Ap, B + c0, ldb, Bp, mr, K, std::min(Ns, N - c0), st));
     }

@@ -21,7 +21,9 @@
 //     fetched by two waves of the same CU back to back (L1 hits).
 //
 // Work per operand byte: a k-step moves 16 KiB per wave for 64 matrix instructions (>= 2048 cycles of the matrix pipe), so the
-// kernel is bound by the matrix pipe, not by L2.  Measured: profiles/r5_probe_matmul.txt.
+// kernel is bound by the matrix pipe, not by L2.  Measured: profiles/r5_probe_matmul.txt (19.2 T multiply-adds/s at 4096^3: 0.55 of
+// the matrix instruction's own measured issue rate, profiles/r1_mfma_chain_issue.txt).  Compiled as a unit of its own without
+// -amdgpu-mfma-vgpr-form (gemm_unit.hip): the accumulators belong in the accumulation registers here.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_mfma_m61(u64* C, size_t ldc, co
       for (int d = 0; d < 15; ++d) acc[d] = zero;
       // software pipeline over the k-steps, two register images of the sixteen fragments: with ONE wave per SIMD (the accumulators
       // take half the register file) nothing else hides the loads' latency, so step kt + 1 is requested before step kt's 64 matrix
-      // instructions are issued (2048+ cycles of matrix pipe per step against ~1-2 us of L2 latency)
+      // instructions are issued (2048+ cycles of matrix pipe per step against ~1-2 us of L2 latency).  A third image -- two steps
+      // ahead -- does not fit: 144 spills (round 5).
       auto fetch = [&](v4i (&af)[MF_LIMBS], v4i (&bf)[MF_LIMBS], size_t kt) {
 #pragma unroll
         for (int l = 0; l < MF_LIMBS; ++l) {
