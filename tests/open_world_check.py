@@ -95,6 +95,11 @@ def main():
                                                          C.c_size_t(cnt), mine_p, C.c_size_t(N), C.c_size_t(chunk), every,
                                                          C.c_void_p(s.cuda_stream))
                     assert rc == 0, lib.scl_hip_last_error()
+            if field == O.M61 and world > 8:
+                # nine canonical partials could wrap a 64-bit sum: the reduce-scatter form refuses, before any collective is issued
+                rc = lib.scl_hip_open_reduce_scatter(h, field, dp(outs[0]), dp(local) if cnt else None, C.c_size_t(N), C.c_size_t(cnt),
+                                                     mine_p, C.c_size_t(N), C.c_size_t(chunk), 1, C.c_void_p(sA.cuda_stream))
+                assert rc != 0 and b"8 ranks" in lib.scl_hip_last_error(), (rc, lib.scl_hip_last_error())
             sA.synchronize()
             sB.synchronize()
             results[r] = [o.cpu().numpy().view(np.uint64) for o in outs]
