@@ -290,7 +290,7 @@ struct M61 {
 struct M127 {
   typedef u128 E;
   struct Ctx {};
-  enum { LIMBS = 2, ACC_TERMS = 1 << 24, TAG = 1 };
+  enum { LIMBS = 2, ACC_TERMS = 1 << 30, TAG = 1 };
   static SCL_HD u128 P() { return (((u128)0x7FFFFFFFFFFFFFFFull) << 64) | (u128)0xFFFFFFFFFFFFFFFFull; }
 
   static SCL_HD E zero() { return 0; }
@@ -356,51 +356,23 @@ struct M127 {
   static SCL_HD u128 muladd_small_lazy(const Ctx&, u128 y, u32 x, u128 c) { return muladd_small_lazy(y, x, c); }
   static SCL_HD E muladd_small(const Ctx&, E y, u32 x, E c) { return canon(muladd_small_lazy(y, x, c)); }
 
-  // Lazy accumulator: products are summed UNREDUCED as seven column sums of 32 x 32 partial products (LazyCols: one v_mad_u64_u32
-  // and one v_addc per partial product -- 32 instructions a term where the 256-bit product with its fold to 128 bits takes ~70),
-  // plain elements in a multi-word sum beside them; one reduction at the end: 2^128 = 2 and 2^256 = 4 (mod p).
-  struct Sum {
-    u128 lo;
-    u64 hi;  // how often lo has wrapped
-  };
   struct Acc {
-    LazyCols<4> c;
-    Sum s;
+    u128 lo;
+    u64 hi;
   };
-  static SCL_HD Acc acc_zero() {
-    Acc a;
-    lazy_zero(a.c);
-    a.s = Sum{0, 0};
-    return a;
+  static SCL_HD Acc acc_zero() { return Acc{0, 0}; }
+  static SCL_HD void acc_add_raw(Acc& acc, u128 a) {
+    const u128 t = acc.lo + a;
+    acc.hi += (t < a);
+    acc.lo = t;
   }
-  static SCL_HD void sum_add(Sum& s, u128 a) {
-    const u128 t = s.lo + a;
-    s.hi += (t < a);
-    s.lo = t;
-  }
-  static SCL_HD void acc_add(const Ctx&, Acc& acc, E a) { sum_add(acc.s, a); }
-  static SCL_HD void mac(const Ctx&, Acc& acc, E a, E b) {
-    const u32 al[4] = {(u32)a, (u32)(a >> 32), (u32)(a >> 64), (u32)(a >> 96)};
-    const u32 bl[4] = {(u32)b, (u32)(b >> 32), (u32)(b >> 64), (u32)(b >> 96)};
-    lazy_mac<4>(acc.c, al, bl);
-  }
+  static SCL_HD void acc_add(const Ctx&, Acc& acc, E a) { acc_add_raw(acc, a); }
+  static SCL_HD void mac(const Ctx&, Acc& acc, E a, E b) { acc_add_raw(acc, mul_lazy(a, b)); }
   // hi*2^128 + lo = 2*hi + lo (mod p)
-  static SCL_HD E sum_fold(const Sum& s) {
-    const u128 v = (s.lo & P()) + (s.lo >> 127) + ((u128)s.hi << 1);
+  static SCL_HD E acc_fold(const Ctx&, const Acc& acc) {
+    const u128 v = (acc.lo & P()) + (acc.lo >> 127) + ((u128)acc.hi << 1);
     const u128 r = (v & P()) + (v >> 127);
     return r >= P() ? r - P() : r;
-  }
-  static SCL_HD E acc_fold(const Ctx&, const Acc& acc) {
-    u32 t[9];
-    lazy_limbs<4, 9>(acc.c, t);  // the products' sum, < 2^288 for up to 2^32 terms
-    const u128 lo = (u128)t[0] | ((u128)t[1] << 32) | ((u128)t[2] << 64) | ((u128)t[3] << 96);
-    const u128 hi = (u128)t[4] | ((u128)t[5] << 32) | ((u128)t[6] << 64) | ((u128)t[7] << 96);
-    Sum s = acc.s;
-    sum_add(s, lo);
-    sum_add(s, hi);  // 2^128 = 2
-    sum_add(s, hi);
-    sum_add(s, (u128)t[8] << 2);  // 2^256 = 4
-    return sum_fold(s);
   }
 
   // Prepared constant c: for each 32-bit limb position i of x, the 22-bit limbs w[6i..6i+5] of c*2^(32i) mod p:
@@ -432,15 +404,15 @@ struct M127 {
 #pragma unroll
       for (int j = 0; j < 6; ++j) mad32(a.c[j], xi[i], k.w[6 * i + j]);
   }
-  static SCL_HD E kacc_fold(const Ctx&, const KAcc& a) {
-    Sum t{0, 0};
+  static SCL_HD E kacc_fold(const Ctx& ctx, const KAcc& a) {
+    Acc t = acc_zero();
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int sh = 22 * j;  // column weight 2^sh; the part at or above 2^128 goes to t.hi
-      sum_add(t, (u128)a.c[j] << sh);
+      acc_add_raw(t, (u128)a.c[j] << sh);
       if (sh > 64) t.hi += a.c[j] >> (128 - sh);
     }
-    return sum_fold(t);
+    return acc_fold(ctx, t);
   }
 
   static SCL_HD E sqn_mul(const Ctx& c, E x, int k, E y) {

@@ -2994,6 +2994,50 @@ __global__ __launch_bounds__(1024) void k_bw_solve(typename F::Ctx ctx, u64* f_o
   }
 }
 
+// The accumulator of the matrix kernels.  For most fields it is the field's own lazy accumulator (F::Acc / F::mac).  Mersenne127's
+// folds every 256-bit product to 128 bits as it goes (~70 instructions a term): right for the streaming reconstruct kernels, which
+// are HBM-bound and want few registers (the column-sum form below cost k_recover_fixed<M127> 8 % in an A/B on one box,
+// profiles/r5_probe_ab_c3_m127_acc.txt), wrong for a product's inner loop -- there the products are summed unreduced as seven
+// column sums of 32 x 32 partial products (LazyCols: 32 instructions a term) and reduced once: 2^128 = 2, 2^256 = 4 (mod p).
+template <class F>
+struct MatAcc {
+  typename F::Acc a;
+  enum { TERMS = F::ACC_TERMS };
+  __device__ __forceinline__ void zero() { a = F::acc_zero(); }
+  __device__ __forceinline__ void mac(const typename F::Ctx& c, const typename F::E& x, const typename F::E& y) { F::mac(c, a, x, y); }
+  __device__ __forceinline__ void add(const typename F::Ctx& c, const typename F::E& x) { F::acc_add(c, a, x); }
+  __device__ __forceinline__ typename F::E fold(const typename F::Ctx& c) const { return F::acc_fold(c, a); }
+};
+template <>
+struct MatAcc<M127> {
+  LazyCols<4> cols;
+  u128 plain;  // elements added as they are (the restart value after a fold): < 2^127 each, few of them
+  enum { TERMS = 1 << 24 };
+  __device__ __forceinline__ void zero() {
+    lazy_zero(cols);
+    plain = 0;
+  }
+  __device__ __forceinline__ void mac(const M127::Ctx&, u128 x, u128 y) {
+    const u32 xl[4] = {(u32)x, (u32)(x >> 32), (u32)(x >> 64), (u32)(x >> 96)};
+    const u32 yl[4] = {(u32)y, (u32)(y >> 32), (u32)(y >> 64), (u32)(y >> 96)};
+    lazy_mac<4>(cols, xl, yl);
+  }
+  __device__ __forceinline__ void add(const M127::Ctx& c, u128 x) { plain = M127::add(c, plain, x); }
+  __device__ __forceinline__ u128 fold(const M127::Ctx& c) const {
+    u32 t[9];
+    lazy_limbs<4, 9>(cols, t);  // the products' sum, < 2^288
+    const u128 lo = (u128)t[0] | ((u128)t[1] << 32) | ((u128)t[2] << 64) | ((u128)t[3] << 96);
+    const u128 hi = (u128)t[4] | ((u128)t[5] << 32) | ((u128)t[6] << 64) | ((u128)t[7] << 96);
+    M127::Acc s = M127::acc_zero();
+    M127::acc_add_raw(s, lo);
+    M127::acc_add_raw(s, hi);  // 2^128 = 2
+    M127::acc_add_raw(s, hi);
+    M127::acc_add_raw(s, (u128)t[8] << 2);  // 2^256 = 4
+    M127::acc_add_raw(s, plain);
+    return M127::acc_fold(c, s);
+  }
+};
+
 // ---- matrices ---------------------------------------------------------------------------------------
 // Matrix::multiply (matrix.h:477-495): C[M x N] = A[M x K] * B[K x N].  One thread per column j,
 // RM rows of A at a time (A tile in LDS, wave-uniform reads), B streamed coalesced.
@@ -3009,35 +3053,35 @@ __global__ __launch_bounds__(BLOCK) void k_matmul(typename F::Ctx ctx, u64* C, s
   __syncthreads();
   SCL_GRID_STRIDE(j, N) {
     for (int r0 = 0; r0 < rows; r0 += RM) {
-      typename F::Acc acc[RM];
+      MatAcc<F> acc[RM];
       typename F::E run[RM];
 #pragma unroll
       for (int r = 0; r < RM; ++r) {
-        acc[r] = F::acc_zero();
+        acc[r].zero();
         run[r] = F::zero();
       }
       int terms = 0;
       for (int k = 0; k < K; ++k) {
         const typename F::E b = F::ld(B + ((size_t)k * ldb + j) * F::LIMBS);
-        if (terms + 1 > F::ACC_TERMS) {
+        if (terms + 1 > (int)MatAcc<F>::TERMS) {
 #pragma unroll
           for (int r = 0; r < RM; ++r) {
-            run[r] = F::add(ctx, run[r], F::acc_fold(ctx, acc[r]));
-            acc[r] = F::acc_zero();
+            run[r] = F::add(ctx, run[r], acc[r].fold(ctx));
+            acc[r].zero();
           }
           terms = 0;
         }
 #pragma unroll
         for (int r = 0; r < RM; ++r) {
           const int rr = (r0 + r < rows) ? r0 + r : rows - 1;  // clamp: duplicates are discarded below
-          F::mac(ctx, acc[r], As[rr * K + k], b);
+          acc[r].mac(ctx, As[rr * K + k], b);
         }
         ++terms;
       }
 #pragma unroll
       for (int r = 0; r < RM; ++r) {
         if (r0 + r < rows)
-          F::st(C + ((size_t)(row0 + r0 + r) * ldc + j) * F::LIMBS, F::add(ctx, run[r], F::acc_fold(ctx, acc[r])));
+          F::st(C + ((size_t)(row0 + r0 + r) * ldc + j) * F::LIMBS, F::add(ctx, run[r], acc[r].fold(ctx)));
       }
     }
   }
@@ -3075,11 +3119,11 @@ __global__ __launch_bounds__(BLOCK) void k_matmul_tiled(typename F::Ctx ctx, u64
   const size_t tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
   for (size_t tile = blockIdx.x; tile < tiles_m * tiles_n; tile += gridDim.x) {
     const size_t row0 = (tile / tiles_n) * TM, col0 = (tile % tiles_n) * TN;
-    typename F::Acc acc[RM][RN];
+    MatAcc<F> acc[RM][RN];
 #pragma unroll
     for (int r = 0; r < RM; ++r)
 #pragma unroll
-      for (int c = 0; c < RN; ++c) acc[r][c] = F::acc_zero();
+      for (int c = 0; c < RN; ++c) acc[r][c].zero();
     int terms = 0;
     const size_t kbeg = blockIdx.y * kslice, kend = kbeg + kslice < K ? kbeg + kslice : K;
     for (size_t k0 = kbeg; k0 < kend; k0 += TK) {
@@ -3093,14 +3137,14 @@ __global__ __launch_bounds__(BLOCK) void k_matmul_tiled(typename F::Ctx ctx, u64
         Bs[i] = (k < kend && c < N) ? F::ld(B + (k * ldb + c) * F::LIMBS) : F::zero();
       }
       __syncthreads();
-      if (terms + TK > (int)F::ACC_TERMS) {  // fold: the accumulator restarts from its own canonical value
+      if (terms + TK > (int)MatAcc<F>::TERMS) {  // fold: the accumulator restarts from its own canonical value
 #pragma unroll
         for (int r = 0; r < RM; ++r)
 #pragma unroll
           for (int c = 0; c < RN; ++c) {
-            const E f = F::acc_fold(ctx, acc[r][c]);
-            acc[r][c] = F::acc_zero();
-            F::acc_add(ctx, acc[r][c], f);
+            const E f = acc[r][c].fold(ctx);
+            acc[r][c].zero();
+            acc[r][c].add(ctx, f);
           }
         terms = 1;
       }
@@ -3114,7 +3158,7 @@ __global__ __launch_bounds__(BLOCK) void k_matmul_tiled(typename F::Ctx ctx, u64
 #pragma unroll
         for (int r = 0; r < RM; ++r)
 #pragma unroll
-          for (int c = 0; c < RN; ++c) F::mac(ctx, acc[r][c], a[r], b[c]);
+          for (int c = 0; c < RN; ++c) acc[r][c].mac(ctx, a[r], b[c]);
       }
       terms += TK;
     }
@@ -3123,7 +3167,7 @@ __global__ __launch_bounds__(BLOCK) void k_matmul_tiled(typename F::Ctx ctx, u64
 #pragma unroll
       for (int c = 0; c < RN; ++c) {
         const size_t row = row0 + ty * RM + r, col = col0 + tx + 16 * c;
-        if (row < M && col < N) F::st(C + blockIdx.y * cslice + (row * ldc + col) * F::LIMBS, F::acc_fold(ctx, acc[r][c]));
+        if (row < M && col < N) F::st(C + blockIdx.y * cslice + (row * ldc + col) * F::LIMBS, acc[r][c].fold(ctx));
       }
   }
 }
@@ -3137,19 +3181,20 @@ __global__ __launch_bounds__(BLOCK) void k_matvec(typename F::Ctx ctx, u64* y, s
   typedef typename F::E E;
   const int lane = threadIdx.x & 63;
   for (size_t row = (size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); row < M; row += (size_t)gridDim.x * (BLOCK / 64)) {
-    typename F::Acc acc = F::acc_zero();
+    MatAcc<F> acc;
+    acc.zero();
     E run = F::zero();
     int terms = 0;
     for (size_t k = lane; k < K; k += 64) {
-      if (terms + 1 > (int)F::ACC_TERMS) {
-        run = F::add(ctx, run, F::acc_fold(ctx, acc));
-        acc = F::acc_zero();
+      if (terms + 1 > (int)MatAcc<F>::TERMS) {
+        run = F::add(ctx, run, acc.fold(ctx));
+        acc.zero();
         terms = 0;
       }
-      F::mac(ctx, acc, F::ld(A + (row * lda + k) * F::LIMBS), F::ld(x + k * ldb * F::LIMBS));
+      acc.mac(ctx, F::ld(A + (row * lda + k) * F::LIMBS), F::ld(x + k * ldb * F::LIMBS));
       ++terms;
     }
-    run = F::add(ctx, run, F::acc_fold(ctx, acc));
+    run = F::add(ctx, run, acc.fold(ctx));
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) run = F::add(ctx, run, shfl_xor_elem<F>(run, m));
     if (lane == 0) F::st(y + row * ldc * F::LIMBS, run);
