@@ -208,6 +208,33 @@ def test_gf2_128_products_on_the_lds_table(scl, port):
 
 
 @pytest.mark.parametrize("f", ALL_FIELDS)
+def test_batched_inverse_ragged_sizes(scl, port, f):
+    """Thirty batch sizes between 1 and 70 000 (around every chain length x 64 lanes, and random ones) x every chain length: the last
+    lane's chain, the last wave and the last tile are all partial somewhere.  x * x^-1 = 1 and (b / x) * x = b over the batch; the
+    fast-oracle fields also against the oracle's Euclid element for element."""
+    rng = np.random.default_rng(77 + f)
+    sizes = sorted({1, 2, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 8191, 8192, 8193, 65535, 65537} | {int(x) for x in rng.integers(1, 70_000, 14)})
+    a_all, b_all = rand_elems(port, f, 70_000, b"rag-a"), rand_elems(port, f, 70_000, b"rag-b")
+    zero = port.from_int(f, 0)
+    a_all[np.all(a_all == zero, axis=1)] = port.from_int(f, 3)
+    want_all = port.ew(f, O.INV, a_all) if f not in SLOW_ORACLE else None
+    one = port.from_int(f, 1)
+    for chain in ([0] if f == O.M61 else [0, 8, 16, 32, 64, 128]):
+        scl.set_tuning("inv_batch", chain)
+        try:
+            for n in sizes:
+                da, db = dev(scl, a_all[:n]), dev(scl, b_all[:n])
+                inv, quo = scl.ew(f, O.INV, da), scl.ew(f, O.DIV, db, da)
+                if want_all is not None:
+                    assert np.array_equal(host(scl, inv), want_all[:n]), (f, chain, n)
+                else:
+                    assert np.array_equal(host(scl, scl.ew(f, O.MUL, inv, da)), np.broadcast_to(one, (n, O.LIMBS[f]))), (f, chain, n)
+                assert np.array_equal(host(scl, scl.ew(f, O.MUL, quo, da)), b_all[:n]), (f, chain, n)
+        finally:
+            scl.set_tuning("inv_batch", 0)
+
+
+@pytest.mark.parametrize("f", ALL_FIELDS)
 def test_inverse_of_zero_is_the_reference_error(scl, port, f):
     a = rand_elems(port, f, 100, b"z")
     a[37] = port.from_int(f, 0)
@@ -1004,6 +1031,35 @@ def test_reconstruct_with_small_integer_coefficients(scl, port, f, n):
         got2 = host(scl, scl.shamir_recover(f, sh2, lam2))
         aos2 = np.ascontiguousarray(np.transpose(host(scl, sh2), (1, 0, 2)))
         assert np.array_equal(got2[:200], port.shamir_recover_lambda(f, aos2[:200], lam2))
+
+
+@pytest.mark.parametrize("f", [O.M61, O.M127, O.SECP256K1_SCALAR])
+def test_matmul_random_shapes_every_path(scl, port, f):
+    """Forty pseudo-random shapes up to 260 x 700 x 260 (ones, primes, powers of two and tile sizes +- 1 among them) through every
+    matmul path the field has -- automatic choice, matrix cores forced (general kernel, then the block / chunk form), vector ALU --
+    the whole product against the oracle's i-k-j loop."""
+    rng = np.random.default_rng(20261004 + f)
+    L = O.LIMBS[f]
+    special = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 256, 257]
+    shapes = []
+    for i in range(40 if f != O.SECP256K1_SCALAR else 14):
+        pick = lambda hi: int(rng.choice(special)) if rng.random() < 0.5 else int(rng.integers(1, hi))  # noqa: E731
+        M, K, N = min(pick(260), 260), min(pick(700), 700), min(pick(260), 260)
+        if f == O.SECP256K1_SCALAR:
+            M, K, N = min(M, 40), min(K, 200), min(N, 40)
+        shapes.append((M, K, N))
+    for (M, K, N) in shapes:
+        A = rand_elems(port, f, M * K, b"rs-A%d" % (M * 1000 + K)).reshape(M, K, L)
+        B = rand_elems(port, f, K * N, b"rs-B%d" % (N * 1000 + K)).reshape(K, N, L)
+        want = port.matmul(f, A, B)
+        dA, dB = dev(scl, A), dev(scl, B)
+        for mode in ((0, 1, 2, -1) if f == O.M61 else (0,)):
+            scl.set_tuning("mfma", mode)
+            try:
+                got = host(scl, scl.matmul(f, dA, dB))
+            finally:
+                scl.set_tuning("mfma", 0)
+            assert np.array_equal(got, want), (f, M, K, N, mode)
 
 
 def test_vandermonde_matmul_is_sharing(scl, port):
