@@ -110,6 +110,15 @@ SCL_STATE(thread_local unsigned long g_mont_gen, = 0);
 SCL_STATE(thread_local bool g_mont_own, = false);
 // per-thread device scratch (only used by calls that synchronise before returning)
 SCL_STATE(thread_local Scratch g_scratch);
+// the "a zero was inverted" flag of scl_hip_ew in pinned host memory the device writes straight into: the call then needs no
+// memset launch and no copy back, only the stream synchronisation it owes its caller anyway.  host == nullptr: not allocated
+// (yet, or the allocation failed once: then the flag lives in the device scratch as before)
+struct HostFlag {
+  unsigned* host = nullptr;
+  unsigned* dev = nullptr;
+  bool failed = false;
+};
+SCL_STATE(thread_local HostFlag g_hflag);
 // arena 0: tables, queues and products of one call; arena 1: the coefficient rows of a two-pass PRG sharing (whose second
 // pass may take arena 0 itself)
 SCL_STATE(thread_local TempArena g_temps[2]);
@@ -1338,6 +1347,10 @@ int scl_hip_thread_cleanup(void) {
     HIP_TRY(hipFree(g_scratch.dev));
     g_scratch = Scratch{};
   }
+  if (g_hflag.host) {
+    HIP_TRY(hipHostFree(g_hflag.host));
+    g_hflag = HostFlag{};
+  }
   for (TempArena& g_temp : g_temps) {
     if (!g_temp.dev) continue;
     if (g_temp.pending) HIP_TRY(hipEventSynchronize(g_temp.done));
@@ -1400,11 +1413,30 @@ int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64
     SCL_TRY(check_align<F>({dst, a, binary ? b : nullptr}));
     unsigned* flag = nullptr;
     const bool needs_flag = (op == SCL_OP_INV || op == SCL_OP_DIV);
+    bool host_flag = false;
     if (needs_flag) {
-      void* sc;
-      SCL_TRY(scratch(64, &sc));
-      flag = static_cast<unsigned*>(sc);
-      HIP_TRY(hipMemsetAsync(flag, 0, 4, S(stream)));
+      if (!g_hflag.host && !g_hflag.failed) {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+          g_hflag.host = static_cast<unsigned*>(hp);
+          g_hflag.dev = static_cast<unsigned*>(dp);
+        } else {
+          if (hp) (void)hipHostFree(hp);
+          (void)hipGetLastError();
+          g_hflag.failed = true;
+        }
+      }
+      if (g_hflag.host) {  // (the previous call on this thread synchronised before it returned: nobody writes the word now)
+        *g_hflag.host = 0;
+        flag = g_hflag.dev;
+        host_flag = true;
+      } else {
+        void* sc;
+        SCL_TRY(scratch(64, &sc));
+        flag = static_cast<unsigned*>(sc);
+        HIP_TRY(hipMemsetAsync(flag, 0, 4, S(stream)));
+      }
     }
     const int vec = vec_width<F>({dst, a, binary ? b : nullptr}, {});
     const bool nt = g_nontemporal.load() != 0;
@@ -1444,8 +1476,9 @@ int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64
     SCL_TRY(rc_);
     if (needs_flag) {
       unsigned h = 0;
-      HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, S(stream)));
+      if (!host_flag) HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, S(stream)));
       HIP_TRY(hipStreamSynchronize(S(stream)));
+      if (host_flag) h = *static_cast<volatile unsigned*>(g_hflag.host);
       if (h) {
         const int code = (F::TAG == 5 || F::TAG == 6) ? SCL_ERR_NOT_INVERTIBLE_2K : SCL_ERR_ZERO_INVERSE;
         return fail(code, scl_hip_status_message(code));
