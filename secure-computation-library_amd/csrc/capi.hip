@@ -2582,6 +2582,7 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
   //                                                             factors, K looped in the kernel
   //   Mersenne61, long right factor, M*K >= 512                 matrix cores: row blocks of 128, k-chunks of 64 (the chunks
   //                                                             after the first add to C in the kernel's epilogue)
+  //   K <= 16 (8 for 32-byte elements), long right factor       k_matmul_thin: B's rows in registers, A in LDS, 16-byte accesses
   //   left factor within 48 KiB and a long right factor          k_matmul: the left factor in LDS, a thread per column
   //   anything else                                              k_matmul_tiled: LDS tiles of both factors, K in steps
   return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
@@ -2613,6 +2614,20 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
         return matmul_mfma_blocks<F>(ctx, C, ldc, A, lda, B, ldb, M, K, N, S(stream));
     }
     const size_t esz = F::LIMBS * 8;
+    {
+      // a thin inner dimension (a Vandermonde matrix times the coefficient rows): B's K rows in registers, 16-byte accesses
+      constexpr int KMAX = F::LIMBS == 4 ? 8 : 16;
+      if (K <= (size_t)KMAX && M * K * esz <= 48 * 1024 && N >= 1024 && g_force_table.load() == 0) {
+        const int vec = vec_width<F>({C, B}, {ldc, ldb});
+        return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
+          constexpr int VEC = decltype(V)::value;
+          hipLaunchKernelGGL((k_matmul_thin<F, VEC, KMAX>), dim3(grid_for(npacks)), dim3(BLOCK), M * K * esz, S(stream), ctx,
+                             C + first * F::LIMBS, ldc, A, lda, B + first * F::LIMBS, ldb, (int)M, (int)K, npacks);
+          LAUNCH_CHECK();
+          return SCL_OK;
+        });
+      }
+    }
     if (M * K * esz <= 48 * 1024 && N >= 1024) {
       const unsigned gx = grid_for(N);
       hipLaunchKernelGGL((k_matmul<F, 4>), dim3(gx, 1), dim3(BLOCK), M * K * esz, S(stream), ctx, C, ldc, A, lda, B, ldb, (int)M,

@@ -3087,6 +3087,44 @@ __global__ __launch_bounds__(BLOCK) void k_matmul(typename F::Ctx ctx, u64* C, s
   }
 }
 
+// A thin inner dimension against a long right factor -- Matrix::vandermonde(n, t + 1) times the coefficient matrix, the
+// reference's own way of writing a sharing (test/scl/math/test_matrix.cc:342-365): the K <= KMAX rows of B a lane needs stay in
+// registers (16-byte packs: two columns of a one-limb field per lane), A sits in LDS and is read as broadcasts, every row of C
+// is one sum of K products folded once.  B is read once and C written once, whole lines both: HBM-bound like the share kernels
+// (k_matmul re-reads B for every four rows of C and moves 8 bytes per lane).
+template <class F, int VEC, int KMAX>
+__global__ __launch_bounds__(BLOCK) void k_matmul_thin(typename F::Ctx ctx, u64* C, size_t ldc, const u64* A, size_t lda, const u64* B,
+                                                       size_t ldb, int M, int K, size_t npacks) {
+  extern __shared__ unsigned char smem_raw[];
+  typename F::E* As = reinterpret_cast<typename F::E*>(smem_raw);  // [M][K]
+  for (int i = threadIdx.x; i < M * K; i += BLOCK) As[i] = F::ld(A + ((size_t)(i / K) * lda + (i % K)) * F::LIMBS);
+  __syncthreads();
+  SCL_GRID_STRIDE(q, npacks) {
+    const size_t off = q * VEC * F::LIMBS;
+    Pack<F, VEC> b[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) b[k] = load_pack<F, VEC, true>(B + (size_t)k * ldb * F::LIMBS + off);
+    for (int r = 0; r < M; ++r) {
+      MatAcc<F> acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v].zero();
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          const typename F::E a = As[r * K + k];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v].mac(ctx, a, b[k].v[v]);
+        }
+      }
+      Pack<F, VEC> y;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) y.v[v] = acc[v].fold(ctx);
+      store_pack<F, VEC, true>(C + (size_t)r * ldc * F::LIMBS + off, y);
+    }
+  }
+}
+
 // Matrix::multiply(Matrix) for any shape (matrix.h:477-495 is an unbounded i-k-j loop): C tile TM x TN per workgroup, K walked in
 // steps of TK through LDS (A tile row-major, B tile row-major), a thread owns RM x RN outputs -- rows ty*RM + r, columns
 // tx + 16*c, so that a wave's B reads and C stores run along consecutive columns -- each a lazy accumulator folded every

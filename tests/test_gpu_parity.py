@@ -1062,6 +1062,39 @@ def test_matmul_random_shapes_every_path(scl, port, f):
             assert np.array_equal(got, want), (f, M, K, N, mode)
 
 
+@pytest.mark.parametrize("f", ALL_FIELDS)
+@pytest.mark.parametrize("M,K,N", [(10, 4, 5001), (3, 16, 2049), (40, 8, 1500), (1, 1, 1024), (128, 7, 4097)])
+def test_matmul_thin_inner_dimension(scl, port, f, M, K, N):
+    """A Vandermonde-sized left factor against long coefficient rows (test_matrix.cc:342-365's way of sharing) through
+    k_matmul_thin -- B's rows in registers, 16-byte packs, odd tails -- against the oracle (a window of columns for the slow-oracle
+    fields), against the column-per-thread kernel ("force_table"), and as a window of wider matrices through the raw ABI."""
+    import ctypes as C
+    L = O.LIMBS[f]
+    A = rand_elems(port, f, M * K, b"thin-A").reshape(M, K, L)
+    B = rand_elems(port, f, K * N, b"thin-B").reshape(K, N, L)
+    A[0, 0] = B[0, 0] = B[K - 1, N - 1] = port.from_int(f, -1)
+    got = host(scl, scl.matmul(f, dev(scl, A), dev(scl, B)))
+    cols = list(range(N)) if f not in SLOW_ORACLE else sorted({0, 1, 2, 3, 255, 256, 257, N // 2, N - 2, N - 1})
+    assert np.array_equal(got[:, cols], port.matmul(f, A, np.ascontiguousarray(B[:, cols])))
+    scl.set_tuning("force_table", 1)
+    scl.set_tuning("mfma", -1)
+    try:
+        assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), got)
+    finally:
+        scl.set_tuning("force_table", 0)
+        scl.set_tuning("mfma", 0)
+    ldb, ldc = N + 3, N + 5      # odd pitches: the 8-byte path of the one-limb fields
+    Bw = torch.full((K, ldb, L), -1, dtype=torch.int64, device="cuda")
+    Bw[:, :N] = dev(scl, B)
+    Cw = torch.full((M, ldc, L), -1, dtype=torch.int64, device="cuda")
+    dA = dev(scl, A)
+    st = scl.lib.scl_hip_matmul(f, C.c_void_p(Cw.data_ptr()), C.c_size_t(ldc), C.c_void_p(dA.data_ptr()), C.c_size_t(K),
+                                C.c_void_p(Bw.data_ptr()), C.c_size_t(ldb), C.c_size_t(M), C.c_size_t(K), C.c_size_t(N), None)
+    assert st == 0, scl.lib.scl_hip_last_error()
+    hw = host(scl, Cw)
+    assert np.array_equal(hw[:, :N], got) and (hw[:, N:] == np.uint64(2 ** 64 - 1)).all()
+
+
 def test_vandermonde_matmul_is_sharing(scl, port):
     """test_matrix.cc:342-365: V(n, t+1) x coefficient matrix == Shamir shares at nodes 1..n"""
     f, L, n, t, N = O.M61, 1, 10, 3, 500

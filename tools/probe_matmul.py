@@ -42,7 +42,10 @@ run(M61, "Mersenne61", 128, 256, 4_000_000, 2, "matrix cores, 4 k-chunks")
 run(M61, "Mersenne61", 512, 512, 1_000_000, 2, "matrix cores, 4 x 8 blocks")
 run(M61, "Mersenne61", 512, 512, 1_000_000, 1, "matrix cores, general kernel")
 run(M61, "Mersenne61", 128, 43, 10_000_000, -1, "k_matmul (left factor in LDS)")
-run(M61, "Mersenne61", 10, 4, 100_000_000, -1, "k_matmul (10 x 4: HBM-bound)")
+run(M61, "Mersenne61", 10, 4, 100_000_000, -1, "k_matmul_thin (10 x 4: HBM-bound)")
+run(M61, "Mersenne61", 40, 14, 12_500_000, -1, "k_matmul_thin (40 x 14)")
+run(M127, "Mersenne127", 10, 4, 10_000_000, 0, "k_matmul_thin (10 x 4)")
+run(SECP, "secp256k1", 10, 4, 10_000_000, 0, "k_matmul_thin (10 x 4)")
 run(M61, "Mersenne61", 4096, 4096, 4096, -1, "k_matmul_tiled")
 run(M61, "Mersenne61", 4096, 4096, 4096, 2, "matrix cores, 32 x 64 blocks")
 run(M61, "Mersenne61", 4096, 4096, 4096, 1, "matrix cores, general kernel")
