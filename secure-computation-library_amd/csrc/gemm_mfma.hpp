@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_mfma_m61(u64* C, size_t ldc, co
       // instructions are issued (2048+ cycles of matrix pipe per step against ~1-2 us of L2 latency).  A third image -- two steps
       // ahead -- does not fit: 144 spills (round 5).
       auto fetch = [&](v4i (&af)[MF_LIMBS], v4i (&bf)[MF_LIMBS], size_t kt) {
+#if defined(GEMM_PROBE_NO_LOADS)  // tools/gemm_bench.hip: every step reads step 0's fragments (L1 hits): the matrix pipe's own ceiling
+        kt = 0;
+#endif
 #pragma unroll
         for (int l = 0; l < MF_LIMBS; ++l) {
           af[l] = a_tile[(kt * MF_LIMBS + l) * 64];
