@@ -1095,6 +1095,32 @@ def test_matmul_thin_inner_dimension(scl, port, f, M, K, N):
     assert np.array_equal(hw[:, :N], got) and (hw[:, N:] == np.uint64(2 ** 64 - 1)).all()
 
 
+@pytest.mark.parametrize("f,mode", [(O.M61, 1), (O.M61, -1), (O.M61, 0), (O.M127, 0), (O.SECP256K1_SCALAR, 0)])
+def test_matmul_on_windows_of_wider_matrices(scl, port, f, mode):
+    """scl_hip_matmul with row pitches beyond the matrices' widths on all three operands (lda > K, ldb > N, ldc > N: windows of
+    wider matrices, odd pitches) through the general matrix-core kernel, the tiled kernel and split-K's fallback: the product
+    against the oracle, the padding of C untouched."""
+    import ctypes as C
+    L = O.LIMBS[f]
+    M, K, N = (130, 700, 140) if f != O.SECP256K1_SCALAR else (40, 300, 36)
+    lda, ldb, ldc = K + 3, N + 5, N + 7
+    A = rand_elems(port, f, M * K, b"win-A").reshape(M, K, L)
+    B = rand_elems(port, f, K * N, b"win-B").reshape(K, N, L)
+    Aw = torch.full((M, lda, L), -1, dtype=torch.int64, device="cuda")
+    Bw = torch.full((K, ldb, L), -1, dtype=torch.int64, device="cuda")
+    Cw = torch.full((M, ldc, L), -1, dtype=torch.int64, device="cuda")
+    Aw[:, :K], Bw[:, :N] = dev(scl, A), dev(scl, B)
+    scl.set_tuning("mfma", mode)
+    try:
+        st = scl.lib.scl_hip_matmul(f, C.c_void_p(Cw.data_ptr()), C.c_size_t(ldc), C.c_void_p(Aw.data_ptr()), C.c_size_t(lda),
+                                    C.c_void_p(Bw.data_ptr()), C.c_size_t(ldb), C.c_size_t(M), C.c_size_t(K), C.c_size_t(N), None)
+    finally:
+        scl.set_tuning("mfma", 0)
+    assert st == 0, scl.lib.scl_hip_last_error()
+    hw = host(scl, Cw)
+    assert np.array_equal(hw[:, :N], port.matmul(f, A, B)) and (hw[:, N:] == np.uint64(2 ** 64 - 1)).all()
+
+
 def test_vandermonde_matmul_is_sharing(scl, port):
     """test_matrix.cc:342-365: V(n, t+1) x coefficient matrix == Shamir shares at nodes 1..n"""
     f, L, n, t, N = O.M61, 1, 10, 3, 500
