@@ -1,12 +1,14 @@
 // integration/binding_check.cc -- compiles integration/include/scl/hip/binding.h against the REAL reference
 // (/root/reference/include + its translation units, oracle/Makefile `binding`) and runs it on a GPU: reference Vector<FF> in
 // -> C ABI -> reference Vector<FF> out, compared with what the reference itself computes for the same inputs
-// (Vector::multiplyEntryWise, ss::shamirSecretShare on one PRG, ss::shamirRecoverP).  Exit code 0 iff everything agreed.
+// (Vector::multiplyEntryWise, ss::shamirSecretShare on one PRG, ss::shamirRecoverP, FF::inverse element by element,
+// Matrix::multiply).  Exit code 0 iff everything agreed.
 #include <cstdio>
 #include <string>
 
 #include "scl/hip/binding.h"
 #include "scl/math/fp.h"
+#include "scl/math/matrix.h"
 #include "scl/ss/shamir.h"
 #include "scl/util/prg.h"
 
@@ -56,6 +58,38 @@ static void run(const char* name, std::size_t N, std::size_t t, std::size_t n) {
   std::size_t bad2 = 0;
   for (std::size_t s = 0; s < N; s += 97) bad2 += !(ss::shamirRecoverP(dev_shares[s]) == a[s]);
   EXPECT(bad2 == 0);
+  // (4) every element's inverse: the batch call (simultaneous inversion on the GPU) against FF::inverse one by one (ff.h:225-231)
+  {
+    std::vector<FF> nz;
+    for (std::size_t s = 0; s < N; ++s) nz.push_back(a[s] == FF::zero() ? FF::one() : a[s]);
+    const math::Vector<FF> v(nz);
+    const auto inv = hip::inverseEntryWise<F>(v);
+    std::size_t bad3 = 0;
+    for (std::size_t s = 0; s < N; ++s) bad3 += !(inv[s] == v[s].inverse());
+    EXPECT(bad3 == 0);
+    bool threw0 = false;
+    try {
+      nz[N / 2] = FF::zero();
+      (void)hip::inverseEntryWise<F>(math::Vector<FF>(nz));
+    } catch (const std::logic_error& e) {
+      threw0 = std::string(e.what()) == "0 not invertible modulo prime";  // test_ff.cc:168-171
+    }
+    EXPECT(threw0);
+  }
+  // (5) Matrix::multiply with an inner dimension no LDS tile bounds, against the reference's own i-k-j loop (matrix.h:477-495)
+  {
+    const std::size_t M = 37, K = sizeof(FF) == 8 ? 7000 : 700, Nc = 41;
+    const auto A = math::Matrix<FF>::random(M, K, prg);
+    const auto B = math::Matrix<FF>::random(K, Nc, prg);
+    EXPECT(hip::multiply<F>(A, B).equals(A.multiply(B)));
+    bool threwm = false;
+    try {
+      (void)hip::multiply<F>(A, A);
+    } catch (const std::invalid_argument& e) {
+      threwm = std::string(e.what()) == "matmul: this->cols() != that->rows()";
+    }
+    EXPECT(threwm);
+  }
   std::printf("[%s] %s: %zu secrets, (n, t) = (%zu, %zu)\n", g_fail ? "FAIL" : " ok ", name, N, n, t);
 }
 

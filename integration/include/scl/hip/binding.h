@@ -27,6 +27,7 @@
 #include "scl/math/fields/secp256k1_field.h"
 #include "scl/math/fields/secp256k1_scalar.h"
 #include "scl/math/ff.h"
+#include "scl/math/matrix.h"
 #include "scl/math/vector.h"
 
 namespace scl::hip {
@@ -96,6 +97,41 @@ math::Vector<math::FF<F>> multiplyEntryWise(const math::Vector<math::FF<F>>& a, 
   std::vector<math::FF<F>> out(a.size());
   check(scl_hip_memcpy_d2h(out.data(), dc.p, bytes, nullptr));
   return out;
+}
+
+// every element's FF::inverse (include/scl/math/ff.h:225-231; throws like the reference when an element is zero) -- on the GPU one
+// inversion per chain of elements instead of one per element, the same unique inverses
+template <typename F>
+math::Vector<math::FF<F>> inverseEntryWise(const math::Vector<math::FF<F>>& a) {
+  const std::size_t bytes = a.byteSize();
+  DevBuf da(bytes), dc(bytes);
+  check(scl_hip_memcpy_h2d(da.p, a.toStlVector().data(), bytes, nullptr));
+  check(scl_hip_ew(FieldTag<F>::value, SCL_OP_INV, dc.u64(), da.u64(), nullptr, a.size(), nullptr));
+  std::vector<math::FF<F>> out(a.size());
+  check(scl_hip_memcpy_d2h(out.data(), dc.p, bytes, nullptr));
+  return out;
+}
+
+// Matrix<FF<F>>::multiply (include/scl/math/matrix.h:477-495) on the GPU: row-major FF elements are the C ABI's limbs as they are
+template <typename F>
+math::Matrix<math::FF<F>> multiply(const math::Matrix<math::FF<F>>& a, const math::Matrix<math::FF<F>>& b) {
+  using FF = math::FF<F>;
+  if (a.cols() != b.rows()) throw std::invalid_argument("matmul: this->cols() != that->rows()");
+  const std::size_t M = a.rows(), K = a.cols(), N = b.cols(), E = sizeof(FF);
+  std::vector<FF> ha, hb;
+  ha.reserve(M * K);
+  hb.reserve(K * N);
+  for (std::size_t i = 0; i < M; ++i)
+    for (std::size_t k = 0; k < K; ++k) ha.push_back(a(i, k));
+  for (std::size_t k = 0; k < K; ++k)
+    for (std::size_t j = 0; j < N; ++j) hb.push_back(b(k, j));
+  DevBuf da(M * K * E), db(K * N * E), dc(M * N * E);
+  check(scl_hip_memcpy_h2d(da.p, ha.data(), M * K * E, nullptr));
+  check(scl_hip_memcpy_h2d(db.p, hb.data(), K * N * E, nullptr));
+  check(scl_hip_matmul(FieldTag<F>::value, dc.u64(), N, da.u64(), K, db.u64(), N, M, K, N, nullptr));
+  std::vector<FF> hc(M * N);
+  check(scl_hip_memcpy_d2h(hc.data(), dc.p, M * N * E, nullptr));
+  return math::Matrix<FF>::fromVector(M, N, hc);
 }
 
 // ss::shamirSecretShare for N secrets on ONE prg, bit-identical to N sequential calls of include/scl/ss/shamir.h:52-68.

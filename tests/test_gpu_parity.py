@@ -1628,7 +1628,8 @@ def test_reference_binding_compiled_against_the_reference():
     static_asserts on sizeof / alignment / standard layout of FF<Mersenne61 | Mersenne127 | Secp256k1Scalar | Secp256k1Field>
     held at that build) and run here: reference Vector<FF> -> C ABI -> reference Vector<FF> equals the reference's own
     multiplyEntryWise, N sequential shamirSecretShare calls on one PRG, and shamirRecoverP.  The binary is built where the
-    reference is and travels like oracle/_ref/libscl_ref.so."""
+    reference is and travels like oracle/_ref/libscl_ref.so.  Round 5: the same binary also sends every element's FF::inverse and a Matrix::multiply
+    with an inner dimension of 7000 through the binding, against the reference's own element-by-element results."""
     import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", "binding_check")
     assert os.path.exists(exe), "oracle/_ref/binding_check is built by `make -C oracle binding` where /root/reference exists"
