@@ -764,8 +764,27 @@ def main():
                               "bytes_per_element": nb, "GBps": nb * N_ / mean / 1e6, "frac": nb * N_ / mean / 1e6 / HBM_PEAK_GBPS,
                               "bound": bound, "verified": ok}
                 ok_all = ok_all and ok
+            # the reference's own element-wise path on one host core beside it (oracle/_ref: Vector::add / multiplyEntryWise and
+            # FF::inverse element by element; the oracle port for GF(2^128), which the reference does not have), 10^6 elements
+            cpu = None
+            try:
+                n_cpu = min(N_, 1_000_000 if fkey != "gf2_128" else 20_000)
+                ca, cb = scl.to_host(a[:n_cpu]), scl.to_host(b[:n_cpu])
+                lib_, kind_ = port, "port"
+                if fkey != "gf2_128":
+                    try:
+                        lib_, kind_ = O.Ref(), "reference"
+                    except Exception:
+                        pass
+                cpu = {"kind": kind_, "cores": 1, "elements": n_cpu}
+                for name, op, two in (("add", O.ADD, True), ("mul", O.MUL, True), ("inv", O.INV, False)):
+                    t0_ = time.perf_counter()
+                    lib_.ew(f_, op, ca, cb if two else None)
+                    cpu[name + "_ns_per_element"] = (time.perf_counter() - t0_) * 1e9 / n_cpu
+            except Exception as e:
+                cpu = {"error": str(e)}
             rep["fields"][FIELD_NAMES[fkey]] = {"elements": N_, "dtype": {1: "u64", 2: "u128"}[L_], "warmup": warm, "launches": reps,
-                                                **legs, "verified": ok_all}
+                                                **legs, "cpu_reference": cpu, "verified": ok_all}
             del a, b, out
             torch.cuda.empty_cache()
         rep["verified"] = all(v["verified"] for v in rep["fields"].values())
@@ -1319,7 +1338,7 @@ def side_legs(line):
                 elif "verified" in obj:
                     legs[path] = bool(obj["verified"])
             for k, v in obj.items():
-                if k not in ("cpu_baseline", "verified_legs"):
+                if k not in ("cpu_baseline", "cpu_reference", "verified_legs"):
                     walk(v, f"{path}.{k}" if path else k)
     walk(line, "")
     return legs, errors
