@@ -1190,8 +1190,8 @@ int ew_inverse(const typename F::Ctx& ctx, bool div, u64* dst, const u64* a, con
     if (vec == 2 && n >= 2) {
       const size_t npacks = n / 2, tiles = (npacks + (size_t)BLOCK * 16 - 1) / ((size_t)BLOCK * 16);
       const dim3 g(grid_for_block(tiles, 1)), blk(BLOCK);
-      if (div) hipLaunchKernelGGL((k_ew_inv<F, true, 2, 16, true>), g, blk, 0, st, ctx, dst, a, b, npacks, flag);
-      else hipLaunchKernelGGL((k_ew_inv<F, false, 2, 16, true>), g, blk, 0, st, ctx, dst, a, b, npacks, flag);
+      if (div) hipLaunchKernelGGL((k_ew_inv<F, true, 2, 16, 4, 3>), g, blk, 0, st, ctx, dst, a, b, npacks, flag);
+      else hipLaunchKernelGGL((k_ew_inv<F, false, 2, 16, 4, 3>), g, blk, 0, st, ctx, dst, a, b, npacks, flag);
       LAUNCH_CHECK();
       if (n & 1) {  // the odd element out
         const size_t o = n - 1;

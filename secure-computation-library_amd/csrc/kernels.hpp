@@ -180,62 +180,116 @@ __global__ __launch_bounds__(BLOCK) void k_ew(typename F::Ctx ctx, u64* dst, con
 // 3 (L - 1) products and one inversion for L elements where k_ew<F, 4 | 5> spends 70 (Mersenne61) to 380 (secp256k1) products
 // on each.  A zero sets the flag and goes through the chain as a one; its slot gets 0, which is what F::inv(0) returns.
 // A workgroup owns BLOCK * R consecutive packs, lane l the packs l, l + BLOCK, ...: every access is a whole line.
-template <class F, bool DIV, int VEC, int R, bool NT>
-__global__ __launch_bounds__(BLOCK) void k_ew_inv(typename F::Ctx ctx, u64* dst, const u64* a, const u64* b, size_t npacks,
-                                                  unsigned* zero_flag) {
+// Register discipline (what took the kernel from 214 to 168 registers and from 2 to 3 waves per SIMD, +12 %): the loads go
+// G packs at a time between scheduling barriers; a full tile is straight-line code; the zero mask is pinned after every group;
+// the pack indices are recomputed where they are used (lane_now).  KEEP = false keeps only the prefix products and reads the
+// operand a second time on the walk back (the tile is still in L2 / the memory-side cache): half the registers per slot, so L
+// can double -- measured equal to KEEP at best (profiles/r5_ew_bench_grouped.txt), kept for the record.
+
+// the lane's index through an empty asm: what is computed from the result cannot be hoisted out of the enclosing loop, so the 3 R
+// pack indices of a tile are one add each where they are used, not 3 R registers (or 64-bit addresses) alive across the kernel
+__device__ __forceinline__ unsigned lane_now(unsigned l) {
+  asm volatile("" : "+v"(l));
+  return l;
+}
+
+template <class F, bool DIV, int VEC, int R, int G, bool FULL, bool KEEP>
+__device__ __forceinline__ void ew_inv_tile(const typename F::Ctx& ctx, u64* out, const u64* numer, const u64* src, unsigned rem,
+                                                   unsigned* zero_flag) {
   typedef typename F::E E;
   constexpr int L = R * VEC;
-  const u64* src = DIV ? b : a;  // the operand that is inverted
-  for (size_t tile = blockIdx.x; tile * ((size_t)BLOCK * R) < npacks; tile += gridDim.x) {
-    const size_t q0 = tile * ((size_t)BLOCK * R) + threadIdx.x;
-    E x[L], c[L];
-    unsigned zmask = 0;  // which slots held a zero (L <= 32)
+  constexpr unsigned PW = VEC * F::LIMBS;  // words per pack
+  const unsigned l = threadIdx.x;
+  E c[L];
+  E xk[KEEP ? L : 1];  // KEEP: the operand stays in registers too (no second read, twice the registers per slot)
+  unsigned zm[2] = {0u, 0u};  // which slots held a zero
+  // G packs in flight at a time: left alone the scheduler hoists every load of the tile to the top and the registers are gone.
+  // (A full tile is straight-line code -- no branch around a load or a store -- or the barriers mean nothing: the products sink
+  // into the blocks of their uses.)
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const size_t q = q0 + (size_t)r * BLOCK;
-      Pack<F, VEC> pk;
-      if (q < npacks) {
-        pk = load_pack<F, VEC, NT>(src + q * VEC * F::LIMBS);
-      } else {
+  for (int r0 = 0; r0 < R; r0 += G) {
+    Pack<F, VEC> pk[G];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) pk.v[v] = F::one(ctx);
+    for (int g = 0; g < G; ++g) {
+      const unsigned q = lane_now(l) + (unsigned)(r0 + g) * BLOCK;
+      const unsigned qc = FULL ? q : (q < rem ? q : rem - 1);  // past the end: the tile's last pack, dropped below
+      pk[g] = load_pack<F, VEC, KEEP>(src + qc * PW);  // streaming unless it is read again below
+      if (!FULL && q >= rem) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) pk[g].v[v] = F::one(ctx);
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const bool z = F::is_zero(pk.v[v]);
-        zmask |= z ? (1u << (r * VEC + v)) : 0u;
-        x[r * VEC + v] = z ? F::one(ctx) : pk.v[v];
+        const int i = (r0 + g) * VEC + v;
+        const bool z = F::is_zero(pk[g].v[v]);
+        zm[i >> 5] |= z ? (1u << (i & 31)) : 0u;
+        const E x = z ? F::one(ctx) : pk[g].v[v];
+        if constexpr (KEEP) xk[i] = x;
+        if (i == 0) c[0] = x;
+        else c[i] = F::mul(ctx, c[i - 1], x);
       }
     }
-    if (zmask) raise_flag(zero_flag);
-    c[0] = x[0];
+    // the mask is final for this group here: without this the sixty-four tests are re-associated into one tree at the end of
+    // the pass and every operand stays in its registers until then
+    asm volatile("" : "+v"(zm[0]), "+v"(zm[1]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  E inv = F::inv(ctx, c[L - 1]);
 #pragma unroll
-    for (int i = 1; i < L; ++i) c[i] = F::mul(ctx, c[i - 1], x[i]);
-    E inv = F::inv(ctx, c[L - 1]);
+  for (int r0 = R - G; r0 >= 0; r0 -= G) {
+    Pack<F, VEC> pk[G], num[G];
 #pragma unroll
-    for (int i = L - 1; i > 0; --i) {
-      const E o = F::mul(ctx, inv, c[i - 1]);
-      inv = F::mul(ctx, inv, x[i]);
-      x[i] = o;
-    }
-    x[0] = inv;
+    for (int g = 0; g < G; ++g) {
+      const unsigned q = lane_now(l) + (unsigned)(r0 + g) * BLOCK;
+      const unsigned qc = FULL ? q : (q < rem ? q : rem - 1);
+      if constexpr (!KEEP) {
+        pk[g] = load_pack<F, VEC, true>(src + qc * PW);
+        if (!FULL && q >= rem) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const size_t q = q0 + (size_t)r * BLOCK;
-      if (q < npacks) {
-        Pack<F, VEC> o;
-        Pack<F, VEC> num;
-        if constexpr (DIV) num = load_pack<F, VEC, NT>(a + q * VEC * F::LIMBS);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const int i = r * VEC + v;
-          E y = ((zmask >> i) & 1u) ? F::zero() : x[i];
-          if constexpr (DIV) y = F::mul(ctx, num.v[v], y);
-          o.v[v] = y;
+          for (int v = 0; v < VEC; ++v) pk[g].v[v] = F::one(ctx);
         }
-        store_pack<F, VEC, NT>(dst + q * VEC * F::LIMBS, o);
       }
+      if constexpr (DIV) num[g] = load_pack<F, VEC, true>(numer + qc * PW);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = G - 1; g >= 0; --g) {
+      const unsigned q = lane_now(l) + (unsigned)(r0 + g) * BLOCK;
+      Pack<F, VEC> o;
+#pragma unroll
+      for (int v = VEC - 1; v >= 0; --v) {
+        const int i = (r0 + g) * VEC + v;
+        const bool z = (zm[i >> 5] >> (i & 31)) & 1u;
+        E y = i > 0 ? F::mul(ctx, inv, c[i - 1]) : inv;
+        if (i > 0) inv = F::mul(ctx, inv, KEEP ? xk[i] : (z ? F::one(ctx) : pk[g].v[v]));
+        if (z) y = F::zero();
+        if constexpr (DIV) y = F::mul(ctx, num[g].v[v], y);
+        o.v[v] = y;
+      }
+      if (FULL || q < rem) store_pack<F, VEC, true>(out + q * PW, o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (zm[0] | zm[1]) raise_flag(zero_flag);
+}
+
+template <class F, bool DIV, int VEC, int R, int G = (R < 4 ? R : 4), int WAVES = 2, bool KEEP = true>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_ew_inv(typename F::Ctx ctx, u64* dst, const u64* a, const u64* b, size_t npacks,
+                                                         unsigned* zero_flag) {
+  static_assert(R * VEC <= 64 && R % G == 0, "one bit of the zero mask per slot; whole groups of loads");
+  constexpr unsigned PW = VEC * F::LIMBS;
+  for (size_t tile = blockIdx.x; tile * ((size_t)BLOCK * R) < npacks; tile += gridDim.x) {
+    // a uniform base per tile and 32-bit pack indices below it
+    const size_t t0 = tile * ((size_t)BLOCK * R);
+    const u64* src = (DIV ? b : a) + t0 * PW;
+    if (npacks - t0 >= (size_t)BLOCK * R)
+      ew_inv_tile<F, DIV, VEC, R, G, true, KEEP>(ctx, dst + t0 * PW, a + t0 * PW, src, BLOCK * R, zero_flag);
+    else
+      ew_inv_tile<F, DIV, VEC, R, G, false, KEEP>(ctx, dst + t0 * PW, a + t0 * PW, src, (unsigned)(npacks - t0), zero_flag);
   }
 }
 

@@ -72,13 +72,31 @@ static void run_batch(const char* name, typename F::Ctx ctx, u64* out, const u64
   const size_t tiles = (npacks + (size_t)BLOCK * R - 1) / ((size_t)BLOCK * R);
   CK(hipMemset(out, 0xAB, n * F::LIMBS * 8));
   CK(hipMemset(flag, 0, 4));
-  auto launch = [&] { hipLaunchKernelGGL((k_ew_inv<F, DIV, VEC, R, true>), dim3((unsigned)tiles), dim3(BLOCK), 0, 0, ctx, out, a, b, npacks, flag); };
+  auto launch = [&] { hipLaunchKernelGGL((k_ew_inv<F, DIV, VEC, R>), dim3((unsigned)tiles), dim3(BLOCK), 0, 0, ctx, out, a, b, npacks, flag); };
   const double ms = time_ms(launch);
   unsigned h = 0;
   CK(hipMemcpy(&h, flag, 4, hipMemcpyDeviceToHost));
   const size_t d = diff_words(out, ref, n * F::LIMBS);
   const double E = F::LIMBS * 8.0;
   std::printf("%-8s %s batch L=%2d  %8.3f ms  %7.2f G/s  %6.0f GB/s  x%.1f vs per-element  flag=%u  diff=%zu\n", name, DIV ? "div" : "inv", R * VEC, ms,
+              n / ms / 1e6, (DIV ? 3 : 2) * E * n / ms / 1e6, base_ms / ms, h, d);
+  std::fflush(stdout);
+}
+
+template <class F, bool DIV, int VEC, int R, int W = 2, int G = 4, bool KEEP = false>
+static void run_reread(const char* name, typename F::Ctx ctx, u64* out, const u64* ref, const u64* a, const u64* b, size_t n, unsigned* flag,
+                       double base_ms) {
+  const size_t npacks = n / VEC;
+  const size_t tiles = (npacks + (size_t)BLOCK * R - 1) / ((size_t)BLOCK * R);
+  CK(hipMemset(out, 0xAB, n * F::LIMBS * 8));
+  CK(hipMemset(flag, 0, 4));
+  auto launch = [&] { hipLaunchKernelGGL((k_ew_inv<F, DIV, VEC, R, G, W, KEEP>), dim3((unsigned)tiles), dim3(BLOCK), 0, 0, ctx, out, a, b, npacks, flag); };
+  const double ms = time_ms(launch);
+  unsigned h = 0;
+  CK(hipMemcpy(&h, flag, 4, hipMemcpyDeviceToHost));
+  const size_t d = diff_words(out, ref, n * F::LIMBS);
+  const double E = F::LIMBS * 8.0;
+  std::printf("%-8s %s %s L=%2d W=%d G=%d  %8.3f ms  %7.2f G/s  %6.0f GB/s  x%.1f vs per-element  flag=%u  diff=%zu\n", name, DIV ? "div" : "inv", KEEP ? "grouped" : "reread", R * VEC, W, G, ms,
               n / ms / 1e6, (DIV ? 3 : 2) * E * n / ms / 1e6, base_ms / ms, h, d);
   std::fflush(stdout);
 }
@@ -111,12 +129,41 @@ static void run_field(const char* name, typename F::Ctx ctx, size_t n) {
       run_batch<F, true, VEC, 4>(name, ctx, out, ref, a, b, n, flag, base);
       run_batch<F, true, VEC, 8>(name, ctx, out, ref, a, b, n, flag, base);
       if constexpr (F::LIMBS <= 2) run_batch<F, true, VEC, 16>(name, ctx, out, ref, a, b, n, flag, base);
+      if constexpr (std::is_same<F, M61>::value || std::is_same<F, M127>::value) {
+        run_reread<F, true, VEC, 16, 3>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, true, VEC, 32, 2>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, true, VEC, 16, 3, 4, true>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, true, VEC, 8, 4, 4, true>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, true, VEC, 8, 3, 4, true>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, true, VEC, 12, 3, 4, true>(name, ctx, out, ref, a, b, n, flag, base);
+      }
     } else {
       run_batch<F, false, VEC, 2>(name, ctx, out, ref, a, b, n, flag, base);
       run_batch<F, false, VEC, 4>(name, ctx, out, ref, a, b, n, flag, base);
       run_batch<F, false, VEC, 8>(name, ctx, out, ref, a, b, n, flag, base);
       if constexpr (F::LIMBS <= 2) run_batch<F, false, VEC, 16>(name, ctx, out, ref, a, b, n, flag, base);
       if constexpr (F::LIMBS == 2 || VEC == 1) run_batch<F, false, VEC, 32>(name, ctx, out, ref, a, b, n, flag, base);
+      if constexpr (std::is_same<F, M61>::value) {
+        run_reread<F, false, VEC, 16, 4>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 16, 3>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 16, 4, 8>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 24, 3>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 32, 3>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 32, 3, 8>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 32, 2>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 16, 3, 4, true>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 16, 2, 4, true>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 8, 4, 4, true>(name, ctx, out, ref, a, b, n, flag, base);
+      }
+      if constexpr (std::is_same<F, M127>::value) {
+        run_reread<F, false, VEC, 16, 3, 4, true>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 16, 2, 4, true>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 16, 4>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 16, 3>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 24, 3>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 32, 2>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 32, 3>(name, ctx, out, ref, a, b, n, flag, base);
+      }
     }
   }
   CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(ref)); CK(hipFree(out)); CK(hipFree(flag));
