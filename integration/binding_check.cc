@@ -2,13 +2,14 @@
 // (/root/reference/include + its translation units, oracle/Makefile `binding`) and runs it on a GPU: reference Vector<FF> in
 // -> C ABI -> reference Vector<FF> out, compared with what the reference itself computes for the same inputs
 // (Vector::multiplyEntryWise, ss::shamirSecretShare on one PRG, ss::shamirRecoverP, FF::inverse element by element,
-// Matrix::multiply).  Exit code 0 iff everything agreed.
+// Matrix::multiply, Vector::dot / sum, ss::additiveShare on one PRG, ss::shamirRecoverD).  Exit code 0 iff everything agreed.
 #include <cstdio>
 #include <string>
 
 #include "scl/hip/binding.h"
 #include "scl/math/fp.h"
 #include "scl/math/matrix.h"
+#include "scl/ss/additive.h"
 #include "scl/ss/shamir.h"
 #include "scl/util/prg.h"
 
@@ -89,6 +90,49 @@ static void run(const char* name, std::size_t N, std::size_t t, std::size_t n) {
       threwm = std::string(e.what()) == "matmul: this->cols() != that->rows()";
     }
     EXPECT(threwm);
+  }
+  // (6) Vector::dot and Vector::sum (vector.h:252-267)
+  EXPECT(hip::dot<F>(a, b) == a.dot(b));
+  EXPECT(hip::sum<F>(a) == a.sum());
+  // (7) additive sharing of N secrets on one PRG against N sequential ss::additiveShare calls (additive.h:41-53); every sharing
+  // sums back to its secret
+  {
+    auto add_prg = util::PRG::create(seed.data(), seed.size());
+    const auto dev_add = hip::additiveShare<F>(a, n, seed, /*counter=*/0);
+    std::size_t bad4 = 0;
+    for (std::size_t s = 0; s < N; ++s) {
+      const auto want_s = ss::additiveShare(a[s], n, add_prg);
+      bad4 += !dev_add[s].equals(want_s);
+      if (s % 89 == 0) bad4 += !(dev_add[s].sum() == a[s]);
+    }
+    EXPECT(dev_add.size() == N && bad4 == 0);
+  }
+  // (8) error detection: shares of degree t among n = 2t + 1 parties, every 53rd sharing with one share changed; the batch call
+  // flags exactly the secrets at which ss::shamirRecoverD(shares, t) throws (shamir.h:116-154) and opens the others
+  {
+    const std::size_t nd = 2 * t + 1;
+    auto d_prg = util::PRG::create("binding-check-detect");
+    std::vector<math::Vector<FF>> sh;
+    for (std::size_t s = 0; s < N; ++s) {
+      auto v = ss::shamirSecretShare(a[s], t, nd, d_prg).toStlVector();
+      if (s % 53 == 7) v[(s / 53) % nd] += FF(1);
+      sh.emplace_back(v);
+    }
+    std::vector<unsigned char> flagged;
+    const auto opened_d = hip::shamirRecoverD<F>(sh, t, &flagged);
+    std::size_t bad5 = 0;
+    for (std::size_t s = 0; s < N; ++s) {
+      bool threw_d = false;
+      FF want_d;
+      try {
+        want_d = ss::shamirRecoverD(sh[s], t);
+      } catch (const std::logic_error& e) {
+        threw_d = std::string(e.what()) == "error detected during recovery";
+      }
+      bad5 += (threw_d != (flagged[s] != 0));
+      if (!threw_d) bad5 += !(opened_d[s] == want_d);
+    }
+    EXPECT(bad5 == 0);
   }
   std::printf("[%s] %s: %zu secrets, (n, t) = (%zu, %zu)\n", g_fail ? "FAIL" : " ok ", name, N, n, t);
 }

@@ -191,6 +191,78 @@ math::Vector<math::FF<F>> shamirRecoverP(const std::vector<math::Vector<math::FF
   return out;
 }
 
+// Vector::dot / innerProd (include/scl/math/vector.h:45-52,252-255) and Vector::sum (:261-267) on the GPU
+template <typename F>
+math::FF<F> dot(const math::Vector<math::FF<F>>& a, const math::Vector<math::FF<F>>& b) {
+  if (a.size() != b.size()) throw std::invalid_argument("Vec sizes mismatch");
+  const std::size_t bytes = a.byteSize();
+  DevBuf da(bytes), db(bytes);
+  check(scl_hip_memcpy_h2d(da.p, a.toStlVector().data(), bytes, nullptr));
+  check(scl_hip_memcpy_h2d(db.p, b.toStlVector().data(), bytes, nullptr));
+  math::FF<F> out;
+  check(scl_hip_dot(FieldTag<F>::value, reinterpret_cast<uint64_t*>(&out), da.u64(), db.u64(), a.size(), nullptr));
+  return out;
+}
+
+template <typename F>
+math::FF<F> sum(const math::Vector<math::FF<F>>& a) {
+  DevBuf da(a.byteSize());
+  check(scl_hip_memcpy_h2d(da.p, a.toStlVector().data(), a.byteSize(), nullptr));
+  math::FF<F> out;
+  check(scl_hip_sum(FieldTag<F>::value, reinterpret_cast<uint64_t*>(&out), da.u64(), a.size(), nullptr));
+  return out;
+}
+
+// ss::additiveShare (include/scl/ss/additive.h:41-53) for N secrets on ONE prg, bit-identical to N sequential calls (each of the
+// n - 1 random shares is one FF::random = one AES block, ff.h:72-76); one Vector of n shares per secret out
+template <typename F>
+std::vector<math::Vector<math::FF<F>>> additiveShare(const math::Vector<math::FF<F>>& secrets, std::size_t n,
+                                                     const std::array<unsigned char, 16>& seed, std::uint64_t counter = 0) {
+  using FF = math::FF<F>;
+  const std::size_t N = secrets.size(), E = sizeof(FF);
+  DevBuf ds(N * E), dsh(n * N * E), daos(n * N * E);
+  check(scl_hip_memcpy_h2d(ds.p, secrets.toStlVector().data(), N * E, nullptr));
+  check(scl_hip_additive_share_prg(FieldTag<F>::value, dsh.u64(), N, ds.u64(), N, n, seed.data(), seed.size(), counter, nullptr));
+  check(scl_hip_soa_to_aos(FieldTag<F>::value, daos.u64(), dsh.u64(), N, N, n, nullptr));
+  std::vector<FF> flat(n * N);
+  check(scl_hip_memcpy_d2h(flat.data(), daos.p, n * N * E, nullptr));
+  std::vector<math::Vector<FF>> out;
+  out.reserve(N);
+  for (std::size_t s = 0; s < N; ++s) out.emplace_back(flat.begin() + s * n, flat.begin() + (s + 1) * n);
+  return out;
+}
+
+// ss::shamirRecoverD(shares, t) (include/scl/ss/shamir.h:116-154) for N secrets: the batch call reports the secrets whose shares
+// are inconsistent in `bad` (the reference throws "error detected during recovery" at each of them) and opens the others
+template <typename F>
+math::Vector<math::FF<F>> shamirRecoverD(const std::vector<math::Vector<math::FF<F>>>& shares, std::size_t t,
+                                         std::vector<unsigned char>* bad) {
+  using FF = math::FF<F>;
+  const std::size_t N = shares.size(), n = N ? shares[0].size() : 0, E = sizeof(FF);
+  std::vector<FF> flat;
+  flat.reserve(n * N);
+  for (const auto& v : shares) {
+    if (v.size() != n) throw std::invalid_argument("Vec sizes mismatch");
+    flat.insert(flat.end(), v.begin(), v.end());
+  }
+  DevBuf daos(n * N * E), dsoa(n * N * E), dout(N * E), dstatus(N);
+  check(scl_hip_memcpy_h2d(daos.p, flat.data(), n * N * E, nullptr));
+  check(scl_hip_aos_to_soa(FieldTag<F>::value, dsoa.u64(), N, daos.u64(), N, n, nullptr));
+  std::size_t nbad = 0;
+  const int st = scl_hip_shamir_recover_detect(FieldTag<F>::value, dout.u64(), static_cast<unsigned char*>(dstatus.p), dsoa.u64(), N, n,
+                                               N, t, t, nullptr, nullptr, &nbad, nullptr);
+  if (st != SCL_OK && st != SCL_ERR_ERROR_DETECTED) check(st);
+  std::vector<FF> out(N);
+  check(scl_hip_memcpy_d2h(out.data(), dout.p, N * E, nullptr));
+  if (bad) {
+    bad->resize(N);
+    check(scl_hip_memcpy_d2h(bad->data(), dstatus.p, N, nullptr));
+  } else if (nbad) {
+    throw std::logic_error("error detected during recovery");
+  }
+  return out;
+}
+
 }  // namespace scl::hip
 
 #endif  // SCL_HIP_BINDING_H
