@@ -104,7 +104,10 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-live", type=int, default=1,
                     help="1: roofline.traffic observed in THIS run -- two child runs of the headline under rocprofv3 --pmc FETCH_SIZE / "
                          "WRITE_SIZE after everything else (one GPU, BASELINE configs[1] only; falls back to profiles/pmc_traffic.json)")
-    ap.add_argument("--inject-error", default="", choices=["", "c_abi"],
+    ap.add_argument("--side-timeout", type=float, default=600.0,
+                    help="multi-rank runs: seconds the legs after the headline (RCCL through torch and through the C ABI) may take "
+                         "before rank 0 writes the line with what it has and every rank exits (0 = no limit)")
+    ap.add_argument("--inject-error", default="", choices=["", "c_abi", "hang"],
                     help="tests only: make the named side leg fail, to see the line report it and the exit code follow")
     return ap.parse_args(argv)
 
@@ -1186,54 +1189,82 @@ def main():
     del secrets, coeffs, shares, out, src, dst, sets
     torch.cuda.empty_cache()
 
+    def headline_line(rccl):
+        rec_bytes = (n + 1) * E            # n shares in, 1 secret out            
+        share_bytes = (1 + t) * E + n * E if args.share_mode == "coeffs" else E + n * E
+        kernels = {
+            "shamir_recover": {"ms": rec_ms, "bytes_per_secret": rec_bytes, "GBps": rec_bytes * N / (rec_ms * 1e-3) / 1e9},
+            "shamir_share": {"ms": share_ms, "bytes_per_secret": share_bytes,
+                             "GBps": share_bytes * N / (share_ms * 1e-3) / 1e9},
+        }
+        dom = "shamir_share" if share_ms >= rec_ms else "shamir_recover"
+        ach = kernels[dom]["GBps"]
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args),
+                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes run by the builder over this command, stamped "
+                                      "with a hash of the kernel sources; null once they differ) -- not observed by this run",
+                    "algorithmic_bytes": kernels[dom]["bytes_per_secret"] * N,
+                    "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": ach / copy_gbps}
+        if dom == "shamir_share" and args.share_mode == "coeffs" and on_matrix_cores(args.field, n, t):
+            # --config c5: the dominant kernel runs on the matrix cores; its HBM-equivalent figures stay beside the matrix roofline
+            hbm = roofline
+            roofline = mfma_share_roofline(n, t, N, share_ms)
+            roofline["traffic"] = hbm["traffic"]
+            if roofline["traffic"] is None and (n, t, N) == (128, 42, 125_000_000):
+                # the stamped PMC run measured this very launch as its side configuration C5 (same kernel, same shard size)
+                side = pmc_config_traffic("C5_shard_mersenne61_128_42")
+                roofline["traffic"] = side["share"] if side else None
+            roofline["hbm_equivalent"] = {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes")}
+        total = pl["total"] * args.steps       # c2: N per GPU x ranks; c5: BASELINE's total, split over the ranks
+        line = {
+            "metric": "shamir_reconstructions_per_sec", "value": total / elapsed, "unit": "reconstructions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_by_rank": [1e3 * x / args.steps for x in rank_elapsed], "rccl": rccl,
+            "higher_is_better": True, "scaling": pl["scaling"], "vs_baseline": None,
+            "dtype": {1: "u64", 2: "u128", 4: "u256"}[L], "data": "synthetic",
+            "config": {"workload": pl["workload"],
+                       "field": FIELD_NAMES[args.field], "n": n, "t": t, "secrets_per_gpu": N, "total_secrets": pl["total"],
+                       "share_mode": args.share_mode, "layout": "SoA [party][secret]",
+                       "allocation": f"plain; the steps rotate over {nsets} independently allocated operand set(s)",
+                       "parallelism": pl["parallelism"]},
+            "roofline": roofline, "kernels": kernels, "by_allocation": by_alloc, "verified": verified,
+            "reconstruct_only_per_s": N * world / (rec_ms * 1e-3), "share_only_per_s": N * world / (share_ms * 1e-3),
+        }
+        return line, roofline, kernels, dom
+
+    # The multi-rank legs below run RCCL through torch and through the C ABI -- code no one-GPU box can rehearse with real RCCL.
+    # If one of them never returns, the headline measured above must not be lost with it: after --side-timeout seconds rank 0
+    # writes the line with what it has (the missing legs as errors) and every rank leaves.
+    watchdog = None
+    if world > 1 and args.side_timeout > 0:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                why = f"no result after {args.side_timeout:g} s: the process was ended by bench.py's own watchdog"
+                early, _, _, _ = headline_line({"error": why})
+                early["open"] = {"error": why}
+                legs, errors = side_legs(early)
+                early["verified_headline"], early["verified"], early["verified_legs"], early["errors"] = verified, False, legs, errors
+                emit(early)
+                print("bench.py: " + why, file=sys.stderr)
+            os._exit(3)
+        # (the other ranks leave a little later: a launcher that sees a worker die ends the rest, rank 0's line must be out by then)
+        watchdog = threading.Timer(args.side_timeout + (0 if rank == 0 else 5), give_up)
+        watchdog.daemon = True
+        watchdog.start()
     rccl = rccl_report()                                 # (collective: every rank)
+    if args.inject_error == "hang" and rank == world - 1:
+        time.sleep(10 ** 6)                              # (test: a rank that never reaches the collectives)
     open_rep = open_report() if args.open else None      # every rank takes part in the collectives
+    if watchdog is not None:
+        watchdog.cancel()
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-
-    rec_bytes = (n + 1) * E            # n shares in, 1 secret out            
-    share_bytes = (1 + t) * E + n * E if args.share_mode == "coeffs" else E + n * E
-    kernels = {
-        "shamir_recover": {"ms": rec_ms, "bytes_per_secret": rec_bytes, "GBps": rec_bytes * N / (rec_ms * 1e-3) / 1e9},
-        "shamir_share": {"ms": share_ms, "bytes_per_secret": share_bytes,
-                         "GBps": share_bytes * N / (share_ms * 1e-3) / 1e9},
-    }
-    dom = "shamir_share" if share_ms >= rec_ms else "shamir_recover"
-    ach = kernels[dom]["GBps"]
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args),
-                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes run by the builder over this command, stamped "
-                                  "with a hash of the kernel sources; null once they differ) -- not observed by this run",
-                "algorithmic_bytes": kernels[dom]["bytes_per_secret"] * N,
-                "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": ach / copy_gbps}
-    if dom == "shamir_share" and args.share_mode == "coeffs" and on_matrix_cores(args.field, n, t):
-        # --config c5: the dominant kernel runs on the matrix cores; its HBM-equivalent figures stay beside the matrix roofline
-        hbm = roofline
-        roofline = mfma_share_roofline(n, t, N, share_ms)
-        roofline["traffic"] = hbm["traffic"]
-        if roofline["traffic"] is None and (n, t, N) == (128, 42, 125_000_000):
-            # the stamped PMC run measured this very launch as its side configuration C5 (same kernel, same shard size)
-            side = pmc_config_traffic("C5_shard_mersenne61_128_42")
-            roofline["traffic"] = side["share"] if side else None
-        roofline["hbm_equivalent"] = {k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes")}
-    total = pl["total"] * args.steps       # c2: N per GPU x ranks; c5: BASELINE's total, split over the ranks
-    line = {
-        "metric": "shamir_reconstructions_per_sec", "value": total / elapsed, "unit": "reconstructions/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "ms_per_step_by_rank": [1e3 * x / args.steps for x in rank_elapsed], "rccl": rccl,
-        "higher_is_better": True, "scaling": pl["scaling"], "vs_baseline": None,
-        "dtype": {1: "u64", 2: "u128", 4: "u256"}[L], "data": "synthetic",
-        "config": {"workload": pl["workload"],
-                   "field": FIELD_NAMES[args.field], "n": n, "t": t, "secrets_per_gpu": N, "total_secrets": pl["total"],
-                   "share_mode": args.share_mode, "layout": "SoA [party][secret]",
-                   "allocation": f"plain; the steps rotate over {nsets} independently allocated operand set(s)",
-                   "parallelism": pl["parallelism"]},
-        "roofline": roofline, "kernels": kernels, "by_allocation": by_alloc, "verified": verified,
-        "reconstruct_only_per_s": N * world / (rec_ms * 1e-3), "share_only_per_s": N * world / (share_ms * 1e-3),
-    }
+    line, roofline, kernels, dom = headline_line(rccl)
     if open_rep is not None:
         line["open"] = open_rep
     if world == 1 and args.configs and pl["key"] == "c2":

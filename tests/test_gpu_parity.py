@@ -2131,6 +2131,30 @@ def test_bench_two_ranks_rehearsal_on_one_device(scl):
     assert len(line["by_allocation"]) == 2      # two timed steps on the first two of the three operand sets
 
 
+def test_bench_line_survives_a_rank_that_never_reaches_the_open_step(scl):
+    """The legs after the headline are collectives; real multi-rank RCCL runs only on the driver's node.  A rank that never
+    arrives (--inject-error hang: the last rank sleeps before the open step) must not cost the headline: after --side-timeout
+    seconds rank 0 writes the line with the headline it measured and the missing leg as an error, and every rank exits."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCL_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--secrets", "1000000",
+                        "--open-secrets", "100000", "--open-chunk", "32768", "--configs", "0", "--cpu-sample", "0", "--steps", "2",
+                        "--warmup", "1", "--inject-error", "hang", "--side-timeout", "20"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stderr[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["verified_headline"] is True and line["verified"] is False
+    assert "watchdog" in line["open"]["error"] and any("watchdog" in e for e in line["errors"])
+    assert line["roofline"]["frac"] > 0 and len(line["ms_per_step_by_rank"]) == 2
+
+
 @pytest.mark.parametrize("config,extra,check", [
     ("c4", ["--total-secrets", "100000", "--open-chunk", "32768"],
      lambda ln: ln["scaling"] == "strong" and ln["config"]["total_secrets"] == 100000 and ln["config"]["parallelism"] == "parties2"
