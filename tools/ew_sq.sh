@@ -35,7 +35,7 @@ for ln in open("/tmp/ew_sq_rows.txt"):
     tag, c, v = ln.rstrip("\n").split("\t")
     rows[tag][c] = float(v)
 print("\n# derived (SQ_ACTIVE_INST_* count instructions on this chip, like SQ_INSTS_*; GRBM_GUI_ACTIVE is summed over the 8 XCDs):")
-print("# cycles = GUI / 8; per SIMD: instructions / 1024; an LDS instruction here is a 64-lane ds_read_b128 / ds_write_b128 = 1 KiB")
+print("# cycles = GUI / 8; per SIMD: instructions / 1024; an LDS instruction here is a 64-lane ds_read_b128 (4 cycles of the pipe) or ds_write_b128 (11-14, profiles/r4_ldsbank.txt) = 1 KiB")
 for tag, r in rows.items():
     if "SQ_INSTS_VALU" in r and "GRBM_GUI_ACTIVE" in r:
         cyc = r["GRBM_GUI_ACTIVE"] / 8
