@@ -148,7 +148,9 @@ def _dev_rows(t: torch.Tensor):
     if not t.is_cuda:
         raise SclError(ERR_BAD_ARG, "tensor is not on the GPU")
     rows, N, L = t.shape
-    if N and (t.stride(2) != 1 or t.stride(1) != L or (rows > 1 and (t.stride(0) % L or t.stride(0) < N * L))):
+    # (the stride of a dimension of extent 1 means nothing: a [rows][1][L] view of a transposed array carries any value there)
+    if N and ((L > 1 and t.stride(2) != 1) or (N > 1 and t.stride(1) != L) or
+              (rows > 1 and (t.stride(0) % L or t.stride(0) < N * L))):
         raise SclError(ERR_BAD_ARG, "share matrix rows must be dense (a row pitch is allowed)")
     return C.c_void_p(t.data_ptr()), (t.stride(0) // L if rows > 1 else max(N, 1))
 

@@ -2131,6 +2131,19 @@ def test_bench_two_ranks_rehearsal_on_one_device(scl):
     assert len(line["by_allocation"]) == 2      # two timed steps on the first two of the three operand sets
 
 
+def test_share_matrix_of_one_secret_from_a_transposed_array(scl, port):
+    """Found by tools/fuzz_abi.py: a [m][1][L] share matrix made by transposing the reference's [1][m][L] layout keeps the
+    source's stride in its dimension of extent 1; the harness took that for a non-dense row and refused the call."""
+    for f in (O.M61, O.M127, O.SECP256K1_SCALAR):
+        L = O.LIMBS[f]
+        m = 7
+        aos = rand_elems(port, f, m, b"one-secret").reshape(1, m, L)
+        t = scl.to_device(np.ascontiguousarray(aos.transpose(1, 0, 2)))
+        assert np.array_equal(host(scl, scl.shamir_recover(f, t)), port.shamir_recover(f, aos))
+        view = scl.to_device(aos).permute(1, 0, 2)          # the same bytes as a strided torch view
+        assert np.array_equal(host(scl, scl.shamir_recover(f, view)), port.shamir_recover(f, aos))
+
+
 def test_bench_line_survives_a_rank_that_never_reaches_the_open_step(scl):
     """The legs after the headline are collectives; real multi-rank RCCL runs only on the driver's node.  A rank that never
     arrives (--inject-error hang: the last rank sleeps before the open step) must not cost the headline: after --side-timeout

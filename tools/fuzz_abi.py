@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the batch entry points against the CPU oracle (oracle/scl_oracle.c through tests/oracle_lib.py) on the
+GPU box: random field, entry point, sizes (0, 1, odd, tile edges +-1), party counts, thresholds, zeros planted in inverse
+operands, in-place outputs.  Test infrastructure like tests/: prints one line per mismatch with the seed that reproduces it and
+a summary; exit code 1 if anything differed.
+
+    python3 tools/fuzz_abi.py [seconds=240] [seed=1]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "secure-computation-library_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import scl_amd as scl  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+FIELDS = [scl.M61, scl.M127, scl.MONT128, scl.GF2_128, scl.SECP256K1_SCALAR, scl.SECP256K1_FIELD]
+EDGES = [0, 1, 2, 3, 63, 64, 65, 127, 255, 256, 257, 511, 512, 513, 1023, 1025, 4095, 4096, 4097, 8191, 8193, 16385, 65537]
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    port = O.Port()
+    scl.set_mont128_prime(2 ** 128 - 159)
+    port.mont128_set_prime(2 ** 128 - 159)
+    rng = np.random.default_rng(seed0)
+    t_end = time.time() + budget
+    runs, bad, by_kind, secs = 0, 0, {}, {}
+
+    def size(cap):
+        r = rng.random()
+        if r < 0.5:
+            return int(min(cap, EDGES[rng.integers(len(EDGES))]))
+        return int(rng.integers(0, cap + 1))
+
+    def rand(f, n, tag):
+        return port.vector_random(f, b"fuzz-%d-%s" % (runs, tag), n) if n else np.zeros((0, scl.limbs(f)), dtype=np.uint64)
+
+    def dev(a):
+        return scl.to_device(np.ascontiguousarray(a))
+
+    def report(kind, detail):
+        nonlocal bad
+        bad += 1
+        print(f"MISMATCH {kind}: {detail} (run {runs}, seed {seed0})", flush=True)
+
+    while time.time() < t_end:
+        runs += 1
+        f = FIELDS[rng.integers(len(FIELDS))]
+        L = scl.limbs(f)
+        slow = L == 4 or f in (scl.MONT128, scl.GF2_128)   # Fermat / bit-serial oracle arithmetic
+        kind = ["ew", "inv", "scalar", "dotsum", "shamir", "recover_at", "additive", "matmul", "layout", "detect"][rng.integers(10)]
+        by_kind[kind] = by_kind.get(kind, 0) + 1
+        t_case = time.time()
+        try:
+            if kind == "ew":
+                n = size(70000)
+                op = [scl.ADD, scl.SUB, scl.MUL, scl.NEG][rng.integers(4)]
+                a, b = rand(f, n, b"a"), rand(f, n, b"b")
+                want = port.ew(f, {scl.ADD: O.ADD, scl.SUB: O.SUB, scl.MUL: O.MUL, scl.NEG: O.NEG}[op], a, None if op == scl.NEG else b)
+                if n == 0:
+                    continue
+                da, db = dev(a), dev(b)
+                inplace = rng.random() < 0.3
+                got = scl.ew(f, op, da, None if op == scl.NEG else db, out=da if inplace else None)
+                if not np.array_equal(scl.to_host(got), want):
+                    report(kind, f"field {f} op {op} n {n} inplace {inplace}")
+            elif kind == "inv":
+                n = size(700 if slow else 40000)
+                if n == 0:
+                    continue
+                a, b = rand(f, n, b"a"), rand(f, n, b"b")
+                div = rng.random() < 0.5
+                zeros = rng.random() < 0.3
+                tgt = b if div else a
+                tgt[(tgt == 0).all(axis=1)] = port.from_int(f, 1)
+                want_err = False
+                if zeros:
+                    idx = rng.integers(0, n, size=min(n, 3))
+                    tgt[idx] = 0
+                    want_err = True
+                if want_err:
+                    keep = np.ones(n, dtype=bool)
+                    keep[idx] = False
+                    safe = tgt.copy()
+                    safe[idx] = port.from_int(f, 1)
+                    want = port.ew(f, O.DIV if div else O.INV, a if div else safe, safe if div else None)
+                    want[idx] = 0
+                else:
+                    want = port.ew(f, O.DIV if div else O.INV, a, b if div else None)
+                da, db = dev(a), dev(b)
+                inplace = rng.random() < 0.3
+                out = (db if div else da) if inplace else scl.empty(f, n)
+                err = False
+                try:
+                    scl.ew(f, scl.DIV if div else scl.INV, da, db if div else None, out=out)
+                except scl.SclError as e:
+                    err = "0 not invertible" in str(e)
+                if err != want_err or not np.array_equal(scl.to_host(out), want):
+                    report(kind, f"field {f} div {div} n {n} zeros {zeros} inplace {inplace} err {err}")
+            elif kind == "scalar":
+                n = size(50000)
+                if n == 0:
+                    continue
+                a, s = rand(f, n, b"a"), rand(f, 1, b"s")
+                want = port.scalar_mul(f, a, s[0])
+                got = scl.scalar_mul(f, dev(a), s[0])
+                if not np.array_equal(scl.to_host(got), want):
+                    report(kind, f"field {f} n {n}")
+            elif kind == "dotsum":
+                n = size(50000)
+                a, b = rand(f, n, b"a"), rand(f, n, b"b")
+                if n == 0:
+                    continue
+                if not np.array_equal(np.asarray(scl.dot(f, dev(a), dev(b))).reshape(-1), np.asarray(port.dot(f, a, b)).reshape(-1)):
+                    report(kind, f"dot field {f} n {n}")
+                if not np.array_equal(np.asarray(scl.vsum(f, dev(a))).reshape(-1), np.asarray(port.sum(f, a)).reshape(-1)):
+                    report(kind, f"sum field {f} n {n}")
+            elif kind == "shamir":
+                N = max(1, size(600 if slow else 5000))
+                n = int(rng.integers(1, 70 if not slow else 24))
+                t = int(rng.integers(0, n))
+                secrets = rand(f, N, b"s")
+                sd = b"fuzz-seed-%d" % runs
+                got = scl.shamir_share_prg(f, dev(secrets), t, n, sd)
+                back = scl.shamir_recover(f, got)
+                if f == scl.GF2_128:
+                    # the oracle walks the reference's x++ over the nodes, which in characteristic 2 alternates 1, 0, 1, ..: the
+                    # library shares GF(2^128) at the bit patterns 1..n (tests/test_gpu_parity.py); checked by the round trip
+                    if not np.array_equal(scl.to_host(back), secrets):
+                        report(kind, f"round trip field {f} N {N} n {n} t {t}")
+                else:
+                    want = port.shamir_share(f, sd, secrets, t, n)           # [N][n][L]: one Vector of n shares per secret
+                    if not np.array_equal(scl.to_host(got).transpose(1, 0, 2), np.asarray(want).reshape(N, n, L)):
+                        report(kind, f"share_prg field {f} N {N} n {n} t {t}")
+                    want_back = port.shamir_recover(f, np.asarray(want).reshape(N, n, L))
+                    if not np.array_equal(scl.to_host(back), np.asarray(want_back).reshape(N, L)):
+                        report(kind, f"recover field {f} N {N} n {n} t {t}")
+            elif kind == "recover_at":
+                N = max(1, size(40 if slow else 400))
+                m = int(rng.integers(1, 30 if not slow else 12))
+                shares = rand(f, N * m, b"sh").reshape(N, m, L)
+                nodes = port.vector_random(f, b"fuzz-nodes-%d" % runs, m + 1)
+                if len({tuple(r) for r in nodes.tolist()}) != m + 1:
+                    continue
+                x = nodes[m]
+                want = port.shamir_recover_at(f, shares, nodes[:m], x)
+                lam = scl.lagrange_basis(f, m, alphas=nodes[:m], x=x)
+                got = scl.shamir_recover(f, dev(np.ascontiguousarray(shares.transpose(1, 0, 2))), lam)
+                if not np.array_equal(scl.to_host(got), np.asarray(want).reshape(N, L)):
+                    report(kind, f"field {f} N {N} m {m}")
+            elif kind == "additive":
+                N = max(1, size(5000))
+                n = int(rng.integers(1, 40))
+                secrets = rand(f, N, b"s")
+                sd = b"fuzz-add-%d" % runs
+                want = np.asarray(port.additive_share(f, sd, secrets, n)).reshape(N, n, L)
+                got = scl.additive_share_prg(f, dev(secrets), n, sd)
+                if not np.array_equal(scl.to_host(got).transpose(1, 0, 2), want):
+                    report(kind, f"share field {f} N {N} n {n}")
+                if not np.array_equal(scl.to_host(scl.additive_recover(f, got)), secrets):
+                    report(kind, f"recover field {f} N {N} n {n}")
+            elif kind == "matmul":
+                cap = 24 if slow else 90
+                M, K, N = int(rng.integers(1, cap)), int(rng.integers(0, cap * 3)), int(rng.integers(1, cap))
+                if rng.random() < 0.2:
+                    N = 1
+                A, B = rand(f, M * K, b"A").reshape(M, K, L), rand(f, K * N, b"B").reshape(K, N, L)
+                want = np.asarray(port.matmul(f, A, B)).reshape(M, N, L) if K else np.zeros((M, N, L), dtype=np.uint64)
+                got = scl.matmul(f, dev(A) if K else scl.empty(f, M, 0), dev(B) if K else scl.empty(f, 0, N))
+                if not np.array_equal(scl.to_host(got), want):
+                    report(kind, f"field {f} M {M} K {K} N {N}")
+            elif kind == "layout":
+                N, n = max(1, size(5000)), int(rng.integers(1, 50))
+                aos = rand(f, N * n, b"l").reshape(N, n, L)
+                soa = scl.aos_to_soa(f, dev(aos))
+                if not np.array_equal(scl.to_host(soa), aos.transpose(1, 0, 2)):
+                    report(kind, f"aos_to_soa field {f} N {N} n {n}")
+                if not np.array_equal(scl.to_host(scl.soa_to_aos(f, soa)), aos):
+                    report(kind, f"soa_to_aos field {f} N {N} n {n}")
+            elif kind == "detect":
+                if f == scl.GF2_128:
+                    continue               # (the oracle's sharing has no usable nodes in characteristic 2, see above)
+                t = int(rng.integers(1, 9 if not slow else 5))
+                n = 2 * t + 1
+                N = max(1, size(300 if slow else 2000))
+                secrets = rand(f, N, b"s")
+                sh = np.asarray(port.shamir_share(f, b"fuzz-det-%d" % runs, secrets, t, n)).reshape(N, n, L).copy()
+                hit = rng.random(N) < 0.1
+                for s in np.nonzero(hit)[0]:
+                    j = int(rng.integers(n))
+                    sh[s, j] = port.ew(f, O.ADD, sh[s, j:j + 1], port.from_int(f, 1).reshape(1, L))[0]
+                out, status = scl.shamir_recover_detect(f, dev(np.ascontiguousarray(sh.transpose(1, 0, 2))), t)[:2]
+                st = status.cpu().numpy().reshape(-1).astype(bool)
+                want_val, want_st = port.shamir_recover_d(f, sh, t)
+                want_bad = np.asarray(want_st).astype(bool)
+                if not np.array_equal(st, want_bad) or not np.array_equal(scl.to_host(out)[~want_bad], want_val[~want_bad]):
+                    report(kind, f"field {f} N {N} t {t}")
+        except Exception as e:  # an exception the oracle did not raise too is a finding
+            report(kind, f"field {f}: {type(e).__name__}: {e}")
+        secs[kind] = secs.get(kind, 0.0) + time.time() - t_case
+    torch.cuda.synchronize()
+    print(f"fuzz_abi: {runs} cases in {budget:g} s, {bad} mismatches; by kind {by_kind}; seconds by kind { {k: round(v, 1) for k, v in secs.items()} }", flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
