@@ -55,7 +55,9 @@ def main():
         f = FIELDS[rng.integers(len(FIELDS))]
         L = scl.limbs(f)
         slow = L == 4 or f in (scl.MONT128, scl.GF2_128)   # Fermat / bit-serial oracle arithmetic
-        kind = ["ew", "inv", "scalar", "dotsum", "shamir", "recover_at", "additive", "matmul", "layout", "detect"][rng.integers(10)]
+        KINDS = ["ew", "inv", "scalar", "dotsum", "shamir", "recover_at", "additive", "matmul", "layout", "detect",
+                 "coeffs", "correct", "wire", "vdm", "matmul_big", "ring", "inv_big"]
+        kind = KINDS[rng.integers(len(KINDS))]
         by_kind[kind] = by_kind.get(kind, 0) + 1
         t_case = time.time()
         try:
@@ -202,6 +204,137 @@ def main():
                 want_bad = np.asarray(want_st).astype(bool)
                 if not np.array_equal(st, want_bad) or not np.array_equal(scl.to_host(out)[~want_bad], want_val[~want_bad]):
                     report(kind, f"field {f} N {N} t {t}")
+            elif kind == "coeffs":
+                # explicit coefficients, custom nodes, the share matrix a window of a wider one (row pitch > N)
+                N = max(1, size(300 if slow else 3000))
+                n = int(rng.integers(1, 50 if not slow else 14))
+                t = int(rng.integers(0, min(n, 24 if not slow else 8)))
+                secrets = rand(f, N, b"s")
+                coeffs = rand(f, t * N, b"c").reshape(N, t, L)
+                nodes = port.vector_random(f, b"fuzz-cn-%d" % runs, n)
+                if len({tuple(r) for r in nodes.tolist()}) != n or (nodes == 0).all(axis=1).any():
+                    continue
+                want = np.stack([port.poly_eval(f, np.concatenate([secrets[s_:s_ + 1], coeffs[s_]]), nodes) for s_ in range(N)])
+                dco = dev(np.ascontiguousarray(coeffs.transpose(1, 0, 2))) if t else None
+                pitch = N + int(rng.integers(0, 9)) * 2
+                wide = scl.empty(f, n, pitch)
+                out = scl.shamir_share(f, dev(secrets), dco, n, alphas=nodes, out=None)
+                if not np.array_equal(scl.to_host(out).transpose(1, 0, 2), want):
+                    report(kind, f"share field {f} N {N} n {n} t {t}")
+                wide[:, :N] = out
+                lam = scl.lagrange_basis(f, n, alphas=nodes)
+                back = scl.shamir_recover(f, wide[:, :N], lam)
+                if not np.array_equal(scl.to_host(back), secrets):
+                    report(kind, f"recover through a pitched window field {f} N {N} n {n} t {t} pitch {pitch}")
+            elif kind == "correct":
+                if f == scl.GF2_128:
+                    continue
+                t = int(rng.integers(1, 6 if not slow else 3))
+                n = 3 * t + 1 + int(rng.integers(0, 3))
+                N = max(1, size(60 if slow else 600))
+                secrets = rand(f, N, b"s")
+                sh = np.asarray(port.shamir_share(f, b"fuzz-bw-%d" % runs, secrets, t, n)).reshape(N, n, L).copy()
+                for s_ in np.nonzero(rng.random(N) < 0.3)[0]:
+                    for j in rng.choice(n, size=int(rng.integers(1, t + 2)), replace=False):   # up to t + 1 errors: some uncorrectable
+                        sh[s_, j] = port.ew(f, O.ADD, sh[s_, j:j + 1], port.from_int(f, int(rng.integers(1, 99))).reshape(1, L))[0]
+                fo, eo, st, ne = port.shamir_recover_c(f, sh)
+                r = scl.shamir_recover_correct(f, dev(np.ascontiguousarray(sh.transpose(1, 0, 2))))
+                st_g = r["status"].cpu().numpy().astype(bool)
+                ok = np.array_equal(st_g, np.asarray(st).astype(bool))
+                good = ~np.asarray(st).astype(bool)
+                ok = ok and np.array_equal(scl.to_host(r["f"]).transpose(1, 0, 2)[good], np.asarray(fo)[good])
+                ok = ok and np.array_equal(scl.to_host(r["err"]).transpose(1, 0, 2)[good], np.asarray(eo)[good])
+                ok = ok and np.array_equal(r["nerr"].cpu().numpy()[good], np.asarray(ne)[good].astype(np.int32))
+                if not ok:
+                    report(kind, f"field {f} N {N} n {n} t {t}")
+            elif kind == "wire":
+                n = size(5000)
+                a = rand(f, n, b"w")
+                img = port.wire_vector(f, a)
+                got = scl.wire_pack(f, dev(a) if n else scl.empty(f, 0))
+                if bytes(got.cpu().numpy().tobytes()) != img:
+                    report(kind, f"wire_pack field {f} n {n}")
+                back = scl.wire_unpack(f, got)
+                if n and not np.array_equal(scl.to_host(back), a):
+                    report(kind, f"wire_unpack field {f} n {n}")
+                fr = port.frame(f, a)
+                gfr = scl.frame_pack(f, dev(a) if n else scl.empty(f, 0))
+                if bytes(gfr.cpu().numpy().tobytes()) != fr:
+                    report(kind, f"frame_pack field {f} n {n}")
+                rows, cols = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+                mat = rand(f, rows * cols, b"wm").reshape(rows, cols, L)
+                if bytes(scl.wire_pack_matrix(f, dev(mat)).cpu().numpy().tobytes()) != port.wire_matrix(f, mat):
+                    report(kind, f"wire_pack_matrix field {f} {rows}x{cols}")
+            elif kind == "vdm":
+                n, m = int(rng.integers(1, 60 if not slow else 16)), int(rng.integers(1, 40 if not slow else 12))
+                xs = rand(f, n, b"x") if rng.random() < 0.5 else None
+                if f == scl.GF2_128 and xs is None:
+                    continue
+                want = port.vandermonde(f, n, m, xs)
+                got = scl.vandermonde(f, n, m, xs)
+                if not np.array_equal(scl.to_host(got), want):
+                    report(kind, f"field {f} n {n} m {m} xs {xs is not None}")
+            elif kind == "matmul_big":
+                # Mersenne61 through every matmul path: the matrix cores (one tile, row blocks, k chunks, the general kernel) and the
+                # vector-ALU kernels, picked by the shape or pinned by the tuning knob
+                M, K, N = int(rng.integers(1, 200)), int(rng.integers(1, 1200)), int(rng.integers(1, 300))
+                if rng.random() < 0.3:
+                    N = int(rng.integers(4096, 9000))
+                    M, K = int(rng.integers(1, 130)), int(rng.integers(1, 70))
+                A, B = rand(scl.M61, M * K, b"A").reshape(M, K, 1), rand(scl.M61, K * N, b"B").reshape(K, N, 1)
+                want = np.asarray(port.matmul(scl.M61, A, B)).reshape(M, N, 1)
+                mode = int(rng.integers(-1, 3))
+                scl.set_tuning("mfma", mode)
+                try:
+                    got = scl.matmul(scl.M61, dev(A), dev(B))
+                finally:
+                    scl.set_tuning("mfma", 0)
+                if not np.array_equal(scl.to_host(got), want):
+                    report(kind, f"M {M} K {K} N {N} mode {mode}")
+            elif kind == "ring":
+                # Z2k<K>: every width; additive sharing and the matrix product are what the reference runs over rings
+                bits = int(rng.integers(1, 129))
+                fr_ = scl.Z2K(bits)
+                Lr, bs = scl.limbs(fr_), O.byte_size(fr_)
+                n = max(1, size(20000))
+                raw = port.prg(b"fuzz-ring-%d" % runs, [2 * n * bs])
+                a, b = port.from_bytes(fr_, raw[: n * bs]), port.from_bytes(fr_, raw[n * bs:])
+                op = [scl.ADD, scl.SUB, scl.MUL, scl.NEG][rng.integers(4)]
+                want = port.ew(fr_, {scl.ADD: O.ADD, scl.SUB: O.SUB, scl.MUL: O.MUL, scl.NEG: O.NEG}[op], a, None if op == scl.NEG else b)
+                got = scl.ew(fr_, op, dev(a), None if op == scl.NEG else dev(b))
+                if not np.array_equal(scl.to_host(got), want):
+                    report(kind, f"Z2k<{bits}> op {op} n {n}")
+                odd = a.copy()
+                odd[:, 0] |= np.uint64(1)
+                if not np.array_equal(scl.to_host(scl.ew(fr_, scl.DIV, dev(b), dev(odd))), port.ew(fr_, O.DIV, b, odd)):
+                    report(kind, f"Z2k<{bits}> divide n {n}")
+                if not np.array_equal(np.asarray(scl.dot(fr_, dev(a), dev(b))).reshape(-1), np.asarray(port.dot(fr_, a, b)).reshape(-1)):
+                    report(kind, f"Z2k<{bits}> dot n {n}")
+                nn = int(rng.integers(1, 20))
+                sec = a[: min(n, 700)]
+                sd = b"fuzz-radd-%d" % runs
+                want = np.asarray(port.additive_share(fr_, sd, sec, nn)).reshape(sec.shape[0], nn, Lr)
+                got = scl.additive_share_prg(fr_, dev(sec), nn, sd)
+                if not np.array_equal(scl.to_host(got).transpose(1, 0, 2), want):
+                    report(kind, f"Z2k<{bits}> additive_share_prg N {sec.shape[0]} n {nn}")
+                M_, K_, N_ = int(rng.integers(1, 30)), int(rng.integers(1, 60)), int(rng.integers(1, 80))
+                rawm = port.prg(b"fuzz-rm-%d" % runs, [(M_ * K_ + K_ * N_) * bs])
+                A_ = port.from_bytes(fr_, rawm[: M_ * K_ * bs]).reshape(M_, K_, Lr)
+                B_ = port.from_bytes(fr_, rawm[M_ * K_ * bs:]).reshape(K_, N_, Lr)
+                if not np.array_equal(scl.to_host(scl.matmul(fr_, dev(A_), dev(B_))), np.asarray(port.matmul(fr_, A_, B_)).reshape(M_, N_, Lr)):
+                    report(kind, f"Z2k<{bits}> matmul {M_}x{K_}x{N_}")
+            elif kind == "inv_big":
+                if rng.random() < 0.9:
+                    continue               # (a few seconds of oracle each: one in ten)
+                # sizes at which the chained inversion picks its longer chains (n >= L * 64 * 4096); the fast-oracle fields only
+                fb = [scl.M61, scl.M127][rng.integers(2)]
+                n = int(rng.integers(1_000_000, 9_000_000))
+                a = port.vector_random(fb, b"fuzz-ib-%d" % runs, n)
+                a[(a == 0).all(axis=1)] = port.from_int(fb, 1)
+                want = port.ew(fb, O.INV, a)
+                got = scl.ew(fb, scl.INV, dev(a))
+                if not np.array_equal(scl.to_host(got), want):
+                    report(kind, f"field {fb} n {n}")
         except Exception as e:  # an exception the oracle did not raise too is a finding
             report(kind, f"field {f}: {type(e).__name__}: {e}")
         secs[kind] = secs.get(kind, 0.0) + time.time() - t_case
