@@ -43,7 +43,13 @@ def main():
         return port.vector_random(f, b"fuzz-%d-%s" % (runs, tag), n) if n else np.zeros((0, scl.limbs(f)), dtype=np.uint64)
 
     def dev(a):
-        return scl.to_device(np.ascontiguousarray(a))
+        a = np.ascontiguousarray(a)
+        if a.ndim == 2 and a.shape[1] == 1 and a.shape[0] and rng.random() < 0.3:
+            # a Mersenne61 vector that starts 8 bytes into a 16-byte pack (legal: elements are 8-byte aligned): the kernels must take
+            # their one-element-per-lane forms
+            wide = scl.to_device(np.concatenate([np.zeros((1, 1), dtype=np.uint64), a]))
+            return wide[1:]
+        return scl.to_device(a)
 
     def report(kind, detail):
         nonlocal bad
