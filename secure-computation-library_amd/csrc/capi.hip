@@ -1288,6 +1288,7 @@ int scl_hip_memset(void* dev, int value, size_t bytes, void* stream) {
   return SCL_OK;
 }
 int scl_hip_stream_create(void** stream) {
+  if (!stream) return fail(SCL_ERR_BAD_ARG, "stream is NULL");
   hipStream_t s;
   HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   *stream = s;
@@ -1306,6 +1307,7 @@ struct SclTimer {
   hipEvent_t a, b;
 };
 int scl_hip_timer_create(void** timer) {
+  if (!timer) return fail(SCL_ERR_BAD_ARG, "timer is NULL");
   SclTimer* t = new SclTimer;
   hipError_t e = hipEventCreate(&t->a);
   if (e == hipSuccess) e = hipEventCreate(&t->b);
@@ -1325,15 +1327,18 @@ int scl_hip_timer_destroy(void* timer) {
   return SCL_OK;
 }
 int scl_hip_timer_start(void* timer, void* stream) {
+  if (!timer) return fail(SCL_ERR_BAD_ARG, "timer is NULL");
   HIP_TRY(hipEventRecord(static_cast<SclTimer*>(timer)->a, S(stream)));
   return SCL_OK;
 }
 int scl_hip_timer_stop(void* timer, void* stream) {
+  if (!timer) return fail(SCL_ERR_BAD_ARG, "timer is NULL");
   HIP_TRY(hipEventRecord(static_cast<SclTimer*>(timer)->b, S(stream)));
   return SCL_OK;
 }
 int scl_hip_timer_elapsed_ms(void* timer, float* ms) {
   SclTimer* t = static_cast<SclTimer*>(timer);
+  if (!t || !ms) return fail(SCL_ERR_BAD_ARG, "timer or ms is NULL");
   HIP_TRY(hipEventSynchronize(t->b));
   HIP_TRY(hipEventElapsedTime(ms, t->a, t->b));
   return SCL_OK;
@@ -1388,13 +1393,17 @@ int scl_hip_set_tuning(const char* key, long value) {
   return SCL_OK;
 }
 
-int scl_hip_mont128_set_prime(const uint64_t p[2]) { return mont_set(((u128)p[1] << 64) | p[0]); }
+int scl_hip_mont128_set_prime(const uint64_t p[2]) {
+  if (!p) return fail(SCL_ERR_BAD_ARG, "p is NULL");
+  return mont_set(((u128)p[1] << 64) | p[0]);
+}
 int scl_hip_mont128_relatch(void) {
   std::lock_guard<std::mutex> lk(g_mont_default_mu);
   mont_latch_locked();
   return SCL_OK;
 }
 int scl_hip_mont128_get_prime(uint64_t p[2]) {
+  if (!p) return fail(SCL_ERR_BAD_ARG, "p is NULL");
   const Mont128::Ctx c = mont_ctx();
   p[0] = (u64)c.p;
   p[1] = (u64)(c.p >> 64);

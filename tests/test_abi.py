@@ -120,6 +120,25 @@ def test_mont128_default_latch_goes_stale_loudly(scl):
         scl.set_mont128_prime(p0)
 
 
+def test_null_handles_are_an_error_not_a_crash(scl):
+    """the small host-side entry points check their pointers before they touch the runtime: a NULL handle or output is
+    SCL_ERR_BAD_ARG with a message, never a dereference"""
+    lib = scl.lib
+    bad = 3  # SCL_ERR_BAD_ARG
+    null = C.c_void_p(None)
+    ms = C.c_float(0)
+    assert lib.scl_hip_timer_start(null, null) == bad and b"NULL" in lib.scl_hip_last_error()
+    assert lib.scl_hip_timer_stop(null, null) == bad
+    assert lib.scl_hip_timer_elapsed_ms(null, C.byref(ms)) == bad
+    assert lib.scl_hip_timer_create(null) == bad
+    assert lib.scl_hip_timer_destroy(null) == 0          # like free(NULL)
+    assert lib.scl_hip_stream_create(null) == bad
+    assert lib.scl_hip_mont128_set_prime(null) == bad
+    assert lib.scl_hip_mont128_get_prime(null) == bad
+    assert lib.scl_hip_malloc(null, C.c_size_t(16)) == bad
+    assert lib.scl_hip_comm_destroy(null) == 0
+
+
 def test_batch_calls_fail_loudly_without_a_gpu(scl):
     import torch
     if torch.cuda.is_available():
