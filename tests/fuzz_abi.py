@@ -4,7 +4,7 @@ GPU box: random field, entry point, sizes (0, 1, odd, tile edges +-1), party cou
 operands, in-place outputs.  Test infrastructure like tests/: prints one line per mismatch with the seed that reproduces it and
 a summary; exit code 1 if anything differed.
 
-    python3 tools/fuzz_abi.py [seconds=240] [seed=1]
+    python3 tests/fuzz_abi.py [seconds=240] [seed=1]
 """
 import os
 import sys
@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "secure-computation-library_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))     # oracle_lib: the oracle is for tests/ only, and so is this file
 import torch  # noqa: E402
 import scl_amd as scl  # noqa: E402
 import oracle_lib as O  # noqa: E402
@@ -56,8 +56,12 @@ def main():
         bad += 1
         print(f"MISMATCH {kind}: {detail} (run {runs}, seed {seed0})", flush=True)
 
+    t_note = time.time() + 60
     while time.time() < t_end:
         runs += 1
+        if time.time() > t_note:       # a line a minute: a silent GPU job is taken for a hung one
+            print(f"fuzz_abi: {runs} cases so far, {bad} mismatches", flush=True)
+            t_note = time.time() + 60
         f = FIELDS[rng.integers(len(FIELDS))]
         L = scl.limbs(f)
         slow = L == 4 or f in (scl.MONT128, scl.GF2_128)   # Fermat / bit-serial oracle arithmetic

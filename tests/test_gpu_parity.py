@@ -2131,8 +2131,21 @@ def test_bench_two_ranks_rehearsal_on_one_device(scl):
     assert len(line["by_allocation"]) == 2      # two timed steps on the first two of the three operand sets
 
 
+def test_differential_fuzz_of_the_entry_points_for_twenty_seconds(scl):
+    """tests/fuzz_abi.py (random field / entry point / sizes / parties / thresholds / zeros / in-place / unaligned operands
+    against the CPU oracle) with a fixed seed: a regression net under the hand-picked cases above.  The campaigns behind
+    profiles/r5_fuzz_abi.txt ran it for minutes per seed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_abi.py"), "20", "2024"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert " 0 mismatches" in r.stdout and "MISMATCH" not in r.stdout
+
+
 def test_share_matrix_of_one_secret_from_a_transposed_array(scl, port):
-    """Found by tools/fuzz_abi.py: a [m][1][L] share matrix made by transposing the reference's [1][m][L] layout keeps the
+    """Found by tests/fuzz_abi.py: a [m][1][L] share matrix made by transposing the reference's [1][m][L] layout keeps the
     source's stride in its dimension of extent 1; the harness took that for a non-dense row and refused the call."""
     for f in (O.M61, O.M127, O.SECP256K1_SCALAR):
         L = O.LIMBS[f]
