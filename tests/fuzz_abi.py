@@ -23,6 +23,16 @@ FIELDS = [scl.M61, scl.M127, scl.MONT128, scl.GF2_128, scl.SECP256K1_SCALAR, scl
 EDGES = [0, 1, 2, 3, 63, 64, 65, 127, 255, 256, 257, 511, 512, 513, 1023, 1025, 4095, 4096, 4097, 8191, 8193, 16385, 65537]
 
 
+# tuning knobs (scl_hip_set_tuning) and the values the library documents for them; defaults in KNOB_DEFAULTS
+KNOBS = {"force_table": [1, 2], "prg_two_pass": [-1, 1], "nontemporal": [0], "force_scalar": [1], "stream_block": [256],
+         "stream_waves": [0, 4, 8], "share_waves": [0, 6, 12], "share_waves128": [0, 8, 16], "max_blocks": [1, 7, 300],
+         "gf_tiles": [0], "mfma": [-1, 1, 2], "mfma_areg": [0], "mfma_pipe": [0, 1], "inv_batch": [-1, 8, 16, 32, 64, 128],
+         "transpose_tile": [64, 128, 256], "gemm_slab_mib": [1, 4], "aes_blocks": [1, 64], "prg_t3": [0]}
+KNOB_DEFAULTS = {"force_table": 0, "prg_two_pass": 0, "nontemporal": 1, "force_scalar": 0, "stream_block": 64, "stream_waves": -1,
+                 "share_waves": 9, "share_waves128": 12, "max_blocks": 0, "gf_tiles": 1, "mfma": 0, "mfma_areg": 1, "mfma_pipe": 2,
+                 "inv_batch": 0, "transpose_tile": 0, "gemm_slab_mib": 0, "aes_blocks": 0, "prg_t3": 1}
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -31,7 +41,7 @@ def main():
     port.mont128_set_prime(2 ** 128 - 159)
     rng = np.random.default_rng(seed0)
     t_end = time.time() + budget
-    runs, bad, by_kind, secs = 0, 0, {}, {}
+    runs, bad, by_kind, secs, by_knob = 0, 0, {}, {}, {}
 
     def size(cap):
         r = rng.random()
@@ -54,7 +64,7 @@ def main():
     def report(kind, detail):
         nonlocal bad
         bad += 1
-        print(f"MISMATCH {kind}: {detail} (run {runs}, seed {seed0})", flush=True)
+        print(f"MISMATCH {kind}: {detail} knob {knob} (run {runs}, seed {seed0})", flush=True)
 
     t_note = time.time() + 60
     while time.time() < t_end:
@@ -70,6 +80,14 @@ def main():
         kind = KINDS[rng.integers(len(KINDS))]
         by_kind[kind] = by_kind.get(kind, 0) + 1
         t_case = time.time()
+        # one case in three runs with a tuning knob off its default: the alternative kernels and launch geometries behind every
+        # entry point (the knobs pin paths for A/B runs; none of them may change a result)
+        knob = None
+        if rng.random() < 0.33 and kind != "matmul_big":
+            key = list(KNOBS)[rng.integers(len(KNOBS))]
+            knob = (key, int(KNOBS[key][rng.integers(len(KNOBS[key]))]))
+            scl.set_tuning(*knob)
+            by_knob[key] = by_knob.get(key, 0) + 1
         try:
             if kind == "ew":
                 n = size(70000)
@@ -347,9 +365,12 @@ def main():
                     report(kind, f"field {fb} n {n}")
         except Exception as e:  # an exception the oracle did not raise too is a finding
             report(kind, f"field {f}: {type(e).__name__}: {e}")
+        finally:
+            if knob is not None:
+                scl.set_tuning(knob[0], KNOB_DEFAULTS[knob[0]])
         secs[kind] = secs.get(kind, 0.0) + time.time() - t_case
     torch.cuda.synchronize()
-    print(f"fuzz_abi: {runs} cases in {budget:g} s, {bad} mismatches; by kind {by_kind}; seconds by kind { {k: round(v, 1) for k, v in secs.items()} }", flush=True)
+    print(f"fuzz_abi: {runs} cases in {budget:g} s, {bad} mismatches; by kind {by_kind}; seconds by kind { {k: round(v, 1) for k, v in secs.items()} }; cases by knob {by_knob}", flush=True)
     return 1 if bad else 0
 
 
