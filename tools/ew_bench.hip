@@ -163,6 +163,10 @@ static void run_field(const char* name, typename F::Ctx ctx, size_t n) {
         run_reread<F, false, VEC, 24, 3>(name, ctx, out, ref, a, b, n, flag, base);
         run_reread<F, false, VEC, 32, 2>(name, ctx, out, ref, a, b, n, flag, base);
         run_reread<F, false, VEC, 32, 3>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 32, 3, 2>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 28, 3, 4>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 28, 3, 2>(name, ctx, out, ref, a, b, n, flag, base);
+        run_reread<F, false, VEC, 40, 2, 4>(name, ctx, out, ref, a, b, n, flag, base);
       }
     }
   }
