@@ -76,7 +76,7 @@ def main():
         L = scl.limbs(f)
         slow = L == 4 or f in (scl.MONT128, scl.GF2_128)   # Fermat / bit-serial oracle arithmetic
         KINDS = ["ew", "inv", "scalar", "dotsum", "shamir", "recover_at", "additive", "matmul", "layout", "detect",
-                 "coeffs", "correct", "wire", "vdm", "matmul_big", "ring", "inv_big"]
+                 "coeffs", "correct", "wire", "vdm", "matmul_big", "ring", "inv_big", "random", "packed", "misc"]
         kind = KINDS[rng.integers(len(KINDS))]
         by_kind[kind] = by_kind.get(kind, 0) + 1
         t_case = time.time()
@@ -363,6 +363,68 @@ def main():
                 got = scl.ew(fb, scl.INV, dev(a))
                 if not np.array_equal(scl.to_host(got), want):
                     report(kind, f"field {fb} n {n}")
+            elif kind == "random":
+                # the PRG discipline: blocks at a counter, FF::read of raw bytes, Vector::random (seeds of any length: the reference
+                # zero-pads or truncates to 16 bytes)
+                sd = bytes(rng.integers(0, 256, size=int(rng.integers(0, 40)), dtype=np.uint8))
+                c0 = int(rng.integers(0, 2 ** 40)) if rng.random() < 0.5 else int(2 ** 32 - rng.integers(0, 50))
+                nb = int(rng.integers(0, 5000))
+                want = port.prg_blocks(sd, c0, nb)
+                got = scl.prg_blocks(nb, sd, c0)
+                if bytes(got.cpu().numpy().tobytes()) != want:
+                    report(kind, f"prg_blocks seed {len(sd)} bytes counter {c0} blocks {nb}")
+                n = size(20000)
+                bs = 8 * L
+                raw = port.prg(b"fuzz-raw-%d" % runs, [max(1, n) * bs])[: n * bs]
+                if n:
+                    rt = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+                    if not np.array_equal(scl.to_host(scl.from_bytes(f, rt)), port.from_bytes(f, raw)):
+                        report(kind, f"from_bytes field {f} n {n}")
+                    if not np.array_equal(scl.to_host(scl.vector_random(f, n, sd)), port.vector_random(f, sd, n)):
+                        report(kind, f"vector_random field {f} n {n} seed {len(sd)} bytes")
+            elif kind == "packed":
+                # shamirSecretShare over Array<FF, W> (what Pedersen shares): W interleaved sharings on one PRG draw
+                if f == scl.GF2_128:
+                    continue
+                W = int(rng.integers(1, 5))
+                N = max(1, size(200 if slow else 1500))
+                n = int(rng.integers(1, 20 if not slow else 9))
+                t = int(rng.integers(0, n))
+                sec = rand(f, N * W, b"p").reshape(N, W, L)
+                sd = b"fuzz-packed-%d" % runs
+                want = np.asarray(port.shamir_share_packed(f, sd, sec, t, n))                  # [N][n][W][L]
+                got = scl.shamir_share_prg_packed(f, dev(np.ascontiguousarray(sec.transpose(1, 0, 2))), t, n, sd)   # [W][n][N][L]
+                if not np.array_equal(scl.to_host(got).transpose(2, 1, 0, 3), want):
+                    report(kind, f"field {f} N {N} n {n} t {t} W {W}")
+            elif kind == "misc":
+                n = max(1, size(30000))
+                a = rand(f, n, b"a")
+                b = a.copy()
+                da = dev(a)
+                if not scl.equals(f, da, dev(b)):
+                    report(kind, f"equals(a, a) field {f} n {n}")
+                j = int(rng.integers(n))
+                b[j, int(rng.integers(L))] ^= np.uint64(1) << np.uint64(rng.integers(0, 60))
+                if scl.equals(f, da, dev(b)):
+                    report(kind, f"equals misses a flipped bit: field {f} n {n} at {j}")
+                m = int(rng.integers(1, 30 if not slow else 10))
+                nodes = port.vector_random(f, b"fuzz-lb-%d" % runs, m + 1)
+                if len({tuple(r) for r in nodes.tolist()}) == m + 1:
+                    if not np.array_equal(scl.lagrange_basis(f, m, alphas=nodes[:m], x=nodes[m]), port.lagrange_basis(f, nodes[:m], nodes[m])):
+                        report(kind, f"lagrange_basis field {f} m {m}")
+                nn = int(rng.integers(2, 12))
+                N = min(n, 2000)
+                rnd = rand(f, (nn - 1) * N, b"r").reshape(nn - 1, N, L)
+                sh = scl.additive_share(f, dev(a[:N]), dev(rnd), nn)
+                hs = scl.to_host(sh)
+                if not np.array_equal(hs[: nn - 1], rnd) or not np.array_equal(scl.to_host(scl.additive_recover(f, sh)), a[:N]):
+                    report(kind, f"additive_share with explicit randomness field {f} N {N} n {nn}")
+                rows, cols = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+                mat = rand(f, rows * cols, b"m").reshape(rows, cols, L)
+                if not np.array_equal(scl.to_host(scl.wire_unpack_matrix(f, scl.wire_pack_matrix(f, dev(mat)))), mat):
+                    report(kind, f"matrix wire round trip field {f} {rows}x{cols}")
+                if not np.array_equal(scl.to_host(scl.frame_unpack(f, scl.frame_pack(f, da))), a):
+                    report(kind, f"frame round trip field {f} n {n}")
         except Exception as e:  # an exception the oracle did not raise too is a finding
             report(kind, f"field {f}: {type(e).__name__}: {e}")
         finally:
