@@ -716,7 +716,8 @@ def main():
 
     def ew_report():
         """The element-wise path north_star names first: Vector::add / multiplyEntryWise (vector.h:199-245) and FF::inverse
-        (ff.h:203-246, small_ff.h:61-92) over Mersenne61 (10^8 elements), Mersenne127 and GF(2^128) (10^7 each) through scl_hip_ew.
+        (ff.h:203-246, small_ff.h:61-92) over Mersenne61 (10^8 elements), Mersenne127, the 128-bit Montgomery prime field (north_star's
+        "Fp": BASELINE configs[2]) and GF(2^128) (10^7 each) through scl_hip_ew.
         HIP events around every launch, each kernel in its own steady state (100 warm-up launches for the sub-millisecond
         sizes, see share_recover_config); algorithmic bytes 3E for a binary op, 2E for a unary one.  The
         inverse's figure includes its 4-byte zero-flag read-back (the call returns the reference's error for a zero).  Checked
@@ -727,7 +728,7 @@ def main():
         rep = {"workload": "scl_hip_ew: add, multiplyEntryWise, inverse over whole vectors resident in HBM",
                "bytes_per_element": "3E for add / mul, 2E for inv (E = element bytes)", "fields": {}}
         win = min(2048, args.ew_elements) if args.ew_elements else 2048
-        for fkey, N_ in (("m61", 100_000_000), ("m127", 10_000_000), ("gf2_128", 10_000_000)):
+        for fkey, N_ in (("m61", 100_000_000), ("m127", 10_000_000), ("mont128", 10_000_000), ("gf2_128", 10_000_000)):
             N_ = args.ew_elements or N_
             f_, L_ = tag_limbs(fkey)
             E_ = 8 * L_
@@ -755,8 +756,7 @@ def main():
                     ok = ok and bool(scl.equals(f_, scl.ew(f_, scl.SUB, out, b), a))
                 if name == "inv":
                     prod = scl.ew(f_, scl.MUL, out, a)
-                    one = torch.zeros_like(prod)
-                    one[:, 0] = 1
+                    one = scl.to_device(np.ascontiguousarray(np.broadcast_to(port.from_int(f_, 1), (N_, L_))))   # FF::one(): R mod p in a Montgomery field
                     ok = ok and bool(scl.equals(f_, prod, one))
                     del prod, one
                 # what limits the kernel: the streaming ops are HBM-bound; inverses are vector-ALU work (3 + I / L
@@ -771,10 +771,10 @@ def main():
             # FF::inverse element by element; the oracle port for GF(2^128), which the reference does not have), 10^6 elements
             cpu = None
             try:
-                n_cpu = min(N_, 1_000_000 if fkey != "gf2_128" else 20_000)
+                n_cpu = min(N_, 1_000_000 if fkey in ("m61", "m127") else 20_000)   # (the port's Fermat / bit-serial inverses are slow)
                 ca, cb = scl.to_host(a[:n_cpu]), scl.to_host(b[:n_cpu])
                 lib_, kind_ = port, "port"
-                if fkey != "gf2_128":
+                if fkey in ("m61", "m127"):       # (the reference has neither a 128-bit Montgomery field nor GF(2^128): the port)
                     try:
                         lib_, kind_ = O.Ref(), "reference"
                     except Exception:

@@ -1150,9 +1150,9 @@ static int share_chunked(int field, uint64_t* shares, size_t share_stride, const
 }
 
 // Inverse / divide by Montgomery's simultaneous inversion (kernels.hpp, k_ew_inv / k_ew_inv_rolled).  Chain length: Mersenne61
-// keeps 32 elements per lane in registers (16-byte packs); the other fields keep the chain in memory and take the longest of
-// 8 / 16 / 32 / 64 / 128 that still leaves ~4000 single-wave workgroups (the inversion's share of a chain is I / L products per element,
-// I = 138 for Mersenne127 up to ~450 for secp256k1, against 3 for the walk).
+// keeps 32 elements per lane in registers (16-byte packs); the other fields keep the chain in memory and take 8 / 16 / 32 / 64 / 128
+// by the batch size (ew_inverse_rolled; the inversion's share of a chain is I / L products per element, I = 138 for Mersenne127 up
+// to ~330 for secp256k1, against 3 for the walk).
 template <class F, bool DIV, int L>
 int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, unsigned* flag, hipStream_t st) {
   // single-wave workgroups; GF(2^128): 256 threads around a 32 KiB window table (3-bit windows; 16.0 against 14.1 G inversions/s with 64,
@@ -1170,11 +1170,17 @@ int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const 
 
 template <class F, bool DIV>
 int ew_inverse_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, long want, unsigned* flag, hipStream_t st) {
-  // the longest chain that still leaves ~4000 single-wave workgroups (four per SIMD): measured optimum 32 at 10^7 elements and
-  // 128 at 10^8 (profiles/r5_ew_bench.txt)
+  // The chain length by batch size, from the sweeps of tools/probe_inv_chain.py (profiles/r5_probe_inv_chain.txt): the one
+  // inversion of a chain is 50-65 % of a lane's work at L = 32, so a longer chain wins as soon as about 500 (L = 16) to 3000
+  // (L = 128) waves remain -- one to three per SIMD, not four.  Elements from which a length is taken, for 16 / 32 / 64 / 128:
+  // the 16-byte prime fields; secp256k1 (the costliest inversion: longer chains sooner); GF(2^128) (256-thread workgroups around
+  // their LDS tables: later).
+  static const size_t from_plain[4] = {500000, 2050000, 6000000, 24600000}, from_wide[4] = {500000, 1800000, 4000000, 15000000},
+                      from_gf[4] = {500000, 6000000, 15000000, 50000000};
+  const size_t* from = F::TAG == 3 ? from_gf : F::LIMBS == 4 ? from_wide : from_plain;
   int L = 8;
-  for (int cand : {16, 32, 64, 128})
-    if (n >= (size_t)cand * 64 * 4096) L = cand;
+  for (int i = 0; i < 4; ++i)
+    if (n >= from[i]) L = 16 << i;
   if (want > 0) L = want >= 128 ? 128 : want >= 64 ? 64 : want >= 32 ? 32 : want >= 16 ? 16 : 8;
   if (L == 128) return launch_inv_rolled<F, DIV, 128>(ctx, dst, a, b, n, flag, st);
   if (L == 64) return launch_inv_rolled<F, DIV, 64>(ctx, dst, a, b, n, flag, st);

@@ -2041,7 +2041,7 @@ def test_bench_contract_small(scl):
     assert line["rccl"]["ranks"] == 1 and len(line["ms_per_step_by_rank"]) == 1
     # the element-wise path north_star names first, and the layout bridge: add / mul / inv per field with their rooflines
     ew = line["ew"]
-    assert ew["verified"] is True and set(ew["fields"]) == {"Mersenne61", "Mersenne127", "GF(2^128)"}
+    assert ew["verified"] is True and set(ew["fields"]) == {"Mersenne61", "Mersenne127", "Mont128", "GF(2^128)"}
     for fld in ew["fields"].values():
         assert fld["elements"] == 300001 and all(fld[op]["verified"] and fld[op]["GBps"] > 0 for op in ("add", "mul", "inv"))
         assert fld["add"]["bytes_per_element"] == 3 * fld["inv"]["bytes_per_element"] // 2
