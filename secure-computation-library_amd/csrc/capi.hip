@@ -2618,14 +2618,18 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
       // (a (row block, k-chunk) launch needs ~10^5 columns to outweigh its launches: 4096^3 runs at 1.5 T multiply-adds/s
       // this way and at 3.3 through k_matmul_tiled, profiles/r5_probe_matmul.txt)
       const bool one_tile = M <= 128 && K <= 64;
-      // beyond one tile: the general kernel (gemm_mfma.hpp) where all three dimensions are sizeable (its digit planes are a
-      // temporary of at most 2 GiB: longer factors go slab by slab); "mfma" 2 forces the (row block, k-chunk) form for A/B runs
-      // (K <= 64 is one k-chunk: row blocks on the sharing kernels need no pass over B and run at 18 T multiply-adds/s against 7;
-      // one row block against a very long right factor: the k-chunk form is as fast and needs no temporary)
-      const bool gemm_ok = K > 64 && M >= 33 && N >= 33 && (M > 128 || N < 131072);
-      if (gemm_ok && mode != 2 && (mode > 0 || (mode == 0 && M * N * K >= ((size_t)1 << 25))))
+      // beyond one tile: the general kernel (gemm_mfma.hpp) wherever K > 64 and both outer dimensions reach a tile -- its three
+      // launches take 23 us against 49 us and more for the vector-ALU kernels on every small shape tried, 2-12 x ahead from
+      // 33 x 65 x 33 up (profiles/r5_probe_matmul_paths.txt); its digit planes are a temporary of at most 2 GiB, longer factors
+      // go slab by slab.  One or two k-chunks against a long right factor (64 < K <= 128, N >= 24576) stay on the sharing
+      // kernels (no pass over B: 24-31 % ahead there); K <= 64 is one k-chunk: row blocks on the sharing kernels, from 131072
+      // columns (below that the vector-ALU kernel is ahead).  "mfma" 2 forces the (row block, k-chunk) form for A/B runs.
+      const bool two_chunks_long = K > 64 && K <= 128 && N >= 24576;
+      const bool gemm_ok = K > 64 && M >= 33 && N >= 33;
+      if (gemm_ok && mode != 2 && (mode > 0 || (mode == 0 && !two_chunks_long)))
         return matmul_gemm_mfma<F>(C, ldc, A, lda, B, ldb, M, K, N, S(stream));
-      if (mode > 0 || (mode == 0 && std::min<size_t>(M, 128) * std::min<size_t>(K, 64) >= 512 && N >= (one_tile ? 4096u : 131072u)))
+      if (mode > 0 || (mode == 0 && std::min<size_t>(M, 128) * std::min<size_t>(K, 64) >= 512 &&
+                       N >= (one_tile ? 4096u : two_chunks_long ? 24576u : 131072u)))
         return matmul_mfma_blocks<F>(ctx, C, ldc, A, lda, B, ldb, M, K, N, S(stream));
     }
     const size_t esz = F::LIMBS * 8;

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""The library's automatic path choices against the pinned alternatives (tuning knobs), over sizes away from the bench's: Mersenne61
+matrix products (the "mfma" knob), the streaming share / reconstruct kernels' residency caps, the PRG-driven sharing's one or two
+passes, the layout bridge's tile.  Prints auto / best per case: anything well above 1 is a threshold to re-measure."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "secure-computation-library_amd"))
+import torch  # noqa: E402
+import scl_amd as scl  # noqa: E402
+
+
+def timed(fn, warm=10, reps=20):
+    for _ in range(warm):
+        fn()
+    tm = scl.Timer()
+    tm.start()
+    for _ in range(reps):
+        fn()
+    tm.stop()
+    return tm.elapsed_ms() / reps
+
+
+def sweep(label, fn, knob, values, default):
+    row = []
+    for v in list(values) + [None]:
+        if v is not None:
+            scl.set_tuning(knob, v)
+        try:
+            row.append((v, timed(fn)))
+        except scl.SclError:
+            row.append((v, float("inf")))
+        finally:
+            scl.set_tuning(knob, default)
+    best = min(row[:-1], key=lambda r: r[1])
+    print(f"{label:58s} {knob:14s} " + "  ".join(f"{'auto' if v is None else v}: {ms:.4f}" for v, ms in row) +
+          f"   auto / best = {row[-1][1] / best[1]:.2f} (best {best[0]})", flush=True)
+
+
+f = scl.M61
+for (M, K, N) in [(64, 64, 64), (128, 128, 128), (256, 256, 256), (384, 384, 384), (512, 512, 512), (768, 768, 768), (1024, 1024, 1024),
+                  (33, 4096, 33), (64, 8192, 64), (100, 100, 100000), (200, 65, 50000), (2048, 64, 2048), (40, 2000, 40), (300, 300, 3000)]:
+    A = scl.vector_random(f, M * K, b"A").reshape(M, K, -1)
+    B = scl.vector_random(f, K * N, b"B").reshape(K, N, -1)
+    out = scl.empty(f, M, N)
+    sweep(f"matmul {M} x {K} x {N}", lambda: scl.matmul(f, A, B, out=out), "mfma", (-1, 1, 2), 0)
+for fld, name in ((scl.M61, "Mersenne61"), (scl.M127, "Mersenne127")):
+    for N in (100_000, 1_000_000, 10_000_000):
+        n, t = 10, 3
+        secrets = scl.vector_random(fld, N, b"s")
+        coeffs = scl.vector_random(fld, t * N, b"c").reshape(t, N, -1)
+        shares = scl.empty(fld, n, N)
+        lam = scl.lagrange_basis(fld, n)
+        out = scl.empty(fld, N)
+        sweep(f"share (10,3) {name} N {N}", lambda: scl.shamir_share(fld, secrets, coeffs, n, out=shares),
+              "share_waves" if fld == scl.M61 else "share_waves128", (0, 6, 9, 12, 16), 9 if fld == scl.M61 else 12)
+        sweep(f"reconstruct (10,3) {name} N {N}", lambda: scl.shamir_recover(fld, shares, lam, out=out), "stream_waves", (0, 6, 8, 10, 12, 16), -1)
+        for (n2, t2) in ((10, 3), (10, 7), (20, 8), (40, 13)):
+            sh2 = scl.empty(fld, n2, N)
+            sweep(f"share_prg ({n2},{t2}) {name} N {N}", lambda: scl.shamir_share_prg(fld, secrets, t2, n2, b"seed", out=sh2), "prg_two_pass", (-1, 1), 0)
+            del sh2
+        del secrets, coeffs, shares, out
+for fld, name in ((scl.M61, "Mersenne61"), (scl.M127, "Mersenne127"), (scl.SECP256K1_SCALAR, "secp256k1")):
+    for (N, n) in ((100_000, 10), (1_000_000, 10), (1_000_000, 3), (1_000_000, 40), (200_000, 128)):
+        soa = scl.vector_random(fld, N * n, b"l").reshape(n, N, -1)
+        sweep(f"soa_to_aos {name} N {N} n {n}", lambda: scl.soa_to_aos(fld, soa), "transpose_tile", (64, 128, 256, 512), 0)
+        del soa
