@@ -66,3 +66,29 @@ for fld, name in ((scl.M61, "Mersenne61"), (scl.M127, "Mersenne127"), (scl.SECP2
         soa = scl.vector_random(fld, N * n, b"l").reshape(n, N, -1)
         sweep(f"soa_to_aos {name} N {N} n {n}", lambda: scl.soa_to_aos(fld, soa), "transpose_tile", (64, 128, 256, 512), 0)
         del soa
+
+# explicit-coefficient sharing and reconstruction at larger (n, t): matrix cores or vector ALU ("mfma"), the Horner forms ("force_table")
+for (n, t) in ((16, 5), (20, 6), (32, 10), (40, 13), (64, 21), (100, 33), (128, 42)):
+    for N in (200_000, 2_000_000):
+        secrets = scl.vector_random(scl.M61, N, b"s")
+        coeffs = scl.vector_random(scl.M61, t * N, b"c").reshape(t, N, -1)
+        shares = scl.empty(scl.M61, n, N)
+        lam = scl.lagrange_basis(scl.M61, n)
+        out = scl.empty(scl.M61, N)
+        sweep(f"share ({n},{t}) Mersenne61 N {N}", lambda: scl.shamir_share(scl.M61, secrets, coeffs, n, out=shares), "mfma", (-1, 1), 0)
+        sweep(f"share ({n},{t}) Mersenne61 N {N}", lambda: scl.shamir_share(scl.M61, secrets, coeffs, n, out=shares), "force_table", (1, 2), 0)
+        sweep(f"reconstruct ({n}) Mersenne61 N {N}", lambda: scl.shamir_recover(scl.M61, shares, lam, out=out), "stream_block", (64, 256), 64)
+        del secrets, coeffs, shares, out
+# the element-wise inverse at small sizes: one chain per lane or one Fermat chain per element ("inv_batch" -1)
+for fld, name in ((scl.M61, "Mersenne61"), (scl.M127, "Mersenne127"), (scl.SECP256K1_SCALAR, "secp256k1"), (scl.GF2_128, "GF(2^128)")):
+    for n in (1_000, 10_000, 50_000, 100_000, 300_000):
+        a = scl.vector_random(fld, n, b"i")
+        out = scl.empty(fld, n)
+
+        def call():
+            try:
+                scl.ew(fld, scl.INV, a, out=out)
+            except scl.SclError:
+                pass
+        sweep(f"inverse {name} n {n}", call, "inv_batch", (-1, 8, 16, 32), 0)
+        del a, out
