@@ -104,7 +104,7 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-live", type=int, default=1,
                     help="1: roofline.traffic observed in THIS run -- two child runs of the headline under rocprofv3 --pmc FETCH_SIZE / "
                          "WRITE_SIZE after everything else (one GPU, BASELINE configs[1] only; falls back to profiles/pmc_traffic.json)")
-    ap.add_argument("--side-timeout", type=float, default=600.0,
+    ap.add_argument("--side-timeout", type=float, default=300.0,
                     help="multi-rank runs: seconds the legs after the headline (RCCL through torch and through the C ABI) may take "
                          "before rank 0 writes the line with what it has and every rank exits (0 = no limit)")
     ap.add_argument("--inject-error", default="", choices=["", "c_abi", "hang"],
