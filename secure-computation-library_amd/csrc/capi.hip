@@ -1913,7 +1913,11 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
     }
     // (256-bit elements: 49 register-resident coefficients would be 392 registers -- the 48-coefficient Horner kernel spills --
     // so past 16 they take the chunked kernel's 24 at a time)
-    if (t > 48 || (L == 4 && t > 16))
+    // (Mersenne61 with up to 63 coefficients and up to 128 parties is one tile of the matrix-core kernel -- 64 rows of K -- and
+    // 5-7 x faster there than chunk by chunk: (128,63) 0.95 against 7.3 ms per 2 * 10^6, profiles/r5_probe_auto_choices.txt)
+    const bool one_mfma_tile = field == SCL_M61 && t <= 63 && n <= 128 && n * (t + 1) >= 1024 && g_mfma.load() >= 0 &&
+                               !g_force_table.load();
+    if ((t > 48 && !one_mfma_tile) || (L == 4 && t > 16))
       return share_chunked(field, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, alphas_host, 0, stream);
   }
   return with_field(field, [&](auto f, auto ctx) -> int {
@@ -1936,8 +1940,8 @@ int scl_hip_shamir_share(int field, uint64_t* shares, size_t share_stride, const
       BlockVdm bprobe;
       const bool blocked = t <= (size_t)BlockVdm::TMAX && blocked_vandermonde<F>(ctx, al, n, bprobe) != 0;
       const size_t work_min = blocked ? 1024 : 512;
-      if (eligible && (mode > 0 || (mode == 0 && n * (t + 1) >= work_min && !small_vandermonde<F>(ctx, al, n, t, probe) &&
-                                    !g_force_table.load())))
+      if (eligible && (mode > 0 || t > 48 || (mode == 0 && n * (t + 1) >= work_min && !small_vandermonde<F>(ctx, al, n, t, probe) &&
+                                              !g_force_table.load())))  // (t > 48 arrives here only as one_mfma_tile)
         return share_mfma<F>(al, shares, share_stride, secrets, coeffs, coeff_stride, N, t, n, S(stream));
     }
     if constexpr (F::TAG <= 2 || F::LIMBS == 4) {  // the Mersenne fields and the Montgomery primes (Mont128: of full width)
@@ -2169,7 +2173,7 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
     const size_t cap = (size_t)256 / (size_t)L;
     // One fused kernel (coefficients drawn into registers, evaluated in place) or two passes (rows drawn into a temporary,
     // then the explicit-coefficient kernel of the shape).  Fused wins where its kernel is small and the evaluation cheap: the
-    // small-node kernels of the Mersenne fields (t <= 7) and GF(2^128) up to t = 11.  Beyond that the fused kernels unroll
+    // small-node kernels of the Mersenne fields (t <= 7) and GF(2^128) up to t = 4.  Beyond that the fused kernels unroll
     // 9 .. 25 AES blocks per lane (100 - 260 KB of code) and evaluate by plain Horner, and the Montgomery fields' fused
     // kernels multiply by full-width Vandermonde entries: (40,13) Mersenne61 3.0 -> 2.1 ms, (128,42) 6.4 -> 1.6 ms,
     // secp256k1 (10,3) 1.9 -> 1.0 ms per 5 * 10^6 (profiles/r2_probe_prg_share.txt).  "prg_two_pass": 1 always, -1 never
@@ -2177,7 +2181,9 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
     const bool must = n > cap || t > 48;  // more parties than one node table / more coefficients than registers hold
     const long pref = g_prg_two_pass.load();
     const bool montgomery = field == SCL_MONT128 || L == 4;
-    const bool want = t >= 1 && (montgomery || (field == SCL_GF2_128 ? t >= 12 : t >= 8));
+    // (GF(2^128) from t = 5 where the eight-nodes-per-loop kernel shares the drawn rows (default nodes, n <= 64): 1.1-1.9 x the
+    // fused kernel at (10..40, 5..11), profiles/r5_probe_auto_choices.txt)
+    const bool want = t >= 1 && (montgomery || (field == SCL_GF2_128 ? (t >= 12 || (t >= 5 && n <= 64)) : t >= 8));
     if (must || pref > 0 || (pref == 0 && want))
       return share_prg_two_pass(field, shares, share_stride, secrets, N, t, n, seed, seed_len, counter0, lane, stream);
   }
@@ -2628,8 +2634,11 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
       const bool gemm_ok = K > 64 && M >= 33 && N >= 33;
       if (gemm_ok && mode != 2 && (mode > 0 || (mode == 0 && !two_chunks_long)))
         return matmul_gemm_mfma<F>(C, ldc, A, lda, B, ldb, M, K, N, S(stream));
+      // (one tile: two launches, 17-20 us whatever the shape, where the vector-ALU kernels need 30 us and more from 2^18
+      // multiply-adds on -- (100 x 43)(43 x 3000) 0.017 against 0.33 ms)
+      const bool one_tile_pays = one_tile && (N >= 4096 || M * K * N >= ((size_t)1 << 18));
       if (mode > 0 || (mode == 0 && std::min<size_t>(M, 128) * std::min<size_t>(K, 64) >= 512 &&
-                       N >= (one_tile ? 4096u : two_chunks_long ? 24576u : 131072u)))
+                       (one_tile ? one_tile_pays : N >= (two_chunks_long ? 24576u : 131072u))))
         return matmul_mfma_blocks<F>(ctx, C, ldc, A, lda, B, ldb, M, K, N, S(stream));
     }
     const size_t esz = F::LIMBS * 8;

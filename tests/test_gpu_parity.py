@@ -361,7 +361,10 @@ def test_shamir_golden(scl, f, name):
 
 @pytest.mark.parametrize("f", ALL_FIELDS)
 @pytest.mark.parametrize("n,t,N", [(10, 3, 1000), (4, 3, 257), (3, 1, 2), (10, 0, 65), (40, 13, 300), (128, 42, 130),
-                                   (17, 16, 64), (1, 0, 5), (5, 4, 1)])
+                                   (17, 16, 64), (1, 0, 5), (5, 4, 1),
+                                   # 49..63 coefficients: one tile of the matrix-core kernel over Mersenne61 (since round 5; the
+                                   # chunked Horner kernel for the other fields and for fewer than 1024 multiply-adds per secret)
+                                   (128, 63, 130), (70, 49, 90), (64, 50, 70), (60, 59, 33)])
 def test_shamir_share_recover_vs_oracle(scl, port, f, n, t, N):
     L = O.LIMBS[f]
     if f in SLOW_ORACLE:

@@ -92,3 +92,45 @@ for fld, name in ((scl.M61, "Mersenne61"), (scl.M127, "Mersenne127"), (scl.SECP2
                 pass
         sweep(f"inverse {name} n {n}", call, "inv_batch", (-1, 8, 16, 32), 0)
         del a, out
+
+# PRG-driven sharing over GF(2^128) by threshold: fused or two passes
+fld = scl.GF2_128
+for N in (200_000, 2_000_000):
+    secrets = scl.vector_random(fld, N, b"s")
+    for n in (10, 20, 40):
+        for t in (3, 4, 5, 6, 8, 11, 12):
+            if t < n:
+                sh = scl.empty(fld, n, N)
+                sweep(f"share_prg ({n},{t}) GF(2^128) N {N}", lambda: scl.shamir_share_prg(fld, secrets, t, n, b"seed", out=sh), "prg_two_pass", (-1, 1), 0)
+                del sh
+# explicit-coefficient sharing over Mersenne61 around 48 coefficients: the matrix cores take up to 63
+N = 2_000_000
+secrets = scl.vector_random(scl.M61, N, b"s")
+for n in (64, 128):
+    for t in (42, 48, 49, 56, 63):
+        if t < n:
+            coeffs = scl.vector_random(scl.M61, t * N, b"c").reshape(t, N, -1)
+            sh = scl.empty(scl.M61, n, N)
+            sweep(f"share ({n},{t}) Mersenne61 N {N}", lambda: scl.shamir_share(scl.M61, secrets, coeffs, n, out=sh), "mfma", (-1, 1), 0)
+            del coeffs, sh
+# the Montgomery fields and GF(2^128): passes of the PRG-driven sharing, Horner forms, small-integer reconstruct, matrix-core variants
+for fld, name in ((scl.MONT128, "Mont128"), (scl.SECP256K1_SCALAR, "secp256k1"), (scl.GF2_128, "GF(2^128)")):
+    N = 2_000_000
+    secrets = scl.vector_random(fld, N, b"s")
+    for (n, t) in ((10, 3), (10, 7), (20, 11), (40, 13)):
+        sh = scl.empty(fld, n, N)
+        if fld != scl.GF2_128:
+            sweep(f"share_prg ({n},{t}) {name} N {N}", lambda: scl.shamir_share_prg(fld, secrets, t, n, b"seed", out=sh), "prg_two_pass", (-1, 1), 0)
+        coeffs = scl.vector_random(fld, t * N, b"c").reshape(t, N, -1)
+        sweep(f"share ({n},{t}) {name} N {N}", lambda: scl.shamir_share(fld, secrets, coeffs, n, out=sh), "force_table", (1, 2), 0)
+        lam = scl.lagrange_basis(fld, n)
+        out = scl.empty(fld, N)
+        sweep(f"reconstruct ({n}) {name} N {N}", lambda: scl.shamir_recover(fld, sh, lam, out=out), "force_table", (1,), 0)
+        del sh, coeffs, out
+for (n, t) in ((64, 21), (128, 42)):
+    coeffs = scl.vector_random(scl.M61, t * N, b"c").reshape(t, N, -1)
+    sh = scl.empty(scl.M61, n, N)
+    secrets = scl.vector_random(scl.M61, N, b"s")
+    sweep(f"share ({n},{t}) Mersenne61 N {N}", lambda: scl.shamir_share(scl.M61, secrets, coeffs, n, out=sh), "mfma_pipe", (0, 1, 2), 2)
+    sweep(f"share ({n},{t}) Mersenne61 N {N}", lambda: scl.shamir_share(scl.M61, secrets, coeffs, n, out=sh), "mfma_areg", (0, 1), 1)
+    del coeffs, sh
