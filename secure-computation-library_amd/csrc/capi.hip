@@ -99,6 +99,7 @@ SCL_STATE(thread_local Knob g_aes_blocks, {0});
 // of rounds 1-4); GF(2^128) multiply: -1 = the register-only product ("inv_batch")
 SCL_STATE(thread_local Knob g_inv_batch, {0});
 SCL_STATE(thread_local Knob g_gemm_slab_mib, {0});  // digit planes per factor and launch of the general matrix-core product, MiB (0 = 1024) ("gemm_slab_mib")
+SCL_STATE(thread_local Knob g_matmul_lds_min, {0});  // columns from which k_matmul (left factor in LDS, a thread per column) is taken; thin kernel likewise (0 = default) ("matmul_lds_min")
 SCL_STATE(thread_local Knob g_transpose_tile, {0});  // secrets per LDS tile of the 16-byte layout bridge (0 = 512 within 40 KiB) ("transpose_tile")
 // Mont128 modulus: a process-wide default, latched per host thread at its first use (mont_ctx below)
 SCL_STATE(thread_local Mont128::Ctx g_mont, = {0, 0, 0, 0});  // p == 0: this thread has not latched a modulus yet
@@ -1387,6 +1388,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "inv_batch") g_inv_batch = value;
   else if (k == "transpose_tile") g_transpose_tile = value;
   else if (k == "gemm_slab_mib") g_gemm_slab_mib = value;
+  else if (k == "matmul_lds_min") g_matmul_lds_min = value;
   else if (k == "stream_block") g_stream_block = (value == 256 ? 256 : 64);
   else if (k == "stream_waves") g_stream_waves = value;
   else if (k == "share_waves") g_share_waves = value;
@@ -2312,7 +2314,8 @@ int scl_hip_shamir_recover_detect(int field, uint64_t* out, unsigned char* statu
       // many rows over many shares (large t and d): the rows-times-shares product on the matrix cores, then one compare
       // pass -- 1.26 G secrets/s for the vector-ALU kernel at t = d = 42 (profiles/r2_probe_detect.txt)
       const long mode = g_mfma.load();
-      if (rows <= 128 && d1 >= 2 && d1 <= 64 && (mode > 0 || (mode == 0 && rows * d1 >= 512 && N >= 4096))) {
+      // (few secrets: the contraction still wins from about 30 check rows on -- 0.26 against 0.37 ms at t = 42, profiles/r5_probe_auto_choices.txt)
+      if (rows <= 128 && d1 >= 2 && d1 <= 64 && (mode > 0 || (mode == 0 && rows * d1 >= 512 && (N >= 4096 || rows * d1 >= 900)))) {
         void* sc;
         SCL_TRY(scratch(64, &sc));
         unsigned long long* cnt = static_cast<unsigned long long*>(sc);
@@ -2645,7 +2648,12 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
     {
       // a thin inner dimension (a Vandermonde matrix times the coefficient rows): B's K rows in registers, 16-byte accesses
       constexpr int KMAX = F::LIMBS == 4 ? 8 : 16;
-      if (K <= (size_t)KMAX && M * K * esz <= 48 * 1024 && N >= 1024 && g_force_table.load() == 0) {
+      // (a thread per pack of columns loops over the M rows: from 1024 columns for a tiny left factor, from 65536 otherwise --
+      // below that the tiled kernel's workgroups fill the chip and it is 2-15 x ahead: (40 x 14)(14 x 3000) over secp256k1 0.024
+      // against 0.26 ms, profiles/r5_probe_auto_choices.txt; "matmul_lds_min" pins the bound for tests and A/B runs)
+      const long thin_min_knob = g_matmul_lds_min.load();
+      const size_t thin_min = thin_min_knob > 0 ? (size_t)thin_min_knob : M * K <= 64 ? 1024 : 65536;
+      if (K <= (size_t)KMAX && M * K * esz <= 48 * 1024 && N >= thin_min && g_force_table.load() == 0) {
         const int vec = vec_width<F>({C, B}, {ldc, ldb});
         return split_vec<F>(vec, N, [&](auto V, size_t first, size_t npacks) -> int {
           constexpr int VEC = decltype(V)::value;
@@ -2656,7 +2664,9 @@ int scl_hip_matmul(int field, uint64_t* C, size_t ldc, const uint64_t* A, size_t
         });
       }
     }
-    if (M * K * esz <= 48 * 1024 && N >= 1024) {
+    const long lds_min_knob = g_matmul_lds_min.load();
+    const size_t lds_min = lds_min_knob > 0 ? (size_t)lds_min_knob : 131072;  // (a thread per column: level with the tiled kernel at 10^5 columns, ahead beyond)
+    if (M * K * esz <= 48 * 1024 && N >= lds_min) {
       const unsigned gx = grid_for(N);
       hipLaunchKernelGGL((k_matmul<F, 4>), dim3(gx, 1), dim3(BLOCK), M * K * esz, S(stream), ctx, C, ldc, A, lda, B, ldb, (int)M,
                          (int)K, N, (int)M);

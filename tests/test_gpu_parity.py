@@ -1076,16 +1076,22 @@ def test_matmul_thin_inner_dimension(scl, port, f, M, K, N):
     A = rand_elems(port, f, M * K, b"thin-A").reshape(M, K, L)
     B = rand_elems(port, f, K * N, b"thin-B").reshape(K, N, L)
     A[0, 0] = B[0, 0] = B[K - 1, N - 1] = port.from_int(f, -1)
-    got = host(scl, scl.matmul(f, dev(scl, A), dev(scl, B)))
-    cols = list(range(N)) if f not in SLOW_ORACLE else sorted({0, 1, 2, 3, 255, 256, 257, N // 2, N - 2, N - 1})
-    assert np.array_equal(got[:, cols], port.matmul(f, A, np.ascontiguousarray(B[:, cols])))
-    scl.set_tuning("force_table", 1)
+    # "matmul_lds_min" 1024 pins the thread-per-column kernels at these sizes (the automatic choice takes them from 65536 columns
+    # on unless the left factor is tiny: below that the tiled kernel is ahead)
+    scl.set_tuning("matmul_lds_min", 1024)
     scl.set_tuning("mfma", -1)
     try:
+        got = host(scl, scl.matmul(f, dev(scl, A), dev(scl, B)))
+        cols = list(range(N)) if f not in SLOW_ORACLE else sorted({0, 1, 2, 3, 255, 256, 257, N // 2, N - 2, N - 1})
+        assert np.array_equal(got[:, cols], port.matmul(f, A, np.ascontiguousarray(B[:, cols])))
+        scl.set_tuning("force_table", 1)
         assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), got)
     finally:
         scl.set_tuning("force_table", 0)
         scl.set_tuning("mfma", 0)
+        scl.set_tuning("matmul_lds_min", 0)
+    assert np.array_equal(host(scl, scl.matmul(f, dev(scl, A), dev(scl, B))), got)      # whatever the automatic choice is
+    scl.set_tuning("matmul_lds_min", 1024)      # (the raw-ABI window below: the thin kernel's odd pitches)
     ldb, ldc = N + 3, N + 5      # odd pitches: the 8-byte path of the one-limb fields
     Bw = torch.full((K, ldb, L), -1, dtype=torch.int64, device="cuda")
     Bw[:, :N] = dev(scl, B)
@@ -1094,6 +1100,7 @@ def test_matmul_thin_inner_dimension(scl, port, f, M, K, N):
     st = scl.lib.scl_hip_matmul(f, C.c_void_p(Cw.data_ptr()), C.c_size_t(ldc), C.c_void_p(dA.data_ptr()), C.c_size_t(K),
                                 C.c_void_p(Bw.data_ptr()), C.c_size_t(ldb), C.c_size_t(M), C.c_size_t(K), C.c_size_t(N), None)
     assert st == 0, scl.lib.scl_hip_last_error()
+    scl.set_tuning("matmul_lds_min", 0)
     hw = host(scl, Cw)
     assert np.array_equal(hw[:, :N], got) and (hw[:, N:] == np.uint64(2 ** 64 - 1)).all()
 

@@ -134,3 +134,17 @@ for (n, t) in ((64, 21), (128, 42)):
     sweep(f"share ({n},{t}) Mersenne61 N {N}", lambda: scl.shamir_share(scl.M61, secrets, coeffs, n, out=sh), "mfma_pipe", (0, 1, 2), 2)
     sweep(f"share ({n},{t}) Mersenne61 N {N}", lambda: scl.shamir_share(scl.M61, secrets, coeffs, n, out=sh), "mfma_areg", (0, 1), 1)
     del coeffs, sh
+
+# the thread-per-column matrix kernels (thin inner dimension; left factor in LDS) against the tiled one ("matmul_lds_min": 1024 pins
+# the former from 1024 columns on, 10^9 never takes them)
+for fld, name in ((scl.M127, "Mersenne127"), (scl.SECP256K1_SCALAR, "secp256k1"), (scl.M61, "Mersenne61 (vector ALU)")):
+    for (M, K) in ((10, 4), (40, 14), (20, 200)):
+        for N in (1024, 10_000, 100_000, 1_000_000):
+            A = scl.vector_random(fld, M * K, b"A").reshape(M, K, -1)
+            B = scl.vector_random(fld, K * N, b"B").reshape(K, N, -1)
+            out = scl.empty(fld, M, N)
+            if fld == scl.M61:
+                scl.set_tuning("mfma", -1)
+            sweep(f"matmul {M} x {K} x {N} {name}", lambda: scl.matmul(fld, A, B, out=out), "matmul_lds_min", (1024, 10 ** 9), 0)
+            scl.set_tuning("mfma", 0)
+            del A, B, out
