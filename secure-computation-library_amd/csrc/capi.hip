@@ -2185,7 +2185,18 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
     const bool montgomery = field == SCL_MONT128 || L == 4;
     // (GF(2^128) from t = 5 where the eight-nodes-per-loop kernel shares the drawn rows (default nodes, n <= 64): 1.1-1.9 x the
     // fused kernel at (10..40, 5..11), profiles/r5_probe_auto_choices.txt)
-    const bool want = t >= 1 && (montgomery || (field == SCL_GF2_128 ? (t >= 12 || (t >= 5 && n <= 64)) : t >= 8));
+    // (the Mersenne fields: fused only while the small-node kernel applies -- every power n^k, k <= t, below 2^29 as
+    // small_vandermonde wants it, i.e. (10, <= 8), (20, <= 6), (40, <= 5) -- the generic fused Horner kernel behind it is 1.2-2.3 x
+    // behind the two passes: (40,6) 0.37 against 0.23 ms per 2 * 10^6, profiles/r5_probe_auto_choices.txt)
+    bool small_nodes_fit = true;
+    {
+      unsigned long long pw = 1;
+      for (size_t k = 0; k < t && small_nodes_fit; ++k) {
+        pw *= (unsigned long long)n;
+        if (n >= ((size_t)1 << 29) || pw >= (1ull << 29)) small_nodes_fit = false;
+      }
+    }
+    const bool want = t >= 1 && (montgomery || (field == SCL_GF2_128 ? (t >= 12 || (t >= 5 && n <= 64)) : (t >= 8 || !small_nodes_fit)));
     if (must || pref > 0 || (pref == 0 && want))
       return share_prg_two_pass(field, shares, share_stride, secrets, N, t, n, seed, seed_len, counter0, lane, stream);
   }
