@@ -82,6 +82,10 @@ typedef enum {
   SCL_ERR_NOT_INVERTIBLE_2K = 11 /* std::invalid_argument("value not invertible modulo 2^K") z2k/z2k_ops.h:82 */
 } scl_status;
 
+/* Version of this boundary.  2: scl_hip_ew_status (round 6), scl_hip_open_reduce_scatter, scl_hip_mont128_relatch and the
+ * export map (round 5: nothing but these prototypes is a dynamic symbol).  A binding checks it BEFORE it looks up symbols:
+ * a stale library then fails with a version message, not with an undefined symbol. */
+#define SCL_HIP_ABI_VERSION 2
 int scl_hip_abi_version(void);
 const char* scl_hip_last_error(void);
 const char* scl_hip_status_message(int status);
@@ -144,9 +148,18 @@ int scl_hip_thread_cleanup(void);
  * FF::negate / invert / operator/ per element (ff.h:203-246).  dst may alias a or b.
  * b is ignored for NEG and INV.  INV and DIV are synchronous: a zero operand yields
  * SCL_ERR_ZERO_INVERSE after the launch completes (the reference throws at the
- * first zero; here every other element is still computed, the zero's slot gets 0). */
+ * first zero; here every other element is still computed, the slot of a zero -- of an even element, in a ring -- gets 0). */
 int scl_hip_ew(int field, int op, uint64_t* dst_dev, const uint64_t* a_dev, const uint64_t* b_dev,
                size_t n, void* stream);
+/* The same call, asynchronous for every op: the "an operand was not invertible" report of INV / DIV (the reference's throw,
+ * small_ff.h:61-70, ff_ops_gmp.h:250-260, z2k_ops.h:81-83) stays on the device.  status_dev points to ONE 32-bit word in
+ * device memory: the call ORs 1 into it when an operand of INV / DIV is zero (even, in a ring) -- every other element is still
+ * computed, the offending slot gets 0 -- and never clears it, so one word can collect a sequence of calls; clear it with
+ * scl_hip_memset / hipMemsetAsync on the same stream, read it whenever the caller synchronises anyway (cf. the status vector of
+ * scl_hip_shamir_recover_detect).  No host synchronisation, no host read: small batches do not pay a stream round trip and the
+ * call can be captured into a hipGraph.  status_dev may be NULL for ops that cannot fail (ADD, SUB, MUL, NEG). */
+int scl_hip_ew_status(int field, int op, uint64_t* dst_dev, const uint64_t* a_dev, const uint64_t* b_dev,
+                      size_t n, unsigned* status_dev, void* stream);
 /* Vector::scalarMultiply(InPlace) (vector.h:274-301): dst[i] = scalar * a[i] */
 int scl_hip_scalar_mul(int field, uint64_t* dst_dev, const uint64_t* a_dev,
                        const uint64_t* scalar_host, size_t n, void* stream);

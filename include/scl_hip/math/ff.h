@@ -124,10 +124,12 @@ inline V parseHex(const std::string& s) {
 // montyFromString (include/scl/math/fields/ff_ops_gmp.h:370-398): an odd-length string gets a leading "0",
 // more than 64 digits is an error, and the digits are cut into 16-character limbs FROM THE LEFT (first
 // chunk = top limb (n-1)/16; a short last chunk becomes limb 0 as it stands).  Kept as the reference does it.
-inline sclhip::U256 parseHexLimbs(const std::string& str) {
+// `limbs` = N of the instance: 4 for the secp256k1 fields; 2 for Mont128, where the reference's template would write limbs
+// 2 and 3 of a two-limb value for 33..64 digits (its bound is 64 whatever N is) -- undefined there, refused here.
+inline sclhip::U256 parseHexLimbs(const std::string& str, std::size_t limbs = 4) {
   sclhip::U256 out = sclhip::Secp256k1Scalar::zero();
   if (str.empty()) return out;
-  if (str.size() > 64) throw std::invalid_argument("hex string too large to parse");
+  if (str.size() > 16 * limbs) throw std::invalid_argument("hex string too large to parse");
   const std::string s = str.size() % 2 ? "0" + str : str;
   int c = (int)((s.size() - 1) / 16);
   for (std::size_t i = 0; i < s.size() && c >= 0; i += 16)
@@ -160,10 +162,14 @@ inline void fromString(typename FIELD::ValueType& out, const std::string& hexstr
   if constexpr (FIELD::Impl::LIMBS == 4) {
     const V limbs = parseHexLimbs(hexstr);
     out = hexstr.empty() ? limbs : Impl::to_mont(c, limbs);
+  } else if constexpr (FIELD::TAG == SCL_MONT128) {
+    // the Montgomery family's montyFromString at N = 2 (pinned by the reference's template compiled at two limbs,
+    // oracle/ref_harness.cc): limbs cut from the left, an odd length padded, the empty string 0
+    const sclhip::U256 limbs = parseHexLimbs(hexstr, 2);
+    const V raw = ((V)limbs.w[1] << 64) | limbs.w[0];
+    out = hexstr.empty() ? raw : Impl::to_mont(c, raw);
   } else {
-    const V raw = parseHex<V>(hexstr);
-    if constexpr (FIELD::TAG == SCL_MONT128) out = Impl::to_mont(c, raw);
-    else out = Impl::from_le_word(c, raw);
+    out = Impl::from_le_word(c, parseHex<V>(hexstr));
   }
 }
 

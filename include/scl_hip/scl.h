@@ -3,6 +3,7 @@
 #define SCL_HIP_SCL_H
 
 #include "hip/device.h"
+#include "hip/elementwise.h"
 #include "hip/open.h"
 #include "math/fields/ff_ops.h"
 #include "math/ff.h"

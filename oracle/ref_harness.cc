@@ -36,8 +36,117 @@
 #include <string>
 #include <vector>
 
+// ---- field tag 2: a 128-bit prime field on the reference's OWN Montgomery code ---------------------------------------------
+// The reference's Montgomery arithmetic is a family of templates on the limb count (include/scl/math/fields/ff_ops_gmp.h:
+// RedParams<N> :44-58, montyIn :66-74, montyRedc :82-100, montyModAdd/Sub/Neg :128-162, the interleaved montyModMul :174-191,
+// montyModSqr :200-206, montyModExp :225-237, montyModInv :250-260, byte / string I/O :279-392) that the reference
+// instantiates once, at N = 4, for its two secp256k1 fields (src/scl/math/fields/secp256k1_scalar.cc:50-135).  This is the
+// same instantiation at N = 2 through the reference's field plug-in boundary (fields/ff_ops.h:35-118): a traits struct and the
+// eleven specialisations, each a call of the reference's template -- the way secp256k1_scalar.cc is written, with the modulus
+// a run-time parameter (sclref_mont128_set_prime) instead of a literal.  Nothing here computes: RedParams.mc = -p^-1 mod 2^128
+// and p - 2 are the only derived constants (Newton's iteration on machine words), ONE = montyIn(1).  BASELINE configs[2]'s
+// "Fp (128-bit prime, Montgomery)" is thereby pinned by the reference's code compiled here, not by a restatement.
+#include <scl/math/ff.h>
+#include <scl/math/fields/ff_ops.h>
+#include <scl/math/fields/ff_ops_gmp.h>
+
+#include <array>
+
+namespace scl::math::ff {
+struct Mont128Ref {
+  using ValueType = std::array<mp_limb_t, 2>;
+  constexpr static const char* NAME = "Mont128";
+  constexpr static const std::size_t BYTE_SIZE = 2 * sizeof(mp_limb_t);
+  constexpr static const std::size_t BIT_SIZE = 8 * BYTE_SIZE;
+};
+}  // namespace scl::math::ff
+
+namespace mont128ref {
+using Field = scl::math::ff::Mont128Ref;
+using Elem = Field::ValueType;
+inline scl::math::ff::RedParams<2> RD = {{0xFFFFFFFFFFFFFF61ull, 0xFFFFFFFFFFFFFFFFull}, {0, 0}};
+inline mp_limb_t PRIME_MINUS_2[2] = {0, 0};
+inline Elem ONE = {0, 0};
+inline void setPrime(unsigned __int128 p) {
+  RD.prime[0] = (mp_limb_t)p;
+  RD.prime[1] = (mp_limb_t)(p >> 64);
+  unsigned __int128 inv = p;  // p * inv = 1 mod 2^(3 * 2^k) after k steps
+  for (int k = 0; k < 7; ++k) inv *= 2 - p * inv;
+  const unsigned __int128 mc = (unsigned __int128)0 - inv;
+  RD.mc[0] = (mp_limb_t)mc;
+  RD.mc[1] = (mp_limb_t)(mc >> 64);
+  const unsigned __int128 pm2 = p - 2;
+  PRIME_MINUS_2[0] = (mp_limb_t)pm2;
+  PRIME_MINUS_2[1] = (mp_limb_t)(pm2 >> 64);
+  ONE = {1, 0};
+  scl::math::ff::montyIn<2>(ONE.data(), RD);
+}
+// FF<F>::one() and zero() are function-local statics (include/scl/math/ff.h:90-101): the first use latches the Montgomery
+// image of 1 under the modulus of that moment, and shamirSecretShare walks its nodes from T::one() (shamir.h:62-65).  One
+// loaded copy of this library therefore serves ONE modulus: sclref_mont128_set_prime refuses a different prime once field 2
+// has been used (tests load a second copy of the .so for a second prime: oracle_lib.Ref(fresh=True)).
+inline bool used = false;
+struct Init {
+  Init() { setPrime((((unsigned __int128)0xFFFFFFFFFFFFFFFFull) << 64) | 0xFFFFFFFFFFFFFF61ull); }  // 2^128 - 159
+};
+inline Init init;
+}  // namespace mont128ref
+
+#define M128_PTR(X) (X).data()
+namespace scl::math::ff {
+template <>
+void convertTo<Mont128Ref>(mont128ref::Elem& out, const int value) {
+  out = {0};
+  montyInFromInt<2>(M128_PTR(out), value, mont128ref::RD);
+}
+template <>
+void convertTo<Mont128Ref>(mont128ref::Elem& out, const std::string& src) {
+  out = {0};
+  montyFromString<2>(M128_PTR(out), src, mont128ref::RD);
+}
+template <>
+void add<Mont128Ref>(mont128ref::Elem& out, const mont128ref::Elem& op) {
+  montyModAdd<2>(M128_PTR(out), M128_PTR(op), mont128ref::RD);
+}
+template <>
+void subtract<Mont128Ref>(mont128ref::Elem& out, const mont128ref::Elem& op) {
+  montyModSub<2>(M128_PTR(out), M128_PTR(op), mont128ref::RD);
+}
+template <>
+void negate<Mont128Ref>(mont128ref::Elem& out) {
+  montyModNeg<2>(M128_PTR(out), mont128ref::RD);
+}
+template <>
+void multiply<Mont128Ref>(mont128ref::Elem& out, const mont128ref::Elem& op) {
+  montyModMul<2>(M128_PTR(out), M128_PTR(op), mont128ref::RD);
+}
+template <>
+void invert<Mont128Ref>(mont128ref::Elem& out) {
+  mont128ref::Elem res = mont128ref::ONE;
+  montyModInv<2>(M128_PTR(res), M128_PTR(out), mont128ref::PRIME_MINUS_2, mont128ref::RD);
+  out = res;
+}
+template <>
+bool equal<Mont128Ref>(const mont128ref::Elem& in1, const mont128ref::Elem& in2) {
+  return compareValues<2>(M128_PTR(in1), M128_PTR(in2)) == 0;
+}
+template <>
+void fromBytes<Mont128Ref>(mont128ref::Elem& dest, const unsigned char* src) {
+  montyFromBytes<2>(M128_PTR(dest), src, mont128ref::RD);
+}
+template <>
+void toBytes<Mont128Ref>(unsigned char* dest, const mont128ref::Elem& src) {
+  montyToBytes<2>(dest, M128_PTR(src), mont128ref::RD);
+}
+template <>
+std::string toString<Mont128Ref>(const mont128ref::Elem& in) {
+  return montyToString<2>(M128_PTR(in), mont128ref::RD);
+}
+}  // namespace scl::math::ff
+
 namespace {
 
+using F128M = scl::math::FF<scl::math::ff::Mont128Ref>;     // field tag 2 (2 limbs, Montgomery form)
 using F61 = scl::math::Fp<61>;
 using F127 = scl::math::Fp<127>;
 using F256 = scl::math::FF<scl::math::ff::Secp256k1Scalar>;  // field tag 4 (4 limbs, Montgomery form)
@@ -224,6 +333,10 @@ void storeMat(std::uint64_t* p, const Matrix<F>& m) {
     } else if ((field) == 1) {     \
       using F = F127;              \
       __VA_ARGS__;                 \
+    } else if ((field) == 2) {     \
+      mont128ref::used = true;     \
+      using F = F128M;             \
+      __VA_ARGS__;                 \
     } else if ((field) == 4) {     \
       using F = F256;              \
       __VA_ARGS__;                 \
@@ -268,11 +381,26 @@ extern "C" {
 
 int sclref_limbs(int field) {
   if (field > 0x100 && field <= 0x100 + 128) return field - 0x100 <= 64 ? 1 : 2;
-  return field == 0 ? 1 : field == 1 ? 2 : (field == 4 || field == 5) ? 4 : -1;
+  return field == 0 ? 1 : (field == 1 || field == 2) ? 2 : (field == 4 || field == 5) ? 4 : -1;
+}
+
+// the modulus of field tag 2 (odd, >= 3; the reference's templates are handed whatever prime the caller names)
+int sclref_mont128_set_prime(const std::uint64_t p[2]) {
+  const unsigned __int128 v = ((unsigned __int128)p[1] << 64) | p[0];
+  if (!(v & 1) || v < 3) return -1;
+  const unsigned __int128 cur = ((unsigned __int128)mont128ref::RD.prime[1] << 64) | mont128ref::RD.prime[0];
+  if (mont128ref::used && v != cur) return -3;  // FF::one() may have latched the previous modulus (see mont128ref::used)
+  mont128ref::setPrime(v);
+  return 0;
+}
+void sclref_mont128_get_prime(std::uint64_t p[2]) {
+  p[0] = mont128ref::RD.prime[0];
+  p[1] = mont128ref::RD.prime[1];
 }
 
 const char* sclref_field_name(int field) {
-  return field == 0 ? F61::name() : field == 1 ? F127::name() : field == 4 ? F256::name() : field == 5 ? F256F::name() : "";
+  return field == 0 ? F61::name() : field == 1 ? F127::name() : field == 2 ? F128M::name() : field == 4 ? F256::name()
+         : field == 5 ? F256F::name() : "";
 }
 
 // returns 0 ok, 1 if the reference threw (message copied to err, NUL terminated)

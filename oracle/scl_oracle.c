@@ -822,12 +822,15 @@ int sclo_from_bytes(int field, const unsigned char* src, size_t n, uint64_t* dst
  * THE LEFT -- the first chunk is the top limb (index (n-1)/16), a short last chunk becomes limb 0 as it
  * stands.  For lengths that are not a multiple of 16 this is not the usual big-endian reading; restated
  * as is.  The empty string leaves the element 0. */
-static int hex_parse256(const char* s, fe256* out) {
+static int hex_parse_limbs(const char* s, fe256* out, size_t nlimbs) {
   size_t n = strlen(s);
   fe256 t = {{0, 0, 0, 0}};
   *out = t;
   if (n == 0) return SCLO_OK;
-  if (n > 64) return SCLO_BAD_ARG; /* "hex string too large to parse" */
+  /* "hex string too large to parse" beyond 64 digits (ff_ops_gmp.h:377-379).  The template's bound is 64 whatever N is: at
+   * N = 2 a string of 33 .. 64 digits makes it write limbs 2 and 3 of a two-limb value -- undefined behaviour in the
+   * reference; refused here */
+  if (n > 16 * nlimbs) return SCLO_BAD_ARG;
   char buf[66];
   if (n % 2) {
     buf[0] = '0';
@@ -854,6 +857,7 @@ static int hex_parse256(const char* s, fe256* out) {
   *out = t;
   return SCLO_OK;
 }
+static int hex_parse256(const char* s, fe256* out) { return hex_parse_limbs(s, out, 4); }
 
 int sclo_from_hex(int field, const char* hex, uint64_t* dst) {
   if (IS_SECP256(field)) {
@@ -864,13 +868,21 @@ int sclo_from_hex(int field, const char* hex, uint64_t* dst) {
     secpq_st(dst, hex[0] ? secpq_to_mont(t) : t);
     return SCLO_OK;
   }
+  if (field == SCLO_MONT128) { /* the Montgomery family's montyFromString at two limbs (pinned by oracle/_ref, field tag 2) */
+    fe256 t;
+    int st2 = hex_parse_limbs(hex, &t, 2);
+    if (st2) return st2;
+    mont128_ensure();
+    const u128 raw = ((u128)t.w[1] << 64) | t.w[0];
+    mont128_st(dst, hex[0] ? mont128_to_mont(raw) : raw);
+    return SCLO_OK;
+  }
   u128 v;
   int st = hex_parse(hex, &v, field == SCLO_M61 ? 64 : 128);
   if (st) return st;
   switch (field) {
     case SCLO_M61: dst[0] = (uint64_t)v % P61; return SCLO_OK;
     case SCLO_M127: m127_st(dst, v % P127); return SCLO_OK;
-    case SCLO_MONT128: mont128_ensure(); mont128_st(dst, mont128_to_mont(v)); return SCLO_OK;
     case SCLO_GF2_128: gf128_st(dst, v); return SCLO_OK;
     default: return SCLO_BAD_ARG;
   }

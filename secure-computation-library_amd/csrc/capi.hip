@@ -231,8 +231,13 @@ int mont_set(u128 p) {
   g_mont = Mont128::make_ctx(p);
   g_mont_own = true;
   std::lock_guard<std::mutex> lk(g_mont_default_mu);
-  g_mont_default = g_mont;
-  g_mont_gen = ++g_mont_default_gen;
+  // the generation moves only when the default's VALUE does: pool workers that each set the same prime at start-up (or the
+  // built-in 2^128 - 159) change nothing for the threads that latched it
+  if (g_mont_default.p != g_mont.p) {
+    g_mont_default = g_mont;
+    ++g_mont_default_gen;
+  }
+  g_mont_gen = g_mont_default_gen;
   return SCL_OK;
 }
 
@@ -359,9 +364,23 @@ int temp_acquire(size_t bytes, hipStream_t st, void** out, int which = 0) {
   return SCL_OK;
 }
 
+// An arena is kept for the thread's next call up to TEMP_RETAIN_BYTES; a larger one (the digit planes of a matrix product
+// with both factors beyond ~4096 x 4096, or with K beyond 2^21: the planes grow with K, 512 bytes per 32-row tile and inner
+// column) goes back when the call that grew it ends -- hipFree waits for that call's kernels, which run for milliseconds
+// at such sizes; the retained arenas are what scl_hip_thread_cleanup frees.
+constexpr size_t TEMP_RETAIN_BYTES = (size_t)1 << 30;
+
 int temp_release(hipStream_t st, int which = 0) {
-  HIP_TRY(hipEventRecord(g_temps[which].done, st));
-  g_temps[which].pending = true;
+  TempArena& a = g_temps[which];
+  if (a.dev && a.bytes > TEMP_RETAIN_BYTES) {
+    HIP_TRY(hipStreamSynchronize(st));
+    (void)hipFree(a.dev);
+    (void)hipEventDestroy(a.done);
+    a = TempArena{};
+    return SCL_OK;
+  }
+  HIP_TRY(hipEventRecord(a.done, st));
+  a.pending = true;
   return SCL_OK;
 }
 
@@ -522,22 +541,33 @@ bool node_value(const typename F::Ctx& ctx, const typename F::E& e, u128& out) {
   }
 }
 
+// every power a^k, k <= t, as an integer below 2^29: the one criterion of the small-node kernels, used by small_vandermonde
+// (node by node) and by share_prg_impl's fused-or-two-pass choice (on the largest default node) -- so the two cannot drift
+inline bool small_powers_fit(u128 a, size_t t) {
+  const u128 lim = (u128)1 << 29;
+  u128 pw = 1;
+  for (size_t k = 0; k <= t; ++k) {
+    if (pw >= lim) return false;
+    if (k < t) {
+      if (a >= lim) return false;
+      pw *= a;  // < 2^58
+    }
+  }
+  return true;
+}
+
 // Small-node test: every power alpha_i^k, k <= t, as an integer (no reduction) stays below 2^29.
 template <class F>
 bool small_vandermonde(const typename F::Ctx& ctx, const BigTable<F>& al, size_t n, size_t t, SmallVdm& sv) {
   if (g_force_table.load() || t > (size_t)SmallVdm::TMAX || n * (t + 1) > (size_t)SmallVdm::CAP) return false;
-  const u128 lim = (u128)1 << 29;
   for (size_t i = 0; i < n; ++i) {
     u128 a;
     if (!node_value<F>(ctx, al.v[i], a)) return false;
+    if (!small_powers_fit(a, t)) return false;
     u128 pw = 1;
     for (size_t k = 0; k <= t; ++k) {
-      if (pw >= lim) return false;
       sv.v[i * (t + 1) + k] = (u32)pw;
-      if (k < t) {
-        if (a >= lim) return false;
-        pw *= a;  // < 2^58
-      }
+      pw *= a;  // (a^t < 2^29 and a < 2^29 checked above: < 2^58)
     }
   }
   return true;
@@ -1218,7 +1248,7 @@ int ew_inverse(const typename F::Ctx& ctx, bool div, u64* dst, const u64* a, con
 extern "C" {
 
 #if SCL_TU_COMMON
-int scl_hip_abi_version(void) { return 1; }
+int scl_hip_abi_version(void) { return SCL_HIP_ABI_VERSION; }
 
 const char* scl_hip_last_error(void) { return g_err.c_str(); }
 
@@ -1420,18 +1450,25 @@ int scl_hip_mont128_get_prime(uint64_t p[2]) {
 #endif  // SCL_TU_COMMON
 
 // ---- element-wise ---------------------------------------------------------------------------------------
-int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
+// status_dev == nullptr: scl_hip_ew, which reports a zero operand of INV / DIV itself (and therefore synchronises);
+// otherwise scl_hip_ew_status: the flag is the caller's device word, nothing waits.
+static int ew_impl(int field, int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n, unsigned* status_dev,
+                   bool async, void* stream) {
   if (op < 0 || op > 5) return fail(SCL_ERR_BAD_ARG, "unknown element-wise op");
   const bool binary = (op == SCL_OP_ADD || op == SCL_OP_SUB || op == SCL_OP_MUL || op == SCL_OP_DIV);
+  const bool needs_flag = (op == SCL_OP_INV || op == SCL_OP_DIV);
+  if (async && needs_flag && !status_dev) return fail(SCL_ERR_BAD_ARG, "status_dev is NULL (INV / DIV report through it)");
+  if (async && status_dev && (reinterpret_cast<uintptr_t>(status_dev) & 3)) return fail(SCL_ERR_BAD_ARG, "status_dev is not 4-byte aligned");
   if (n == 0) return SCL_OK;
   if (!dst || !a || (binary && !b)) return fail(SCL_ERR_BAD_ARG, "NULL operand");
   return with_ring_or_field(field, [&](auto f, auto ctx) -> int {
     using F = decltype(f);
     SCL_TRY(check_align<F>({dst, a, binary ? b : nullptr}));
     unsigned* flag = nullptr;
-    const bool needs_flag = (op == SCL_OP_INV || op == SCL_OP_DIV);
     bool host_flag = false;
-    if (needs_flag) {
+    if (needs_flag && async) {
+      flag = status_dev;
+    } else if (needs_flag) {
       if (!g_hflag.host && !g_hflag.failed) {
         void* hp = nullptr;
         void* dp = nullptr;
@@ -1490,8 +1527,13 @@ int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64
         return SCL_OK;
       });
     }
-    SCL_TRY(rc_);
-    if (needs_flag) {
+    if (rc_ != SCL_OK) {
+      // some launches of the call may be in flight with the flag in their arguments: nothing of this call runs on once it has
+      // returned (the next call on this thread resets the host-mapped word)
+      if (needs_flag && !async) (void)hipStreamSynchronize(S(stream));
+      return rc_;
+    }
+    if (needs_flag && !async) {
       unsigned h = 0;
       if (!host_flag) HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, S(stream)));
       HIP_TRY(hipStreamSynchronize(S(stream)));
@@ -1503,6 +1545,14 @@ int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64
     }
     return SCL_OK;
   });
+}
+
+int scl_hip_ew(int field, int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
+  return ew_impl(field, op, dst, a, b, n, nullptr, false, stream);
+}
+int scl_hip_ew_status(int field, int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n, unsigned* status_dev,
+                      void* stream) {
+  return ew_impl(field, op, dst, a, b, n, status_dev, true, stream);
 }
 
 int scl_hip_scalar_mul(int field, uint64_t* dst, const uint64_t* a, const uint64_t* scalar_host, size_t n,
@@ -2188,14 +2238,8 @@ static int share_prg_impl(int field, uint64_t* shares, size_t share_stride, cons
     // (the Mersenne fields: fused only while the small-node kernel applies -- every power n^k, k <= t, below 2^29 as
     // small_vandermonde wants it, i.e. (10, <= 8), (20, <= 6), (40, <= 5) -- the generic fused Horner kernel behind it is 1.2-2.3 x
     // behind the two passes: (40,6) 0.37 against 0.23 ms per 2 * 10^6, profiles/r5_probe_auto_choices.txt)
-    bool small_nodes_fit = true;
-    {
-      unsigned long long pw = 1;
-      for (size_t k = 0; k < t && small_nodes_fit; ++k) {
-        pw *= (unsigned long long)n;
-        if (n >= ((size_t)1 << 29) || pw >= (1ull << 29)) small_nodes_fit = false;
-      }
-    }
+    // (this entry point shares at the default nodes 1..n only: the largest node, n, decides for all of them)
+    const bool small_nodes_fit = small_powers_fit((u128)n, t);
     const bool want = t >= 1 && (montgomery || (field == SCL_GF2_128 ? (t >= 12 || (t >= 5 && n <= 64)) : (t >= 8 || !small_nodes_fit)));
     if (must || pref > 0 || (pref == 0 && want))
       return share_prg_two_pass(field, shares, share_stride, secrets, N, t, n, seed, seed_len, counter0, lane, stream);

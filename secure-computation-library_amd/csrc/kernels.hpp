@@ -139,10 +139,15 @@ __device__ __forceinline__ bool not_invertible(const typename F::E& a) {
   else return F::is_zero(a);
 }
 
-// the batch's "a zero was inverted" flag: set once -- a batch with many zeros (an error path, but 10^5 atomics on one word cost a
-// 0.3 ms kernel another 0.25 ms) reads the word first and leaves it alone when somebody has raised it already
+// the batch's "a zero was inverted" flag: set once -- a batch with many zeros (an error path, but 10^5 writes to one word cost a
+// 0.3 ms kernel another 0.25 ms) reads the word first and leaves it alone when somebody has raised it already.  The word may
+// be pinned HOST memory mapped into the device (scl_hip_ew) or device memory (scl_hip_ew_status): a plain system-scope STORE
+// of 1 -- idempotent, so racing lanes need no read-modify-write, and a store reaches host memory on every platform where a
+// device atomic would need PCIe atomic routing (absent under VFIO passthrough and on some root complexes).  The only other
+// bit anyone sets in the word is this one, so storing 1 is the OR.
 __device__ __forceinline__ void raise_flag(unsigned* flag) {
-  if (__atomic_load_n(flag, __ATOMIC_RELAXED) == 0) atomicOr(flag, 1u);
+  if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)
+    __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Vector::add/subtract/multiplyEntryWise, FF::negate/invert/operator/ (vector.h:199-245, ff.h:203-246)
@@ -159,13 +164,22 @@ __global__ __launch_bounds__(BLOCK) void k_ew(typename F::Ctx ctx, u64* dst, con
       if constexpr (OP == 1) r.v[v] = F::sub(ctx, x.v[v], y.v[v]);
       if constexpr (OP == 2) r.v[v] = F::mul(ctx, x.v[v], y.v[v]);
       if constexpr (OP == 3) r.v[v] = F::neg(ctx, x.v[v]);
+      // a non-invertible operand raises the flag and leaves 0 in its slot: Fermat's chain maps 0 to 0 by itself; a ring's
+      // Newton iteration on an even value would leave an arbitrary word, so the rings say so explicitly
+      constexpr bool RING = F::TAG == 5 || F::TAG == 6;
       if constexpr (OP == 4) {
-        if (not_invertible<F>(x.v[v])) raise_flag(zero_flag);
+        const bool bad = not_invertible<F>(x.v[v]);
+        if (bad) raise_flag(zero_flag);
         r.v[v] = F::inv(ctx, x.v[v]);
+        if constexpr (RING)
+          if (bad) r.v[v] = F::zero();
       }
       if constexpr (OP == 5) {
-        if (not_invertible<F>(y.v[v])) raise_flag(zero_flag);
+        const bool bad = not_invertible<F>(y.v[v]);
+        if (bad) raise_flag(zero_flag);
         r.v[v] = F::mul(ctx, x.v[v], F::inv(ctx, y.v[v]));
+        if constexpr (RING)
+          if (bad) r.v[v] = F::zero();
       }
     }
     store_pack<F, VEC, NT>(dst + off, r);

@@ -64,6 +64,14 @@ def _declare_prototypes():
                 getattr(lib, name).restype = ret
         return 0
     src = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    # the boundary's version first: a library built from an older header fails HERE, with a message that says so, not at the
+    # lookup of a symbol it does not have
+    want = re.search(r"#define\s+SCL_HIP_ABI_VERSION\s+(\d+)", src)
+    lib.scl_hip_abi_version.restype = C.c_int
+    have = lib.scl_hip_abi_version()
+    if want and have != int(want.group(1)):
+        raise ImportError(f"scl_amd: {_SO} implements ABI version {have}, {hdr} declares {want.group(1)}: rebuild the extension "
+                          "(make -C secure-computation-library_amd/csrc)")
     scalars = {"int": C.c_int, "long": C.c_long, "size_t": C.c_size_t, "uint64_t": C.c_uint64, "unsigned": C.c_uint,
                "float": C.c_float}
     rets = {"int": C.c_int, "size_t": C.c_size_t, "const char*": C.c_char_p}
@@ -210,6 +218,28 @@ def ew(field, op, a, b=None, out=None):
         out = torch.empty_like(a)
     n = a.numel() // L
     _chk(lib.scl_hip_ew(field, op, _dev(out), _dev(a), _dev(b) if b is not None else None, C.c_size_t(n), _stream()))
+    return out
+
+
+def ew_status_buffer(device="cuda") -> torch.Tensor:
+    """one cleared 32-bit device word for ew_status (scl_hip_ew_status's status_dev)"""
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def ew_status(field, op, a, b, status, out=None):
+    """scl_hip_ew_status: the element-wise call without a host synchronisation -- a zero (even, in a ring) operand of INV / DIV
+    ORs 1 into the device word `status` (an int32 tensor of one element, never cleared by the call) instead of raising; read it
+    with status.item() when the caller synchronises anyway.  Capturable into a hipGraph."""
+    L = limbs(field)
+    if b is not None and b.shape != a.shape:
+        raise SclError(ERR_SIZE_MISMATCH, "")
+    if out is None:
+        out = torch.empty_like(a)
+    if status is not None and (status.dtype != torch.int32 or status.numel() != 1 or not status.is_cuda):
+        raise SclError(ERR_BAD_ARG, "status: one int32 element on the GPU")
+    n = a.numel() // L
+    _chk(lib.scl_hip_ew_status(field, op, _dev(out), _dev(a), _dev(b) if b is not None else None, C.c_size_t(n),
+                               C.c_void_p(status.data_ptr()) if status is not None else None, _stream()))
     return out
 
 

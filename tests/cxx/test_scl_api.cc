@@ -177,6 +177,40 @@ TEST_CASE(ff_secp256k1_field, "FF<Secp256k1Field> identities + metadata", HOST) 
   REQUIRE(buf[0] == 0xff && buf[27] == 0xfe && buf[31] == 0x2d && FP::read(buf) == FP(-2));  // value, big-endian
 }
 
+TEST_CASE(ff_mont128_reference_kats, "FF<Mont128>: strings, ints, bytes as the reference's Montgomery templates give them at N = 2", HOST) {
+  // known answers from tests/golden/golden_mont128.json: include/scl/math/fields/ff_ops_gmp.h compiled at two limbs
+  // (oracle/ref_harness.cc, field tag 2), modulus 2^128 - 159.  value().w = the Montgomery image, like FF::m_value.
+  using FM = math::FF<math::ff::Mont128>;
+  auto image = [](const FM& x) {
+    std::uint64_t w[2];
+    x.toLimbs(w);
+    char buf[40];
+    if (w[1]) std::snprintf(buf, sizeof buf, "%llx%016llx", (unsigned long long)w[1], (unsigned long long)w[0]);
+    else std::snprintf(buf, sizeof buf, "%llx", (unsigned long long)w[0]);
+    return std::string(buf);
+  };
+  REQUIRE(image(FM(1)) == "9f" && image(FM(-1)) == "fffffffffffffffffffffffffffffec2" && image(FM(123)) == "4c65");
+  REQUIRE(image(FM(-2147483647)) == "ffffffffffffffffffffffb080000000" && image(FM(65536)) == "9f0000");
+  REQUIRE(image(FM::fromString("7b")) == "4c65" && FM::fromString("7b").toString() == "7b");
+  REQUIRE(FM::fromString("") == FM(0) && FM::fromString("00") == FM(0));
+  REQUIRE(FM::fromString("ffffffffffffffffffffffffffffff61") == FM(0));            // p = 0
+  REQUIRE(FM::fromString("ffffffffffffffffffffffffffffffff").toString() == "9e");  // 2^128 - 1 = 158 mod p
+  REQUIRE(FM::fromString("abc") == FM(0xabc));                                     // odd length is padded (ff_ops_gmp.h:383-386)
+  // limbs are cut from the LEFT in 16-digit pieces; a short last piece becomes limb 0 as it stands (ff_ops_gmp.h:388-395)
+  REQUIRE(FM::fromString("0123456789ABCDEFabcdef").toString() == "123456789abcdef0000000000abcdef");
+  REQUIRE(image(FM::fromString("0123456789ABCDEFabcdef")) == "b4e81b4e81b4e771000000006ab4e771");
+  REQUIRE(FM::fromString("123456789abcdef0f").toString() == "123456789abcdef000000000000000f");
+  REQUIRE_THROWS_MSG(FM::fromString("zz"), std::invalid_argument, "encountered invalid hex character");
+  REQUIRE_THROWS_MSG(FM::fromString(std::string(33, '1')), std::invalid_argument, "hex string too large to parse");
+  unsigned char be[16];
+  for (int i = 0; i < 16; ++i) be[i] = (unsigned char)i;                           // montyFromBytes: big-endian value
+  REQUIRE(image(FM::read(be)) == "a03fdf7f1ebe5dfd9d3cdc7c1bbb51");
+  unsigned char back[16];
+  FM::read(be).write(back);
+  REQUIRE(std::memcmp(back, be, 16) == 0);
+  REQUIRE_THROWS_MSG(FM(0).inverse(), std::logic_error, "0 not invertible modulo prime");
+}
+
 TEST_CASE(ff_plugins, "plug-in fields: Mont128, GF(2^128) identities", HOST) {
   field_identities<math::FF<math::ff::Mont128>>("c");
   using G = math::FF<math::ff::GF2_128>;
@@ -1325,6 +1359,83 @@ TEST_CASE(open_rccl, "hip::open / openByPartialSums over a one-rank RCCL communi
   long ragged[12];  // 10 parties on 4 ranks: 3 per rank, the last rank holds one party and two padding rows
   hip::check(scl_hip_open_row_order(10, 4, ragged));
   REQUIRE(ragged[3] == 9 && ragged[7] == -1 && ragged[11] == -1 && ragged[4] == 1);
+}
+
+// ---------------------------------------------------------------------------- hip::DeviceVector element-wise, lazy zero flag
+// FF::operator/ throws std::logic_error("0 not invertible modulo prime") at the first zero divisor (ff.h:203-205 through
+// small_ff.h:61-70; pinned by test_ff.cc:168-171).  Over device-resident vectors the same exception arrives LATE, from
+// hip::ZeroFlag::check_for, after any number of asynchronous calls; the flag-less forms throw before they return.
+template <typename FF>
+static void device_elementwise(const char* seed) {
+  auto prg = util::PRG::create(seed);
+  const std::size_t N = 5000;
+  std::vector<FF> a(N), b(N);
+  for (std::size_t i = 0; i < N; ++i) {
+    a[i] = FF::random(prg);
+    b[i] = FF::random(prg);
+    if (b[i] == FF::zero()) b[i] = FF::one();
+  }
+  hip::DeviceVector<FF> da(a), db(b), out(N);
+  hip::add(out, da, db);
+  auto h = out.toHost();
+  bool ok = true;
+  for (std::size_t i = 0; i < N; ++i) ok = ok && h[i] == a[i] + b[i];
+  REQUIRE(ok);
+  hip::multiplyEntryWise(out, da, db);
+  h = out.toHost();
+  for (std::size_t i = 0; i < N; ++i) ok = ok && h[i] == a[i] * b[i];
+  REQUIRE(ok);
+  hip::ZeroFlag flag;
+  hip::divide(out, da, db, flag);
+  hip::inverse(db, db, flag);           // in place; several calls on one flag
+  hip::multiplyEntryWise(db, db, da);   // a * b^-1 once more
+  REQUIRE(!flag.raised());
+  flag.template check_for<FF>();        // nothing to throw
+  h = out.toHost();
+  auto h2 = db.toHost();
+  for (std::size_t i = 0; i < N; ++i) ok = ok && h[i] == a[i] / b[i] && h2[i] == h[i];
+  REQUIRE(ok);
+  // a zero among the divisors: the asynchronous call returns, the other slots are computed, the zero's slot holds 0, and the
+  // reference's exception comes out of check_for -- once
+  b[N / 2] = FF::zero();
+  hip::DeviceVector<FF> dz(b);
+  hip::divide(out, da, dz, flag);
+  REQUIRE(flag.raised());
+  REQUIRE_THROWS_MSG(flag.template check_for<FF>(), std::logic_error, "0 not invertible modulo prime");
+  REQUIRE(!flag.raised());              // cleared by the throw
+  h = out.toHost();
+  REQUIRE(h[N / 2] == FF::zero());
+  REQUIRE(h[0] == a[0] / b[0] && h[N - 1] == a[N - 1] / b[N - 1]);
+  // the synchronous forms throw before they return
+  REQUIRE_THROWS_MSG(hip::divide(out, da, dz), std::logic_error, "0 not invertible modulo prime");
+  REQUIRE_THROWS_MSG(hip::inverse(out, dz), std::logic_error, "0 not invertible modulo prime");
+  hip::DeviceVector<FF> shorter(N - 1);
+  REQUIRE_THROWS_MSG(hip::add(shorter, da, db), std::invalid_argument, "Vec sizes mismatch");
+}
+TEST_CASE(device_elementwise_m61, "hip::add / multiplyEntryWise / divide / inverse over DeviceVector, lazy ZeroFlag (Mersenne61)", GPU) {
+  device_elementwise<F61>("device ew 61");
+}
+TEST_CASE(device_elementwise_m127, "hip::divide / inverse over DeviceVector, lazy ZeroFlag (Mersenne127)", GPU) {
+  device_elementwise<F127>("device ew 127");
+}
+TEST_CASE(device_elementwise_ring, "hip::inverse over DeviceVector<Z2k<64>>: an even element raises the ring's exception late", GPU) {
+  using R = math::Z2k<64>;
+  auto prg = util::PRG::create("device ew ring");
+  const std::size_t N = 300;
+  std::vector<R> a(N);
+  for (auto& x : a) x = R::random(prg) * R(2) + R(1);   // odd: invertible modulo 2^64
+  hip::DeviceVector<R> da(a), out(N);
+  hip::ZeroFlag flag;
+  hip::inverse(out, da, flag);
+  flag.check_for<R>();
+  auto h = out.toHost();
+  bool ok = true;
+  for (std::size_t i = 0; i < N; ++i) ok = ok && h[i] * a[i] == R(1);
+  REQUIRE(ok);
+  a[7] = R(10);
+  hip::DeviceVector<R> de(a);
+  hip::inverse(out, de, flag);
+  REQUIRE_THROWS_MSG(flag.check_for<R>(), std::invalid_argument, "value not invertible modulo 2^K");
 }
 
 int main(int argc, char** argv) {

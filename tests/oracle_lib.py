@@ -482,12 +482,36 @@ class Ref(_Base):
     prefix = "sclref_"
     has_err = True
 
-    def __init__(self, path: str | None = None):
+    def __init__(self, path: str | None = None, fresh: bool = False):
+        """fresh=True loads a private COPY of the library (its own statics): the reference's FF::one() / zero() are
+        function-local statics that latch the modulus of field tag 2 at first use, so a second Mont128 prime needs a second
+        instance"""
         if path is None:
             path = REF_SO if os.path.exists(REF_SO) else build_ref()
         if path is None or not os.path.exists(path):
             raise FileNotFoundError("oracle/_ref/libscl_ref.so unavailable (no /root/reference here)")
+        self._tmp = None
+        if fresh:
+            import shutil
+            import tempfile
+            fd, tmp = tempfile.mkstemp(prefix="libscl_ref_", suffix=".so")
+            os.close(fd)
+            shutil.copyfile(path, tmp)
+            self._tmp = path = tmp
         super().__init__(path)
+        if self._tmp:            # (the mapping stays valid after the name is gone)
+            os.unlink(self._tmp)
+
+    def mont128_set_prime(self, p: int):
+        """modulus of field tag 2: the reference's Montgomery templates (ff_ops_gmp.h) instantiated at two limbs
+        (oracle/ref_harness.cc); 2^128 - 159 until set"""
+        a = from_ints([p], 2)[0]
+        self._call("mont128_set_prime", _p(a))
+
+    def mont128_get_prime(self) -> int:
+        a = np.zeros(2, dtype=np.uint64)
+        self.lib.sclref_mont128_get_prime(_p(a))
+        return to_ints(a.reshape(1, 2))[0]
 
 
 def ref_available() -> bool:

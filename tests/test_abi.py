@@ -44,7 +44,7 @@ def test_nothing_but_the_declared_symbols_is_exported(scl):
 
 
 def test_metadata_and_messages(scl):
-    assert scl.lib.scl_hip_abi_version() == 1
+    assert scl.lib.scl_hip_abi_version() == 2
     assert [scl.limbs(f) for f in range(6)] == [1, 2, 2, 2, 4, 4]
     # names pinned by test/scl/math/test_mersenne61.cc:28-33, test_mersenne127.cc:28-33
     assert scl.field_name(0) == "Mersenne61" and scl.field_name(1) == "Mersenne127"

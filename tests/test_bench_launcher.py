@@ -25,6 +25,7 @@ def test_plain_start_with_gpus_2_launches_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
+    assert len(lines[0]) < 8192
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
     assert line["config"]["parallelism"] == "shard2"
@@ -38,9 +39,18 @@ def test_plain_start_with_gpus_2_launches_two_ranks():
 def test_single_rank_dry_run_prints_one_line():
     r = _run(["--dry-run", "--steps", "1", "--warmup", "0"])
     assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("\n") == 1 and len(r.stdout) < 8192      # ONE line, short enough for the driver's record
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1
     assert line["rccl"] == {"ranks": 1, "backend": None, "devices": [0]} and len(line["ms_per_step_by_rank"]) == 1
+    # the driver's own command, dry: every key of the contract is there whatever the flags
+    r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config"):
+        assert k in line, k
+    assert line["steps"] == 20 and line["warmup"] == 5 and "workload" in line["config"] and "model" not in line["config"]
 
 
 def test_world_size_that_disagrees_with_gpus_fails():
@@ -80,13 +90,14 @@ def test_pmc_traffic_is_stamped_and_only_quoted_for_its_own_kernels():
         assert sk in tr["share_kernel"] and rk in tr["recover_kernel"], (key, tr)
         c = pmc["configs"][key]
         assert abs(c["share"]["traffic_over_algorithmic"] - 1) < 1e-2 and abs(c["recover"]["traffic_over_algorithmic"] - 1) < 1e-2, (key, c)
-    real = bench.kernel_source_hash
+    import bench_legs.pmc as pmc_mod
+    real = pmc_mod.kernel_source_hash
     try:
-        bench.kernel_source_hash = lambda: "0" * 16      # what an edited kernel source looks like
+        pmc_mod.kernel_source_hash = lambda: "0" * 16      # what an edited kernel source looks like
         assert bench.pmc_traffic("shamir_share", args) is None
         assert bench.pmc_config_traffic("C4_shard_gf2_128_40_13") is None
     finally:
-        bench.kernel_source_hash = real
+        pmc_mod.kernel_source_hash = real
 
 
 def test_configs_quoted_on_eight_gpus_dry_run():
@@ -143,6 +154,7 @@ def test_side_legs_and_pmc_parsing_are_pure_functions():
     the largest size only)."""
     sys.path.insert(0, ROOT)
     import bench
+    assert bench.side_legs is __import__("bench_legs.common", fromlist=["side_legs"]).side_legs
     line = {"verified": True, "roofline": {"frac": 0.8}, "cpu_baseline": {"all_cores": {"error": "x"}},
             "configs": {"A": {"verified": True, "share_roofline": {"frac": 0.3}}, "B": {"error": "boom", "verified": False}},
             "open": {"c4": {"verified": True, "c_abi": {"skipped": "why"}, "partial_gather": {"verified": False}}}}
@@ -169,3 +181,27 @@ def test_side_legs_and_pmc_parsing_are_pure_functions():
     assert rep["shamir_share"]["bytes"] == 112 * 10**8 and rep["shamir_share"]["launches"] == 1
     assert rep["shamir_recover"]["bytes"] == 88 * 10**8
     assert abs(rep["calibration_k_copy16"]["fetch_correction"] - 2.0) < 1e-9 and rep["configs"] == {}
+
+
+def test_the_line_is_cut_to_size_and_the_detail_keeps_everything():
+    """bench.finish_line: `verified` = AND over the headline and every leg of the detail object, errors listed, floats to six
+    figures, and a line that would pass the limit sheds its digest and then its per-leg map -- it never grows past what the
+    driver's record takes (BENCH_r05: a 20 KB line, parsed = null)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    line = {"metric": "shamir_reconstructions_per_sec", "value": 3.123456789e10, "verified_headline": True,
+            "roofline": {"frac": 0.8123456789}}
+    detail = {"configs": {"A": {"verified": True, "share_frac": 0.5, "recover_frac": 0.4},
+                          "B": {"error": "boom " * 100, "verified": False}},
+              "open": {"c4_all_gather": {"verified": True, "opened_secrets_per_s": 1.0, "rccl_busbw_GBps": 0.0,
+                                         "reconstruct_hbm_frac": 0.4, "c_abi": {"skipped": "why"}}}}
+    out, legs, errors = bench.finish_line(dict(line), detail)
+    assert out["verified"] is False and out["verified_headline"] is True
+    assert legs == {"configs.A": True, "configs.B": False, "open.c4_all_gather": True} and len(errors) == 1
+    assert len(out["errors"][0]) <= 240 and out["value"] == 3.12346e10 and out["roofline"]["frac"] == 0.812346
+    assert out["legs"]["A"] == {"share_frac": 0.5, "recover_frac": 0.4} and "B" not in out["legs"]
+    assert len(json.dumps(out)) < bench.LINE_LIMIT
+    many = {"configs": {f"leg{i:04d}": {"verified": True, "share_frac": 0.5, "recover_frac": 0.4} for i in range(400)}}
+    out, legs, _ = bench.finish_line(dict(line), many)
+    assert len(json.dumps(out)) < bench.LINE_LIMIT and "legs" not in out
+    assert out["verified_legs"] == {"count": 400, "failed": []} and out["verified"] is True

@@ -20,8 +20,15 @@ with open(os.path.join(HERE, "golden", "golden_v1.json")) as fh:
 with open(os.path.join(HERE, "golden", "golden_secp256k1_field.json")) as fh:   # FF<Secp256k1Field>, same generator
     GOLD["fields"].update(json.load(fh)["fields"])
 
+GOLDEN_NAME = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.MONT128: "Mont128", O.SECP256K1_SCALAR: "secp256k1_order",
+               O.SECP256K1_FIELD: "secp256k1_field"}     # the reference-emitted fixture of a field (Mont128: its default modulus)
+# the two-limb instance of the reference's Montgomery family (field tag 2; golden_mont128.json, emitted by the reference's
+# own templates compiled at N = 2): BASELINE configs[2]'s field, one fixture per modulus
+with open(os.path.join(HERE, "golden", "golden_mont128.json")) as fh:
+    MONT = json.load(fh)["fields"]
+GOLD["fields"].update(MONT)
 FIELDS = [(O.M61, "Mersenne61"), (O.M127, "Mersenne127"), (O.SECP256K1_SCALAR, "secp256k1_order"),
-          (O.SECP256K1_FIELD, "secp256k1_field")]
+          (O.SECP256K1_FIELD, "secp256k1_field")] + [(O.MONT128, name) for name in sorted(MONT)]
 ALL_FIELDS = [O.M61, O.M127, O.MONT128, O.GF2_128, O.SECP256K1_SCALAR, O.SECP256K1_FIELD]
 SLOW_ORACLE = (O.MONT128, O.GF2_128, O.SECP256K1_SCALAR, O.SECP256K1_FIELD)  # bit-serial / Fermat inversions in the C oracle
 
@@ -37,6 +44,24 @@ def scl():
 @pytest.fixture(scope="module")
 def port():
     return O.Port()
+
+
+@pytest.fixture(autouse=True)
+def _mont128_modulus(request):
+    """a Mont128 golden fixture is taken with ITS modulus: set on the library and on the oracle, 2^128 - 159 again after"""
+    name = getattr(request.node, "callspec", None) and request.node.callspec.params.get("name")
+    if not (isinstance(name, str) and name in MONT):
+        yield
+        return
+    scl_, port_ = request.getfixturevalue("scl"), request.getfixturevalue("port")
+    p = int(MONT[name]["prime"], 16)
+    scl_.set_mont128_prime(p)
+    port_.mont128_set_prime(p)
+    try:
+        yield
+    finally:
+        scl_.set_mont128_prime((1 << 128) - 159)
+        port_.mont128_set_prime((1 << 128) - 159)
 
 
 def rand_elems(port, f, n, seed):
@@ -327,6 +352,20 @@ def test_from_bytes_and_vector_random(scl, port, f):
     c0 = 11
     skip = port.prg(b"vec", [16 * c0, 8 * L * 9])[16 * c0:]
     assert np.array_equal(host(scl, scl.vector_random(f, 9, b"vec", c0)), port.from_bytes(f, skip))
+
+
+@pytest.mark.parametrize("name", sorted(MONT))
+def test_mont128_c3_shapes_golden(scl, port, name):
+    """BASELINE configs[2] -- Shamir (10,3) over the 128-bit Montgomery prime field -- and (40,13): PRG-driven shares and
+    reconstructions emitted by the reference's shamirSecretShare / shamirRecoverP over FF<the reference's own Montgomery
+    templates at N = 2> (golden_mont128.json), for three moduli; the kernels must give those bits."""
+    f, L = O.MONT128, 2
+    for c in MONT[name]["shamir_c3"]:
+        secrets = O.from_ints(ints(c["secrets"]), L)
+        shares = scl.shamir_share_prg(f, dev(scl, secrets), c["t"], c["n"], bytes.fromhex(c["seed"]))
+        want = O.from_ints(ints(c["shares"]), L).reshape(len(secrets), c["n"], L)
+        assert np.array_equal(host(scl, shares), soa(want)), (name, c["n"], c["t"])
+        assert O.to_ints(host(scl, scl.shamir_recover(f, shares))) == ints(c["recovered_all_n"]) == ints(c["secrets"])
 
 
 @pytest.mark.parametrize("f,name", FIELDS)
@@ -1148,7 +1187,7 @@ def test_vandermonde_matmul_is_sharing(scl, port):
 def test_wire_image(scl, port, f):
     """seri::Serializer<Vector<FF>>: u32 count || FF::write images; golden bytes from the reference"""
     L = O.LIMBS[f]
-    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order", O.SECP256K1_FIELD: "secp256k1_field"}.get(f)
+    name = GOLDEN_NAME.get(f)
     if name:
         for c in GOLD["fields"][name]["wire"]:
             el = O.from_ints(ints(c["elems"]), L) if c["elems"] else np.zeros((0, L), np.uint64)
@@ -1173,7 +1212,7 @@ def test_wire_image(scl, port, f):
 def test_wire_matrix_image(scl, port, f):
     """seri::Serializer<Matrix<FF>>: u32 rows || u32 cols || vector image; golden bytes from the reference"""
     L = O.LIMBS[f]
-    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order", O.SECP256K1_FIELD: "secp256k1_field"}.get(f)
+    name = GOLDEN_NAME.get(f)
     if name:
         for c in GOLD["fields"][name]["wire_matrix"]:
             m = O.from_ints(ints(c["elems"]), L).reshape(c["rows"], c["cols"], L) if c["elems"] else None
@@ -1204,7 +1243,7 @@ def test_shamir_over_arrays(scl, port, f):
     """shamirSecretShare<Array<FF, W>> (pedersen.h:138): golden shares from the reference, then the oracle at more
     shapes; every component reconstructs on its own"""
     L = O.LIMBS[f]
-    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order", O.SECP256K1_FIELD: "secp256k1_field"}.get(f)
+    name = GOLDEN_NAME.get(f)
     cases = []
     if name:
         for c in GOLD["fields"][name]["shamir_packed"]:
@@ -1234,7 +1273,7 @@ def test_shamir_over_arrays(scl, port, f):
 def test_tcp_frames(scl, port, f):
     """TcpChannel frame = u32 packet size || Packet bytes (tcp_channel.h:125-160); golden frames from the reference"""
     L = O.LIMBS[f]
-    name = {O.M61: "Mersenne61", O.M127: "Mersenne127", O.SECP256K1_SCALAR: "secp256k1_order", O.SECP256K1_FIELD: "secp256k1_field"}.get(f)
+    name = GOLDEN_NAME.get(f)
     if name:
         for c in GOLD["fields"][name]["frame"]:
             if c["kind"] == "vector":
@@ -1632,6 +1671,100 @@ def test_batch_calls_capture_into_a_hip_graph(scl, port):
         assert np.array_equal(host(scl, sh3), soa(port.additive_share(f, b"graph-seed", fresh, 3)))
 
 
+@pytest.mark.parametrize("f", ALL_FIELDS + [scl_ring for scl_ring in (0x100 + 64, 0x100 + 128)])
+def test_ew_status_leaves_the_zero_flag_on_the_device(scl, port, f):
+    """scl_hip_ew_status: FF::inverse / operator/ (ff.h:203-246; the throw of small_ff.h:61-70, ff_ops_gmp.h:250-260,
+    z2k_ops.h:81-83) without a host synchronisation -- same values as scl_hip_ew and the oracle, the "not invertible" report a
+    device word the call ORs into and never clears, the offending slots 0 and every other slot computed."""
+    ring = f > 0x100
+    L = scl.limbs(f)
+    n = 3001 if (ring or f in SLOW_ORACLE) else 20011
+    if ring:
+        rng = np.random.default_rng(f)
+        a = rng.integers(0, 2**63, size=(n, L), dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+        a[:, 1:] = rng.integers(0, 2**63, size=(n, L - 1), dtype=np.uint64)
+        b = a[::-1].copy()
+        bad_value = np.zeros(L, np.uint64)
+        bad_value[0] = 6                        # even: not invertible modulo 2^K
+    else:
+        a, b = rand_elems(port, f, n, b"ews-a"), rand_elems(port, f, n, b"ews-b")
+        zero = port.from_int(f, 0)
+        for x, sub in ((a, 7), (b, 9)):
+            x[np.all(x == zero, axis=1)] = port.from_int(f, sub)
+        bad_value = zero
+    da, db = dev(scl, a), dev(scl, b)
+    status = scl.ew_status_buffer()
+    want_inv = host(scl, scl.ew(f, O.INV, da))            # (the synchronous call is checked against the oracle elsewhere)
+    want_div = host(scl, scl.ew(f, O.DIV, db, da))
+    if not ring:
+        w = slice(0, 200)
+        assert np.array_equal(want_inv[w], port.ew(f, O.INV, a[w])) and np.array_equal(want_div[w], port.ew(f, O.DIV, b[w], a[w]))
+    assert np.array_equal(host(scl, scl.ew_status(f, O.INV, da, None, status)), want_inv)
+    assert np.array_equal(host(scl, scl.ew_status(f, O.DIV, db, da, status)), want_div)
+    assert np.array_equal(host(scl, scl.ew_status(f, O.ADD, da, db, None)), host(scl, scl.ew(f, O.ADD, da, db)))   # ops that cannot fail: no word needed
+    assert int(status.item()) == 0
+    spots = np.array(sorted({0, 1, 63, 64, n // 2, n - 2, n - 1}))
+    z = a.copy()
+    z[spots] = bad_value
+    out = scl.ew_status(f, O.INV, dev(scl, z), None, status)
+    assert int(status.item()) == 1
+    got, keep = host(scl, out), np.ones(n, bool)
+    keep[spots] = False
+    assert np.array_equal(got[keep], want_inv[keep]) and not got[spots].any()
+    # never cleared by the call: a clean batch afterwards leaves the word raised; the caller clears it
+    scl.ew_status(f, O.INV, da, None, status)
+    assert int(status.item()) == 1
+    status.zero_()
+    got = host(scl, scl.ew_status(f, O.DIV, db, dev(scl, z), status))
+    assert int(status.item()) == 1 and np.array_equal(got[keep], want_div[keep]) and not got[spots].any()
+    with pytest.raises(scl.SclError) as ei:
+        scl.ew_status(f, O.INV, da, None, None)           # INV / DIV report through the word: it must be there
+    assert ei.value.status == scl.ERR_BAD_ARG
+
+
+def test_inverse_and_divide_capture_into_a_hip_graph(scl, port):
+    """The asynchronous inverse / divide (scl_hip_ew_status) neither synchronises nor copies: a sequence of small batches is
+    captured on a stream (through torch.cuda.CUDAGraph) together with the clearing of its status word, replayed on new operands,
+    and the flag is read once after the replay -- clean operands leave it 0, a planted zero raises it.  The synchronous
+    scl_hip_ew cannot be captured: it waits for the stream to report the reference's error."""
+    for f, N in ((O.M61, 4097), (O.M127, 1025), (O.MONT128, 513)):
+        a, b = scl.vector_random(f, N, b"graph-inv-a"), scl.vector_random(f, N, b"graph-inv-b")
+        inv, quo, status = scl.empty(f, N), scl.empty(f, N), scl.ew_status_buffer()
+
+        def step():
+            status.zero_()
+            scl.ew_status(f, O.INV, a, None, status, out=inv)
+            scl.ew_status(f, O.DIV, b, a, status, out=quo)
+
+        g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            step()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                step()
+        torch.cuda.synchronize()
+        for rep in range(3):
+            fresh = scl.vector_random(f, N, b"graph-inv-%d" % rep)
+            if rep == 2:
+                fresh[N // 3] = 0                       # a zero operand in the last replay
+            a.copy_(fresh)
+            inv.zero_()
+            quo.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert int(status.item()) == (1 if rep == 2 else 0)
+            keep = np.ones(N, bool)
+            if rep == 2:
+                keep[N // 3] = False
+            w = np.flatnonzero(keep)[:128]
+            ha, hb = host(scl, a), host(scl, b)
+            assert np.array_equal(host(scl, inv)[w], port.ew(f, O.INV, ha[w]))
+            assert np.array_equal(host(scl, quo)[w], port.ew(f, O.DIV, hb[w], ha[w]))
+            mask = torch.from_numpy(keep).cuda()
+            ones = scl.to_device(np.broadcast_to(port.from_int(f, 1), (int(keep.sum()), scl.limbs(f))).copy())
+            assert bool(scl.equals(f, scl.ew(f, O.MUL, inv, a)[mask].contiguous(), ones))
+
+
 def test_reference_binding_compiled_against_the_reference():
     """integration/include/scl/hip/binding.h -- the header INTEGRATION.md section 2 tells a maintainer of the reference to add --
     compiled against the REAL reference (/root/reference/include + its translation units, oracle/Makefile `binding`; the
@@ -2011,102 +2144,128 @@ def test_c5_shard_size(scl, port):
 
 
 def test_bench_contract_small(scl):
-    """bench.py end to end on a small batch: one JSON line with the contract's keys, the roofline and cpu_baseline objects,
-    a verified round trip on plain allocations, the open-step report and (with --configs 0) no side configurations."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--secrets", "300000", "--steps", "2", "--warmup", "1",
-                        "--cpu-sample", "2000", "--configs", "0", "--open-secrets", "50000", "--open-chunk", "20000",
-                        "--c4-rank-secrets", "60001", "--ew-elements", "300001"],
-                       capture_output=True, text=True, timeout=600)
+    """bench.py end to end on a small batch: ONE compact JSON line on stdout with the contract's keys, the roofline, kernels and
+    cpu_baseline objects and the verdict over every leg -- short enough for the driver's record -- and, in the detail file it
+    names, everything the legs measured: the open-step report, the element-wise path with its compute rooflines and the
+    asynchronous inverse, the layout bridge, Matrix::multiply, the full CPU baseline."""
+    from bench_util import assert_compact, run_bench
+    r = run_bench(["--secrets", "300000", "--steps", "2", "--warmup", "1", "--cpu-sample", "2000", "--cpu-all-cores", "1",
+                   "--configs", "0", "--open-secrets", "50000", "--open-chunk", "20000", "--c4-rank-secrets", "60001",
+                   "--ew-elements", "300001"], timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line, detail = assert_compact(r), r.detail
     # the line tells the truth about its side legs: top-level verified = AND over the headline and every leg, the CPU model
     # beside the core count, where the traffic figure comes from, and (below) a failed leg -> error listed, exit code 1
     assert line["verified_headline"] is True and line["verified_legs"] and all(line["verified_legs"].values())
     assert {"open.c4_all_gather", "open.c4_all_gather.c_abi", "open.c4_all_gather.partial_gather", "open.m61_partial_sums",
-            "open.c4_rank_shape"} <= set(line["verified_legs"])
-    assert "errors" not in line
-    assert line["cpu_baseline"]["cpu_model"] and line["cpu_baseline"]["host_cores_available"] >= 1
-    assert "pmc_traffic.json" in line["roofline"]["traffic_source"]
-    rs = line["open"]["c4_rank_shape"]
+            "open.c4_rank_shape", "ew", "layout", "matmul"} <= set(line["verified_legs"])
+    assert "errors" not in line and detail["line"] == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "kernels", "cpu_baseline", "verified", "verified_legs", "detail"):
+        assert k in line, k
+    for k in ("ew", "layout", "matmul", "open", "configs", "prg_mode", "by_allocation", "c1_additive"):
+        assert k not in line, k                      # the legs' own figures live in the detail file
+    assert line["verified"] is True and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2
+    assert set(("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes",
+                "traffic_over_algorithmic")) <= set(line["roofline"])
+    assert set(line["kernels"]) == {"shamir_share", "shamir_recover"} and all(k["ms"] > 0 and 0 < k["frac"] < 1 for k in line["kernels"].values())
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample", "cpu_model"}
+    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["cpu_model"]
+    assert line["config"]["allocations"] == 3 and "configs" not in detail and "model" not in line["config"]
+    assert line["rccl"]["ranks"] == 1 and len(line["ms_per_step_by_rank"]) == 1
+    # the committed PMC traffic describes BASELINE configs[1] only: any other configuration reports null
+    assert line["roofline"]["traffic"] is None and line["roofline"]["traffic_source"] is None
+    # the headline's steps rotate over independently allocated operand sets; the per-allocation kernel times ride along
+    assert len(detail["by_allocation"]) == 2 and all(b["steps"] == 1 and b["share_ms"] > 0 for b in detail["by_allocation"])
+    rs = detail["open"]["c4_rank_shape"]
     assert rs["verified"] is True and rs["partial_bytes_per_secret"] == 96 and rs["sum_bytes_per_secret"] == 144
-    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--secrets", "300000", "--steps", "2", "--warmup", "1",
-                          "--cpu-sample", "0", "--configs", "0", "--open-secrets", "50000", "--open-chunk", "20000",
-                          "--c4-rank-secrets", "0", "--ew", "0", "--inject-error", "c_abi"], capture_output=True, text=True, timeout=600)
-    bl = json.loads(bad.stdout.strip().splitlines()[-1])
+    # the element-wise path north_star names first, and the layout bridge: add / mul / inv per field with their rooflines
+    ew = detail["ew"]
+    assert ew["verified"] is True and set(ew["fields"]) == {"Mersenne61", "Mersenne127", "Mont128", "GF(2^128)"}
+    for name, fld in ew["fields"].items():
+        assert fld["elements"] == 300001 and all(fld[op]["verified"] and fld[op]["GBps"] > 0 for op in ("add", "mul", "inv", "inv_async"))
+        assert fld["add"]["bytes_per_element"] == 3 * fld["inv"]["bytes_per_element"] // 2
+        # legs HBM does not bound carry the ceiling they do run against: instructions per element x rate against the issue rate
+        rc = fld["inv"]["roofline_compute"]
+        assert rc["bound"] == "vector ALU" and rc["per_element"] > 50 and 0 < rc["frac"] < 1.2 and rc["peak"] > 1e11
+        assert set(fld["inverse_small_batches"]) == {"10000", "100000"} and fld["inverse_small_batches"]["10000"]["async_wall_us_per_call"] > 0
+        assert line["legs"]["ew " + name]["inv"] > 0 and line["legs"]["ew " + name]["inv_frac_valu"] > 0
+    assert "roofline_lds" in ew["fields"]["GF(2^128)"]["mul"] and ew["fields"]["Mersenne127"]["inv"]["traffic_over_algorithmic"]["expected"] == 2.5
+    mm = detail["matmul"]
+    assert mm["verified"] is True and any(v["path"].startswith("matrix cores") and v["frac_of_int8_peak"] > 0 for v in mm["shapes"].values())
+    lay = detail["layout"]
+    assert lay["verified"] is True and all(v["soa_to_aos"]["frac"] > 0 and v["aos_to_soa"]["frac"] > 0 for v in lay["fields"].values())
+    cb = detail["cpu_baseline"]
+    assert cb["physical_cores"] >= 1 and cb["all_cores"]["cores"] == cb["physical_cores"] and cb["cores_per_gpu"]["cores"] <= 16
+    c4 = detail["open"]["c4_all_gather"]
+    assert c4["verified"] is True and c4["secrets"] == 50000 and c4["chunk"] == 20000 and c4["parties_per_rank"] == 40
+    assert detail["open"]["m61_partial_sums"]["verified"] is True
+    bad = run_bench(["--secrets", "300000", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--configs", "0",
+                     "--open-secrets", "50000", "--open-chunk", "20000", "--c4-rank-secrets", "0", "--ew", "0", "--inject-error", "c_abi"],
+                    timeout=600)
+    bl = assert_compact(bad)
     assert bad.returncode != 0 and bl["verified"] is False and bl["verified_headline"] is True
     assert any("c_abi" in e for e in bl["errors"]) and bl["verified_legs"]["open.c4_all_gather.c_abi"] is False
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in line, k
-    assert line["verified"] is True and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
-    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["cores"] == 1
-    assert line["config"]["allocation"].startswith("plain") and "configs" not in line
-    # the headline's steps rotate over independently allocated operand sets; the per-allocation kernel times ride along
-    assert len(line["by_allocation"]) == 2 and all(b["steps"] == 1 and b["share_ms"] > 0 for b in line["by_allocation"])
-    assert line["rccl"]["ranks"] == 1 and len(line["ms_per_step_by_rank"]) == 1
-    # the element-wise path north_star names first, and the layout bridge: add / mul / inv per field with their rooflines
-    ew = line["ew"]
-    assert ew["verified"] is True and set(ew["fields"]) == {"Mersenne61", "Mersenne127", "Mont128", "GF(2^128)"}
-    for fld in ew["fields"].values():
-        assert fld["elements"] == 300001 and all(fld[op]["verified"] and fld[op]["GBps"] > 0 for op in ("add", "mul", "inv"))
-        assert fld["add"]["bytes_per_element"] == 3 * fld["inv"]["bytes_per_element"] // 2
-    mm = line["matmul"]
-    assert mm["verified"] is True and any(v["path"].startswith("matrix cores") and v["frac_of_int8_peak"] > 0 for v in mm["shapes"].values())
-    lay = line["layout"]
-    assert lay["verified"] is True and all(v["soa_to_aos"]["frac"] > 0 and v["aos_to_soa"]["frac"] > 0 for v in lay["fields"].values())
-    cb = line["cpu_baseline"]
-    assert cb["physical_cores"] >= 1 and cb["all_cores"]["cores"] == cb["physical_cores"] and cb["cores_per_gpu"]["cores"] <= 16
-    c4 = line["open"]["c4_all_gather"]
-    assert c4["verified"] is True and c4["secrets"] == 50000 and c4["chunk"] == 20000 and c4["parties_per_rank"] == 40
-    assert line["open"]["m61_partial_sums"]["verified"] is True
-    # the committed PMC traffic describes BASELINE configs[1] only: any other configuration reports null
-    assert line["roofline"]["traffic"] is None
+    assert "cpu_baseline" not in bl
+
+
+def test_bench_default_command_prints_one_short_line(scl):
+    """The driver's own command at full size -- `python3 bench.py --gpus 1 --steps 20 --warmup 5`: BASELINE configs[1], 10^8
+    secrets, every leg on -- prints ONE line of less than 8 KB that parses and carries `roofline` and `cpu_baseline`
+    (BENCH_r05.json: a 20 KB line, "parsed": null), and finishes in about half a minute."""
+    import time
+    from bench_util import assert_compact, run_bench
+    t0 = time.time()
+    r = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"], timeout=900)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = assert_compact(r)
+    assert len(r.lines[0]) < 6500, len(r.lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["verified"] is True
+    assert "BASELINE configs[1]" in line["config"]["workload"] and line["config"]["secrets_per_gpu"] == 100_000_000
+    assert line["roofline"]["bound"] == "hbm" and 0.5 < line["roofline"]["frac"] < 1 and line["roofline"]["peak"] == 8000.0
+    assert line["cpu_baseline"]["value"] > 1e5 and line["cpu_baseline"]["kind"] == "reference"
+    assert abs(line["value"] - 1e8 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+    assert {"C3_mersenne127_10_3", "C3_mont128_10_3", "C4_shard_gf2_128_40_13", "C5_shard_mersenne61_128_42"} <= set(line["legs"])
+    assert set(r.detail["configs"]) >= {"C3_mont128_10_3", "F3_secp256k1_scalar_10_3"} and r.detail["line"] == line
+    c4 = r.detail["configs"]["C4_shard_gf2_128_40_13"]
+    assert c4["recover_roofline_compute"]["bound"] == "LDS table reads" and c4["share_roofline_compute"]["bound"] == "vector ALU"
+    assert r.detail["prg_mode"]["k_prg_blocks"]["roofline_compute"]["frac"] > 0
+    assert wall < 120, wall
 
 
 def test_bench_observes_its_hbm_traffic(scl):
-    """roofline.traffic is OBSERVED by the run that prints it: after its timed regions bench.py runs the headline alone twice
-    as a child under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (no trace domain beside --pmc; the program itself after
-    `--`) and reads the two kernels' counters; the doubling of FETCH_SIZE is checked on k_copy16 in the same pass.  At 10^7
-    secrets here: traffic = the algorithmic bytes within 1 %."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--secrets", "10000000", "--steps", "2", "--warmup", "1",
-                        "--cpu-sample", "0", "--configs", "0", "--open", "0"], capture_output=True, text=True, timeout=900)
+    """--pmc-live 1: roofline.traffic is OBSERVED by the run that prints it: after its timed regions bench.py runs the headline
+    alone twice as a child under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (no trace domain beside --pmc; the program
+    itself after `--`) and reads the two kernels' counters; the doubling of FETCH_SIZE is checked on k_copy16 in the same
+    pass.  At 10^7 secrets here: traffic = the algorithmic bytes within 1 %."""
+    from bench_util import assert_compact, run_bench
+    r = run_bench(["--secrets", "10000000", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--configs", "0", "--open", "0",
+                   "--ew", "0", "--pmc-live", "1"], timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line = assert_compact(r)
     rf = line["roofline"]
-    assert "observed in this run" in rf["traffic_source"], rf["traffic_source"]
-    live = rf["traffic_live"]
+    assert rf["traffic_source"].startswith("live"), (rf["traffic_source"], r.detail.get("pmc_live"))
+    live = r.detail["traffic_live"]
     assert abs(live["fetch_correction_measured_on_k_copy16"] - 2.0) < 0.02
     assert abs(live["shamir_share"]["bytes"] / (112 * 10**7) - 1) < 1e-2 and abs(live["shamir_recover"]["bytes"] / (88 * 10**7) - 1) < 1e-2
     assert rf["traffic"] == live[rf["kernel"]]["bytes"] and abs(rf["traffic_over_algorithmic"] - 1) < 1e-2
     assert rf["traffic_stamped"] is None     # the stamped file describes 10^8 secrets only
+    assert r.detail["pmc_live"]["ran"] is True
 
 
 def test_bench_open_mode_line(scl):
     """--mode open: the exchange step alone (reference: Network::send + Network::recv, include/scl/net/network.h:148-185),
     with the collective's bandwidth fields beside the reconstruct kernel's HBM fraction"""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "open", "--secrets", "200000",
-                        "--open-secrets", "70000", "--open-chunk", "1 << 15".replace("1 << 15", "32768")],
-                       capture_output=True, text=True, timeout=600)
+    from bench_util import assert_compact, run_bench
+    r = run_bench(["--mode", "open", "--secrets", "200000", "--open-secrets", "70000", "--open-chunk", "32768"], timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line = assert_compact(r)
     assert line["metric"] == "shamir_open_reconstructions_per_sec" and line["n_gpus"] == 1 and line["value"] > 0
-    c4 = line["open"]["c4_all_gather"]
+    c4 = r.detail["open"]["c4_all_gather"]
     for k in ("rccl_busbw_GBps", "rccl_algbw_GBps", "gather_ms_per_chunk", "reconstruct_hbm_frac", "pipeline_ms"):
         assert k in c4, k
-    assert c4["verified"] and line["open"]["m61_partial_sums"]["verified"]
+    assert c4["verified"] and r.detail["open"]["m61_partial_sums"]["verified"] and line["verified"] is True
     assert line["roofline"]["kernel"] == "shamir_recover" and 0 < line["roofline"]["frac"] < 1
 
 
@@ -2115,30 +2274,22 @@ def test_bench_two_ranks_rehearsal_on_one_device(scl):
     tensors (SCL_BENCH_ONE_DEVICE=1: a rehearsal, never a measurement; the driver's multi-GPU run uses RCCL, one rank per GPU).
     Started plainly with --gpus 2, so the self-launcher runs too.  Covers the sharded headline, the all-gather open
     (20 parties per rank) and the reduce-scatter partial-sum open; every round trip must verify."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SCL_BENCH_ONE_DEVICE="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--secrets", "1000000",
-                        "--open-secrets", "100000", "--open-chunk", "32768", "--configs", "0", "--cpu-sample", "0", "--steps", "2",
-                        "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
+    from bench_util import assert_compact, run_bench
+    r = run_bench(["--gpus", "2", "--backend", "gloo", "--secrets", "1000000", "--open-secrets", "100000", "--open-chunk", "32768",
+                   "--configs", "0", "--cpu-sample", "0", "--steps", "2", "--warmup", "1"], {"SCL_BENCH_ONE_DEVICE": "1"}, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    line = json.loads(lines[0])
+    line = assert_compact(r)
     assert line["n_gpus"] == 2 and line["verified"] is True and line["config"]["parallelism"] == "shard2"
-    c4, ps = line["open"]["c4_all_gather"], line["open"]["m61_partial_sums"]
+    c4, ps = r.detail["open"]["c4_all_gather"], r.detail["open"]["m61_partial_sums"]
     assert c4["verified"] and c4["parties_per_rank"] == 20 and c4["collective"] == "all_gather_into_tensor"
     assert c4["rccl_busbw_GBps"] > 0 and ps["verified"] and ps["collective"].startswith("reduce_scatter_tensor")
-    assert "cpu_baseline" not in line and "configs" not in line
+    assert "cpu_baseline" not in line and "configs" not in r.detail
     assert "skipped in the one-device rehearsal" in c4["c_abi"]["skipped"] and "errors" not in line
     # what the process group reports about the job, and every rank's own time per step (the line's is their maximum)
     assert line["rccl"]["ranks"] == 2 and line["rccl"]["backend"] == "gloo" and line["rccl"]["devices"] == [0, 0]
     assert len(line["ms_per_step_by_rank"]) == 2 and abs(max(line["ms_per_step_by_rank"]) - line["ms_per_step"]) < 1e-9
-    assert len(line["by_allocation"]) == 2      # two timed steps on the first two of the three operand sets
+    assert len(r.detail["by_allocation"]) == 2      # two timed steps on the first two of the three operand sets
+    assert line["value"] > 0 and abs(line["value"] - 2 * 1e6 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
 
 
 def test_differential_fuzz_of_the_entry_points_for_twenty_seconds(scl):
@@ -2171,52 +2322,34 @@ def test_bench_line_survives_a_rank_that_never_reaches_the_open_step(scl):
     """The legs after the headline are collectives; real multi-rank RCCL runs only on the driver's node.  A rank that never
     arrives (--inject-error hang: the last rank sleeps before the open step) must not cost the headline: after --side-timeout
     seconds rank 0 writes the line with the headline it measured and the missing leg as an error, and every rank exits."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SCL_BENCH_ONE_DEVICE="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--secrets", "1000000",
-                        "--open-secrets", "100000", "--open-chunk", "32768", "--configs", "0", "--cpu-sample", "0", "--steps", "2",
-                        "--warmup", "1", "--inject-error", "hang", "--side-timeout", "20"],
-                       capture_output=True, text=True, timeout=600, env=env)
+    from bench_util import assert_compact, run_bench
+    r = run_bench(["--gpus", "2", "--backend", "gloo", "--secrets", "1000000", "--open-secrets", "100000", "--open-chunk", "32768",
+                   "--configs", "0", "--cpu-sample", "0", "--steps", "2", "--warmup", "1", "--inject-error", "hang",
+                   "--side-timeout", "20"], {"SCL_BENCH_ONE_DEVICE": "1"}, timeout=600)
     assert r.returncode != 0
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stderr[-3000:]
-    line = json.loads(lines[0])
+    line = assert_compact(r)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["verified_headline"] is True and line["verified"] is False
-    assert "watchdog" in line["open"]["error"] and any("watchdog" in e for e in line["errors"])
-    assert line["roofline"]["frac"] > 0 and len(line["ms_per_step_by_rank"]) == 2
+    assert "watchdog" in r.detail["open"]["error"] and any("watchdog" in e for e in line["errors"])
+    assert line["roofline"]["frac"] > 0 and len(line["ms_per_step_by_rank"]) == 2 and line["verified_legs"]["open"] is False
 
 
 @pytest.mark.parametrize("config,extra,check", [
     ("c4", ["--total-secrets", "100000", "--open-chunk", "32768"],
-     lambda ln: ln["scaling"] == "strong" and ln["config"]["total_secrets"] == 100000 and ln["config"]["parallelism"] == "parties2"
-     and ln["open"]["c4_all_gather"]["parties_per_rank"] == 20 and ln["rccl_busbw_GBps"] > 0),
+     lambda ln, d: ln["scaling"] == "strong" and ln["config"]["total_secrets"] == 100000 and ln["config"]["parallelism"] == "parties2"
+     and d["open"]["c4_all_gather"]["parties_per_rank"] == 20 and ln["rccl_busbw_GBps"] > 0),
     ("c5", ["--total-secrets", "200003"],
-     lambda ln: ln["scaling"] == "strong" and ln["config"]["total_secrets"] == 200003 and ln["config"]["n"] == 128
-     and ln["config"]["secrets_per_gpu"] == 100002 and ln["dtype"] == "u64")])
+     lambda ln, d: ln["scaling"] == "strong" and ln["config"]["total_secrets"] == 200003 and ln["config"]["n"] == 128
+     and ln["config"]["secrets_per_gpu"] == 100002 and ln["dtype"] == "u64" and ln["roofline"]["bound"] == "mfma")])
 def test_bench_configs_quoted_on_eight_gpus_rehearsal_on_one_device(scl, config, extra, check):
     """`bench.py --gpus 2 --config c4 / c5` with the HIP kernels, both ranks on this box's one GPU over gloo (a rehearsal of
     the code the driver runs on eight GPUs over RCCL, never a measurement): BASELINE configs[3] as the open step over the
     total, configs[4] as share + reconstruct of ragged shards of the total; every round trip must verify."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SCL_BENCH_ONE_DEVICE="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", config,
-                        "--cpu-sample", "0", "--steps", "2", "--warmup", "1"] + extra, capture_output=True, text=True, timeout=900,
-                       env=env)
+    from bench_util import assert_compact, run_bench
+    r = run_bench(["--gpus", "2", "--backend", "gloo", "--config", config, "--cpu-sample", "0", "--steps", "2", "--warmup", "1"] + extra,
+                  {"SCL_BENCH_ONE_DEVICE": "1"}, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["verified"] is True and check(line), line
+    line = assert_compact(r)
+    assert line["n_gpus"] == 2 and line["verified"] is True and check(line, r.detail), line
 
 
 @pytest.mark.parametrize("n,t,N", [(128, 42, 3 * 256 * 32 + 17), (97, 5, 2 * 256 * 32 + 31), (128, 48, 256 * 32 + 1), (100, 33, 4 * 256 * 32)])

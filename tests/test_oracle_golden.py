@@ -16,13 +16,34 @@ with open(os.path.join(HERE, "golden", "golden_v1.json")) as fh:
 with open(os.path.join(HERE, "golden", "golden_secp256k1_field.json")) as fh:   # FF<Secp256k1Field>, same generator
     GOLD["fields"].update(json.load(fh)["fields"])
 
+# the N = 2 instance of the reference's Montgomery family (ff_ops_gmp.h compiled at two limbs, oracle/ref_harness.cc: field
+# tag 2), one fixture per modulus -- BASELINE configs[2]'s "Fp (128-bit prime, Montgomery)"
+with open(os.path.join(HERE, "golden", "golden_mont128.json")) as fh:
+    MONT = json.load(fh)["fields"]
+GOLD["fields"].update(MONT)
+
 FIELDS = [(O.M61, "Mersenne61"), (O.M127, "Mersenne127"), (O.SECP256K1_SCALAR, "secp256k1_order"),
-          (O.SECP256K1_FIELD, "secp256k1_field")]
+          (O.SECP256K1_FIELD, "secp256k1_field")] + [(O.MONT128, name) for name in sorted(MONT)]
 
 
 @pytest.fixture(scope="module")
 def port():
     return O.Port()
+
+
+@pytest.fixture(autouse=True)
+def _mont128_modulus(request):
+    """a Mont128 fixture is taken with ITS modulus: set on the oracle before the test, back to 2^128 - 159 after"""
+    name = getattr(request.node, "callspec", None) and request.node.callspec.params.get("name")
+    if not (isinstance(name, str) and name in MONT):
+        yield
+        return
+    port = request.getfixturevalue("port")
+    port.mont128_set_prime(int(MONT[name]["prime"], 16))
+    try:
+        yield
+    finally:
+        port.mont128_set_prime((1 << 128) - 159)
 
 
 def ints(hexes):
@@ -353,8 +374,7 @@ def test_reference_test_suite_kats(port):
         "0x10c9a04e00a8277a", "0xe0c7bcabdee0f5b", "0x129e3e74169f963"]
 
 
-PLUGIN_FIELDS = [(O.MONT128, "Mont128"), (O.GF2_128, "GF(2^128)")]   # not in the reference; big-integer / shift-xor
-                                                                      # pins in test_plugin_field_pins.py
+PLUGIN_FIELDS = [(O.GF2_128, "GF(2^128)")]   # not in the reference; shift-xor pins in test_plugin_field_pins.py
 
 
 @pytest.mark.parametrize("f,name", FIELDS + PLUGIN_FIELDS)
@@ -398,7 +418,10 @@ def test_field_identities(port, f, name):
 @pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built and /root/reference absent")
 @pytest.mark.parametrize("f,name", FIELDS)
 def test_port_vs_live_reference(port, f, name):
-    ref = O.Ref()
+    # (a Mont128 modulus gets its own copy of the library: FF::one() latches the first modulus a copy sees, ff.h:90-101)
+    ref = O.Ref(fresh=True) if f == O.MONT128 else O.Ref()
+    if f == O.MONT128:
+        ref.mont128_set_prime(int(MONT[name]["prime"], 16))
     L = O.LIMBS[f]
     rng = np.random.default_rng(7)
     a = ref.from_bytes(f, rng.bytes(8 * L * 2000))
@@ -416,3 +439,16 @@ def test_port_vs_live_reference(port, f, name):
         assert np.array_equal(port.shamir_recover(f, s1), ref.shamir_recover(f, s1))
     s1 = port.additive_share(f, b"live", a[:500], 3)
     assert np.array_equal(s1, ref.additive_share(f, b"live", a[:500], 3))
+
+
+@pytest.mark.parametrize("name", sorted(MONT))
+def test_mont128_c3_shapes_against_the_reference_at_two_limbs(port, name):
+    """BASELINE configs[2], Shamir (10,3) over the 128-bit Montgomery prime field (and (40,13)): shares and reconstructions
+    emitted by the reference's shamirSecretShare / shamirRecoverP over FF<its own Montgomery templates at N = 2>"""
+    f, L = O.MONT128, 2
+    for c in MONT[name]["shamir_c3"]:
+        secrets = arr(c["secrets"], L)
+        shares = port.shamir_share(f, bytes.fromhex(c["seed"]), secrets, c["t"], c["n"])
+        eq(shares, c["shares"])
+        eq(port.shamir_recover(f, shares), c["recovered_all_n"])
+        assert c["recovered_all_n"] == c["secrets"]

@@ -85,6 +85,70 @@ __global__ __launch_bounds__(1024) void k_lds128(u32* out, int iters) {
   out[blockIdx.x * 1024 + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
 }
 
+// ---- round 6: a RANDOM entry of a table of 2^LOGE 16-byte entries per lane (what a window of LOGE bits of a share looks up) ----
+// LOGE 4 is the 256-byte table of k_recover_gf128_pos (one bank row: conflict-free by construction); 8 is the byte window's
+// 4 KiB table (16 bank rows: lanes that pick the same bank quad in different rows collide).  Sixteen random slots per lane are
+// drawn BEFORE the loop (sixteen address registers; the loop itself is the reads and the xors of the probes above -- a first
+// form that drew new slots every iteration spent as long on its address arithmetic as on the reads), 16 waves per CU x 256 CUs
+// of different lanes: the figure is a mean over 65 536 random wave patterns.  SAME: every lane of a wave the same entry.
+template <int LOGE, bool SAME>
+__global__ __launch_bounds__(1024) void k_lds128_random(u32* out, int iters) {
+  __shared__ __attribute__((aligned(16))) u32 t[16384];   // 64 KiB: eight regions of 8 KiB
+  for (int i = threadIdx.x; i < 16384; i += 1024) t[i] = i * 2654435761u;
+  __syncthreads();
+  const u32 base = (u32)(uintptr_t)t;
+  u32 x = ((SAME ? (threadIdx.x >> 6) : threadIdx.x) + blockIdx.x * 1024u) * 2654435761u + 12345u;
+  constexpr u32 MASK = (1u << LOGE) - 1;
+  u32 a[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    x = x * 1664525u + 1013904223u;
+    a[u] = base + (u32)(u & 7) * 8192u + (((x >> 13) & MASK) << 4);
+  }
+  u32x4v acc = {0, 0, 0, 0};
+  for (int i = 0; i < iters; i += 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x4v v[8];
+      asm volatile(
+          "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+          "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+          : "v"(a[8 * h + 0]), "v"(a[8 * h + 1]), "v"(a[8 * h + 2]), "v"(a[8 * h + 3]), "v"(a[8 * h + 4]), "v"(a[8 * h + 5]),
+            "v"(a[8 * h + 6]), "v"(a[8 * h + 7])
+          : "memory");
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc ^= v[u];
+    }
+  }
+  out[blockIdx.x * 1024 + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+// How many lanes does the LDS serve per cycle of a ds_read_b128, and does it merge equal addresses?  Lane l reads entry
+// (l / GROUP) of a table whose entries sit STRIDE16 x 16 bytes apart: GROUP lanes share an address (a broadcast if the
+// hardware merges them), distinct addresses fall into the same bank quad when STRIDE16 is a multiple of 16.
+template <int GROUP, int STRIDE16>
+__global__ __launch_bounds__(1024) void k_lds128_pattern(u32* out, int iters) {
+  __shared__ __attribute__((aligned(16))) u32 t[16384];
+  for (int i = threadIdx.x; i < 16384; i += 1024) t[i] = i * 2654435761u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const u32 a = (u32)(uintptr_t)t + 16u * (u32)STRIDE16 * (u32)(lane / GROUP);
+  u32x4v acc = {0, 0, 0, 0};
+  for (int i = 0; i < iters; ++i) {
+    u32x4v v[8];
+    asm volatile(
+        "ds_read_b128 %0, %8 offset:0\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+        "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+        "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(a)
+        : "memory");
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= v[u];
+  }
+  out[blockIdx.x * 1024 + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+
 int main() {
   u32* out;
   CK(hipMalloc(&out, 256 * 1024 * 4));
@@ -124,6 +188,22 @@ int main() {
   run128(k_lds128<1>, "ds_read_b128, every lane a random entry of one 256-byte table");
   run128(k_lds128<2>, "ds_read_b128, 16 l with slots swizzled within groups of 8");
   run128(k_lds128<3>, "ds_write_b128, lane l at byte 16 l (1 KiB contiguous)");
+  std::printf("# round 6: ds_read_b128, every lane a RANDOM entry of a table of 2^k 16-byte entries (sixteen slots per lane drawn before the loop)\n");
+  run128(k_lds128_random<4, false>, "random entry of a 256-byte table (16 entries: 4-bit window)");
+  run128(k_lds128_random<5, false>, "random entry of a 512-byte table (32 entries: 5-bit window)");
+  run128(k_lds128_random<6, false>, "random entry of a 1 KiB table (64 entries: 6-bit window)");
+  run128(k_lds128_random<7, false>, "random entry of a 2 KiB table (128 entries: 7-bit window)");
+  run128(k_lds128_random<8, false>, "random entry of a 4 KiB table (256 entries: 8-bit window)");
+  run128(k_lds128_random<9, false>, "random entry of an 8 KiB table (512 entries)");
+  run128(k_lds128_random<8, true>, "4 KiB table, all lanes of a wave the same random entry");
+  std::printf("# which lanes collide: lane l reads entry l / GROUP, entries STRIDE x 16 bytes apart\n");
+  run128(k_lds128_pattern<1, 16>, "64 distinct addresses, all in ONE bank quad (stride 256 B)");
+  run128(k_lds128_pattern<4, 16>, "16 distinct addresses in one bank quad, 4 lanes each");
+  run128(k_lds128_pattern<16, 16>, "4 distinct addresses in one bank quad, 16 lanes each");
+  run128(k_lds128_pattern<32, 16>, "2 distinct addresses in one bank quad, 32 lanes each");
+  run128(k_lds128_pattern<16, 17>, "4 distinct addresses in 4 bank quads, 16 lanes each");
+  run128(k_lds128_pattern<4, 17>, "16 distinct addresses in 16 bank quads, 4 lanes each");
+  run128(k_lds128_pattern<2, 17>, "32 distinct addresses, 2 per bank quad two rows apart, 2 lanes each");
   CK(hipGetLastError());
   return 0;
 }
