@@ -3,72 +3,96 @@ number: its instruction stream against the rate the chip issues that stream at.
 
 Chip: 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md).  Two ceilings:
 
-* vector ALU -- wave64 vector instructions per second.  `per_element` = vector instructions per element and lane, from the SQ
-  counters (SQ_INSTS_VALU x 64 / elements; profiles/r6_sq_counters.txt, tools/sq_counters.sh).  `issue_cycles` = cycles a
-  SIMD needs per wave instruction of THIS kernel's opcode mix at its occupancy: the static mix of the kernel's ISA
-  (tools/isa_mix.py, profiles/r6_isa_mix.txt) weighted with the per-class issue intervals measured by tools/oprate.hip
-  (profiles/r2_oprate.txt: a plain VOP2 every 2.3-2.8 cycles at >= 4 waves per SIMD, VOP3 / shifts / bitop3 4.3-4.7,
-  v_mad_u64_u32 5.2-5.5; 4.5-5.1 for everything at 2 waves per SIMD).  peak = 1024 SIMDs x 2.4e9 / issue_cycles.
-* LDS -- 64-lane 16-byte LDS instructions per second.  `per_element` = ds_read_b128 / ds_write_b128 per element and lane;
-  a CU's LDS pipe takes `cycles_per_access` per wave instruction (tools/ldsbank.hip, profiles/r4_ldsbank.txt and
-  r6_ldsbank.txt: 5.3 cycles per ds_read_b128 whatever the bank pattern, 13.8 per ds_write_b128).
-  peak = 256 CUs x 2.4e9 / cycles_per_access.
+* vector ALU -- wave64 vector instructions per second.  `per_element` = vector instructions per element and lane, counted by
+  the SQ (SQ_INSTS_VALU x 64 / elements: tools/sq_counters.sh -> profiles/sq_counters.json, r6_sq_counters.txt).
+  `issue_cycles` = cycles a SIMD needs per wave instruction of THIS kernel's opcode mix when nothing else holds it up: the
+  static mix of the kernel's ISA (tools/isa_mix.py -> profiles/isa_mix.json, r6_isa_mix.txt) weighted with the per-class
+  issue intervals measured by tools/oprate.hip (profiles/r2_oprate.txt: a plain VOP2 every 2.3-2.8 cycles with >= 4 waves per
+  SIMD, VOP3 encodings / shifts / bitop3 / SDWA 4.3-4.7, v_mad_u64_u32 5.2-5.5).  peak = 1024 SIMDs x 2.4e9 / issue_cycles.
+* LDS -- 64-lane LDS instructions per second.  `per_element` = LDS instructions per element and lane (SQ_INSTS_LDS); a CU's
+  LDS pipe takes `cycles_per_access` per wave instruction (LDS_CYCLES below: the pipe's 256 bytes per clock for 16-byte
+  reads, tools/ldsbank.hip's best patterns for the rest, profiles/r6_ldsbank.txt).  peak = 256 CUs x 2.4e9 /
+  cycles_per_access.
 
-Every entry names where its constants were measured; `gap` says what stands between the kernel and the ceiling when the
-fraction is below 0.6."""
+Both JSON files are measurements committed under profiles/ (the counters on an MI355X box, the mix from the built library);
+the constants below stand in for a kernel the files do not hold.  `gap` says what stands between a kernel and its ceiling
+when the fraction is below 0.6."""
+import json
+import os
+
+from .common import ROOT
+
 SIMDS, CUS, CLOCK_HZ = 1024, 256, 2.4e9
+# cycles of a CU's LDS pipe per 64-lane instruction.  ds_read_b128: 4.0 = 1 KiB at the pipe's 256 bytes per clock -- the C4
+# reconstruct kernel itself sustains one every 4.78 cycles (profiles/r6_sq_counters.txt), where the loop of tools/ldsbank.hip
+# reaches 5.2 (its xors share the issue slots); ds_write_b128 13.5 and ds_read_b32 2.3 are that probe's best patterns
+LDS_CYCLES = {"ds_read_b128": 4.0, "ds_write_b128": 13.5, "ds_read_b32": 2.3}
 
-# vector-ALU legs: lane instructions per element (SQ counters), issue cycles of the kernel's own mix (ISA mix x oprate)
-VALU = {
-    "m61_inv": {"per_element": 113.0, "issue_cycles": 3.3, "waves_per_simd": 3,
-                "source": "profiles/r5_ew_sq.txt (176.6 M wave instructions per 10^8 elements); mix: 5.2 products of 19-21 "
-                          "instructions, v_mad_u64_u32 (5.3 cycles) : VOP2 (2.5) about 1 : 2.5"},
-    "m127_inv": {"per_element": 642.0, "issue_cycles": 4.0, "waves_per_simd": 4.8,
-                 "source": "profiles/r5_ew_sq.txt (100.3 M wave instructions per 10^7 elements)",
-                 "gap": "4.8 waves per SIMD in one round: 40 % of the wave cycles wait (scratch round trips of the rolled chain)"},
-    "mont128_inv": {"per_element": 1010.0, "issue_cycles": 4.0, "waves_per_simd": 4,
-                    "source": "profiles/r6_sq_counters.txt",
-                    "gap": "the one Fermat inversion per chain (174 products) runs at the lane's own latency"},
-    "gf2_128_inv": {"per_element": 1882.0, "issue_cycles": 4.4, "waves_per_simd": 5,
-                    "source": "profiles/r5_ew_sq.txt (294.0 M wave instructions per 10^7 elements; 185 LDS accesses beside them)"},
-    "gf2_128_mul": {"per_element": 411.0, "issue_cycles": 4.4, "waves_per_simd": 5,
-                    "source": "profiles/r5_ew_sq.txt (64.2 M wave instructions per 10^7 products: shifts, v_bitop3_b32 -- VOP3 classes)"},
-    "c4_share": {"per_element": 8027.0, "issue_cycles": 3.6, "waves_per_simd": 2,
-                 "source": "profiles/r3_c4_sq.txt (1.568 G wave instructions per 1.25e7 secrets of (40,13))"},
+
+def _load(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            return json.load(fh)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return {}
+
+
+SQ = _load("sq_counters.json")      # per kernel: valu_per_element, lds_per_element, valu_issue_cycles_measured, ...
+MIX = _load("isa_mix.json")         # per kernel: mix, issue_cycles_4_waves, lds_static
+
+# stand-ins (rounds 3-5's counters: profiles/r5_ew_sq.txt, r3_c4_sq.txt) for a kernel the two files do not hold
+FALLBACK = {
+    "m61_inv": {"valu": 113.0, "lds": 0.0, "issue": 3.57}, "m127_inv": {"valu": 642.0, "lds": 0.0, "issue": 3.89},
+    "mont128_inv": {"valu": 1010.0, "lds": 0.0, "issue": 4.08}, "gf2_128_inv": {"valu": 1882.0, "lds": 185.7, "issue": 3.48},
+    "gf2_128_mul": {"valu": 411.0, "lds": 52.0, "issue": 3.45}, "c4_share": {"valu": 8027.0, "lds": 56.0, "issue": 3.72},
+    "c4_recover": {"valu": 4757.0, "lds": 1280.0, "issue": 3.91}, "prg_blocks": {"valu": 254.0, "lds": 152.0, "issue": 4.41},
 }
-# LDS-table legs: 16-byte LDS accesses per element and lane
-LDS = {
-    "c4_recover": {"per_element": 1280.0, "cycles_per_access": 5.3,
-                   "source": "profiles/r3_c4_sq.txt (250 M ds_read_b128 wave instructions per 1.25e7 secrets: 40 parties x 32 "
-                             "nibble lookups), profiles/r4_ldsbank.txt (5.28-5.42 cycles per ds_read_b128)"},
-    "prg_blocks": {"per_element": 160.0, "cycles_per_access": 2.5, "width": "ds_read_b32",
-                   "source": "profiles/r3_c4_sq.txt / r2_pmc_aes.txt (159.5 M ds_read_b32 wave instructions per 2^26 blocks: 16 x 10 "
-                             "table lookups), profiles/r2_ldsbank.txt (2.3-2.7 cycles per ds_read_b32)"},
-    "gf2_128_mul": {"per_element": 52.0, "cycles_per_access": 6.6,
-                    "source": "44 ds_read_b128 (5.3 cycles) + 8 ds_write_b128 (13.8) per product: profiles/r5_ew_sq.txt, r4_ldsbank.txt"},
+GAPS = {
+    "m127_inv": "10^7 elements at 64 per lane are 2 442 waves -- 2.4 per SIMD, one round: too few to cover the scratch round trips "
+                "of the rolled chain and the dependent products of the one Fermat inversion (the chain length that is fastest "
+                "all the same: fewer inversions, profiles/r5_probe_inv_chain.txt)",
+    "mont128_inv": "as Mersenne127 (2.4 waves per SIMD), and the one Fermat inversion per chain is 174 dependent Montgomery products",
+    "gf2_128_inv": "shares the SIMD with 186 LDS table accesses per element (the window tables of its products)",
+    "gf2_128_mul": "shares the SIMD with 52 LDS accesses per product: 44 ds_read_b128 + 8 ds_write_b128 = 0.6 of the LDS pipe",
+    "c4_share": "two waves per SIMD (the tile's coefficient registers): little latency cover for its 4.5-cycle shifts",
 }
+
+
+def _figures(key):
+    fb = FALLBACK[key]
+    sq, mix = SQ.get(key), MIX.get(key)
+    return {"valu": sq["valu_per_element"] if sq else fb["valu"], "lds": sq["lds_per_element"] if sq else fb["lds"],
+            "issue": mix["issue_cycles_4_waves"] if mix else fb["issue"],
+            "source": ("profiles/sq_counters.json" if sq else "profiles/r5_ew_sq.txt / r3_c4_sq.txt (stand-in constants)") + " + "
+                      + ("profiles/isa_mix.json" if mix else "a stand-in opcode mix") + " x profiles/r2_oprate.txt",
+            "mix": mix["mix"] if mix else None, "measured_in_profile": sq}
 
 
 def valu_roofline(key, elements_per_s):
-    c = VALU[key]
-    wave_instr_per_s = elements_per_s * c["per_element"] / 64.0
-    peak = SIMDS * CLOCK_HZ / c["issue_cycles"]
-    out = {"bound": "vector ALU", "unit": "wave64 vector instr/s", "per_element": c["per_element"],
-           "achieved": wave_instr_per_s, "peak": peak, "frac": wave_instr_per_s / peak,
-           "issue_cycles_of_the_mix": c["issue_cycles"], "issue_cycles_measured": SIMDS * CLOCK_HZ / wave_instr_per_s,
+    """key: "<field>_inv" | "gf2_128_mul" | "c4_share" ..; elements_per_s: what the bench just measured"""
+    c = _figures(key)
+    wave_instr_per_s = elements_per_s * c["valu"] / 64.0
+    peak = SIMDS * CLOCK_HZ / c["issue"]
+    out = {"bound": "vector ALU", "unit": "wave64 vector instr/s", "per_element": c["valu"], "achieved": wave_instr_per_s, "peak": peak,
+           "frac": wave_instr_per_s / peak, "issue_cycles_of_the_mix": c["issue"], "opcode_mix": c["mix"],
+           "issue_cycles_measured": SIMDS * CLOCK_HZ / wave_instr_per_s,
            "frac_of_plain_vop2_rate": wave_instr_per_s / (SIMDS * CLOCK_HZ / 2.3), "source": c["source"]}
-    if "gap" in c:
-        out["gap"] = c["gap"]
+    if key in GAPS:
+        out["gap"] = GAPS[key]
     return out
 
 
 def lds_roofline(key, elements_per_s):
-    c = LDS[key]
-    acc_per_s = elements_per_s * c["per_element"] / 64.0
-    peak = CUS * CLOCK_HZ / c["cycles_per_access"]
-    out = {"bound": "LDS table reads", "unit": f"64-lane {c.get('width', 'ds_read_b128')} instr/s", "per_element": c["per_element"],
-           "achieved": acc_per_s, "peak": peak, "frac": acc_per_s / peak, "cycles_per_access": c["cycles_per_access"],
-           "source": c["source"]}
-    if "gap" in c:
-        out["gap"] = c["gap"]
+    """the LDS pipe of a CU against the table accesses of `key` (c4_recover, prg_blocks, gf2_128_mul)"""
+    c = _figures(key)
+    if key == "prg_blocks":
+        width, cyc = "ds_read_b32", LDS_CYCLES["ds_read_b32"]
+    elif key in ("gf2_128_mul", "gf2_128_inv"):      # 44 reads + 8 writes of 16 bytes per product
+        width, cyc = "ds_read_b128 / ds_write_b128 (44 : 8)", (44 * LDS_CYCLES["ds_read_b128"] + 8 * LDS_CYCLES["ds_write_b128"]) / 52
+    else:
+        width, cyc = "ds_read_b128", LDS_CYCLES["ds_read_b128"]
+    acc_per_s = elements_per_s * c["lds"] / 64.0
+    peak = CUS * CLOCK_HZ / cyc
+    out = {"bound": "LDS table reads", "unit": f"64-lane {width} instr/s", "per_element": c["lds"], "achieved": acc_per_s, "peak": peak,
+           "frac": acc_per_s / peak, "cycles_per_access": cyc, "source": c["source"].split(" + ")[0] + " + profiles/r6_ldsbank.txt"}
     return out

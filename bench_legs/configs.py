@@ -63,6 +63,7 @@ def share_recover_config(ctx, fkey, n, t, N, steps, seed, warmup=1, allocations=
         # neither kernel of C4 is HBM-bound: the ceilings they do run against (bench_legs/compute_roofline.py)
         res["share_roofline_compute"] = valu_roofline("c4_share", N / (sm * 1e-3))
         res["recover_roofline_compute"] = lds_roofline("c4_recover", N / (rm * 1e-3))
+        res["recover_roofline_valu"] = valu_roofline("c4_recover", N / (rm * 1e-3))     # (its second limit: 3.7 vector instructions per lookup)
     del sets, secrets, coeffs, shares, out
     ctx.free()
     return res

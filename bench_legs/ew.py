@@ -35,7 +35,9 @@ def ew_report(ctx):
         ctx.fill_random(b, f_, b"scl-bench-ew-b-" + fkey.encode())
         ha = np.concatenate([scl.to_host(a[:win]), scl.to_host(a[-win:])])
         hb = np.concatenate([scl.to_host(b[:win]), scl.to_host(b[-win:])])
-        warm, reps = (100, 50) if N_ * E_ < 400_000_000 else (5, 10)
+        # (every leg follows a host-side check of the previous one -- an idle gap: 60 launches of the 0.3 ms kernels are the
+        # 20 ms of load the clocks need to come back, profiles/r4_probe_headline_seq.txt)
+        warm, reps = (100, 50) if N_ * E_ < 400_000_000 else (60, 20)
         status = scl.ew_status_buffer()
         legs, ok_all = {}, True
         for name, op, nb, two in (("add", scl.ADD, 3 * E_, True), ("mul", scl.MUL, 3 * E_, True), ("inv", scl.INV, 2 * E_, False),

@@ -20,7 +20,7 @@ PMC_CONFIGS = {
     "C3_mont128_10_3": ("k_share_small_t<sclhip::Mont128", "k_recover_small<sclhip::Mont128", (224 * 10**7, 176 * 10**7)),
     "F3_secp256k1_scalar_10_3": ("k_share_small_pair<sclhip::Mont256<sclhip::SecpOrderParams>",
                                  "k_recover_small<sclhip::Mont256<sclhip::SecpOrderParams>", (448 * 10**7, 352 * 10**7)),
-    "C4_shard_gf2_128_40_13": ("k_share_gf_tiles<13>", "k_recover_gf128", (864 * 125 * 10**5, 656 * 125 * 10**5)),
+    "C4_shard_gf2_128_40_13": ("k_share_gf_tiles<13>", "k_recover_gf128_pos<512", (864 * 125 * 10**5, 656 * 125 * 10**5)),
     "C5_shard_mersenne61_128_42": ("k_share_mfma_m61", "k_recover_table<sclhip::M61", (1368 * 125 * 10**6, 1032 * 125 * 10**6)),
 }
 

@@ -205,3 +205,27 @@ def test_the_line_is_cut_to_size_and_the_detail_keeps_everything():
     out, legs, _ = bench.finish_line(dict(line), many)
     assert len(json.dumps(out)) < bench.LINE_LIMIT and "legs" not in out
     assert out["verified_legs"] == {"count": 400, "failed": []} and out["verified"] is True
+
+
+def test_first_contact_kit_dry_run():
+    """tools/first_contact_8gpu.sh -- the one script for the first 8-GPU node (the open step over real RCCL on 2 / 4 / 8 ranks,
+    the headline at 1 / 2 / 4 / 8, --config c4 / c5 at 8) -- with FIRST_CONTACT_DRY_RUN=1: every bench command of it through
+    gloo + --dry-run, its checks of each line (rccl.ranks == N, one time per rank, line < 8 KB) applied.  Its N = 1 line is the
+    driver's BENCH command's workload."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, FIRST_CONTACT_DRY_RUN="1")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "first_contact_8gpu.sh"), d], capture_output=True, text=True,
+                           env=env, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert "first contact complete" in r.stdout
+        one = json.loads(open(os.path.join(d, "scale_1.json")).read().strip())
+        bench_cmd = json.loads(_run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--dry-run"]).stdout.strip())
+        assert one["config"] == bench_cmd["config"] and one["metric"] == bench_cmd["metric"] and one["steps"] == 20
+        for n in (2, 4, 8):
+            ln = json.loads(open(os.path.join(d, f"scale_{n}.json")).read().strip())
+            assert ln["n_gpus"] == n and ln["config"]["total_secrets"] == n * 100_000_000 and ln["scaling"] == "weak"
+        c4 = json.loads(open(os.path.join(d, "c4_8.json")).read().strip())
+        assert c4["config"]["parallelism"] == "parties8" and "BASELINE configs[3]" in c4["config"]["workload"]

@@ -2213,8 +2213,11 @@ def test_bench_default_command_prints_one_short_line(scl):
     """The driver's own command at full size -- `python3 bench.py --gpus 1 --steps 20 --warmup 5`: BASELINE configs[1], 10^8
     secrets, every leg on -- prints ONE line of less than 8 KB that parses and carries `roofline` and `cpu_baseline`
     (BENCH_r05.json: a 20 KB line, "parsed": null), and finishes in about half a minute."""
+    import gc
     import time
     from bench_util import assert_compact, run_bench
+    gc.collect()
+    torch.cuda.empty_cache()      # this process's cached blocks go back: the (128,42) shard alone takes 172 of the 288 GB
     t0 = time.time()
     r = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"], timeout=900)
     wall = time.time() - t0
@@ -2252,6 +2255,33 @@ def test_bench_observes_its_hbm_traffic(scl):
     assert rf["traffic"] == live[rf["kernel"]]["bytes"] and abs(rf["traffic_over_algorithmic"] - 1) < 1e-2
     assert rf["traffic_stamped"] is None     # the stamped file describes 10^8 secrets only
     assert r.detail["pmc_live"]["ran"] is True
+
+
+def test_open_step_checker_of_the_first_contact_kit_on_one_rank(scl):
+    """tools/open_rccl_check.py -- step (a) of tools/first_contact_8gpu.sh: the C ABI's three open forms and their
+    torch.distributed twins against the CPU oracle over REAL RCCL, one process per GPU -- started the way the kit starts it,
+    with the one rank this box has: the script's own logic (slabs, padding rows, the agreement all-reduce, the JSON line) and
+    ncclAllGather / ncclReduceScatter of a one-rank communicator.  Ranks 2..8 are what the kit is for."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port_ = s_.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port_), os.path.join(ROOT, "tools", "open_rccl_check.py"), "--secrets", "20001",
+                        "--chunk", "6000"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["ok"] is True and line["world"] == 1 and line["backend"] == "nccl"
+    assert set(line["fields"]) == {"Mersenne61", "Mersenne127", "GF(2^128)"}
+    for name, f in line["fields"].items():
+        assert f["c_abi_all_gather"] and f["c_abi_partial_gather"] and f["torch_all_gather"] and f["torch_partial_gather"], (name, f)
+    assert line["fields"]["Mersenne61"]["c_abi_reduce_scatter"] is True and line["fields"]["GF(2^128)"]["parties_per_rank"] == 40
 
 
 def test_bench_open_mode_line(scl):

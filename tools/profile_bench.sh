@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd "$R" || exit 1
 rm -rf gpurun_out/prof_stats
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats --output-format csv -- \
-  python3 bench.py --pmc-live 0 > gpurun_out/${TAG}_bench_profiled.json 2> gpurun_out/${TAG}_bench_profiled.err || exit 2
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail gpurun_out/${TAG}_bench_profiled_detail.json > gpurun_out/${TAG}_bench_profiled.json 2> gpurun_out/${TAG}_bench_profiled.err || exit 2
 f=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] || exit 3
 cp "$f" gpurun_out/${TAG}_bench_full_kernel_stats.csv

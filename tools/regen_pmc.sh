@@ -7,9 +7,9 @@ export TMPDIR=/tmp
 cd "$R" || exit 1
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
 timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- \
-  python3 bench.py --open 0 --cpu-sample 0 --ew 0 --steps 5 --pmc-live 0 > gpurun_out/pmc_fetch.json 2> gpurun_out/pmc_fetch.err || exit 2
+  python3 bench.py --open 0 --cpu-sample 0 --ew 0 --steps 5 --pmc-live 0 --detail gpurun_out/pmc_fetch_detail.json > gpurun_out/pmc_fetch.json 2> gpurun_out/pmc_fetch.err || exit 2
 timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- \
-  python3 bench.py --open 0 --cpu-sample 0 --ew 0 --steps 5 --pmc-live 0 > gpurun_out/pmc_write.json 2> gpurun_out/pmc_write.err || exit 3
+  python3 bench.py --open 0 --cpu-sample 0 --ew 0 --steps 5 --pmc-live 0 --detail gpurun_out/pmc_write_detail.json > gpurun_out/pmc_write.json 2> gpurun_out/pmc_write.err || exit 3
 python3 tools/make_pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 4000000000 > gpurun_out/pmc_traffic.json || exit 4
 # the raw counter CSVs are large; keep only the summary
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
