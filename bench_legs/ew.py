@@ -71,9 +71,12 @@ def ew_report(ctx):
             if inv:
                 legs[name]["roofline_compute"] = valu_roofline(fkey + "_inv", rate)
                 if fkey != "m61":
-                    legs[name]["traffic_over_algorithmic"] = {"expected": ROLLED_INVERSE_TRAFFIC_OVER_ALGORITHMIC,
-                                                              "why": "rolled chain: x read, prefix written, prefix + x read again, "
-                                                                     "result written = 5E of 2E once the chains outgrow L2"}
+                    from .compute_roofline import SQ
+                    legs[name]["traffic_over_algorithmic"] = {
+                        "expected": ROLLED_INVERSE_TRAFFIC_OVER_ALGORITHMIC,
+                        "measured": (SQ.get(fkey + "_inv") or {}).get("traffic_over_algorithmic"),     # profiles/sq_counters.json (PMC passes)
+                        "why": "rolled chain: x read, prefix written, prefix + x read again, result written = 5E of 2E once the "
+                               "chains outgrow L2"}
             elif name == "mul" and fkey == "gf2_128":
                 legs[name]["roofline_compute"] = valu_roofline("gf2_128_mul", rate)
                 legs[name]["roofline_lds"] = lds_roofline("gf2_128_mul", rate)

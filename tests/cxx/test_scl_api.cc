@@ -221,6 +221,12 @@ TEST_CASE(ff_plugins, "plug-in fields: Mont128, GF(2^128) identities", HOST) {
   REQUIRE((a + b) * a == a * a + b * a);
   // x^127 * x = x^128 = x^7 + x^2 + x + 1
   REQUIRE(G::fromString("80000000000000000000000000000000") * G(2) == G(0x87));
+  // a published product: GHASH step X_1 = C * H of test case 2 of the GCM specification (McGrew & Viega, appendix B),
+  // H = 66e94bd4.., C = 0388dace.., X_1 = 5e2ec746.., each block's 128 bits reversed (GCM keeps x^0 in its top bit);
+  // tests/test_plugin_field_pins.py holds the vectors and the dictionary
+  const G gh = G::fromString("74d42c539a5f3211dc3451f72bd29766"), gc = G::fromString("1e7f4d8e9d4314cf49c56d06735b11c0");
+  REQUIRE(gc * gh == G::fromString("ed7bcaca160da13411460e8962e3747a"));
+  REQUIRE(G::fromString("ed7bcaca160da13411460e8962e3747a") / gh == gc);
 }
 
 TEST_CASE(small_forms, "detail/field.hpp: small-constant and lazy forms == generic mul/add", HOST) {

@@ -128,12 +128,18 @@ def main():
                 inplace = rng.random() < 0.3
                 out = (db if div else da) if inplace else scl.empty(f, n)
                 err = False
-                try:
-                    scl.ew(f, scl.DIV if div else scl.INV, da, db if div else None, out=out)
-                except scl.SclError as e:
-                    err = "0 not invertible" in str(e)
+                use_status = rng.random() < 0.5      # scl_hip_ew_status: the same kernels, the report left in a device word
+                if use_status:
+                    status = scl.ew_status_buffer()
+                    scl.ew_status(f, scl.DIV if div else scl.INV, da, db if div else None, status, out=out)
+                    err = int(status.item()) != 0
+                else:
+                    try:
+                        scl.ew(f, scl.DIV if div else scl.INV, da, db if div else None, out=out)
+                    except scl.SclError as e:
+                        err = "0 not invertible" in str(e)
                 if err != want_err or not np.array_equal(scl.to_host(out), want):
-                    report(kind, f"field {f} div {div} n {n} zeros {zeros} inplace {inplace} err {err}")
+                    report(kind, f"field {f} div {div} n {n} zeros {zeros} inplace {inplace} err {err} status-form {use_status}")
             elif kind == "scalar":
                 n = size(50000)
                 if n == 0:
@@ -444,6 +450,9 @@ def main():
                 scl.set_tuning(knob[0], KNOB_DEFAULTS[knob[0]])
         secs[kind] = secs.get(kind, 0.0) + time.time() - t_case
     torch.cuda.synchronize()
+    sys.path.insert(0, ROOT)
+    from bench_legs.pmc import kernel_source_hash     # one campaign per change of the kernel sources: the line says which
+    print(f"fuzz_abi: kernel sources {kernel_source_hash()}, seed {seed0}")
     print(f"fuzz_abi: {runs} cases in {budget:g} s, {bad} mismatches; by kind {by_kind}; seconds by kind { {k: round(v, 1) for k, v in secs.items()} }; cases by knob {by_knob}", flush=True)
     return 1 if bad else 0
 

@@ -6,7 +6,12 @@ pinned here against arithmetic that shares no code with the oracle or the kernel
   prime 2^128 - 159, the degenerate p = 7 (the reference's GF(7) test field, test/scl/gf7.h), the Mersenne prime 2^127 - 1
   and two random 128-bit primes found by a Miller-Rabin search in this file.
 * GF(2^128) -- multiplication and inversion against a bit-serial shift-xor multiplier with the reduction x^128 = x^7+x^2+x+1
-  written here in Python.
+  written here in Python, AND against published known answers that nobody here wrote: GCM's GHASH is multiplication in
+  exactly this field (same polynomial; GCM writes the coefficient of x^0 in the most significant bit of a block, this field
+  in the least significant bit of the integer), so the intermediate values X_i and the GHASH outputs of test cases 2 and 3 of
+  the GCM specification (McGrew & Viega, "The Galois/Counter Mode of Operation", appendix B; the vectors NIST SP 800-38D
+  validation uses) are products the oracle and the kernels must reproduce after reversing the bits of each block.
+  Mont128's reference pin is tests/golden/golden_mont128.json (the reference's own Montgomery templates at two limbs).
 
 The CPU half checks the oracle; the `gpu` half sends the same vectors through the HIP kernels (scl_hip_ew), so the GPU path
 is pinned against the big-integer model directly, not only against the oracle."""
@@ -198,6 +203,79 @@ def test_oracle_gf2_128_against_python_shift_xor(port):
     assert e.value.message == "0 not invertible modulo prime"
 
 
+# ---- GF(2^128) against published vectors: GHASH of the GCM specification ---------------------------------------------------------
+# A GCM block B (16 bytes, big-endian integer here) stands for sum_i b_i x^i with b_0 the MOST significant bit; an element of
+# this field is the integer with b_i at bit i.  Same field, same polynomial (GCM's R = 11100001 || 0^120 is 1 + x + x^2 + x^7):
+# element = the block's 128 bits reversed.
+def _refl(v: int) -> int:
+    return int(format(v, "0128b")[::-1], 2)
+
+
+GCM_CASES = [
+    # test case 2: K = 0^128, P = 0^128, IV = 0^96
+    {"H": 0x66e94bd4ef8a2c3b884cfa59ca342b2e, "blocks": [0x0388dace60b6a392f328c2b971b2fe78, 0x80],
+     "X": [0x5e2ec746917062882c85b0685353deb7, 0xf38cbb1ad69223dcc3457ae5b6b0f885]},
+    # test case 3: K = feffe9928665731c6d6a8f9467308308, 64 bytes of plaintext: four ciphertext blocks, then len(A) || len(C)
+    {"H": 0xb83b533708bf535d0aa6e52980d53b78,
+     "blocks": [0x42831ec2217774244b7221b784d0d49c, 0xe3aa212f2c02a4e035c17e2329aca12e, 0x21d514b25466931c7d8f6a5aac84aa05,
+                0x1ba30b396a0aac973d58e091473f5985, 0x200],
+     "X": [0x59ed3f2bb1a0aaa07c9f56c6a504647b, 0xb714c9048389afd9f9bc5c1d4378e052, 0x47400c6577b1ee8d8f40b2721e86ff10,
+           0x4796cf49464704b5dd91f159bb1b7f95, 0x7f1b32b81b820d02614f8895ac1d4eac]},
+]
+
+
+def _gcm_products():
+    """(a, b, a * b) as elements of this field, one per GHASH step X_i = (X_{i-1} xor C_i) * H of the published vectors"""
+    out = []
+    for c in GCM_CASES:
+        prev = 0
+        for blk, x in zip(c["blocks"], c["X"]):
+            out.append((_refl(prev ^ blk), _refl(c["H"]), _refl(x)))
+            prev = x
+    return out
+
+
+def test_the_gcm_vectors_are_the_published_ones():
+    """The constants above, checked two ways that share nothing with the engine: (1) the multiplication of the GCM
+    specification as it is written there (Algorithm 1: right shifts, R = e1 || 0^120) reproduces every X_i from H and the
+    blocks; (2) where the image has openssl, H is AES_K(0^128) for the keys of the two test cases."""
+    R_ = 0xe1 << 120
+
+    def spec_mul(X, Y):
+        Z, V = 0, X
+        for i in range(128):
+            if (Y >> (127 - i)) & 1:
+                Z ^= V
+            V = (V >> 1) ^ R_ if V & 1 else V >> 1
+        return Z
+    for c in GCM_CASES:
+        x = 0
+        for blk, want in zip(c["blocks"], c["X"]):
+            x = spec_mul(x ^ blk, c["H"])
+            assert x == want
+    import shutil
+    import subprocess
+    if shutil.which("openssl"):
+        for key, c in (("00" * 16, GCM_CASES[0]), ("feffe9928665731c6d6a8f9467308308", GCM_CASES[1])):
+            r = subprocess.run(["openssl", "enc", "-aes-128-ecb", "-K", key, "-nopad"], input=bytes(16), capture_output=True)
+            if r.returncode == 0:
+                assert int.from_bytes(r.stdout, "big") == c["H"]
+    # and the bit reversal is the right dictionary: the shift-xor model gives the same products
+    for a, b, ab in _gcm_products():
+        assert gf_mul(a, b) == ab
+
+
+def test_oracle_gf2_128_against_published_gcm_vectors(port):
+    f = O.GF2_128
+    prods = _gcm_products()
+    a, b = O.from_ints([p[0] for p in prods], 2), O.from_ints([p[1] for p in prods], 2)
+    assert O.to_ints(port.ew(f, O.MUL, a, b)) == [p[2] for p in prods]
+    assert O.to_ints(port.ew(f, O.MUL, b, a)) == [p[2] for p in prods]
+    # division undoes it: X_i / H = X_{i-1} xor C_i  (H is invertible: the inverse enters through the same vectors)
+    ab = O.from_ints([p[2] for p in prods], 2)
+    assert O.to_ints(port.ew(f, O.DIV, ab, b)) == [p[0] for p in prods]
+
+
 def test_oracle_gf2_128_shamir_against_python(port):
     """Horner evaluation, the Lagrange basis and reconstruction at explicit nodes (the bit patterns of 1..n: the reference's
     x++ walk, which the oracle's shamirSecretShare restates literally, cycles 1, 0, 1, .. in characteristic 2) against the
@@ -299,6 +377,35 @@ def test_gpu_mont128_against_python_big_integers(scl, p):
                     assert O.to_ints(scl.to_host(sh2[i])) == to_mont(want_row, p), f"({n2},{t2}) party {i}"
     finally:
         scl.set_mont128_prime(R - 159)
+
+
+@pytest.mark.gpu
+def test_gpu_gf2_128_against_published_gcm_vectors(scl):
+    """the GHASH steps of the GCM specification's test cases 2 and 3 through the kernels: the LDS-window product
+    (k_ew_gf128_mul), the register product (inv_batch = -1), scalar multiplication by H, the dot product of the step
+    operands with H, and division by H"""
+    f = scl.GF2_128
+    prods = _gcm_products()
+    a = scl.to_device(O.from_ints([p[0] for p in prods], 2))
+    b = scl.to_device(O.from_ints([p[1] for p in prods], 2))
+    want = [p[2] for p in prods]
+    assert O.to_ints(scl.to_host(scl.ew(f, scl.MUL, a, b))) == want
+    scl.set_tuning("inv_batch", -1)
+    try:
+        assert O.to_ints(scl.to_host(scl.ew(f, scl.MUL, a, b))) == want
+    finally:
+        scl.set_tuning("inv_batch", 0)
+    assert O.to_ints(scl.to_host(scl.ew(f, scl.DIV, scl.to_device(O.from_ints(want, 2)), b))) == [p[0] for p in prods]
+    for c in GCM_CASES:
+        h = O.from_ints([_refl(c["H"])], 2)[0]
+        steps = [p for p in prods if p[1] == _refl(c["H"])]
+        xs = scl.to_device(O.from_ints([p[0] for p in steps], 2))
+        assert O.to_ints(scl.to_host(scl.scalar_mul(f, xs, h))) == [p[2] for p in steps]
+        acc = 0
+        for p in steps:
+            acc ^= p[2]
+        hs = scl.to_device(O.from_ints([_refl(c["H"])] * len(steps), 2))
+        assert O.to_ints(scl.dot(f, xs, hs)[None]) == [acc]
 
 
 @pytest.mark.gpu
