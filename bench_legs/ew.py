@@ -2,7 +2,7 @@
 import time
 
 from .common import DTYPES, FIELD_NAMES, HBM_PEAK_GBPS, I8_PEAK_TOPS
-from .compute_roofline import lds_roofline, valu_roofline
+from .compute_roofline import SQ, lds_roofline, valu_roofline
 
 EW_FIELDS = (("m61", 100_000_000), ("m127", 10_000_000), ("mont128", 10_000_000), ("gf2_128", 10_000_000))
 # what the rolled inversion moves through HBM per element once its chains outgrow L2 + MALL: x read,
@@ -71,7 +71,6 @@ def ew_report(ctx):
             if inv:
                 legs[name]["roofline_compute"] = valu_roofline(fkey + "_inv", rate)
                 if fkey != "m61":
-                    from .compute_roofline import SQ
                     legs[name]["traffic_over_algorithmic"] = {
                         "expected": ROLLED_INVERSE_TRAFFIC_OVER_ALGORITHMIC,
                         "measured": (SQ.get(fkey + "_inv") or {}).get("traffic_over_algorithmic"),     # profiles/sq_counters.json (PMC passes)

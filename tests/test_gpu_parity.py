@@ -2025,6 +2025,86 @@ def test_prg_share_two_pass_across_slabs(scl, port):
     assert scl.equals(f, scl.shamir_recover(f, big, lam), secrets)
 
 
+# ---------------------------------------------------------------------------------------------- beyond 2^32 elements
+def test_more_than_2_to_the_32_elements(scl, port):
+    """Vector<T>::SizeType is uint32_t in the reference (vector.h:73): a Vector holds fewer than 2^32 elements.  The batch API
+    takes size_t and the card holds 288 GB, so a batch may be longer: N = 2^32 + 4097 Mersenne61 elements (34 GB per vector)
+    through the element-wise kernels, sum / dot, coefficient-fed and PRG-driven sharing (3, 1) and reconstruction -- every
+    index past 2^32 and every byte offset past 2^35.  Checked by properties over the whole batch and by oracle windows at the
+    start, ACROSS element 2^32 and at the end (PRG blocks addressed by counter, note P of SURVEY.md section 8a)."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    assert free > 225 * 10**9, f"this case needs 215 GB of HBM, {free / 1e9:.0f} GB free"
+    f, L = O.M61, 1
+    N = 2**32 + 4097
+    wins = [(0, 64), (2**32 - 32, 64), (N - 64, 64)]
+
+    def window(t_, lo, w):
+        return host(scl, t_[..., lo:lo + w, :].contiguous())
+
+    a = scl.vector_random(f, N, b"2^32-a")
+    b = scl.vector_random(f, N, b"2^32-b")
+    # Vector::random over more than 2^32 elements: element s = bytes [8 s, 8 s + 8) of the stream, block s / 2
+    for lo, w in wins:
+        raw = port.prg_blocks(b"2^32-a", lo // 2, w // 2 + 1)[8 * (lo % 2): 8 * (lo % 2) + 8 * w]
+        assert np.array_equal(window(a, lo, w), port.from_bytes(f, raw)), lo
+    out = scl.empty(f, N)
+    for op in (O.ADD, O.MUL):
+        scl.ew(f, op, a, b, out=out)
+        for lo, w in wins:
+            assert np.array_equal(window(out, lo, w), port.ew(f, op, window(a, lo, w), window(b, lo, w))), (op, lo)
+    scl.ew(f, O.ADD, a, b, out=out)
+    scl.ew(f, O.SUB, out, b, out=out)
+    assert scl.equals(f, out, a)
+    # inverse (simultaneous inversion, 32 elements per lane: tiles past 2^32) and x * x^-1 = 1 over all of it (a uniform element
+    # is zero with probability 2^-61: the status word must stay clear)
+    status = scl.ew_status_buffer()
+    scl.ew_status(f, O.INV, a, None, status, out=out)
+    assert int(status.item()) == 0
+    for lo, w in wins:
+        assert np.array_equal(window(out, lo, w), port.ew(f, O.INV, window(a, lo, w))), lo
+    scl.ew(f, O.MUL, out, a, out=out)
+    assert int((out.view(-1) != 1).sum().item()) == 0
+    # Vector::sum / dot: the whole = the part below 2^32 + the part above
+    h = 2**32 - 5
+    assert np.array_equal(scl.vsum(f, a), port.ew(f, O.ADD, scl.vsum(f, a[:h])[None], scl.vsum(f, a[h:])[None])[0])
+    assert np.array_equal(scl.dot(f, a, b), port.ew(f, O.ADD, scl.dot(f, a[:h], b[:h])[None], scl.dot(f, a[h:], b[h:])[None])[0])
+    del out
+    torch.cuda.empty_cache()
+    # shamirSecretShare (3, 1) from resident coefficients, shamirRecoverP from all three and from two shares
+    n, t = 3, 1
+    shares = scl.shamir_share(f, a, b.view(1, N, 1), n)
+    for lo, w in wins:
+        want = soa(port.shamir_share_coeffs(f, window(a, lo, w), window(b, lo, w).reshape(w, 1, L), n))
+        assert np.array_equal(window(shares, lo, w), want), lo
+    rec = scl.shamir_recover(f, shares)
+    assert scl.equals(f, rec, a)
+    scl.shamir_recover(f, shares[:2], out=rec)
+    assert scl.equals(f, rec, a)
+    # the reference's own mode: coefficients from the PRG, secret s from block s (Vector::random(2) of 8-byte elements = 1 block)
+    scl.shamir_share_prg(f, a, t, n, b"2^32-seed", out=shares)
+    for lo, w in wins:
+        elems = port.from_bytes(f, port.prg_blocks(b"2^32-seed", lo, w)).reshape(w, 2, L)
+        want = soa(port.shamir_share_coeffs(f, window(a, lo, w), np.ascontiguousarray(elems[:, 1:2]), n))
+        assert np.array_equal(window(shares, lo, w), want), lo
+    scl.shamir_recover(f, shares, out=rec)
+    assert scl.equals(f, rec, a)
+    # additiveShare n = 3 from the PRG (2 blocks per secret) and Vector::sum per secret
+    scl.additive_share_prg(f, a, 3, b"2^32-add", out=shares)
+    for lo, w in wins:      # share i < n - 1 of secret s: the first 8 bytes of block s (n - 1) + i; the last one = secret - the others
+        blk = np.frombuffer(port.prg_blocks(b"2^32-add", 2 * lo, 2 * w), dtype=np.uint8).reshape(w, 2, 16)[:, :, :8]
+        r = port.from_bytes(f, np.ascontiguousarray(blk).tobytes()).reshape(w, 2, L)
+        got = window(shares, lo, w)
+        assert np.array_equal(got[0], r[:, 0]) and np.array_equal(got[1], r[:, 1]), lo
+        assert np.array_equal(got[2], port.ew(f, O.SUB, window(a, lo, w), port.ew(f, O.ADD, r[:, 0], r[:, 1]))), lo
+    scl.additive_recover(f, shares, out=rec)
+    assert scl.equals(f, rec, a)
+    del a, b, shares, rec
+    torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------------------------------------- full size properties
 @pytest.mark.parametrize("f,n,t,N", [(O.M61, 10, 3, 100_000_000), (O.M127, 10, 3, 10_000_000), (O.MONT128, 10, 3, 10_000_000),
                                      (O.GF2_128, 40, 13, 12_500_000)])
