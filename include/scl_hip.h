@@ -14,8 +14,10 @@
  *    SCL_SECP256K1_SCALAR = scl::math::ff::Secp256k1Scalar, the secp256k1 group
  *    order, and SCL_SECP256K1_FIELD = scl::math::ff::Secp256k1Field, the prime the
  *    curve is defined over (src/scl/math/fields/secp256k1_field.cc:43-135) -- the
- *    two N = 4 instances of the reference's Montgomery family (4 limbs, 16-byte aligned); SCL_MONT128 / SCL_GF2_128 are plug-in
- *    fields the reference does not have (2 limbs).  An element's limbs are the
+ *    two N = 4 instances of the reference's Montgomery family (4 limbs, 16-byte aligned); SCL_MONT128 is the N = 2 instance of
+ *    the same family (the templates of include/scl/math/fields/ff_ops_gmp.h:44-392, which the reference itself instantiates at
+ *    N = 4 only; pinned by tests/golden/golden_mont128.json, emitted by those templates compiled at two limbs) over a run-time
+ *    128-bit modulus, SCL_GF2_128 a plug-in field the reference does not have (GHASH's field; 2 limbs each).  An element's limbs are the
  *    in-memory image of FF::m_value (what std::vector<FF>::data() holds): the
  *    canonical integer for the Mersenne fields, the Montgomery residue
  *    x*2^256 mod p for secp256k1_order exactly as the reference keeps it
