@@ -135,6 +135,9 @@ int scl_hip_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the sto
  *                fused kernels (where one exists), 0 (default) = by shape and field
  *   inv_batch    element-wise inverse / divide: 0 (default) simultaneous inversion with the chain length chosen by the batch,
  *                8 | 16 | 32 | 64 | 128 that chain length, -1 one Fermat chain per element and GF(2^128)'s register-only product
+ *   inv_two_level  the chained inversion of the 16-byte prime fields in two levels (checkpoints + recomputed blocks: 3 E instead of
+ *                5 E bytes per element, one more product): 0 (default) by field and chain length (Mersenne127 from chains of 64),
+ *                4 | 8 that block length for chains of 32 and more (also Mont128), -1 never; with inv_batch 256 a chain of 256
  *   matmul_lds_min  columns from which the thread-per-column matrix kernels are taken instead of the tiled one (0 = by shape);
  *   transpose_tile  secrets per LDS tile of the 16-byte layout bridge (0 = up to 512);  gemm_slab_mib  digit planes per factor
  *                and launch of the general matrix-core product in MiB (0 = 1024)

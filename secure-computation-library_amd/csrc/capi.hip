@@ -98,6 +98,7 @@ SCL_STATE(thread_local Knob g_aes_blocks, {0});
 // that chain length (8, 16, 32, 64 or 128; Mersenne61: any N = its register kernel), -1 = one Fermat chain per element (k_ew, the kernels
 // of rounds 1-4); GF(2^128) multiply: -1 = the register-only product ("inv_batch")
 SCL_STATE(thread_local Knob g_inv_batch, {0});
+SCL_STATE(thread_local Knob g_inv_two_level, {0});
 SCL_STATE(thread_local Knob g_gemm_slab_mib, {0});  // digit planes per factor and launch of the general matrix-core product, MiB (0 = 1024) ("gemm_slab_mib")
 SCL_STATE(thread_local Knob g_matmul_lds_min, {0});  // columns from which k_matmul (left factor in LDS, a thread per column) is taken; thin kernel likewise (0 = default) ("matmul_lds_min")
 SCL_STATE(thread_local Knob g_transpose_tile, {0});  // secrets per LDS tile of the 16-byte layout bridge (0 = 512 within 40 KiB) ("transpose_tile")
@@ -1199,6 +1200,33 @@ int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const 
   return SCL_OK;
 }
 
+// the two-level form (k_ew_inv_blocked): the 16-byte prime fields only (their products are the field's own; L2 = 8 operands and
+// 8 prefix products in registers)
+// Block length taken when "inv_two_level" is 0, from tools/probe_inv_two_level.py (profiles/r6_probe_inv_two_level.txt): Mersenne127
+// -- the one field whose rolled inversion is bound by its scratch traffic -- gains from chains of 64 on (10^7 elements: 0.186 ->
+// 0.170 ms with blocks of 4; 3 * 10^7 and 10^8 at chains of 128 with blocks of 8: 0.49 -> 0.40 ms and 1.55 -> 1.14 ms; divide 1.15-1.28 x)
+// and loses below (chains of 32: 0.84-1.0 x); Mont128 sits on vector issue and loses everywhere (0.87-0.95 x): never by itself.
+template <class F>
+constexpr int inv_two_level_default(int L) {
+  return F::TAG == 1 ? (L >= 128 ? 8 : L == 64 ? 4 : 0) : 0;
+}
+template <class F, bool DIV, int L, int L2>
+int launch_inv_blocked(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, unsigned* flag, hipStream_t st) {
+  constexpr int BLK = 64, L1 = L / L2;
+  auto kern = &k_ew_inv_blocked<F, FieldArith<F>, DIV, L1, L2, BLK>;
+  const size_t tiles = (n + (size_t)BLK * L - 1) / ((size_t)BLK * L);
+  hipLaunchKernelGGL(kern, dim3(grid_for_block(tiles, 1)), dim3(BLK), 0, st, ctx, dst, a, b, n, flag);
+  LAUNCH_CHECK();
+  return SCL_OK;
+}
+template <class F, bool DIV, int L2>
+int launch_inv_blocked_by_length(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, int L, unsigned* flag, hipStream_t st) {
+  if (L == 256) return launch_inv_blocked<F, DIV, 256, L2>(ctx, dst, a, b, n, flag, st);
+  if (L == 128) return launch_inv_blocked<F, DIV, 128, L2>(ctx, dst, a, b, n, flag, st);
+  if (L == 64) return launch_inv_blocked<F, DIV, 64, L2>(ctx, dst, a, b, n, flag, st);
+  return launch_inv_blocked<F, DIV, 32, L2>(ctx, dst, a, b, n, flag, st);
+}
+
 template <class F, bool DIV>
 int ew_inverse_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, long want, unsigned* flag, hipStream_t st) {
   // The chain length by batch size, from the sweeps of tools/probe_inv_chain.py (profiles/r5_probe_inv_chain.txt): the one
@@ -1212,8 +1240,16 @@ int ew_inverse_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const 
   int L = 8;
   for (int i = 0; i < 4; ++i)
     if (n >= from[i]) L = 16 << i;
-  if (want > 0) L = want >= 128 ? 128 : want >= 64 ? 64 : want >= 32 ? 32 : want >= 16 ? 16 : 8;
-  if (L == 128) return launch_inv_rolled<F, DIV, 128>(ctx, dst, a, b, n, flag, st);
+  if (want > 0) L = want >= 256 ? 256 : want >= 128 ? 128 : want >= 64 ? 64 : want >= 32 ? 32 : want >= 16 ? 16 : 8;
+  if constexpr (F::TAG == 1 || F::TAG == 2) {
+    // two levels for the field whose rolled inversion is bound by its scratch traffic: Mersenne127 from chains of 32 on
+    // ("inv_two_level": 4 | 8 = that block length, also for Mont128; -1 never)
+    const long knob = g_inv_two_level.load();
+    const long two = knob > 0 ? knob : knob == 0 ? inv_two_level_default<F>(L) : 0;   // block length: 4 or 8; 0 = rolled
+    if (L >= 32 && two >= 8) return launch_inv_blocked_by_length<F, DIV, 8>(ctx, dst, a, b, n, L, flag, st);
+    if (L >= 32 && two >= 1) return launch_inv_blocked_by_length<F, DIV, 4>(ctx, dst, a, b, n, L, flag, st);
+  }
+  if (L >= 128) return launch_inv_rolled<F, DIV, 128>(ctx, dst, a, b, n, flag, st);   // (256: the two-level form only)
   if (L == 64) return launch_inv_rolled<F, DIV, 64>(ctx, dst, a, b, n, flag, st);
   if (L == 32) return launch_inv_rolled<F, DIV, 32>(ctx, dst, a, b, n, flag, st);
   if (L == 16) return launch_inv_rolled<F, DIV, 16>(ctx, dst, a, b, n, flag, st);
@@ -1416,6 +1452,7 @@ int scl_hip_set_tuning(const char* key, long value) {
   else if (k == "mfma_tpb") g_mfma_tpb = value;
   else if (k == "aes_blocks") g_aes_blocks = value;
   else if (k == "inv_batch") g_inv_batch = value;
+  else if (k == "inv_two_level") g_inv_two_level = value;
   else if (k == "transpose_tile") g_transpose_tile = value;
   else if (k == "gemm_slab_mib") g_gemm_slab_mib = value;
   else if (k == "matmul_lds_min") g_matmul_lds_min = value;

@@ -537,6 +537,84 @@ __global__ __launch_bounds__(BLK) void k_ew_inv_rolled(typename F::Ctx ctx, u64*
   }
 }
 
+// ---- the same with the chain in two levels: checkpoints, blocks recomputed ------------------------------------------------------------
+// k_ew_inv_rolled moves 5 E bytes per element through HBM once the resident chains outgrow the caches (x read, every prefix
+// product written to scratch and read back, x read again, the result written: 2.5 x the algorithmic 2 E, measured --
+// profiles/r6_sq_counters.txt).  Here a lane's chain of L = L1 * L2 elements keeps only the prefix product at the END of each
+// block of L2 (L1 checkpoints: a few scratch words per lane); the walk back takes the blocks last to first, recomputes the
+// block's L2 prefix products from the checkpoint before it -- in registers, from the operands it has to read again anyway --
+// and walks the block.  3 E bytes and 4 - 1/L2 + I/L products per element instead of 5 E and 3 + I/L: for a field whose
+// rolled inversion is bound by that traffic (Mersenne127) a gain, for the ones that sit on vector issue a loss
+// (ew_inverse_rolled chooses; "inv_two_level" pins).  Same unique inverses, same zero handling as k_ew_inv_rolled.
+template <class F, class ARITH, bool DIV, int L1, int L2, int BLK>
+__global__ __launch_bounds__(BLK) void k_ew_inv_blocked(typename F::Ctx ctx, u64* dst, const u64* a, const u64* b, size_t n,
+                                                        unsigned* zero_flag) {
+  typedef typename F::E E;
+  constexpr int L = L1 * L2;
+  const ARITH ar(ctx, (int)threadIdx.x);
+  const u64* src = DIV ? b : a;
+  for (size_t tile = blockIdx.x; tile * ((size_t)BLK * L) < n; tile += gridDim.x) {
+    const size_t q0 = tile * ((size_t)BLK * L) + threadIdx.x;
+    E ck[L1];  // ck[j] = x_0 ... x_(L2 (j + 1) - 1), zeros taken as ones
+    E run = ar.one();
+    bool any_zero = false;
+#pragma unroll 1
+    for (int j = 0; j < L1; ++j) {
+      E v[L2];
+#pragma unroll
+      for (int k = 0; k < L2; ++k) {
+        const size_t q = q0 + (size_t)(j * L2 + k) * BLK;
+        v[k] = ar.one();
+        if (q < n) v[k] = load_pack<F, 1, false>(src + q * F::LIMBS).v[0];
+      }
+#pragma unroll
+      for (int k = 0; k < L2; ++k) {
+        if (F::is_zero(v[k])) {
+          any_zero = true;
+          v[k] = ar.one();
+        }
+        run = (j | k) ? ar.product(run, v[k]) : v[k];
+      }
+      ck[j] = run;
+    }
+    if (any_zero) raise_flag(zero_flag);
+    E inv = ar.inverse(run);
+#pragma unroll 1
+    for (int j = L1 - 1; j >= 0; --j) {
+      E v[L2], pre[L2], num[L2];
+#pragma unroll
+      for (int k = 0; k < L2; ++k) {
+        const size_t q = q0 + (size_t)(j * L2 + k) * BLK;
+        v[k] = ar.one();
+        if (q < n) {
+          v[k] = load_pack<F, 1, true>(src + q * F::LIMBS).v[0];
+          if constexpr (DIV) num[k] = load_pack<F, 1, true>(a + q * F::LIMBS).v[0];
+        }
+      }
+      bool z[L2];
+      pre[0] = j ? ck[j - 1] : ar.one();  // everything before the block
+#pragma unroll
+      for (int k = 0; k < L2; ++k) {
+        z[k] = F::is_zero(v[k]);
+        if (z[k]) v[k] = ar.one();
+        if (k + 1 < L2) pre[k + 1] = (j | k) ? ar.product(pre[k], v[k]) : v[k];
+      }
+#pragma unroll
+      for (int k = L2 - 1; k >= 0; --k) {
+        const size_t q = q0 + (size_t)(j * L2 + k) * BLK;
+        E o = inv;
+        if (j | k) ar.product2(inv, pre[k], v[k], o, inv);
+        if (q < n) {
+          Pack<F, 1> out;
+          out.v[0] = z[k] ? F::zero() : o;
+          if constexpr (DIV) out.v[0] = ar.product(num[k], out.v[0]);
+          store_pack<F, 1, true>(dst + q * F::LIMBS, out);
+        }
+      }
+    }
+  }
+}
+
 // Vector::scalarMultiply (vector.h:274-301)
 template <class F, int VEC, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_scalar_mul(typename F::Ctx ctx, u64* dst, const u64* a,

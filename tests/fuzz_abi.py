@@ -26,11 +26,11 @@ EDGES = [0, 1, 2, 3, 63, 64, 65, 127, 255, 256, 257, 511, 512, 513, 1023, 1025, 
 # tuning knobs (scl_hip_set_tuning) and the values the library documents for them; defaults in KNOB_DEFAULTS
 KNOBS = {"force_table": [1, 2], "prg_two_pass": [-1, 1], "nontemporal": [0], "force_scalar": [1], "stream_block": [256],
          "stream_waves": [0, 4, 8], "share_waves": [0, 6, 12], "share_waves128": [0, 8, 16], "max_blocks": [1, 7, 300],
-         "gf_tiles": [0], "mfma": [-1, 1, 2], "mfma_areg": [0], "mfma_pipe": [0, 1], "inv_batch": [-1, 8, 16, 32, 64, 128],
+         "gf_tiles": [0], "mfma": [-1, 1, 2], "mfma_areg": [0], "mfma_pipe": [0, 1], "inv_batch": [-1, 8, 16, 32, 64, 128], "inv_two_level": [-1, 4, 8],
          "transpose_tile": [64, 128, 256], "gemm_slab_mib": [1, 4], "matmul_lds_min": [1024, 4096], "aes_blocks": [1, 64], "prg_t3": [0]}
 KNOB_DEFAULTS = {"force_table": 0, "prg_two_pass": 0, "nontemporal": 1, "force_scalar": 0, "stream_block": 64, "stream_waves": -1,
                  "share_waves": 9, "share_waves128": 12, "max_blocks": 0, "gf_tiles": 1, "mfma": 0, "mfma_areg": 1, "mfma_pipe": 2,
-                 "inv_batch": 0, "transpose_tile": 0, "gemm_slab_mib": 0, "matmul_lds_min": 0, "aes_blocks": 0, "prg_t3": 1}
+                 "inv_batch": 0, "inv_two_level": 0, "transpose_tile": 0, "gemm_slab_mib": 0, "matmul_lds_min": 0, "aes_blocks": 0, "prg_t3": 1}
 
 
 def main():

@@ -33,7 +33,7 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 # key of bench_legs/compute_roofline.py -> needle in the demangled kernel name
 DEFAULT_NEEDLES = {
     "m61_inv": "k_ew_inv<sclhip::M61, false",
-    "m127_inv": "k_ew_inv_rolled<sclhip::M127",
+    "m127_inv": "k_ew_inv_blocked<sclhip::M127, sclhip::FieldArith<sclhip::M127>, false, 16, 4",   # (what 10^7 elements take: chains of 64, blocks of 4)
     "mont128_inv": "k_ew_inv_rolled<sclhip::Mont128",
     "gf2_128_inv": "k_ew_inv_rolled<sclhip::Gf128",
     "gf2_128_mul": "k_ew_gf128_mul<64, 3>",

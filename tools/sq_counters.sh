@@ -17,7 +17,7 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
   python3 - <<'PY'
 import csv, glob
 from collections import defaultdict
-names = {"k_ew_inv<sclhip::M61, false": "m61_inv", "k_ew_inv_rolled<sclhip::M127": "m127_inv", "k_ew_inv_rolled<sclhip::Mont128": "mont128_inv",
+names = {"k_ew_inv<sclhip::M61, false": "m61_inv", "k_ew_inv_blocked<sclhip::M127": "m127_inv", "k_ew_inv_rolled<sclhip::Mont128": "mont128_inv",
          "k_ew_inv_rolled<sclhip::Gf128": "gf2_128_inv", "k_ew_gf128_mul": "gf2_128_mul", "k_share_gf_tiles<13>": "c4_share",
          "k_recover_gf128_pos<512": "c4_recover", "k_prg_blocks": "prg_blocks"}
 acc = defaultdict(lambda: defaultdict(list))
