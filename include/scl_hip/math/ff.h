@@ -67,7 +67,8 @@ struct Secp256k1Field {  // include/scl/math/fields/secp256k1_field.h: the prime
   constexpr static int TAG = SCL_SECP256K1_FIELD;
 };
 
-struct Mont128 {  // plug-in: generic 128-bit prime, Montgomery form (not in the reference)
+struct Mont128 {  // 128-bit prime, Montgomery form: the N = 2 instance of the reference's monty*<N> family (ff_ops_gmp.h:44-392;
+                  // the reference itself instantiates N = 4 only -- pinned by tests/golden/golden_mont128.json), run-time modulus
   using ValueType = __uint128_t;
   using Impl = sclhip::Mont128;
   constexpr static const char* NAME = "Mont128";
