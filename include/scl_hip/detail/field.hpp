@@ -509,7 +509,56 @@ struct Mont128 {
     const bool c2 = hi2 < hi;
     return (c1 || c2 || hi2 >= c.p) ? hi2 - c.p : hi2;
   }
-  static SCL_HD E mul(const Ctx& c, E a, E b) { return redc(c, mulwide(a, b)); }
+  // The Montgomery product a b R^-1 mod p, interleaved over 32-bit words -- the form of the reference's montyModMul over its
+  // 64-bit limbs (ff_ops_gmp.h:174-191) -- column by column (product scanning): column k collects a_i b_j and m_i p_j for
+  // i + j = k in ONE 96-bit accumulator (a v_mad_u64_u32 onto the running 64 bits + a carry into the third word per partial
+  // product: no operand is ever widened or moved), m_k = low word * (-p^-1 mod 2^32) makes the low word vanish, the accumulator
+  // moves down a word.  32 multiply-adds, 4 word products: about half the vector instructions of "128 x 128 -> 256, low product
+  // by -p^-1, 128 x 128 -> 256, add" (redc(mulwide(a, b)), which stays for the lazy accumulators' final reduction).  The result
+  // is the unique residue in [0, p) either way (the sum is < 2p before the last subtraction for a, b < p).
+  static SCL_HD E mul(const Ctx& c, E a, E b) {
+    const u32 aw[4] = {(u32)a, (u32)(a >> 32), (u32)(a >> 64), (u32)(a >> 96)};
+    const u32 bw[4] = {(u32)b, (u32)(b >> 32), (u32)(b >> 64), (u32)(b >> 96)};
+    const u32 pw[4] = {(u32)c.p, (u32)(c.p >> 32), (u32)(c.p >> 64), (u32)(c.p >> 96)};
+    const u32 n0 = (u32)c.mc;
+    u32 m[4], t[4];
+    u64 lo = 0;
+    u32 hi = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < k; ++j) {
+        lazy_col_mad(lo, hi, aw[j], bw[k - j]);
+        lazy_col_mad(lo, hi, m[j], pw[k - j]);
+      }
+      lazy_col_mad(lo, hi, aw[k], bw[0]);
+      m[k] = (u32)lo * n0;
+      lazy_col_mad(lo, hi, m[k], pw[0]);   // the low word is 0 now
+      lo = (lo >> 32) | ((u64)hi << 32);
+      hi = 0;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 4; k < 8; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = k - 3; j < 4; ++j) {
+        lazy_col_mad(lo, hi, aw[j], bw[k - j]);
+        lazy_col_mad(lo, hi, m[j], pw[k - j]);
+      }
+      t[k - 4] = (u32)lo;
+      lo = (lo >> 32) | ((u64)hi << 32);
+      hi = 0;
+    }
+    const u128 r = (u128)((u64)t[0] | ((u64)t[1] << 32)) | ((u128)((u64)t[2] | ((u64)t[3] << 32)) << 64);
+    return (lo || r >= c.p) ? r - c.p : r;   // lo: the ninth word, 0 or 1
+  }
   static SCL_HD E sqr(const Ctx& c, E a) { return mul(c, a, a); }
   // The Horner kernels' small-constant form (SMALLX): the node as a plain integer x < 2^32 (NOT its residue), y*x + c through
   // muladd_small below -- one lazy limb product and one Barrett step instead of a Montgomery product; full-width moduli only
@@ -925,8 +974,66 @@ struct Mont256 {
     return r;
   }
   static SCL_HD E neg(const Ctx& c, const E& a) { return sub(c, zero(), a); }  // montyModNeg
-  // montyModMul (ff_ops_gmp.h:174-191): interleaved Montgomery product a*b/2^256 mod p, valid for a < 2^256, b < p
+  // montyModMul (ff_ops_gmp.h:174-191): interleaved Montgomery product a*b/2^256 mod p, valid for a < 2^256, b < p.
+  // Column by column over 32-bit words (product scanning, as Mont128::mul): column k collects a_i b_j and m_i p_j for i + j = k in
+  // one 96-bit accumulator -- a v_mad_u64_u32 and a carry per partial product, nothing widened or moved --, m_k = low word *
+  // (-p^-1 mod 2^32) clears the low word, the accumulator moves down a word: 128 multiply-adds and 8 word products, about half
+  // the vector instructions of the limb-by-limb form below (615 -> ~330 per product on gfx950).
   static SCL_HD E mul(const Ctx&, const E& a, const E& b) {
+    u32 aw[8], bw[8], pw[8], m[8], t[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 4; ++i) {
+      aw[2 * i] = (u32)a.w[i];
+      aw[2 * i + 1] = (u32)(a.w[i] >> 32);
+      bw[2 * i] = (u32)b.w[i];
+      bw[2 * i + 1] = (u32)(b.w[i] >> 32);
+      pw[2 * i] = (u32)P(i);
+      pw[2 * i + 1] = (u32)(P(i) >> 32);
+    }
+    const u32 n0 = (u32)MC0;
+    u64 lo = 0;
+    u32 hi = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < k; ++j) {
+        lazy_col_mad(lo, hi, aw[j], bw[k - j]);
+        lazy_col_mad(lo, hi, m[j], pw[k - j]);
+      }
+      lazy_col_mad(lo, hi, aw[k], bw[0]);
+      m[k] = (u32)lo * n0;
+      lazy_col_mad(lo, hi, m[k], pw[0]);   // the low word is 0 now
+      lo = (lo >> 32) | ((u64)hi << 32);
+      hi = 0;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 8; k < 16; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = k - 7; j < 8; ++j) {
+        lazy_col_mad(lo, hi, aw[j], bw[k - j]);
+        lazy_col_mad(lo, hi, m[j], pw[k - j]);
+      }
+      t[k - 8] = (u32)lo;
+      lo = (lo >> 32) | ((u64)hi << 32);
+      hi = 0;
+    }
+    E r = make((u64)t[0] | ((u64)t[1] << 32), (u64)t[2] | ((u64)t[3] << 32), (u64)t[4] | ((u64)t[5] << 32), (u64)t[6] | ((u64)t[7] << 32));
+    if (lo || geq_p(r)) sub_n(r, r, prime());   // lo: the seventeenth word, 0 or 1
+    return r;
+  }
+  // the same product limb by limb over 64-bit words (the shape of the reference's loop; what mul was until round 6): kept for
+  // tests/cxx/mont_mul_check.cc
+  static SCL_HD E mul_by_limbs(const Ctx&, const E& a, const E& b) {
     u64 u[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -1202,13 +1202,14 @@ int launch_inv_rolled(const typename F::Ctx& ctx, u64* dst, const u64* a, const 
 
 // the two-level form (k_ew_inv_blocked): the 16-byte prime fields only (their products are the field's own; L2 = 8 operands and
 // 8 prefix products in registers)
-// Block length taken when "inv_two_level" is 0, from tools/probe_inv_two_level.py (profiles/r6_probe_inv_two_level.txt): Mersenne127
-// -- the one field whose rolled inversion is bound by its scratch traffic -- gains from chains of 64 on (10^7 elements: 0.186 ->
-// 0.170 ms with blocks of 4; 3 * 10^7 and 10^8 at chains of 128 with blocks of 8: 0.49 -> 0.40 ms and 1.55 -> 1.14 ms; divide 1.15-1.28 x)
-// and loses below (chains of 32: 0.84-1.0 x); Mont128 sits on vector issue and loses everywhere (0.87-0.95 x): never by itself.
+// Block length taken when "inv_two_level" is 0, from tools/probe_inv_two_level.py (profiles/r6_probe_inv_two_level.txt, _b.txt): the
+// form pays where the rolled inversion is bound by its scratch traffic.  Mersenne127: from chains of 64 on (10^7 elements: 0.186 ->
+// 0.170 ms with blocks of 4; 3 * 10^7 and 10^8 at chains of 128 with blocks of 8: 0.49 -> 0.40 ms and 1.55 -> 1.14 ms; divide
+// 1.15-1.28 x), a loss below (chains of 32: 0.84-1.0 x).  Mont128, once its product had been halved (Mont128::mul, product
+// scanning): chains of 128 with blocks of 8, 1.66 -> 1.50 ms at 10^8 (1.04-1.10 x); level or behind at chains of 64 and below.
 template <class F>
 constexpr int inv_two_level_default(int L) {
-  return F::TAG == 1 ? (L >= 128 ? 8 : L == 64 ? 4 : 0) : 0;
+  return F::TAG == 1 ? (L >= 128 ? 8 : L == 64 ? 4 : 0) : F::TAG == 2 ? (L >= 128 ? 8 : 0) : 0;
 }
 template <class F, bool DIV, int L, int L2>
 int launch_inv_blocked(const typename F::Ctx& ctx, u64* dst, const u64* a, const u64* b, size_t n, unsigned* flag, hipStream_t st) {

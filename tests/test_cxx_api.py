@@ -125,6 +125,21 @@ def test_mont128_small_node_fold_against_long_arithmetic(tmp_path):
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout + r.stderr
 
 
+def test_mont128_interleaved_product_against_long_arithmetic(tmp_path):
+    """Mont128::mul -- since round 6 the Montgomery product interleaved over 32-bit words (the reference's montyModMul form,
+    ff_ops_gmp.h:174-191, half the vector instructions of the two-step form) -- against that two-step form and against plain
+    long arithmetic (a b R^-1 mod p, bit by bit) over fourteen moduli of every shape and edge operands
+    (tests/cxx/mont_mul_check.cc, 840 k products); Mont256::mul over both secp256k1 primes
+    the same way against the limb-by-limb form it replaced (600 k products).  The kernels compile the same function; the reference's own values for it:
+    tests/golden/golden_mont128.json."""
+    exe = str(tmp_path / "mont_mul_check")
+    b = subprocess.run(["g++", "-std=c++20", "-O2", f"-I{ROOT}/include", "-o", exe, os.path.join(CXX, "mont_mul_check.cc")],
+                       capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
 def test_gf2_128_host_arithmetic_against_a_bit_serial_multiplier(tmp_path):
     """Gf128::mul (4-bit-window comb), sqr (bit spread + fold) and inv (Itoh-Tsujii chain) of detail/field.hpp -- the code behind
     FF<GF2_128> on the host and, for sqr / inv, in the kernels -- against a shift-xor multiplier and the 254-product ladder

@@ -78,6 +78,8 @@ def classify(mn, ops):
         return "mad64"
     if mn.endswith(("_dpp", "_sdwa", "_e64_dpp")):
         return "vop3"
+    if base in ("v_addc_co_u32", "v_subb_co_u32", "v_subbrev_co_u32") and mn.endswith("_e32"):
+        return "vop2"     # VOP2 with the implicit vcc carry
     if base == "v_cndmask_b32" and mn.endswith("_e32"):
         return "vop2"     # VOP2 with the implicit vcc select (the 22-cycle line of r2_oprate.txt is that probe's own vcc dependency)
     if base in VOP2_FAST and not mn.endswith("_e64"):

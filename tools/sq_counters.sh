@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: SQ counters of every bench kernel HBM does not bound (tools/run_sq_once.py): rocprofv3 --pmc only, the program itself
-# after `--`, three passes (the counters do not fit one); mean per launch at the largest size of every counter per kernel, the
+# after `--`, five passes (the counters do not fit one); the median over the launches at the largest size of every counter per kernel, the
 # per-element instruction counts and issue intervals derived from them -> gpurun_out/r6_sq_counters.txt and sq_counters.json
 # (copy both to profiles/: bench_legs/compute_roofline.py reads profiles/sq_counters.json).
 export TMPDIR=/tmp
@@ -29,8 +29,9 @@ for path in glob.glob("/tmp/sqp/**/*counter_collection.csv", recursive=True):
 with open("/tmp/sq_rows.txt", "a") as fh:
     for tag, cs in acc.items():
         for c, v in sorted(cs.items()):
-            big = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v     # (the first-use self-check of the reconstruct kernel is a tiny launch)
-            fh.write(f"{tag}\t{c}\t{sum(big) / len(big)}\t{len(big)}\n")
+            big = sorted(x for x in v if x >= 0.25 * max(v)) if max(v) > 0 else sorted(v)   # (the first-use self-check of the reconstruct kernel is a tiny launch)
+            med = big[len(big) // 2] if len(big) % 2 else 0.5 * (big[len(big) // 2 - 1] + big[len(big) // 2])   # the median: one cold first launch does not move it
+            fh.write(f"{tag}\t{c}\t{med}\t{len(big)}\n")
 PY
 done
 python3 - <<'PY' > gpurun_out/r6_sq_counters.txt
@@ -42,7 +43,7 @@ rows = defaultdict(dict)
 for ln in open("/tmp/sq_rows.txt"):
     tag, c, v, n = ln.rstrip("\n").split("\t")
     rows[tag][c] = float(v)
-print("# tools/sq_counters.sh: rocprofv3 --pmc passes over tools/run_sq_once.py; mean per launch (SQ_* summed over the chip, GRBM_GUI_ACTIVE over the 8 XCDs)")
+print("# tools/sq_counters.sh: rocprofv3 --pmc passes over tools/run_sq_once.py; median over the launches (SQ_* summed over the chip, GRBM_GUI_ACTIVE over the 8 XCDs)")
 for tag, r in rows.items():
     for c, v in sorted(r.items()):
         print(f"{tag:14s} {c:24s} {v:18.1f}")
